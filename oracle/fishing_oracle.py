@@ -1,0 +1,220 @@
+"""CPU ORACLE (NumPy) for the gym_fishing hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch restatement of what the reference environment
+computes in ``step()`` / ``reset()`` for fishing-v0/v1/v2/v4, vectorised over
+envs, with every operation individually rounded in the order the reference
+evaluates it.  It is the *checker* for the HIP kernels.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it;
+the product package ``gym_fishing_amd`` never does (tests/test_host_logic.py
+greps for that).
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks it bit-for-bit
+against tests/golden/reference_trajectories.npz, which tests/golden/make_golden.py
+captured from the unmodified reference imported in the build container.
+
+Reference citations are relative to /root/reference/gym_fishing/envs/ :
+  base_fishing_env.py:60-81    step()               -> step()
+  base_fishing_env.py:135-147  get_quota()          -> quota_from_action()
+  base_fishing_env.py:158-160  get_fish_population  -> x = (obs + 1) * K
+  base_fishing_env.py:112-119  harvest_draw()       -> h, x
+  base_fishing_env.py:121-133  population_draw()    -> logistic growth
+  fishing_tipping_env.py:24-35 population_draw()    -> tipping-point growth (v2)
+  base_fishing_env.py:162-164  get_state()          -> obs' = x / K - 1
+  base_fishing_env.py:83-91    reset()              -> reset_obs()
+  fishing_model_error.py:37-48 ctor / reset() (v4)  -> draw_model_error_params(), reset_obs()
+
+The in-kernel noise generator (Philox4x32-10 + Box-Muller) has no counterpart in
+the reference (which uses the global MT19937 stream, base_fishing_env.py:130); its
+restatement here follows the published Philox algorithm (Salmon et al., SC'11,
+"Parallel random numbers: as easy as 1, 2, 3") and is pinned by the Random123
+known-answer vectors in tests/test_oracle_golden.py.
+"""
+import numpy as np
+
+# model ids shared with include/fishing_hip.h
+MODEL_V0 = 0  # logistic, Discrete(n_actions)           fishing_env.py:7-24
+MODEL_V1 = 1  # logistic, continuous                    fishing_cts_env.py:4-12
+MODEL_V2 = 2  # tipping point, continuous               fishing_tipping_env.py:6-35
+MODEL_V4 = 4  # logistic, per-episode K,r uncertainty   fishing_model_error.py:6-48
+
+MODEL_OF_ID = {"fishing-v0": MODEL_V0, "fishing-v1": MODEL_V1,
+               "fishing-v2": MODEL_V2, "fishing-v4": MODEL_V4}
+
+# RNG stream tags (top byte of Philox counter word 1)
+STREAM_NOISE = 0      # per-step process noise z  (+ in-kernel policy action)
+STREAM_AUTORESET = 1  # v4 (K, r) redraw when step() auto-resets a finished env
+STREAM_RESET = 2      # v4 (K, r) redraw in an explicit reset()
+
+
+def quota_from_action(model, action, K, n_actions, dtype=np.float64):
+    """base_fishing_env.py:135-147.  Discrete: (a / n_actions) * K with true
+    division (:140).  Continuous: clip to the Box [-1, 1] (:143-145), then
+    (a + 1) * K (:146).  The float32 action is widened to ``dtype`` first, which
+    is what the reference's pinned NumPy 1.19 does."""
+    dt = np.dtype(dtype).type
+    if model == MODEL_V0:
+        a = np.asarray(action).astype(dtype)       # exact for |a| < 2**24 (f32) / 2**53 (f64)
+        return (a / dt(n_actions)) * K
+    a = np.asarray(action, dtype=np.float32).astype(dtype)
+    a = np.clip(a, dt(-1.0), dt(1.0))
+    return (a + dt(1.0)) * K
+
+
+def step(model, obs, t, action, z, r, K, sigma, C=0.5, Tmax=100, n_actions=100,
+         dtype=np.float64):
+    """One reference step() for every env.  Returns (obs', reward, done, t', x).
+
+    obs, z : arrays of ``dtype``;  t : int array;  r, K, sigma : scalars or arrays
+    of ``dtype`` (arrays for fishing-v4).  ``done`` is uint8.  No auto-reset here:
+    the reference has none (base_fishing_env.py:60-81); see auto_reset()."""
+    dt = np.dtype(dtype).type
+    obs = np.asarray(obs, dtype=dtype)
+    z = np.asarray(z, dtype=dtype)
+    r = np.asarray(r, dtype=dtype)
+    K = np.asarray(K, dtype=dtype)
+    sigma = np.asarray(sigma, dtype=dtype)
+    one, zero = dt(1.0), dt(0.0)
+    with np.errstate(all="ignore"):
+        quota = quota_from_action(model, action, K, n_actions, dtype)
+        x = (obs + one) * K                                   # :159
+        h = np.where(quota < x, quota, x)                     # :117  min(x, quota)
+        d = x - h
+        x = np.where(zero > d, zero, d)                       # :118  max(x - h, 0.0)
+        if model == MODEL_V2:                                 # fishing_tipping_env.py:25-34
+            e = ((r * (one - (x / K))) * (x - dt(C))) + ((x * sigma) * z)
+            g = x * np.exp(e)
+        else:                                                 # :125-131
+            g = (x + ((r * x) * (one - (x / K)))) + ((x * sigma) * z)
+        x = np.maximum(g, zero)                               # NaN-propagating
+        obs_next = x / K - one                                # :163
+        reward = np.where(zero > h, zero, h)                  # :74   max(h, 0.0)
+        t_next = np.asarray(t, dtype=np.int32) + np.int32(1)  # :75
+        done = (t_next > np.int32(Tmax)) | (x <= zero)        # :76-79
+    return (obs_next.astype(dtype), reward.astype(dtype), done.astype(np.uint8),
+            t_next.astype(np.int32), x.astype(dtype))
+
+
+def draw_model_error_params(zK, zr, K_mean, r_mean, sigma_p, dtype=np.float64):
+    """fishing_model_error.py:37-38 / :42-43.  np.random.normal(loc, scale) is
+    loc + scale * z; K is drawn first, then r; both clipped to [0, 1e6]."""
+    dt = np.dtype(dtype).type
+    zK = np.asarray(zK, dtype=dtype)
+    zr = np.asarray(zr, dtype=dtype)
+    K = np.clip(dt(K_mean) + dt(sigma_p) * zK, dt(0.0), dt(1e6))
+    r = np.clip(dt(r_mean) + dt(sigma_p) * zr, dt(0.0), dt(1e6))
+    return K.astype(dtype), r.astype(dtype)
+
+
+def reset_obs(model, x0, K, dtype=np.float64):
+    """base_fishing_env.py:84 -> x0 / K - 1;  fishing-v4 returns the
+    UN-normalised x0 (fishing_model_error.py:44, quirk B8)."""
+    dt = np.dtype(dtype).type
+    if model == MODEL_V4:
+        return np.broadcast_to(dt(x0), np.shape(K)).astype(dtype)
+    return (dt(x0) / np.asarray(K, dtype=dtype) - dt(1.0)).astype(dtype)
+
+
+# --------------------------------------------------------------------------
+# Philox4x32-10 (Salmon et al. 2011) + the uniform / normal maps of the kernels
+# --------------------------------------------------------------------------
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = np.uint32(0x9E3779B9)
+_W1 = np.uint32(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32 with 10 rounds.  All inputs uint32 arrays/scalars."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for rnd in range(10):
+            p0 = _M0 * c0.astype(np.uint64)
+            p1 = _M1 * c2.astype(np.uint64)
+            hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
+            lo0 = (p0 & _MASK).astype(np.uint32)
+            hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
+            lo1 = (p1 & _MASK).astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            if rnd != 9:
+                k0 = np.uint32((int(k0) + int(_W0)) & 0xFFFFFFFF)
+                k1 = np.uint32((int(k1) + int(_W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def philox_words(seed, env_index, step_counter, stream):
+    """Counter layout shared with csrc/fishing_common.h:
+    c0 = env[31:0], c1 = stream<<24 | env[55:32], c2 = step[31:0], c3 = step[63:32];
+    key = (seed[31:0], seed[63:32])."""
+    env = np.asarray(env_index, dtype=np.uint64)
+    step_counter = int(step_counter)
+    c0 = (env & _MASK).astype(np.uint32)
+    c1 = (((env >> np.uint64(32)) & np.uint64(0xFFFFFF)).astype(np.uint32)
+          | np.uint32((int(stream) & 0xFF) << 24))
+    c2 = np.uint32(step_counter & 0xFFFFFFFF)
+    c3 = np.uint32((step_counter >> 32) & 0xFFFFFFFF)
+    seed = int(seed)
+    return philox4x32_10(c0, c1, c2, c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+
+
+def uniform_open(w):
+    """u in (0, 1]:  float32(w) * 2**-32 + 2**-33  (each op rounded to float32)."""
+    return (np.asarray(w, dtype=np.uint32).astype(np.float32) * np.float32(2.0 ** -32)
+            + np.float32(2.0 ** -33))
+
+
+def uniform_turn(w):
+    """u in [0, 1]:  float32(w) * 2**-32 (fraction of a full turn)."""
+    return np.asarray(w, dtype=np.uint32).astype(np.float32) * np.float32(2.0 ** -32)
+
+
+def box_muller(w0, w1):
+    """Two standard normals from two words, evaluated in float64 and rounded to
+    float32 -- the value the device's hardware log2/sqrt/cos/sin approximate."""
+    u1 = uniform_open(w0).astype(np.float64)
+    u2 = uniform_turn(w1).astype(np.float64)
+    rad = np.sqrt(-2.0 * np.log(u1))
+    return ((rad * np.cos(2.0 * np.pi * u2)).astype(np.float32),
+            (rad * np.sin(2.0 * np.pi * u2)).astype(np.float32))
+
+
+def noise_normal(seed, env_index, step_counter):
+    """Process-noise z (float32) of env `env_index` at global step `step_counter`."""
+    w0, w1, _, _ = philox_words(seed, env_index, step_counter, STREAM_NOISE)
+    return box_muller(w0, w1)[0]
+
+
+def policy_random_action(model, seed, env_index, step_counter, n_actions=100):
+    """Random policy sampled in-kernel from word 2 of the noise block: continuous
+    a = float32(w2) * 2**-31 - 1 in [-1, 1]; discrete a = (w2 * n_actions) >> 32."""
+    _, _, w2, _ = philox_words(seed, env_index, step_counter, STREAM_NOISE)
+    if model == MODEL_V0:
+        return ((w2.astype(np.uint64) * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int32)
+    return w2.astype(np.float32) * np.float32(2.0 ** -31) - np.float32(1.0)
+
+
+def reset_normals(seed, env_index, counter, stream):
+    """(zK, zr) float32 for a fishing-v4 parameter redraw: the cos and sin legs of
+    ONE Box-Muller pair, K first then r (fishing_model_error.py:42-43 order)."""
+    w0, w1, _, _ = philox_words(seed, env_index, counter, stream)
+    return box_muller(w0, w1)
+
+
+def auto_reset(model, obs_next, done, t_next, K, r, x0, zK=None, zr=None, K_mean=1.0,
+               r_mean=0.3, sigma_p=0.1, dtype=np.float64):
+    """SB3 DummyVecEnv semantics around the reference: where done,
+    keep obs_next as the terminal observation and return the reset observation,
+    t = 0, and for fishing-v4 freshly drawn (K, r)."""
+    done_b = np.asarray(done).astype(bool)
+    K = np.broadcast_to(np.asarray(K, dtype=dtype), obs_next.shape).copy()
+    r = np.broadcast_to(np.asarray(r, dtype=dtype), obs_next.shape).copy()
+    if model == MODEL_V4:
+        Kn, rn = draw_model_error_params(zK, zr, K_mean, r_mean, sigma_p, dtype)
+        K = np.where(done_b, Kn, K)
+        r = np.where(done_b, rn, r)
+    obs_out = np.where(done_b, reset_obs(model, x0, K, dtype), obs_next).astype(dtype)
+    t_out = np.where(done_b, np.int32(0), t_next).astype(np.int32)
+    return obs_out, t_out, K.astype(dtype), r.astype(dtype)

@@ -1,0 +1,54 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class GoldenCase:
+    """One case of tests/golden/reference_trajectories.npz (captured from the reference)."""
+
+    def __init__(self, name, npz):
+        self.name = name
+        self.meta = json.loads(str(npz[name + "/meta"]))
+        for k in ("action", "z", "obs_in", "obs", "reward", "done", "t", "K", "r", "zK", "zr",
+                  "reset_obs"):
+            setattr(self, k, npz[name + "/" + k])
+        self.id = self.meta["id"]
+        self.kwargs = self.meta["kwargs"]
+        self.nsteps = self.meta["nsteps"]
+        self.auto_reset = self.meta["auto_reset"]
+        self.init_reset = self.meta["init_reset"]
+
+    def param(self, key):
+        defaults = {"r": 0.3, "K": 1.0, "sigma": 0.0, "init_state": 0.75, "Tmax": 100,
+                    "n_actions": 100, "C": 0.5, "K_mean": 1.0, "r_mean": 0.3, "sigma_p": 0.1}
+        return self.kwargs.get(key, defaults[key])
+
+
+def load_golden_cases():
+    npz = np.load(os.path.join(GOLDEN, "reference_trajectories.npz"))
+    names = sorted({k.split("/")[0] for k in npz.files})
+    return [GoldenCase(n, npz) for n in names]
+
+
+@pytest.fixture(scope="session")
+def golden_cases():
+    return load_golden_cases()
+
+
+@pytest.fixture(scope="session")
+def anchors():
+    with open(os.path.join(GOLDEN, "reference_anchors.json")) as f:
+        return json.load(f)

@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the UNMODIFIED reference.
+
+Test infrastructure -- never imported by the product.  Runs only in the build
+container, where the upstream reference is mounted read-only at /root/reference;
+exits 0 without writing anything when it is absent (e.g. on the GPU box).
+
+How the reference is made importable: the reference
+imports ``gym`` but uses only five symbols of it as *containers* -- ``gym.Env``
+(a base class), ``gym.spaces.Box`` / ``Discrete`` (attribute bags),
+``gym.spaces.discrete.Discrete`` (for an isinstance test) and
+``gym.envs.registration.register``.  ``gym`` is not installed and there is no
+network, so an in-memory module with exactly those names is placed in
+``sys.modules``.  None of the arithmetic on the hot path lives in ``gym``: the
+reference's own ``step/reset/population_draw`` run unmodified on NumPy.
+
+What is captured, per case: ctor kwargs, the action fed at every step, the
+standard normal ``z`` the reference consumed in that step (peeked from the legacy
+global RandomState by get_state / draw / set_state, so the stream the reference
+sees is untouched), and the reference's outputs ``obs, reward, done`` plus the
+bookkeeping (``years_passed``; for fishing-v4 the ``K, r`` in force).  Only
+numbers are stored -- no reference source text.
+
+Actions: the reference is pinned to NumPy 1.19 (examples/requirements.txt:14),
+whose value-based promotion evaluates ``(clip(a)+1)*K`` in float64; under
+NumPy 2 the same expression on a float32 scalar stays float32 (SURVEY.md
+Appendix A.3).  Fixtures therefore feed ``float32 action -> .astype(float64)``
+so NumPy 2 reproduces the reference-era float64 arithmetic; the float32 value
+is what is stored.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_gym_stand_in():
+    import numpy as np
+
+    gym = types.ModuleType("gym")
+    spaces = types.ModuleType("gym.spaces")
+    discrete = types.ModuleType("gym.spaces.discrete")
+    envs = types.ModuleType("gym.envs")
+    registration = types.ModuleType("gym.envs.registration")
+
+    class Env:
+        metadata = {}
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low = np.asarray(low, dtype=dtype)
+            self.high = np.asarray(high, dtype=dtype)
+            self.shape = self.low.shape
+            self.dtype = np.dtype(dtype)
+
+    class Discrete:
+        def __init__(self, n):
+            self.n = int(n)
+            self.shape = ()
+            self.dtype = np.dtype(np.int64)
+
+    registry = {}
+
+    def register(id, entry_point, **kw):
+        registry[id] = entry_point
+
+    def make(id, **kw):
+        import importlib
+
+        mod, cls = registry[id].split(":")
+        return getattr(importlib.import_module(mod), cls)(**kw)
+
+    gym.Env = Env
+    gym.spaces = spaces
+    gym.envs = envs
+    gym.make = make
+    spaces.Box = Box
+    spaces.Discrete = Discrete
+    spaces.discrete = discrete
+    discrete.Discrete = Discrete
+    envs.registration = registration
+    registration.register = register
+    for m in (gym, spaces, discrete, envs, registration):
+        sys.modules[m.__name__] = m
+    return gym
+
+
+def _peek_normal(np):
+    """The standard normal the NEXT np.random.normal(0, 1) call will return."""
+    st = np.random.get_state()
+    z = np.random.normal(0, 1)
+    np.random.set_state(st)
+    return z
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not mounted at %s; nothing generated" % REF)
+        return 0
+    sys.dont_write_bytecode = True
+    import matplotlib
+
+    matplotlib.use("Agg")
+    import numpy as np
+
+    gym = _install_gym_stand_in()
+    sys.path.insert(0, REF)
+    import gym_fishing  # noqa: F401  (registers ids)
+    from gym_fishing.models.policies import BMSY, escapement, msy
+
+    out = {}
+    anchors = {}
+
+    def as_action(env_id, a):
+        if env_id == "fishing-v0":
+            return int(a)
+        return np.array([a], dtype=np.float32).astype(np.float64)
+
+    def run_case(name, env_id, kwargs, seeds, nsteps, action_fn, auto_reset=True,
+                 init_reset=True):
+        """One reference env per seed, driven `nsteps` steps.  On done the driver
+        calls reset() (what SB3's DummyVecEnv does around the reference) when
+        auto_reset, else keeps stepping the finished env (reference allows it)."""
+        E = len(seeds)
+        is_v0 = env_id == "fishing-v0"
+        is_v4 = env_id == "fishing-v4"
+        A = np.zeros((E, nsteps), dtype=np.int32 if is_v0 else np.float32)
+        Z = np.zeros((E, nsteps))
+        OBS_IN = np.zeros((E, nsteps))
+        OBS = np.zeros((E, nsteps))
+        REW = np.zeros((E, nsteps))
+        DONE = np.zeros((E, nsteps), dtype=np.uint8)
+        T = np.zeros((E, nsteps), dtype=np.int32)
+        KK = np.zeros((E, nsteps))
+        RR = np.zeros((E, nsteps))
+        ZK = np.full((E, nsteps + 1), np.nan)  # reset draws; column 0 = initial reset
+        ZR = np.full((E, nsteps + 1), np.nan)
+        RESET_OBS = np.full((E, nsteps + 1), np.nan)
+        for e, seed in enumerate(seeds):
+            np.random.seed(seed)
+            env = gym.make(env_id, **kwargs)
+            arng = np.random.RandomState(10_000 + seed)  # action stream, separate from env noise
+
+            def do_reset(col):
+                if is_v4:
+                    st = np.random.get_state()
+                    ZK[e, col] = np.random.normal(0, 1)
+                    ZR[e, col] = np.random.normal(0, 1)
+                    np.random.set_state(st)
+                o = env.reset()
+                RESET_OBS[e, col] = o[0]
+
+            if init_reset:
+                do_reset(0)
+            for s in range(nsteps):
+                a = action_fn(arng, s, e)
+                A[e, s] = a
+                Z[e, s] = _peek_normal(np)
+                OBS_IN[e, s] = env.state[0]
+                KK[e, s] = env.K
+                RR[e, s] = env.r
+                obs, rew, done, info = env.step(as_action(env_id, A[e, s]))
+                OBS[e, s] = obs[0]
+                REW[e, s] = rew
+                DONE[e, s] = done
+                T[e, s] = env.years_passed
+                if done and auto_reset:
+                    do_reset(s + 1)
+        kw = {k: v for k, v in kwargs.items()}
+        out[name + "/meta"] = np.array(json.dumps(
+            {"id": env_id, "kwargs": kw, "seeds": list(seeds), "nsteps": nsteps,
+             "auto_reset": auto_reset, "init_reset": init_reset}))
+        for k, v in (("action", A), ("z", Z), ("obs_in", OBS_IN), ("obs", OBS), ("reward", REW),
+                     ("done", DONE), ("t", T), ("K", KK), ("r", RR), ("zK", ZK), ("zr", ZR),
+                     ("reset_obs", RESET_OBS)):
+            out[name + "/" + k] = v
+        return OBS, REW, DONE
+
+    f32 = np.float32
+    # --- BASELINE config 1: fishing-v1, sigma=0, single env, constant dyadic action
+    o, r, d = run_case("v1_sigma0_const", "fishing-v1", {"sigma": 0.0}, [0], 101,
+                       lambda g, s, e: -0.9375, auto_reset=False)
+    anchors["v1_sigma0_const"] = {
+        "first5_obs_hex": [float(x).hex() for x in o[0, :5]],
+        "return": float(r[0].sum()), "final_obs": float(o[0, -1]),
+        "n_steps_to_done": int(np.argmax(d[0]) + 1)}
+
+    # --- fishing-v1 sigma=0.1, random policy U[-1,1) float32 (BASELINE config 2 at toy N)
+    run_case("v1_sigma01_random", "fishing-v1", {"sigma": 0.1}, list(range(1, 9)), 130,
+             lambda g, s, e: f32(g.uniform(-1, 1)))
+    # conservative policy: keeps the stock alive for whole 101-step episodes
+    run_case("v1_sigma01_low", "fishing-v1", {"sigma": 0.1}, list(range(11, 17)), 210,
+             lambda g, s, e: f32(g.uniform(-1, -0.8)))
+    # non-default parameters
+    run_case("v1_params", "fishing-v1", {"r": 0.5, "K": 2.0, "sigma": 0.2, "init_state": 1.1,
+                                          "Tmax": 17},
+             list(range(21, 27)), 60, lambda g, s, e: f32(g.uniform(-1, -0.5)))
+    # clip + harvest-all + stepping a finished env without reset (quirk B7)
+    edge_actions = [-5.0, -1.0, -0.9375, 0.0, 5.0, 1.0, -0.5, -1.0, 0.25, -0.75]
+    run_case("v1_edge_noreset", "fishing-v1", {"sigma": 0.1, "Tmax": 6}, [31, 32], 10,
+             lambda g, s, e: f32(edge_actions[s]), auto_reset=False)
+    # --- fishing-v0 (BASELINE config 3 at toy N)
+    run_case("v0_sigma01_random", "fishing-v0", {"sigma": 0.1}, list(range(41, 49)), 130,
+             lambda g, s, e: g.randint(0, 100))
+    run_case("v0_sigma0_low", "fishing-v0", {"sigma": 0.0, "n_actions": 64}, [51, 52], 105,
+             lambda g, s, e: g.randint(0, 8))
+    run_case("v0_edge", "fishing-v0", {"sigma": 0.1, "Tmax": 8}, [53], 12,
+             lambda g, s, e: [0, 10, 99, 0, 100, 150, 3, 7, 1, 0, 2, 5][s], auto_reset=True)
+    # --- fishing-v2 tipping point (BASELINE config 4 at toy N)
+    run_case("v2_sigma01_low", "fishing-v2", {"sigma": 0.1}, list(range(61, 69)), 130,
+             lambda g, s, e: f32(g.uniform(-1, -0.8)))
+    run_case("v2_sigma01_random", "fishing-v2", {"sigma": 0.1, "C": 0.4}, list(range(71, 77)), 60,
+             lambda g, s, e: f32(g.uniform(-1, 1)))
+    run_case("v2_sigma0_zeroquota", "fishing-v2", {"sigma": 0.0, "init_state": 0.75}, [0], 3,
+             lambda g, s, e: f32(-1.0), auto_reset=False)
+    run_case("v2_sigma0_zeroquota_low", "fishing-v2", {"sigma": 0.0, "init_state": 0.3}, [0], 3,
+             lambda g, s, e: f32(-1.0), auto_reset=False)
+    # --- fishing-v4 per-episode parameter uncertainty (BASELINE config 5 at toy N)
+    run_case("v4_sigma005", "fishing-v4", {"sigma": 0.05, "sigma_p": 0.1}, list(range(81, 89)), 240,
+             lambda g, s, e: f32(g.uniform(-1, -0.7)))
+    run_case("v4_random", "fishing-v4", {"sigma": 0.1, "sigma_p": 0.3, "K_mean": 1.5,
+                                          "r_mean": 0.4, "init_state": 0.6, "Tmax": 12},
+             list(range(91, 97)), 80, lambda g, s, e: f32(g.uniform(-1, 0.2)))
+    # v4 before the first reset(): constructor draws, obs = x0/K_mean - 1 (quirk a9)
+    run_case("v4_noinitreset", "fishing-v4", {"sigma": 0.05}, [97, 98], 20,
+             lambda g, s, e: f32(g.uniform(-1, -0.7)), init_reset=False)
+
+    # --- anchors from the reference's own test (tests/test-envs.py:93-106)
+    env = gym.make("fishing-v2", sigma=0, init_state=0.75)
+    env.reset()
+    obs, _, _, _ = env.step(env.get_action(0))
+    hi = float(env.get_fish_population(obs))
+    env.init_state = 0.3
+    env.reset()
+    obs, _, _, _ = env.step(env.get_action(0))
+    lo = float(env.get_fish_population(obs))
+    anchors["test_tipping"] = {"from_0.75": hi, "from_0.3": lo}
+    assert hi >= 0.75 and lo <= 0.3
+
+    # --- "next" rows: BMSY / msy / escapement known answers, sigma=0 simulate tables
+    sims = {}
+    for env_id, kw in (("fishing-v0", {}), ("fishing-v1", {}), ("fishing-v2", {}),
+                       ("fishing-v1", {"r": 0.5, "K": 2.0, "init_state": 1.1})):
+        tag = env_id[-2:] + ("_params" if kw else "")
+        env = gym.make(env_id, sigma=0.0, **kw)
+        S = float(BMSY(env))
+        m = msy(env)
+        anchors["policy_" + tag] = {"BMSY": S, "msy": float(m.msy)}
+        for pname, model in (("msy", m), ("escapement", escapement(env))):
+            df = env.simulate(model, reps=1)
+            sims["sim_%s_%s" % (tag, pname)] = df.to_numpy(dtype=np.float64)
+            anchors["policy_" + tag]["sum_reward_" + pname] = float(df.reward.sum())
+            anchors["policy_" + tag]["rows_" + pname] = int(len(df))
+    # get_action / get_quota round trips (base_fishing_env.py:135-156)
+    env0 = gym.make("fishing-v0")
+    env1 = gym.make("fishing-v1")
+    q = np.linspace(0.0, 1.0, 21)
+    anchors["get_action_v0"] = [int(env0.get_action(x)) for x in q]
+    anchors["get_action_v1"] = [float(env1.get_action(x)) for x in q]
+    anchors["get_quota_v0"] = [float(env0.get_quota(int(a))) for a in range(0, 101, 5)]
+    anchors["np_seed42_normals"] = [float(x) for x in np.random.RandomState(42).normal(0, 1, 3)]
+    anchors["versions"] = {"numpy": np.__version__, "python": sys.version.split()[0],
+                           "reference_version": open(os.path.join(REF, "gym_fishing/version.txt")).read().strip()}
+
+    np.savez_compressed(os.path.join(HERE, "reference_trajectories.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "reference_policy_sims.npz"), **sims)
+    with open(os.path.join(HERE, "reference_anchors.json"), "w") as f:
+        json.dump(anchors, f, indent=1, sort_keys=True)
+    print("wrote %d arrays, %d sims, %d anchors" % (len(out), len(sims), len(anchors)))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,168 @@
+"""Pin the CPU oracle (oracle/fishing_oracle.py) to the reference.
+
+The golden vectors were captured from the unmodified reference by
+tests/golden/make_golden.py; every comparison here is bit-for-bit (float64 viewed
+as int64), v2's np.exp included (same NumPy on both sides).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden_cases
+from oracle import fishing_oracle as fo
+
+CASES = load_golden_cases()
+
+
+def bits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64)).view(np.int64)
+
+
+def assert_bit_equal(a, b, what):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), "%s: %d/%d mismatches, first at %s: %r vs %r" % (
+        what, (~same).sum(), same.size, np.argwhere(~same)[0], a[~same][0], b[~same][0])
+
+
+def case_params(c):
+    model = fo.MODEL_OF_ID[c.id]
+    return dict(model=model, sigma=c.param("sigma"), C=c.param("C"), Tmax=c.param("Tmax"),
+                n_actions=c.param("n_actions"))
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c.name for c in CASES])
+def test_single_step_bit_exact(c):
+    """Every recorded step, fed the reference's own input state."""
+    p = case_params(c)
+    t_in = np.where(np.arange(c.nsteps)[None, :] == 0, 0, np.roll(c.t, 1, axis=1))
+    # after an auto-reset the counter restarts at 0
+    if c.auto_reset:
+        prev_done = np.roll(c.done, 1, axis=1).astype(bool)
+        prev_done[:, 0] = False
+        t_in = np.where(prev_done, 0, t_in)
+    obs, rew, done, t, _ = fo.step(p["model"], c.obs_in, t_in, c.action, c.z, c.r, c.K,
+                                   p["sigma"], C=p["C"], Tmax=p["Tmax"], n_actions=p["n_actions"])
+    assert_bit_equal(obs, c.obs, c.name + " obs")
+    assert_bit_equal(rew, c.reward, c.name + " reward")
+    assert (done == c.done).all()
+    assert (t == c.t).all()
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c.name for c in CASES])
+def test_free_running_trajectory_bit_exact(c):
+    """Carry the oracle's own state across steps (and resets), as a rollout does."""
+    p = case_params(c)
+    model = p["model"]
+    E = c.obs.shape[0]
+    x0 = c.param("init_state")
+    if model == fo.MODEL_V4:
+        if c.init_reset:
+            K, r = fo.draw_model_error_params(c.zK[:, 0], c.zr[:, 0], c.param("K_mean"),
+                                              c.param("r_mean"), c.param("sigma_p"))
+            obs = fo.reset_obs(model, x0, K)
+        else:  # constructor state: K, r already drawn; obs = x0 / K_mean - 1 (quirk a9)
+            K, r = c.K[:, 0].copy(), c.r[:, 0].copy()
+            obs = np.full(E, x0 / c.param("K_mean") - 1.0)
+    else:
+        K = np.full(E, float(c.param("K")))
+        r = np.full(E, float(c.param("r")))
+        obs = fo.reset_obs(model, x0, K)
+    if c.init_reset:
+        assert_bit_equal(obs, c.reset_obs[:, 0], c.name + " initial reset obs")
+    t = np.zeros(E, dtype=np.int32)
+    for s in range(c.nsteps):
+        assert_bit_equal(obs, c.obs_in[:, s], "%s obs_in step %d" % (c.name, s))
+        obs, rew, done, t, _ = fo.step(model, obs, t, c.action[:, s], c.z[:, s], r, K, p["sigma"],
+                                       C=p["C"], Tmax=p["Tmax"], n_actions=p["n_actions"])
+        assert_bit_equal(obs, c.obs[:, s], "%s obs step %d" % (c.name, s))
+        assert_bit_equal(rew, c.reward[:, s], "%s reward step %d" % (c.name, s))
+        assert (done == c.done[:, s]).all()
+        assert (t == c.t[:, s]).all()
+        if c.auto_reset:
+            obs, t, K, r = fo.auto_reset(model, obs, done, t, K, r, x0,
+                                         zK=np.nan_to_num(c.zK[:, s + 1]),
+                                         zr=np.nan_to_num(c.zr[:, s + 1]),
+                                         K_mean=c.param("K_mean"), r_mean=c.param("r_mean"),
+                                         sigma_p=c.param("sigma_p"))
+            m = done.astype(bool)
+            assert_bit_equal(obs[m], c.reset_obs[m, s + 1], "%s reset obs step %d" % (c.name, s))
+        if model == fo.MODEL_V4 and s + 1 < c.nsteps:
+            assert_bit_equal(K, c.K[:, s + 1], "%s K step %d" % (c.name, s))
+            assert_bit_equal(r, c.r[:, s + 1], "%s r step %d" % (c.name, s))
+
+
+def test_known_answers_from_survey(anchors):
+    """SURVEY.md Appendix A.4 anchors + the reference's own test_tipping pins
+    (tests/test-envs.py:93-106)."""
+    a = anchors["v1_sigma0_const"]
+    assert a["first5_obs_hex"][0] == "-0x1.fc00000000000p-3"
+    assert a["return"] == 6.3125 and a["n_steps_to_done"] == 101
+    # replay with the oracle
+    obs = fo.reset_obs(fo.MODEL_V1, 0.75, np.array([1.0]))
+    t = np.zeros(1, np.int32)
+    ret = 0.0
+    for s in range(101):
+        obs, rew, done, t, _ = fo.step(fo.MODEL_V1, obs, t, np.float32([-0.9375]), [0.0], 0.3, 1.0, 0.0)
+        if s < 5:
+            assert float(obs[0]).hex() == a["first5_obs_hex"][s]
+        ret += float(rew[0])
+        assert bool(done[0]) == (s == 100)
+    assert ret == a["return"] and float(obs[0]) == a["final_obs"]
+    # reference test_tipping: grows from 0.75, declines from 0.3 (zero quota, sigma = 0)
+    for x0, key, cmp in ((0.75, "from_0.75", np.greater_equal), (0.3, "from_0.3", np.less_equal)):
+        obs = fo.reset_obs(fo.MODEL_V2, x0, np.array([1.0]))
+        obs, *_ , x = fo.step(fo.MODEL_V2, obs, [0], np.float32([-1.0]), [0.0], 0.3, 1.0, 0.0, C=0.5)
+        pop = (obs[0] + 1.0) * 1.0
+        assert cmp(pop, x0)
+        assert pop == anchors["test_tipping"][key]
+
+
+def test_quota_map_anchors(anchors):
+    q = fo.quota_from_action(fo.MODEL_V0, np.arange(0, 101, 5), 1.0, 100)
+    assert_bit_equal(q, anchors["get_quota_v0"], "v0 quota map")
+    # clip: +5 -> quota 2K, -5 -> 0
+    q = fo.quota_from_action(fo.MODEL_V1, np.float32([5.0, -5.0, 0.3337]), 1.0, 100)
+    assert q[0] == 2.0 and q[1] == 0.0 and q[2] == 1.3337000012397766
+
+
+def test_nan_and_zero_K_follow_ieee():
+    """K = 0 is reachable in fishing-v4 (clip at 0): 0/0 -> NaN must propagate like NumPy."""
+    obs, rew, done, t, x = fo.step(fo.MODEL_V4, [0.75], [0], np.float32([-0.9]), [0.3], 0.3, 0.0, 0.1)
+    assert np.isnan(obs[0]) and not done[0]
+    g = np.maximum(np.float64(-0.0), 0.0)
+    assert not np.signbit(g)
+
+
+PHILOX_KAT = [  # Random123 kat_vectors: philox4x32-10
+    ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+    ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+    ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+     (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX_KAT)
+def test_philox_known_answers(ctr, key, want):
+    got = fo.philox4x32_10(*ctr, *key)
+    assert tuple(int(x) for x in got) == want
+
+
+def test_noise_statistics():
+    """The Philox + Box-Muller stream is standard normal and independent of sharding."""
+    n = 1 << 16
+    z = fo.noise_normal(1234, np.arange(n), 7).astype(np.float64)
+    assert abs(z.mean()) < 4.0 / np.sqrt(n)
+    assert abs(z.var() - 1.0) < 0.03
+    from scipy import stats
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    # global env index keys the stream: a shard starting at 1000 sees the same numbers
+    z2 = fo.noise_normal(1234, np.arange(1000, 1100), 7)
+    assert (z2 == z[1000:1100].astype(np.float32)).all()
+    # consecutive steps are uncorrelated
+    z3 = fo.noise_normal(1234, np.arange(n), 8).astype(np.float64)
+    assert abs(np.corrcoef(z, z3)[0, 1]) < 0.02
+    a = fo.policy_random_action(fo.MODEL_V1, 1234, np.arange(n), 7)
+    assert a.min() >= -1.0 and a.max() <= 1.0 and abs(a.mean()) < 0.01
+    ai = fo.policy_random_action(fo.MODEL_V0, 1234, np.arange(n), 7, n_actions=100)
+    assert ai.min() == 0 and ai.max() == 99
