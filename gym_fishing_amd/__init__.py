@@ -1,0 +1,66 @@
+"""gym_fishing_amd -- MI355X-native vectorised fisheries gym.
+
+Drop-in for the rollout path of boettiger-lab/gym_fishing: the ids fishing-v0/v1/v2/v4,
+the gym.Env reset()/step()/render() surface and the constructor kwargs of the reference
+(gym_fishing/envs/__init__.py:17-35), with step()/reset() executed by hand-written HIP
+kernels for gfx950 behind a C ABI (include/fishing_hip.h).
+
+    import gym_fishing_amd as gf
+    env = gf.make("fishing-v1", sigma=0.1, num_envs=1 << 22)   # N envs in lockstep on the GPU
+    obs = env.reset()
+    obs, reward, done, info = env.step(actions)                # torch tensors, on device
+
+    env = gf.make("fishing-v1")                                # the reference's scalar protocol
+
+Importing this package does not load the HIP library; constructing an env does, and
+raises FishingLibraryError if the library or a HIP device is missing.
+"""
+from ._capi import FishingLibraryError
+
+__version__ = "0.1.0"
+
+# id -> class name in .envs (gym_fishing/envs/__init__.py:17-35; ids v5..v11 are out of scope)
+ENTRY_POINTS = {
+    "fishing-v0": "FishingEnv",
+    "fishing-v1": "FishingCtsEnv",
+    "fishing-v2": "FishingTippingEnv",
+    "fishing-v4": "FishingModelError",
+}
+ENV_IDS = tuple(ENTRY_POINTS)
+
+
+def env_class(env_id):
+    if env_id not in ENTRY_POINTS:
+        raise KeyError("unknown env id %r; this build provides %s" % (env_id, ", ".join(ENV_IDS)))
+    from . import envs
+    return getattr(envs, ENTRY_POINTS[env_id])
+
+
+def make(env_id, **kwargs):
+    """gym.make(id, **ctor_kwargs) equivalent.  Extra kwargs: num_envs, device, seed, dtype,
+    auto_reset, env_offset, record_terminal_obs, track_returns, done_bits."""
+    return env_class(env_id)(**kwargs)
+
+
+def register_with_gym():
+    """Register the four ids with gym / gymnasium when one is importable (never required)."""
+    done = []
+    for mod in ("gymnasium", "gym"):
+        try:
+            reg = __import__(mod + ".envs.registration", fromlist=["register"])
+        except Exception:  # noqa: BLE001 - optional dependency
+            continue
+        for env_id, cls in ENTRY_POINTS.items():
+            try:
+                reg.register(id=env_id, entry_point="gym_fishing_amd.envs:" + cls)
+                done.append((mod, env_id))
+            except Exception:  # noqa: BLE001 - already registered
+                pass
+    return done
+
+
+def __getattr__(name):
+    if name in ("FishingEnv", "FishingCtsEnv", "FishingTippingEnv", "FishingModelError", "BaseFishingEnv"):
+        from . import envs
+        return getattr(envs, name)
+    raise AttributeError(name)

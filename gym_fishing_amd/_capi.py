@@ -1,0 +1,109 @@
+"""ctypes binding of libfishing_hip.so (include/fishing_hip.h).
+
+There is exactly one compute backend: the HIP library.  If it cannot be loaded the
+product raises FishingLibraryError -- no CPU fallback exists anywhere in this package
+(the CPU restatement lives in oracle/ and is test infrastructure only).
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
+c_dbl, c_vp = ctypes.c_double, ctypes.c_void_p
+
+ABI_VERSION = 1
+
+MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4 = 0, 1, 2, 4
+FLAG_AUTO_RESET = 1
+POLICY_RANDOM, POLICY_CONSTANT, POLICY_ESCAPEMENT, POLICY_MSY = 0, 1, 2, 3
+STREAM_NOISE, STREAM_AUTORESET, STREAM_RESET = 0, 1, 2
+
+
+class FishingLibraryError(RuntimeError):
+    pass
+
+
+class FishingParams(ctypes.Structure):
+    _fields_ = [("model", c_i32), ("n_actions", c_i32), ("Tmax", c_i32), ("flags", c_u32),
+                ("r", c_dbl), ("K", c_dbl), ("sigma", c_dbl), ("C", c_dbl), ("x0", c_dbl),
+                ("r_mean", c_dbl), ("K_mean", c_dbl), ("sigma_p", c_dbl),
+                ("launch_blocks", c_i32), ("launch_threads", c_i32)]
+
+
+BUFFER_FIELDS = ("obs", "action", "reward", "done", "done_bits", "t", "r", "K", "sigma", "z_ext",
+                 "terminal_obs", "ep_return", "return_partials")
+
+
+class FishingBuffers(ctypes.Structure):
+    _fields_ = [(name, c_vp) for name in BUFFER_FIELDS]
+
+
+# symbol -> (restype, argtypes); must list every function include/fishing_hip.h declares
+_PP = ctypes.POINTER(FishingParams)
+_BP = ctypes.POINTER(FishingBuffers)
+SIGNATURES = {
+    "fishing_abi_version": (c_i32, []),
+    "fishing_error_string": (ctypes.c_char_p, [c_i32]),
+    "fishing_partials_len": (c_i64, []),
+    "fishing_step_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_u64, c_u64, c_vp]),
+    "fishing_step_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_u64, c_u64, c_vp]),
+    "fishing_step_many_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_i64, c_i32, c_i32, c_u64, c_u64, c_vp]),
+    "fishing_step_many_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_i64, c_i32, c_i32, c_u64, c_u64, c_vp]),
+    "fishing_reset_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_reset_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_rollout_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_rollout_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_reduce_returns": (c_i32, [c_vp, c_vp, c_vp]),
+    "fishing_noise_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+def library_path():
+    return os.environ.get("FISHING_HIP_LIB", _build.LIB_PATH)
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises FishingLibraryError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FishingLibraryError(
+            "libfishing_hip.so not found at %s -- build it with `python -m gym_fishing_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback." % path)
+    try:
+        handle = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the host's ROCm install
+        raise FishingLibraryError("cannot load %s: %s" % (path, e)) from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise FishingLibraryError("%s does not export %s (stale build?)" % (path, name)) from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = handle.fishing_abi_version()
+    if got != ABI_VERSION:
+        raise FishingLibraryError("ABI version mismatch: library %d, binding %d" % (got, ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().fishing_error_string(int(rc))
+        raise FishingLibraryError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def make_buffers(**ptrs):
+    """FishingBuffers from {field: int device pointer or None}."""
+    b = FishingBuffers()
+    for k, v in ptrs.items():
+        if k not in BUFFER_FIELDS:
+            raise KeyError(k)
+        setattr(b, k, v if v else None)
+    return b

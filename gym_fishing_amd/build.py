@@ -1,0 +1,73 @@
+"""Build recipe for libfishing_hip.so (gfx950 only, in-tree).
+
+    python -m gym_fishing_amd.build        # (re)build if sources are newer
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting gym_fishing_amd/_lib/libfishing_hip.so is git-ignored but travels to
+the GPU box with the gpurun snapshot.
+
+-ffp-contract=off is part of the numerical contract: the reference's NumPy
+arithmetic rounds every operation separately, so the kernels must not fuse
+a*b+c into an FMA ("Bit-exactness vs NumPy").
+"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "_lib")
+LIB_PATH = os.path.join(LIB_DIR, "libfishing_hip.so")
+ARCH = "gfx950"
+
+HIPCC_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+               "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _deps():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [
+        os.path.join(os.path.dirname(PKG), "include", "fishing_hip.h")]
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in _deps() if os.path.exists(s))
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every csrc/*.hip into one shared library.  Returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build libfishing_hip.so")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + sources() + ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError("hipcc failed (%d):\n%s" % (proc.returncode, proc.stdout))
+    if verbose and proc.stdout.strip():
+        print(proc.stdout)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

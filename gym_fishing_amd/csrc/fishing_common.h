@@ -1,0 +1,288 @@
+// fishing_common.h -- device-side building blocks shared by the step / reset /
+// rollout kernels of libfishing_hip.so (gfx950 only).
+//
+// Arithmetic contract (restated in oracle/fishing_oracle.py):
+// every operation of the reference's step() is a separately rounded IEEE op in the
+// reference's evaluation order.  The library is built with -ffp-contract=off, so the
+// expressions below are NOT fused into FMAs; divisions are correctly rounded
+// (hipcc default for f64, -fhip-fp32-correctly-rounded-divide-sqrt default for f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fishing_hip.h"
+
+namespace fishing {
+
+constexpr int kWave = 64;           // gfx950 wavefront
+constexpr int kEnvsPerThread = 4;   // 16-byte accesses on the f32 streams
+constexpr int kMaxBlocks = 4096;    // slots of the return_partials buffer
+constexpr int kPartialFields = 4;   // {sum R, sum R^2, n_episodes, sum length}
+
+constexpr uint32_t kStreamNoise = 0;      // step noise (+ in-kernel policy action)
+constexpr uint32_t kStreamAutoReset = 1;  // v4 (K, r) redraw inside step()
+constexpr uint32_t kStreamReset = 2;      // v4 (K, r) redraw in reset()
+
+enum NoiseMode { kNoiseNone = 0, kNoiseExt = 1, kNoisePhilox = 2 };
+
+// ---------------------------------------------------------------- Philox4x32-10
+// Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3" (SC'11).
+// Counter-based: no generator state in HBM or LDS; the round keys are wave-uniform and
+// live in SGPRs.  One 32x32->64 multiply (v_mad_u64_u32 / v_mul_hi+lo) per lane pair.
+struct Words4 {
+    uint32_t w0, w1, w2, w3;
+};
+
+__device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int rnd = 0; rnd < 10; ++rnd) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Words4{c0, c1, c2, c3};
+}
+
+// Counter layout (mirrored in oracle/fishing_oracle.py: philox_words):
+//   c0 = index[31:0], c1 = stream << 24 | index[55:32], c2 = counter[31:0], c3 = counter[63:32]
+// `index` is the global env PAIR index (env >> 1) on the noise stream -- one block feeds
+// two envs: (w0, w1) -> Box-Muller cos leg for the even env, sin leg for the odd env,
+// w2 / w3 -> their random-policy actions -- and the global env index on the reset streams.
+__device__ __forceinline__ Words4 philox_block(uint64_t seed, uint64_t index, uint64_t counter,
+                                               uint32_t stream) {
+    return philox4x32_10((uint32_t)index, (stream << 24) | ((uint32_t)(index >> 32) & 0xFFFFFFu),
+                         (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)seed,
+                         (uint32_t)(seed >> 32));
+}
+
+// Two standard normals from two words.  u1 in (0, 1], u2 = fraction of a turn in [0, 1].
+// Hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_cos_f32 / v_sin_f32 (argument
+// in revolutions, so no 2*pi multiply).  |z| <= sqrt(66 ln 2) = 6.76.
+__device__ __forceinline__ void box_muller(uint32_t w0, uint32_t w1, float& zc, float& zs) {
+    const float u1 = (float)w0 * 0x1p-32f + 0x1p-33f;
+    const float u2 = (float)w1 * 0x1p-32f;
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    zc = rad * __builtin_amdgcn_cosf(u2);
+    zs = rad * __builtin_amdgcn_sinf(u2);
+}
+
+// random-policy action from one word: continuous a in [-1, 1]; discrete in [0, n_actions)
+__device__ __forceinline__ float action_cts_from_word(uint32_t w) { return (float)w * 0x1p-31f - 1.0f; }
+__device__ __forceinline__ int32_t action_int_from_word(uint32_t w, int32_t n_actions) {
+    return (int32_t)(((uint64_t)w * (uint64_t)(uint32_t)n_actions) >> 32);
+}
+
+// ---------------------------------------------------------------- scalar params in T
+template <typename T>
+struct ParamsT {
+    int32_t model, n_actions, Tmax;
+    uint32_t flags;
+    T r, K, sigma, C, x0, r_mean, K_mean, sigma_p;
+};
+
+template <typename T>
+inline ParamsT<T> narrow_params(const FishingParams& p) {
+    ParamsT<T> q;
+    q.model = p.model;
+    q.n_actions = p.n_actions;
+    q.Tmax = p.Tmax;
+    q.flags = p.flags;
+    q.r = (T)p.r;
+    q.K = (T)p.K;
+    q.sigma = (T)p.sigma;
+    q.C = (T)p.C;
+    q.x0 = (T)p.x0;
+    q.r_mean = (T)p.r_mean;
+    q.K_mean = (T)p.K_mean;
+    q.sigma_p = (T)p.sigma_p;
+    return q;
+}
+
+template <typename T>
+struct BuffersT {
+    T* obs;
+    const void* action;
+    T* reward;
+    uint8_t* done;
+    uint64_t* done_bits;
+    int32_t* t;
+    T* r;
+    T* K;
+    const T* sigma;
+    const T* z_ext;
+    T* terminal_obs;
+    T* ep_return;
+    double* partials;
+};
+
+template <typename T>
+inline BuffersT<T> typed_buffers(const FishingBuffers& b) {
+    BuffersT<T> q;
+    q.obs = (T*)b.obs;
+    q.action = b.action;
+    q.reward = (T*)b.reward;
+    q.done = b.done;
+    q.done_bits = b.done_bits;
+    q.t = b.t;
+    q.r = (T*)b.r;
+    q.K = (T*)b.K;
+    q.sigma = (const T*)b.sigma;
+    q.z_ext = (const T*)b.z_ext;
+    q.terminal_obs = (T*)b.terminal_obs;
+    q.ep_return = (T*)b.ep_return;
+    q.partials = b.return_partials;
+    return q;
+}
+
+// ---------------------------------------------------------------- the env arithmetic
+template <typename T>
+__device__ __forceinline__ T exp_t(T e);
+template <>
+__device__ __forceinline__ double exp_t<double>(double e) {
+    return exp(e);
+}
+template <>
+__device__ __forceinline__ float exp_t<float>(float e) {
+    return __expf(e);
+}
+
+// get_quota (base_fishing_env.py:135-147).  Continuous: the action (already widened to T;
+// a float32 from the caller, or the T-valued output of an in-kernel policy) is clipped to
+// [-1, 1] (NaN passes through, as np.clip), then (a + 1) * K.
+template <typename T>
+__device__ __forceinline__ T quota_cts(T av, T K) {
+    av = (av < (T)-1) ? (T)-1 : av;
+    av = (av > (T)1) ? (T)1 : av;
+    return (av + (T)1) * K;
+}
+// Discrete: (a / n_actions) * K with true division (:140); no range check (quirk B11).
+template <typename T>
+__device__ __forceinline__ T quota_int(int32_t a, int32_t n_actions, T K) {
+    return ((T)a / (T)n_actions) * K;
+}
+
+// get_action (base_fishing_env.py:149-156), used by the in-kernel escapement / MSY policies
+// (models/policies.py:17-19, :29-31).  Continuous: quota / K - 1, NOT rounded to float32 (the
+// reference hands the Python float straight back to step()); discrete: Python round(),
+// i.e. round-half-even, of quota * n_actions / K.
+template <typename T>
+__device__ __forceinline__ T action_cts_from_quota(T quota, T K) {
+    return quota / K - (T)1;
+}
+template <typename T>
+__device__ __forceinline__ int32_t action_int_from_quota(T quota, int32_t n_actions, T K) {
+    return (int32_t)__builtin_rint((double)(quota * (T)n_actions / K));
+}
+
+// One reference step() on one env.  Returns through refs.
+template <typename T, int MODEL>
+__device__ __forceinline__ void env_step(T obs, int32_t t, T quota, T z, T r, T K, T sigma, T C,
+                                         int32_t Tmax, T& obs_next, T& reward, bool& done,
+                                         int32_t& t_next) {
+    T x = (obs + (T)1) * K;                   // get_fish_population  :159
+    const T h = (quota < x) ? quota : x;      // min(x, quota)        :117
+    const T d = x - h;
+    x = ((T)0 > d) ? (T)0 : d;                // max(x - h, 0.0)      :118
+    T g;
+    if (MODEL == FISHING_MODEL_V2) {          // fishing_tipping_env.py:25-34
+        const T e = ((r * ((T)1 - (x / K))) * (x - C)) + ((x * sigma) * z);
+        g = x * exp_t<T>(e);
+    } else {                                  // base_fishing_env.py:125-131
+        g = (x + ((r * x) * ((T)1 - (x / K)))) + ((x * sigma) * z);
+    }
+    x = (g > (T)0) ? g : ((g != g) ? g : (T)0);   // np.maximum(g, 0.0): NaN-propagating, -0 -> +0
+    obs_next = x / K - (T)1;                  // get_state            :163
+    reward = ((T)0 > h) ? (T)0 : h;           // max(harvest, 0.0)    :74
+    t_next = t + 1;                           //                      :75
+    done = (t_next > Tmax) || (x <= (T)0);    //                      :76-79
+}
+
+// fishing_model_error.py:37-38 / :42-43: K = clip(K_mean + sigma_p * zK, 0, 1e6), then r.
+template <typename T>
+__device__ __forceinline__ T clip_param(T v) {
+    v = (v < (T)0) ? (T)0 : v;
+    v = (v > (T)1e6) ? (T)1e6 : v;
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void draw_model_error(uint64_t seed, uint64_t env, uint64_t counter,
+                                                 uint32_t stream, T K_mean, T r_mean, T sigma_p,
+                                                 T& K, T& r) {
+    const Words4 w = philox_block(seed, env, counter, stream);
+    float zK, zr;
+    box_muller(w.w0, w.w1, zK, zr);
+    K = clip_param<T>(K_mean + sigma_p * (T)zK);
+    r = clip_param<T>(r_mean + sigma_p * (T)zr);
+}
+
+// reset observation: x0 / K - 1 (base_fishing_env.py:84); v4 returns x0 un-normalised
+// (fishing_model_error.py:44, quirk B8).
+template <typename T, int MODEL>
+__device__ __forceinline__ T reset_obs(T x0, T K) {
+    return (MODEL == FISHING_MODEL_V4) ? x0 : (x0 / K - (T)1);
+}
+
+// ---------------------------------------------------------------- 4-wide access helpers
+template <typename T>
+struct alignas(4 * sizeof(T)) Vec4 {
+    T v[4];
+};
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, int64_t base, int64_t n, bool full, T (&out)[4], T fill) {
+    if (full) {
+        const Vec4<T> q = *reinterpret_cast<const Vec4<T>*>(p + base);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = q.v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = (base + j < n) ? p[base + j] : fill;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, int64_t base, int64_t n, bool full, const T (&in)[4]) {
+    if (full) {
+        Vec4<T> q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q.v[j] = in[j];
+        *reinterpret_cast<Vec4<T>*>(p + base) = q;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (base + j < n) p[base + j] = in[j];
+    }
+}
+
+// Wave-ballot done mask in the natural layout (bit i%64 of word i/64 = done[i]).
+// Lane l holds the flags of envs 4l..4l+3 of its wave's 256-env tile as a nibble; word k of
+// the tile collects lanes 16k..16k+15.  Lane L fetches the nibble of lane 16k + L/4 with a
+// ds_bpermute (cross-lane, no LDS memory) and the 64 lanes vote their bit with one ballot.
+// Returns, in lanes 0..3, words 0..3 of the tile.
+__device__ __forceinline__ uint64_t ballot_tile_words(uint32_t nibble, int lane) {
+    uint64_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t nb = (uint32_t)__shfl((int)nibble, 16 * k + (lane >> 2), kWave);
+        const uint64_t word = __ballot((nb >> (lane & 3)) & 1u);
+        mine = (lane == k) ? word : mine;
+    }
+    return mine;
+}
+
+// Block-wide sum of kPartialFields doubles: wave shuffle tree, then one LDS hop.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+}  // namespace fishing

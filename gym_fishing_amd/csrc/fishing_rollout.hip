@@ -1,0 +1,274 @@
+// fishing_rollout.hip -- fused T-step rollout with an in-kernel policy (gfx950).
+//
+// The callers of step() in the reference are Python loops (shared_env.py:29-54 simulate_mdp,
+// examples/const_escapement.py:19-26, SB3's DummyVecEnv).  Here the loop over time runs inside
+// the kernel: a thread keeps its 4 envs' (obs, t, r, K, sigma, ep_return) in registers for
+// T steps, draws noise and the policy's action from the same Philox block a step-by-step
+// run would use, and touches HBM once at entry and once at exit (plus the optional
+// trajectory record).  Results equal T fishing_step_* calls fed the policy's actions.
+//
+// Bound: VALU (Philox + transcendental issue), not HBM -- reported as env-steps/s only.
+//
+// Wave-ballot termination: without FISHING_FLAG_AUTO_RESET a finished env is frozen (the
+// reference's simulate loop breaks on done, shared_env.py:51-52) and a wave whose 256 envs
+// have all finished leaves the time loop (__all over the per-lane masks).
+#include "fishing_common.h"
+
+namespace fishing {
+
+template <typename T, int MODEL, int POLICY>
+__global__ void __launch_bounds__(256)
+rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
+               const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed,
+               const uint64_t step_counter0, const int noise_on) {
+    constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
+    constexpr bool kNeedWords = (POLICY == FISHING_POLICY_RANDOM);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
+    const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
+    const bool auto_reset = (p.flags & FISHING_FLAG_AUTO_RESET) != 0;
+    double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
+        const bool active = base < n;
+        const bool full = base + kEnvsPerThread <= n;
+
+        T obs[4], rr[4], KK[4], sg[4], er[4], rew[4];
+        int32_t t[4];
+        bool dn[4], frozen[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            obs[j] = (T)0;
+            t[j] = 0;
+            rr[j] = p.r;
+            KK[j] = p.K;
+            sg[j] = p.sigma;
+            er[j] = (T)0;
+            rew[j] = (T)0;
+            dn[j] = false;
+            frozen[j] = !(base + j < n);
+        }
+        if (active) {
+            load4<T>(b.obs, base, n, full, obs, (T)0);
+            load4<int32_t>(b.t, base, n, full, t, 0);
+            if (kPerEnv) {
+                load4<T>(b.r, base, n, full, rr, p.r);
+                load4<T>(b.K, base, n, full, KK, p.K);
+            }
+            if (b.sigma) load4<T>(b.sigma, base, n, full, sg, p.sigma);
+            if (b.ep_return) load4<T>(b.ep_return, base, n, full, er, (T)0);
+        }
+        const uint64_t pair = (env_offset + (uint64_t)base) >> 1;
+        bool kr_dirty = false;
+
+        for (int32_t s = 0; s < Tsteps; ++s) {
+            const uint64_t step_counter = step_counter0 + (uint64_t)s;
+            T z[4] = {(T)0, (T)0, (T)0, (T)0};
+            uint32_t aw[4] = {0u, 0u, 0u, 0u};
+            if (noise_on || kNeedWords) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const Words4 w = philox_block(seed, pair + q, step_counter, kStreamNoise);
+                    if (noise_on) {
+                        float zc, zs;
+                        box_muller(w.w0, w.w1, zc, zs);
+                        z[2 * q] = (T)zc;
+                        z[2 * q + 1] = (T)zs;
+                    }
+                    aw[2 * q] = w.w2;
+                    aw[2 * q + 1] = w.w3;
+                }
+            }
+            T obs_in[4], act_rec[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                obs_in[j] = obs[j];
+                // ---- policy: action from the observation (models/policies.py)
+                T a_c = (T)-1;
+                int32_t a_d = 0;
+                if (POLICY == FISHING_POLICY_RANDOM) {
+                    if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_word(aw[j], p.n_actions);
+                    else a_c = (T)action_cts_from_word(aw[j]);
+                } else if (POLICY == FISHING_POLICY_CONSTANT) {
+                    if (MODEL == FISHING_MODEL_V0) a_d = (int32_t)policy_param;
+                    else a_c = (T)(float)policy_param;
+                } else {
+                    T q;
+                    if (POLICY == FISHING_POLICY_ESCAPEMENT) {   // policies.py:27-31
+                        const T x = (obs[j] + (T)1) * KK[j];
+                        const T dq = x - policy_param;
+                        q = ((T)0 > dq) ? (T)0 : dq;             // max(x - S, 0.0)
+                    } else {                                     // MSY, policies.py:16-19
+                        q = policy_param;
+                    }
+                    if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_quota<T>(q, p.n_actions, KK[j]);
+                    else a_c = action_cts_from_quota<T>(q, KK[j]);
+                }
+                const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j])
+                                                            : quota_cts<T>(a_c, KK[j]);
+                act_rec[j] = (MODEL == FISHING_MODEL_V0) ? (T)a_d : a_c;
+                T o2, r2;
+                bool d2;
+                int32_t t2;
+                env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax, o2, r2, d2, t2);
+                if (!frozen[j]) {
+                    obs[j] = o2;
+                    rew[j] = r2;
+                    dn[j] = d2;
+                    t[j] = t2;
+                    er[j] = er[j] + r2;
+                } else {
+                    rew[j] = (T)0;
+                }
+            }
+            if (traj && active) {
+                T* row = traj + (int64_t)s * 4 * n;
+                T dn_rec[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dn_rec[j] = (dn[j] && !frozen[j]) ? (T)1 : (T)0;
+                store4<T>(row, base, n, full, obs_in);
+                store4<T>(row + n, base, n, full, act_rec);
+                store4<T>(row + 2 * n, base, n, full, rew);
+                store4<T>(row + 3 * n, base, n, full, dn_rec);
+            }
+            const bool lane_done = (dn[0] && !frozen[0]) | (dn[1] && !frozen[1]) | (dn[2] && !frozen[2]) |
+                                   (dn[3] && !frozen[3]);
+            if (__any(lane_done)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (dn[j] && !frozen[j]) {
+                        const double R = (double)er[j];
+                        acc[0] += R;
+                        acc[1] += R * R;
+                        acc[2] += 1.0;
+                        acc[3] += (double)t[j];
+                        if (auto_reset) {
+                            er[j] = (T)0;
+                            if (kPerEnv) {
+                                draw_model_error<T>(seed, env_offset + (uint64_t)(base + j), step_counter,
+                                                    kStreamAutoReset, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
+                                kr_dirty = true;
+                            }
+                            obs[j] = reset_obs<T, MODEL>(p.x0, KK[j]);
+                            t[j] = 0;
+                            // dn[j] keeps the flag of this step for the final done output
+                        } else {
+                            frozen[j] = true;
+                        }
+                    }
+                }
+                if (!auto_reset && __all(frozen[0] && frozen[1] && frozen[2] && frozen[3])) break;
+            }
+        }
+
+        if (active) {
+            store4<T>(b.obs, base, n, full, obs);
+            store4<int32_t>(b.t, base, n, full, t);
+            if (b.ep_return) store4<T>(b.ep_return, base, n, full, er);
+            if (b.reward) store4<T>(b.reward, base, n, full, rew);
+            if (kPerEnv && kr_dirty) {
+                store4<T>(b.K, base, n, full, KK);
+                store4<T>(b.r, base, n, full, rr);
+            }
+            if (b.done) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (base + j < n) b.done[base + j] = (uint8_t)dn[j];
+            }
+        }
+        if (b.done_bits) {
+            const uint32_t nibble = (uint32_t)(dn[0] && base + 0 < n) | ((uint32_t)(dn[1] && base + 1 < n) << 1) |
+                                    ((uint32_t)(dn[2] && base + 2 < n) << 2) |
+                                    ((uint32_t)(dn[3] && base + 3 < n) << 3);
+            const uint64_t word = ballot_tile_words(nibble, lane);
+            const int64_t wave_env0 = (tile * blockDim.x + (threadIdx.x & ~(kWave - 1))) * kEnvsPerThread;
+            const int64_t widx = (wave_env0 >> 6) + lane;
+            if (lane < 4 && (widx << 6) < n) b.done_bits[widx] = word;
+        }
+    }
+
+    if (b.partials) {
+        __shared__ double red[4][kPartialFields];
+        const int wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < kPartialFields; ++k) {
+            const double s = wave_sum(acc[k]);
+            if (lane == 0) red[wid][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < kPartialFields) {
+            double s = 0.0;
+            const int nw = blockDim.x >> 6;
+            for (int w = 0; w < nw; ++w) s += red[w][threadIdx.x];
+            if (s != 0.0) b.partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x] += s;
+        }
+    }
+}
+
+int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b);
+void launch_shape(const FishingParams* p, int64_t n, int& blocks, int& threads);
+
+template <typename T, int MODEL>
+int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& bt, int64_t n, uint64_t env_offset,
+                          T policy_param, int32_t Tsteps, T* traj, uint64_t seed, uint64_t step_counter,
+                          int noise_on, int blocks, int threads, hipStream_t s) {
+#define FISHING_LAUNCH_ROLLOUT(POL)                                                                         \
+    rollout_kernel<T, MODEL, POL><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param, Tsteps, \
+                                                             traj, seed, step_counter, noise_on)
+    switch (policy) {
+        case FISHING_POLICY_RANDOM: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_RANDOM); break;
+        case FISHING_POLICY_CONSTANT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_CONSTANT); break;
+        case FISHING_POLICY_ESCAPEMENT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_ESCAPEMENT); break;
+        default: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_MSY); break;
+    }
+#undef FISHING_LAUNCH_ROLLOUT
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b, int32_t policy,
+                 double policy_param, int32_t Tsteps, void* traj, uint64_t seed, uint64_t step_counter,
+                 fishing_stream_t stream) {
+    const int rc = check_common(p, n, env_offset, b);
+    if (rc != FISHING_OK) return rc;
+    if (policy < FISHING_POLICY_RANDOM || policy > FISHING_POLICY_MSY) return FISHING_ERR_POLICY;
+    if (Tsteps < 0) return FISHING_ERR_SIZE;
+    if (traj && (((uintptr_t)traj) & 15u)) return FISHING_ERR_ALIGN;
+    if (traj && (n & 3)) return FISHING_ERR_ALIGN;  // rows of the record must stay 16-byte aligned
+    if (n == 0 || Tsteps == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    const BuffersT<T> bt = typed_buffers<T>(*b);
+    const int noise_on = !(p->sigma == 0.0 && !b->sigma);
+    int blocks, threads;
+    launch_shape(p, n, blocks, threads);
+    hipStream_t s = (hipStream_t)stream;
+    const T pp = (T)policy_param;
+    switch (p->model) {
+        case FISHING_MODEL_V0:
+            return launch_rollout_policy<T, FISHING_MODEL_V0>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+        case FISHING_MODEL_V1:
+            return launch_rollout_policy<T, FISHING_MODEL_V1>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+        case FISHING_MODEL_V2:
+            return launch_rollout_policy<T, FISHING_MODEL_V2>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+        default:
+            return launch_rollout_policy<T, FISHING_MODEL_V4>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+    }
+}
+
+}  // namespace fishing
+
+extern "C" {
+
+int fishing_rollout_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                        int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
+                        uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::rollout_impl<float>(p, n, env_offset, b, policy, policy_param, T, traj, seed, step_counter, stream);
+}
+int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                        int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
+                        uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::rollout_impl<double>(p, n, env_offset, b, policy, policy_param, T, traj, seed, step_counter, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,424 @@
+// fishing_step.hip -- the vectorised step() / reset() kernels and their C ABI (gfx950).
+//
+// Data layout in HBM: structure of arrays, one contiguous stream per field
+// (obs, action, reward, done, t [, r, K, sigma, z_ext, terminal_obs, ep_return]); env i of
+// the shard sits at element i of every stream.  A thread owns 4 consecutive envs, so each
+// f32 / i32 stream is read or written with one 16-byte access per lane (1 KiB per wave
+// instruction) and the done bytes with one dword per lane.  No env ever reads another env's
+// state: there is no LDS staging of the streams (nothing is reused) -- LDS only carries the
+// per-workgroup reduction of the episodic-return record.
+//
+// Roofline: HBM.  Algorithmic bytes per env-step: f32 layout 25 B
+// (R obs 4 + action 4 + t 4; W obs 4 + reward 4 + done 1 + t 4), v4 +12 B (r, K, sigma
+// arrays), f64 parity layout 37 B; +4/8 B per optional stream.
+#include "fishing_common.h"
+
+namespace fishing {
+
+template <typename T, int MODEL, int NOISE>
+__global__ void __launch_bounds__(256)
+step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
+            const uint64_t seed, const uint64_t step_counter) {
+    constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
+    const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
+    const bool auto_reset = (p.flags & FISHING_FLAG_AUTO_RESET) != 0;
+    double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
+        const bool active = base < n;
+        const bool full = base + kEnvsPerThread <= n;
+
+        T obs[4], rr[4], KK[4], sg[4], z[4];
+        int32_t t[4];
+        float a_f[4];
+        int32_t a_i[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            obs[j] = (T)0;
+            t[j] = 0;
+            rr[j] = p.r;
+            KK[j] = p.K;
+            sg[j] = p.sigma;
+            z[j] = (T)0;
+            a_f[j] = -1.0f;
+            a_i[j] = 0;
+        }
+        if (active) {
+            load4<T>(b.obs, base, n, full, obs, (T)0);
+            load4<int32_t>(b.t, base, n, full, t, 0);
+            if (MODEL == FISHING_MODEL_V0)
+                load4<int32_t>((const int32_t*)b.action, base, n, full, a_i, 0);
+            else
+                load4<float>((const float*)b.action, base, n, full, a_f, -1.0f);
+            if (kPerEnv) {
+                load4<T>(b.r, base, n, full, rr, p.r);
+                load4<T>(b.K, base, n, full, KK, p.K);
+            }
+            if (b.sigma) load4<T>(b.sigma, base, n, full, sg, p.sigma);
+            if (NOISE == kNoiseExt) load4<T>(b.z_ext, base, n, full, z, (T)0);
+        }
+        if (NOISE == kNoisePhilox) {
+            // 4 consecutive envs = 2 env pairs = 2 Philox blocks (env_offset and base are
+            // multiples of 4, so the pairs never straddle threads or shards).
+            const uint64_t pair = (env_offset + (uint64_t)base) >> 1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const Words4 w = philox_block(seed, pair + q, step_counter, kStreamNoise);
+                float zc, zs;
+                box_muller(w.w0, w.w1, zc, zs);
+                z[2 * q] = (T)zc;
+                z[2 * q + 1] = (T)zs;
+            }
+        }
+
+        T obs_next[4], rew[4];
+        int32_t t_next[4];
+        bool dn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], p.n_actions, KK[j])
+                                                        : quota_cts<T>((T)a_f[j], KK[j]);
+            env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax,
+                               obs_next[j], rew[j], dn[j], t_next[j]);
+            dn[j] = dn[j] && (base + j < n);
+        }
+        const bool lane_done = dn[0] | dn[1] | dn[2] | dn[3];
+        // wave-ballot termination mask: a wave with no finished env skips everything below
+        const bool wave_done = __any(lane_done);
+
+        if (active) {
+            if (b.reward) store4<T>(b.reward, base, n, full, rew);
+            if (b.terminal_obs) store4<T>(b.terminal_obs, base, n, full, obs_next);
+            if (b.done) {
+                if (full) {
+                    const uint32_t packed = (uint32_t)dn[0] | ((uint32_t)dn[1] << 8) |
+                                            ((uint32_t)dn[2] << 16) | ((uint32_t)dn[3] << 24);
+                    *reinterpret_cast<uint32_t*>(b.done + base) = packed;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (base + j < n) b.done[base + j] = (uint8_t)dn[j];
+                }
+            }
+        }
+        if (b.done_bits) {
+            const uint32_t nibble = (uint32_t)dn[0] | ((uint32_t)dn[1] << 1) | ((uint32_t)dn[2] << 2) |
+                                    ((uint32_t)dn[3] << 3);
+            const uint64_t word = ballot_tile_words(nibble, lane);
+            // first env of this wave's 256-env tile
+            const int64_t wave_env0 = (tile * blockDim.x + (threadIdx.x & ~(kWave - 1))) * kEnvsPerThread;
+            const int64_t widx = (wave_env0 >> 6) + lane;
+            if (lane < 4 && (widx << 6) < n) b.done_bits[widx] = word;
+        }
+
+        if (b.ep_return) {
+            T er[4] = {(T)0, (T)0, (T)0, (T)0};
+            if (active) load4<T>(b.ep_return, base, n, full, er, (T)0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                er[j] = er[j] + rew[j];
+                if (dn[j]) {
+                    const double R = (double)er[j];
+                    acc[0] += R;
+                    acc[1] += R * R;
+                    acc[2] += 1.0;
+                    acc[3] += (double)t_next[j];
+                    if (auto_reset) er[j] = (T)0;
+                }
+            }
+            if (active) store4<T>(b.ep_return, base, n, full, er);
+        }
+
+        if (auto_reset && wave_done) {
+            bool redrawn = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (dn[j]) {
+                    if (kPerEnv) {
+                        draw_model_error<T>(seed, env_offset + (uint64_t)(base + j), step_counter,
+                                            kStreamAutoReset, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
+                        redrawn = true;
+                    }
+                    obs_next[j] = reset_obs<T, MODEL>(p.x0, KK[j]);
+                    t_next[j] = 0;
+                }
+            }
+            if (kPerEnv && redrawn) {
+                store4<T>(b.K, base, n, full, KK);
+                store4<T>(b.r, base, n, full, rr);
+            }
+        }
+        if (active) {
+            store4<T>(b.obs, base, n, full, obs_next);
+            store4<int32_t>(b.t, base, n, full, t_next);
+        }
+    }
+
+    if (b.partials) {
+        // per-workgroup partial of the episodic-return record: shuffle tree per wave, one
+        // LDS hop across waves, then the workgroup's own slot (no atomics: bitwise
+        // reproducible for a fixed launch shape).
+        __shared__ double red[4][kPartialFields];
+        const int wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < kPartialFields; ++k) {
+            const double s = wave_sum(acc[k]);
+            if (lane == 0) red[wid][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < kPartialFields) {
+            double s = 0.0;
+            const int nw = blockDim.x >> 6;
+            for (int w = 0; w < nw; ++w) s += red[w][threadIdx.x];
+            if (s != 0.0) b.partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x] += s;
+        }
+    }
+}
+
+// reset(): one env per thread (not on the hot path; runs once per rollout).
+template <typename T, int MODEL>
+__global__ void __launch_bounds__(256)
+reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
+             const uint8_t* __restrict__ mask, const uint64_t seed, const uint64_t reset_counter) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (mask && !mask[i]) continue;
+        T K = p.K;
+        if (MODEL == FISHING_MODEL_V4) {
+            T r;
+            draw_model_error<T>(seed, env_offset + (uint64_t)i, reset_counter, kStreamReset, p.K_mean,
+                                p.r_mean, p.sigma_p, K, r);
+            b.K[i] = K;
+            b.r[i] = r;
+        }
+        b.obs[i] = reset_obs<T, MODEL>(p.x0, K);
+        b.t[i] = 0;
+        if (b.ep_return) b.ep_return[i] = (T)0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+reduce_returns_kernel(const double* __restrict__ partials, double* __restrict__ out4) {
+    // one workgroup; thread k < 4 sums field k over the slots in slot order
+    if (threadIdx.x < kPartialFields) {
+        double s = 0.0;
+        for (int slot = 0; slot < kMaxBlocks; ++slot) s += partials[slot * kPartialFields + threadIdx.x];
+        out4[threadIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+noise_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, const uint64_t counter,
+             const uint32_t stream_tag, uint32_t* __restrict__ words, float* __restrict__ z0,
+             float* __restrict__ z1) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const Words4 w = philox_block(seed, env_offset + (uint64_t)i, counter, stream_tag);
+        float zc, zs;
+        box_muller(w.w0, w.w1, zc, zs);
+        if (words) {
+            words[4 * i + 0] = w.w0;
+            words[4 * i + 1] = w.w1;
+            words[4 * i + 2] = w.w2;
+            words[4 * i + 3] = w.w3;
+        }
+        if (z0) z0[i] = zc;
+        if (z1) z1[i] = zs;
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static inline bool misaligned(const void* p) { return p && (((uintptr_t)p) & 15u); }
+
+int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b) {
+    if (!p || !b) return FISHING_ERR_NULL;
+    if (p->model != FISHING_MODEL_V0 && p->model != FISHING_MODEL_V1 && p->model != FISHING_MODEL_V2 &&
+        p->model != FISHING_MODEL_V4)
+        return FISHING_ERR_MODEL;
+    if (n < 0 || env_offset < 0 || (env_offset & 3)) return FISHING_ERR_SIZE;
+    if (p->model == FISHING_MODEL_V0 && p->n_actions <= 0) return FISHING_ERR_SIZE;
+    if (p->launch_threads != 0 &&
+        (p->launch_threads < 64 || p->launch_threads > 256 || (p->launch_threads & 63)))
+        return FISHING_ERR_SIZE;
+    if (p->launch_blocks < 0) return FISHING_ERR_SIZE;
+    if (!b->obs || !b->t) return FISHING_ERR_NULL;
+    if (p->model == FISHING_MODEL_V4 && (!b->r || !b->K)) return FISHING_ERR_NULL;
+    if (b->return_partials && !b->ep_return) return FISHING_ERR_NULL;
+    const void* ptrs[] = {b->obs,  b->action, b->reward, b->done,         b->done_bits, b->t,           b->r,
+                          b->K,    b->sigma,  b->z_ext,  b->terminal_obs, b->ep_return, b->return_partials};
+    for (const void* q : ptrs)
+        if (misaligned(q)) return FISHING_ERR_ALIGN;
+    return FISHING_OK;
+}
+
+void launch_shape(const FishingParams* p, int64_t n, int& blocks, int& threads) {
+    threads = p->launch_threads ? p->launch_threads : 256;
+    const int64_t tile = (int64_t)threads * kEnvsPerThread;
+    const int64_t ntiles = (n + tile - 1) / tile;
+    int cap = p->launch_blocks ? p->launch_blocks : 2048;
+    if (cap > kMaxBlocks) cap = kMaxBlocks;
+    blocks = (int)(ntiles < cap ? ntiles : cap);
+    if (blocks < 1) blocks = 1;
+}
+
+template <typename T, int MODEL>
+int launch_step_noise(const ParamsT<T>& pt, const BuffersT<T>& bt, int noise, int64_t n, uint64_t env_offset,
+                      uint64_t seed, uint64_t step_counter, int blocks, int threads, hipStream_t s) {
+    switch (noise) {
+        case kNoiseNone:
+            step_kernel<T, MODEL, kNoiseNone><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, seed, step_counter);
+            break;
+        case kNoiseExt:
+            step_kernel<T, MODEL, kNoiseExt><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, seed, step_counter);
+            break;
+        default:
+            step_kernel<T, MODEL, kNoisePhilox><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, seed, step_counter);
+            break;
+    }
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b, uint64_t seed,
+              uint64_t step_counter, fishing_stream_t stream) {
+    const int rc = check_common(p, n, env_offset, b);
+    if (rc != FISHING_OK) return rc;
+    if (!b->action) return FISHING_ERR_NULL;
+    if (n == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    const BuffersT<T> bt = typed_buffers<T>(*b);
+    // the reference draws a normal even at sigma == 0 (quirk B3) but multiplies it by 0:
+    // skipping the generator there changes no result bit.
+    const int noise = b->z_ext ? kNoiseExt : ((p->sigma == 0.0 && !b->sigma) ? kNoiseNone : kNoisePhilox);
+    int blocks, threads;
+    launch_shape(p, n, blocks, threads);
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->model) {
+        case FISHING_MODEL_V0:
+            return launch_step_noise<T, FISHING_MODEL_V0>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+        case FISHING_MODEL_V1:
+            return launch_step_noise<T, FISHING_MODEL_V1>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+        case FISHING_MODEL_V2:
+            return launch_step_noise<T, FISHING_MODEL_V2>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+        default:
+            return launch_step_noise<T, FISHING_MODEL_V4>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+    }
+}
+
+template <typename T>
+int step_many_impl(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                   int64_t action_stride, int32_t ring_len, int32_t n_steps, uint64_t seed,
+                   uint64_t step_counter, fishing_stream_t stream) {
+    if (!b || !p) return FISHING_ERR_NULL;
+    if (ring_len <= 0 || n_steps < 0 || action_stride < 0) return FISHING_ERR_SIZE;
+    if (ring_len > 1 && (action_stride & 3)) return FISHING_ERR_ALIGN;
+    FishingBuffers bb = *b;
+    for (int32_t k = 0; k < n_steps; ++k) {
+        // action elements are 4 bytes wide in every layout (f32 / i32)
+        bb.action = (const char*)b->action + (size_t)(k % ring_len) * (size_t)action_stride * 4u;
+        const int rc = step_impl<T>(p, n, env_offset, &bb, seed, step_counter + (uint64_t)k, stream);
+        if (rc != FISHING_OK) return rc;
+    }
+    return FISHING_OK;
+}
+
+template <typename T>
+int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+               const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream) {
+    const int rc = check_common(p, n, env_offset, b);
+    if (rc != FISHING_OK) return rc;
+    if (n == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    const BuffersT<T> bt = typed_buffers<T>(*b);
+    const int threads = 256;
+    int64_t nb = (n + threads - 1) / threads;
+    const int blocks = (int)(nb < 2048 ? nb : 2048);
+    hipStream_t s = (hipStream_t)stream;
+    switch (p->model) {
+        case FISHING_MODEL_V0:
+            reset_kernel<T, FISHING_MODEL_V0><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
+            break;
+        case FISHING_MODEL_V1:
+            reset_kernel<T, FISHING_MODEL_V1><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
+            break;
+        case FISHING_MODEL_V2:
+            reset_kernel<T, FISHING_MODEL_V2><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
+            break;
+        default:
+            reset_kernel<T, FISHING_MODEL_V4><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
+            break;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace fishing
+
+extern "C" {
+
+int fishing_abi_version(void) { return FISHING_ABI_VERSION; }
+
+const char* fishing_error_string(int code) {
+    switch (code) {
+        case FISHING_OK: return "ok";
+        case FISHING_ERR_NULL: return "a required pointer is NULL";
+        case FISHING_ERR_MODEL: return "unknown model id";
+        case FISHING_ERR_ALIGN: return "buffer not 16-byte aligned";
+        case FISHING_ERR_SIZE: return "bad size / count / offset argument";
+        case FISHING_ERR_POLICY: return "unknown in-kernel policy";
+        case FISHING_ERR_NO_DEVICE: return "no usable HIP device";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int64_t fishing_partials_len(void) { return (int64_t)fishing::kMaxBlocks * fishing::kPartialFields; }
+
+int fishing_step_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                     uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::step_impl<float>(p, n, env_offset, b, seed, step_counter, stream);
+}
+int fishing_step_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                     uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::step_impl<double>(p, n, env_offset, b, seed, step_counter, stream);
+}
+int fishing_step_many_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                          int64_t action_stride, int32_t ring_len, int32_t n_steps, uint64_t seed,
+                          uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::step_many_impl<float>(p, n, env_offset, b, action_stride, ring_len, n_steps, seed,
+                                          step_counter, stream);
+}
+int fishing_step_many_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                          int64_t action_stride, int32_t ring_len, int32_t n_steps, uint64_t seed,
+                          uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::step_many_impl<double>(p, n, env_offset, b, action_stride, ring_len, n_steps, seed,
+                                           step_counter, stream);
+}
+int fishing_reset_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                      const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream) {
+    return fishing::reset_impl<float>(p, n, env_offset, b, mask, seed, reset_counter, stream);
+}
+int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                      const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream) {
+    return fishing::reset_impl<double>(p, n, env_offset, b, mask, seed, reset_counter, stream);
+}
+
+int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream) {
+    if (!return_partials || !out4) return FISHING_ERR_NULL;
+    fishing::reduce_returns_kernel<<<1, 64, 0, (hipStream_t)stream>>>(return_partials, out4);
+    return (int)hipGetLastError();
+}
+
+int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
+                      uint32_t* words, float* z0, float* z1, fishing_stream_t stream) {
+    if (n < 0 || env_offset < 0 || stream_tag < 0 || stream_tag > 255) return FISHING_ERR_SIZE;
+    if (n == 0) return FISHING_OK;
+    int64_t nb = (n + 255) / 256;
+    const int blocks = (int)(nb < 2048 ? nb : 2048);
+    fishing::noise_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(n, (uint64_t)env_offset, seed, counter,
+                                                                 (uint32_t)stream_tag, words, z0, z1);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,504 @@
+"""Host-side mirror of the reference's env classes, backed by libfishing_hip.so.
+
+Same class names, constructor kwargs, defaults, attributes and methods as
+gym_fishing/envs/{base_fishing_env,fishing_env,fishing_cts_env,fishing_tipping_env,
+fishing_model_error}.py, so it is a drop-in for the rollout path:
+
+* ``num_envs=None`` (default)  -> the reference's scalar protocol: ``reset() -> ndarray(1,)``,
+  ``step(a) -> (ndarray(1,) float64, float, bool, {})`` computed by the fp64 parity kernel
+  on one env (BASELINE config 1, plumbing).
+* ``num_envs=N``              -> N envs in lockstep with the SB3-VecEnv shape the reference's
+  own helpers code against (shared_env.py:15-26,57-79): ``reset() -> obs[N,1]``,
+  ``step(actions[N,1]) -> (obs[N,1], rewards[N], dones[N], info)``; tensors stay on the
+  GPU (torch, zero-copy views of the env's buffers, valid until the next step/reset).
+
+All arithmetic happens in the HIP kernels (csrc/); this file only owns buffers, counters
+and argument plumbing.  No CPU fallback: without the library or a HIP device the
+constructor raises FishingLibraryError.
+"""
+import csv
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import (FLAG_AUTO_RESET, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, POLICY_CONSTANT,
+                    POLICY_ESCAPEMENT, POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
+from .spaces import is_discrete, space_classes
+
+POLICIES = {"random": POLICY_RANDOM, "constant": POLICY_CONSTANT, "escapement": POLICY_ESCAPEMENT,
+            "msy": POLICY_MSY}
+
+
+def _require_device(device):
+    if not torch.cuda.is_available():
+        raise FishingLibraryError(
+            "gym_fishing_amd needs a HIP device (MI355X): torch.cuda.is_available() is False. "
+            "There is no CPU backend; the CPU restatement under oracle/ is test infrastructure.")
+    dev = torch.device("cuda" if device is None else device)
+    if dev.type != "cuda":
+        raise FishingLibraryError("device must be a HIP ('cuda') device, got %r" % (device,))
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+class _Repeat:
+    """What VecEnv.get_attr returns for a value shared by all N envs (no N-long list)."""
+
+    def __init__(self, value, n):
+        self.value, self.n = value, n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self.value] * len(range(*i.indices(self.n)))
+        if not -self.n <= i < self.n:
+            raise IndexError(i)
+        return self.value
+
+    def __iter__(self):
+        return (self.value for _ in range(self.n))
+
+
+class BaseFishingEnv:
+    """base_fishing_env.py:16-164, vectorised.  See the module docstring."""
+
+    metadata = {"render.modes": ["human"]}
+    MODEL = MODEL_V1
+
+    def __init__(self, params=None, Tmax=100, file=None, *, num_envs=None, device=None, seed=0,
+                 dtype=None, auto_reset=None, env_offset=0, record_terminal_obs=False,
+                 track_returns=False, done_bits=False, launch_blocks=0, launch_threads=0):
+        params = dict({"r": 0.3, "K": 1, "sigma": 0.0, "x0": 0.75} if params is None else params)
+        self.params = params
+        self.Tmax = int(Tmax)
+        self.file = file
+        self.init_state = params["x0"]
+        self._scalar = num_envs is None
+        self.num_envs = 1 if self._scalar else int(num_envs)
+        if self.num_envs < 1:
+            raise ValueError("num_envs must be >= 1")
+        if env_offset % 4 or env_offset < 0:
+            raise ValueError("env_offset must be a non-negative multiple of 4 (noise pairs / 16-byte rows)")
+        self.env_offset = int(env_offset)
+        if dtype is None:
+            dtype = torch.float64 if self._scalar else torch.float32
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("dtype must be torch.float32 (fast layout) or torch.float64 (parity layout)")
+        self.dtype = dtype
+        self.auto_reset = (not self._scalar) if auto_reset is None else bool(auto_reset)
+        self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._step_count = 0
+        self._reset_count = 0
+
+        # spaces (base_fishing_env.py:49-58): Box(-1, 1, (1,), float32) for both
+        Box, _ = space_classes()
+        self.action_space = Box(np.array([-1], dtype=np.float32), np.array([1], dtype=np.float32),
+                                dtype=np.float32)
+        self.observation_space = Box(np.array([-1], dtype=np.float32), np.array([1], dtype=np.float32),
+                                     dtype=np.float32)
+
+        self._lib = _capi.lib()                      # raises if the HIP library is missing
+        self.device = _require_device(device)
+        self._suffix = "f32" if dtype == torch.float32 else "f64"
+        self._fn_step = getattr(self._lib, "fishing_step_" + self._suffix)
+        self._fn_reset = getattr(self._lib, "fishing_reset_" + self._suffix)
+        self._fn_rollout = getattr(self._lib, "fishing_rollout_" + self._suffix)
+        self._fn_step_many = getattr(self._lib, "fishing_step_many_" + self._suffix)
+
+        N, dev = self.num_envs, self.device
+        self._per_env = self.MODEL == MODEL_V4
+        self._obs = torch.empty(N, dtype=dtype, device=dev)
+        self._t = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._reward = torch.zeros(N, dtype=dtype, device=dev)
+        self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._r_arr = self._K_arr = self._sigma_arr = None
+        sigma = params["sigma"]
+        if isinstance(sigma, (torch.Tensor, np.ndarray, list, tuple)):
+            self._sigma_arr = torch.as_tensor(sigma).to(device=dev, dtype=dtype).reshape(N).contiguous()
+            self._sigma_scalar = float(self._sigma_arr[0])
+        else:
+            self._sigma_scalar = float(sigma)
+        if self._per_env:
+            self._r_arr = torch.full((N,), float(params["r"]), dtype=dtype, device=dev)
+            self._K_arr = torch.full((N,), float(params["K"]), dtype=dtype, device=dev)
+        self._terminal_obs = torch.empty(N, dtype=dtype, device=dev) if record_terminal_obs else None
+        self._done_bits = (torch.zeros((N + 63) // 64, dtype=torch.int64, device=dev) if done_bits else None)
+        self._ep_return = self._partials = self._record = None
+        if track_returns:
+            self._ep_return = torch.zeros(N, dtype=dtype, device=dev)
+            self._partials = torch.zeros(int(self._lib.fishing_partials_len()), dtype=torch.float64, device=dev)
+            self._record = torch.zeros(4, dtype=torch.float64, device=dev)
+        self._action_buf = None
+        self._last_action = None
+        self._launch = (int(launch_blocks), int(launch_threads))
+
+        # reference attributes (base_fishing_env.py:27-46)
+        self.reward = 0
+        self.harvest = 0
+        self.write_obj = open(file, "w+") if file is not None else None
+        self._set_initial_state()
+
+    # ------------------------------------------------------------------ parameters
+    @property
+    def K(self):
+        return self._K_view() if self._per_env else self.params["K"]
+
+    @K.setter
+    def K(self, v):
+        self._set_param("K", v)
+
+    @property
+    def r(self):
+        return self._r_view() if self._per_env else self.params["r"]
+
+    @r.setter
+    def r(self, v):
+        self._set_param("r", v)
+
+    @property
+    def sigma(self):
+        return self._sigma_arr if self._sigma_arr is not None else self._sigma_scalar
+
+    @sigma.setter
+    def sigma(self, v):
+        if isinstance(v, (torch.Tensor, np.ndarray, list, tuple)):
+            self._sigma_arr = torch.as_tensor(v).to(device=self.device, dtype=self.dtype).reshape(
+                self.num_envs).contiguous()
+        else:
+            self._sigma_arr = None
+            self._sigma_scalar = float(v)
+            self.params["sigma"] = v
+
+    def _K_view(self):
+        return float(self._K_arr[0]) if self._scalar else self._K_arr
+
+    def _r_view(self):
+        return float(self._r_arr[0]) if self._scalar else self._r_arr
+
+    def _set_param(self, name, v):
+        if self._per_env:
+            arr = self._K_arr if name == "K" else self._r_arr
+            if isinstance(v, (torch.Tensor, np.ndarray, list, tuple)):
+                arr.copy_(torch.as_tensor(v).to(device=self.device, dtype=self.dtype).reshape(self.num_envs))
+            else:
+                arr.fill_(float(v))
+        else:
+            self.params[name] = v
+
+    def _c_params(self):
+        p = self.params
+        cp = _capi.FishingParams()
+        cp.model = self.MODEL
+        cp.n_actions = int(getattr(self, "n_actions", 0) or 0)
+        cp.Tmax = int(self.Tmax)
+        cp.flags = FLAG_AUTO_RESET if self.auto_reset else 0
+        cp.r = float(p["r"])
+        cp.K = float(p["K"])
+        cp.sigma = self._sigma_scalar
+        cp.C = float(getattr(self, "C", p.get("C", 0.5)))
+        cp.x0 = float(self.init_state)
+        cp.r_mean = float(getattr(self, "r_mean", p.get("r_mean", p["r"])))
+        cp.K_mean = float(getattr(self, "K_mean", p.get("K_mean", p["K"])))
+        cp.sigma_p = float(getattr(self, "sigma_p", p.get("sigma_p", 0.0)))
+        cp.launch_blocks, cp.launch_threads = self._launch
+        return cp
+
+    def _c_buffers(self, action=None, z_ext=None, with_outputs=True):
+        ptr = lambda t: (t.data_ptr() if t is not None else None)  # noqa: E731
+        return _capi.make_buffers(
+            obs=ptr(self._obs), action=ptr(action), reward=ptr(self._reward) if with_outputs else None,
+            done=ptr(self._done) if with_outputs else None, done_bits=ptr(self._done_bits), t=ptr(self._t),
+            r=ptr(self._r_arr), K=ptr(self._K_arr), sigma=ptr(self._sigma_arr), z_ext=ptr(z_ext),
+            terminal_obs=ptr(self._terminal_obs), ep_return=ptr(self._ep_return),
+            return_partials=ptr(self._partials))
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ------------------------------------------------------------------ state
+    def _set_initial_state(self):
+        """Constructor state (base_fishing_env.py:33-46): obs = x0 / K - 1, t = 0."""
+        self._obs.fill_(float(self.init_state) / float(self.params["K"]) - 1.0)
+        self._t.zero_()
+        self._publish_scalar_state()
+
+    def _publish_scalar_state(self):
+        if self._scalar:
+            self.state = self._obs.cpu().numpy().astype(np.float64)
+            self.years_passed = int(self._t[0])
+            self.fish_population = float((self.state[0] + 1.0) * float(self._K_view() if self._per_env else self.params["K"]))
+        else:
+            self.state = self._obs.view(self.num_envs, 1)
+            self.years_passed = self._t
+
+    def seed(self, seed=None):
+        """The reference has no seed() (base_fishing_env.py:13); this keys the Philox streams."""
+        self._seed = int(0 if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self._step_count = 0
+        self._reset_count = 0
+        return [self._seed]
+
+    def reset(self, mask=None):
+        """base_fishing_env.py:83-91 (v4: fishing_model_error.py:41-48).  `mask` (bool[N]) resets
+        a subset -- what a VecEnv wrapper without in-kernel auto-reset would call."""
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask).to(device=self.device).reshape(self.num_envs).to(torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
+                                self._c_buffers(with_outputs=False), m.data_ptr() if m is not None else None,
+                                self._seed, self._reset_count, self._stream())
+        _capi.check(rc, "fishing_reset")
+        self._reset_count += 1
+        self.reward = 0 if self.MODEL != MODEL_V4 else self.reward   # v4 leaves it (quirk B8)
+        self.harvest = 0
+        self._publish_scalar_state()
+        return self.state
+
+    # ------------------------------------------------------------------ step
+    def _prepare_action(self, action):
+        N = self.num_envs
+        want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
+        if isinstance(action, torch.Tensor):
+            a = action
+            if a.device != self.device:
+                a = a.to(self.device)
+        else:
+            a = torch.as_tensor(np.asarray(action), device=self.device)
+        if a.numel() != N:
+            raise ValueError("expected %d actions, got shape %s" % (N, tuple(a.shape)))
+        a = a.reshape(N)
+        if a.dtype != want:
+            a = a.to(want)
+        if not a.is_contiguous() or a.data_ptr() % 16:
+            if self._action_buf is None:
+                self._action_buf = torch.empty(N, dtype=want, device=self.device)
+            self._action_buf.copy_(a)
+            a = self._action_buf
+        return a
+
+    def step(self, action, noise=None):
+        """base_fishing_env.py:60-81.  `noise` (optional, [N] standard normals) replaces the
+        in-kernel Philox stream -- the external-noise parity mode."""
+        a = self._prepare_action(action)
+        z = None
+        if noise is not None:
+            z = torch.as_tensor(noise).to(device=self.device, dtype=self.dtype).reshape(self.num_envs).contiguous()
+        with torch.cuda.device(self.device):
+            rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(a, z),
+                               self._seed, self._step_count, self._stream())
+        _capi.check(rc, "fishing_step")
+        self._step_count += 1
+        self._last_action = a
+        return self._step_result()
+
+    def _step_result(self):
+        if self._scalar:
+            self._publish_scalar_state()
+            self.reward = float(self._reward[0])
+            self.harvest = self.reward
+            return self.state, self.reward, bool(self._done[0]), {}
+        self.state = self._obs.view(self.num_envs, 1)
+        self.reward = self._reward
+        info = {}
+        if self._terminal_obs is not None:
+            info["terminal_observation"] = self._terminal_obs.view(self.num_envs, 1)
+        if self._done_bits is not None:
+            info["done_bits"] = self._done_bits
+        return self.state, self._reward, self._done.view(torch.bool), info
+
+    def step_many(self, actions, n_steps=None):
+        """n_steps consecutive step() calls enqueued by one C call; `actions` is [R, N]
+        (a ring of R action batches, cycled).  Returns the last step's result."""
+        want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
+        if not (isinstance(actions, torch.Tensor) and actions.device == self.device and actions.dtype == want
+                and actions.is_contiguous() and actions.dim() == 2 and actions.shape[1] == self.num_envs):
+            raise ValueError("actions must be a contiguous [R, %d] %s tensor on %s" % (self.num_envs, want, self.device))
+        R = actions.shape[0]
+        n_steps = R if n_steps is None else int(n_steps)
+        with torch.cuda.device(self.device):
+            rc = self._fn_step_many(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(actions),
+                                    self.num_envs, R, n_steps, self._seed, self._step_count, self._stream())
+        _capi.check(rc, "fishing_step_many")
+        self._step_count += n_steps
+        self._last_action = actions[(n_steps - 1) % R] if n_steps else self._last_action
+        return self._step_result()
+
+    # SB3 VecEnv protocol pieces the reference's helpers use (shared_env.py:15-26,57-79)
+    def step_async(self, actions):
+        self._pending = actions
+
+    def step_wait(self):
+        return self.step(self._pending)
+
+    def get_attr(self, name, indices=None):
+        v = getattr(self, name)
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == self.num_envs:
+            idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+            return [v[i] for i in idx]
+        n = self.num_envs if indices is None else (1 if isinstance(indices, int) else len(indices))
+        return _Repeat(v, n)
+
+    def set_attr(self, name, value, indices=None):
+        setattr(self, name, value)
+
+    def env_method(self, name, *args, indices=None, **kwargs):
+        out = getattr(self, name)(*args, **kwargs)
+        n = self.num_envs if indices is None else (1 if isinstance(indices, int) else len(indices))
+        return _Repeat(out, n)
+
+    # ------------------------------------------------------------------ fused rollout
+    def rollout(self, n_steps, policy="random", param=0.0, record=False):
+        """n_steps of step() inside one kernel with an in-kernel policy (csrc/fishing_rollout.hip).
+        record=True returns the [n_steps, 4, N] table {obs_in, action, reward, done}."""
+        pol = POLICIES[policy] if isinstance(policy, str) else int(policy)
+        traj = None
+        if record:
+            if self.num_envs % 4:
+                raise ValueError("record=True needs num_envs % 4 == 0")
+            traj = torch.empty((int(n_steps), 4, self.num_envs), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._fn_rollout(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(),
+                                  pol, float(param), int(n_steps), traj.data_ptr() if traj is not None else None,
+                                  self._seed, self._step_count, self._stream())
+        _capi.check(rc, "fishing_rollout")
+        self._step_count += int(n_steps)
+        if self._scalar:
+            self._publish_scalar_state()
+        return traj
+
+    def episode_stats(self, all_reduce=True):
+        """Episodic-return record over every episode finished since construction:
+        {sum R, sum R^2, n, sum length}, reduced on the device in slot order and -- when
+        torch.distributed is initialised -- summed across ranks (one RCCL all-reduce)."""
+        if self._partials is None:
+            raise RuntimeError("construct the env with track_returns=True")
+        with torch.cuda.device(self.device):
+            rc = self._lib.fishing_reduce_returns(self._partials.data_ptr(), self._record.data_ptr(), self._stream())
+        _capi.check(rc, "fishing_reduce_returns")
+        rec = self._record
+        if all_reduce:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rec = rec.clone()
+                dist.all_reduce(rec, op=dist.ReduceOp.SUM)
+        from .sharding import summarize_record
+        return summarize_record(rec)
+
+    # ------------------------------------------------------------------ helpers (base_fishing_env.py:135-164)
+    def _K_for_math(self):
+        if self._per_env:
+            return self._K_view()
+        return self.params["K"]
+
+    def get_quota(self, action):
+        """base_fishing_env.py:135-147 (elementwise on tensors in vec mode)."""
+        K = self._K_for_math()
+        if is_discrete(self.action_space):
+            if isinstance(action, torch.Tensor):
+                return (action.to(torch.float64) / self.n_actions) * K
+            return (action / self.n_actions) * K
+        if isinstance(action, torch.Tensor):
+            return (action.to(torch.float64).clamp(-1.0, 1.0).reshape(-1) + 1.0) * K
+        a = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0).reshape(-1)[0]
+        return (a + 1) * K
+
+    def get_action(self, quota):
+        """base_fishing_env.py:149-156."""
+        K = self._K_for_math()
+        if is_discrete(self.action_space):
+            if isinstance(quota, torch.Tensor):
+                return torch.round(quota * self.n_actions / K).to(torch.int64)
+            return round(quota * self.n_actions / K)
+        return quota / K - 1
+
+    def get_fish_population(self, state):
+        """base_fishing_env.py:158-160."""
+        K = self._K_for_math()
+        if isinstance(state, torch.Tensor):
+            pop = (state.to(torch.float64).reshape(-1) + 1.0) * K
+            return pop
+        pop = (np.asarray(state, dtype=np.float64).reshape(-1)[0] + 1) * K
+        if self._scalar:
+            self.fish_population = pop
+        return pop
+
+    def get_state(self, fish_population):
+        """base_fishing_env.py:162-164."""
+        K = self._K_for_math()
+        if isinstance(fish_population, torch.Tensor):
+            return (fish_population / K - 1.0).reshape(-1, 1)
+        return np.array([fish_population / K - 1])
+
+    # ------------------------------------------------------------------ render / close
+    def render(self, mode="human", index=0):
+        """base_fishing_env.py:93-94 -> shared_env.py:8-12.  The reference's version raises
+        (self.action is never assigned, quirk B10); this one reports the last action."""
+        a = None if self._last_action is None else self._last_action[index].item()
+        rew = self._reward[index].item()
+        row = [int(self._t[index]), float(self._obs[index]), a, rew]
+        if self.write_obj is not None:
+            csv.writer(self.write_obj).writerow(row)
+        return row
+
+    def close(self):
+        if self.write_obj is not None:
+            self.write_obj.close()
+            self.write_obj = None
+
+
+class FishingEnv(BaseFishingEnv):
+    """fishing-v0 (fishing_env.py:6-24): Discrete(n_actions), quota = a / n_actions * K."""
+    MODEL = MODEL_V0
+
+    def __init__(self, r=0.3, K=1, sigma=0.0, n_actions=100, init_state=0.75, Tmax=100, file=None, **vec):
+        self.n_actions = int(n_actions)
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "x0": init_state}, Tmax=Tmax, file=file, **vec)
+        _, Discrete = space_classes()
+        self.action_space = Discrete(self.n_actions)
+
+
+class FishingCtsEnv(BaseFishingEnv):
+    """fishing-v1 (fishing_cts_env.py:4-12): continuous action, logistic growth."""
+    MODEL = MODEL_V1
+
+    def __init__(self, r=0.3, K=1, sigma=0.0, init_state=0.75, Tmax=100, file=None, **vec):
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "x0": init_state}, Tmax=Tmax, file=file, **vec)
+
+
+class FishingTippingEnv(BaseFishingEnv):
+    """fishing-v2 (fishing_tipping_env.py:6-35): tipping-point growth with parameter C."""
+    MODEL = MODEL_V2
+
+    def __init__(self, r=0.3, K=1, C=0.5, sigma=0.0, init_state=0.75, Tmax=100, file=None, **vec):
+        self.C = C
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "C": C, "x0": init_state}, Tmax=Tmax,
+                         file=file, **vec)
+
+
+class FishingModelError(BaseFishingEnv):
+    """fishing-v4 (fishing_model_error.py:6-48): K, r ~ N(mean, sigma_p) clipped to [0, 1e6],
+    redrawn per env at construction and at every reset; reset obs is x0 un-normalised."""
+    MODEL = MODEL_V4
+
+    def __init__(self, K_mean=1.0, r_mean=0.3, price=1.0, sigma=0.0, sigma_p=0.1, init_state=0.75, Tmax=100,
+                 file=None, **vec):
+        self.K_mean, self.r_mean, self.sigma_p, self.price = K_mean, r_mean, sigma_p, price
+        super().__init__(params={"r": r_mean, "K": K_mean, "sigma": sigma, "r_mean": r_mean, "K_mean": K_mean,
+                                 "sigma_p": sigma_p, "x0": init_state}, Tmax=Tmax, file=file, **vec)
+
+    def _set_initial_state(self):
+        # constructor: draw (K, r) once (fishing_model_error.py:37-38) but keep the base
+        # class's obs = x0 / K_mean - 1 (base_fishing_env.py:46) until the first reset()
+        with torch.cuda.device(self.device):
+            rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
+                                self._c_buffers(with_outputs=False), None, self._seed, self._reset_count,
+                                self._stream())
+        _capi.check(rc, "fishing_reset")
+        self._reset_count += 1
+        self._obs.fill_(float(self.init_state) / float(self.K_mean) - 1.0)
+        self._publish_scalar_state()

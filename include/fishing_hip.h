@@ -1,0 +1,156 @@
+/*
+ * fishing_hip.h -- C ABI of libfishing_hip.so: the MI355X (gfx950) hot path of the
+ * vectorised fisheries gym.  N independent 1-D environments advance in lockstep.
+ *
+ * The reference (boettiger-lab/gym_fishing, pure Python) has no FFI of its own; the
+ * boundary it exposes for this path is the gym.Env protocol.  Each entry point below
+ * names the reference method it replaces (paths relative to the reference root).
+ * The host-side mirror of that protocol lives in gym_fishing_amd/envs.py and calls
+ * these functions through ctypes; INTEGRATION.md shows the binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Every pointer is a DEVICE pointer
+ *     owned by the caller (e.g. torch tensors), 16-byte aligned, contiguous.
+ *   - every function returns 0 on success or a negative FISHING_ERR_* code (argument
+ *     errors, nothing launched) or a positive hipError_t (launch failure).
+ *   - the library keeps no global state: re-entrant, one call = kernel launches
+ *     enqueued on `stream` (a hipStream_t), no host synchronisation, graph-capturable.
+ *   - `_f32` = fp32 fast layout (obs/reward/params float, 25 B per env-step);
+ *     `_f64` = fp64 parity layout (obs/reward/params double; bit-exact to the
+ *     reference's NumPy arithmetic for v0/v1/v4 given the same noise).
+ *     action is float32 (int32 for fishing-v0), done uint8, t int32 in both.
+ */
+#ifndef FISHING_HIP_H
+#define FISHING_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FISHING_ABI_VERSION 1
+
+typedef void* fishing_stream_t; /* hipStream_t */
+
+/* model ids = the registered env ids (gym_fishing/envs/__init__.py:17-35) */
+#define FISHING_MODEL_V0 0 /* fishing-v0: logistic, Discrete(n_actions)   envs/fishing_env.py:6-24        */
+#define FISHING_MODEL_V1 1 /* fishing-v1: logistic, continuous            envs/fishing_cts_env.py:4-12    */
+#define FISHING_MODEL_V2 2 /* fishing-v2: tipping point, continuous       envs/fishing_tipping_env.py:6-35*/
+#define FISHING_MODEL_V4 4 /* fishing-v4: per-episode (K, r) uncertainty  envs/fishing_model_error.py:6-48*/
+
+/* FishingParams.flags */
+#define FISHING_FLAG_AUTO_RESET 1u /* SB3-VecEnv semantics: a finished env is reset inside step() */
+
+/* error codes */
+#define FISHING_OK 0
+#define FISHING_ERR_NULL -1      /* a required pointer is NULL                    */
+#define FISHING_ERR_MODEL -2     /* unknown model id                              */
+#define FISHING_ERR_ALIGN -3     /* a buffer is not 16-byte aligned               */
+#define FISHING_ERR_SIZE -4      /* n < 0, T < 0, n_actions <= 0, ...             */
+#define FISHING_ERR_POLICY -5    /* unknown in-kernel policy                      */
+#define FISHING_ERR_NO_DEVICE -6 /* no HIP device / wrong architecture            */
+
+/* Scalar parameters of one env family: the constructor kwargs of the reference
+ * (envs/fishing_env.py:7-16, fishing_cts_env.py:5-7, fishing_tipping_env.py:7-16,
+ * fishing_model_error.py:9-19). */
+typedef struct FishingParams {
+    int32_t model;     /* FISHING_MODEL_*                                               */
+    int32_t n_actions; /* fishing-v0 only (default 100)                                 */
+    int32_t Tmax;      /* done when years_passed > Tmax (base_fishing_env.py:76)        */
+    uint32_t flags;    /* FISHING_FLAG_*                                                */
+    double r, K, sigma; /* scalars; ignored where the per-env array in FishingBuffers is set */
+    double C;          /* fishing-v2 tipping point                                      */
+    double x0;         /* init_state                                                    */
+    double r_mean, K_mean, sigma_p; /* fishing-v4 redraw at reset                       */
+    int32_t launch_blocks;  /* 0 = auto; else cap on workgroups (tuning knob)           */
+    int32_t launch_threads; /* 0 = auto (256); 64..1024, multiple of 64                 */
+} FishingParams;
+
+/* Device buffers, all of length n unless noted.  "real" = float (_f32) or double (_f64). */
+typedef struct FishingBuffers {
+    void* obs;           /* real  in/out  normalised state x/K - 1 (base_fishing_env.py:162-164) */
+    const void* action;  /* f32 (i32 for v0)  in; unused by fishing_rollout_*                    */
+    void* reward;        /* real  out     max(harvest, 0) (base_fishing_env.py:74); nullable      */
+    uint8_t* done;       /* u8    out     nullable                                                */
+    uint64_t* done_bits; /* u64[ceil(n/64)] out, bit (i%64) of word i/64 = done[i]; nullable      */
+    int32_t* t;          /* i32   in/out  years_passed (base_fishing_env.py:75)                   */
+    void* r;             /* real  in/out  per-env growth rate; required for v4, else nullable     */
+    void* K;             /* real  in/out  per-env carrying capacity; required for v4              */
+    const void* sigma;   /* real  in      per-env noise scale; nullable => FishingParams.sigma    */
+    const void* z_ext;   /* real  in      externally supplied standard normals; nullable =>
+                                          in-kernel Philox4x32-10 + Box-Muller                    */
+    void* terminal_obs;  /* real  out     obs before the auto-reset (SB3 terminal_observation); nullable */
+    void* ep_return;     /* real  in/out  running episodic return; nullable                       */
+    double* return_partials; /* f64[fishing_partials_len()] in/out: per-workgroup partial sums of
+                                {sum R, sum R^2, n_episodes, sum length} over finished episodes;
+                                needs ep_return; nullable                                         */
+} FishingBuffers;
+
+/* In-kernel policies for the fused rollout (callers of step(): shared_env.py:29-54,
+ * models/policies.py:4-31, examples/const_escapement.py:19-26). */
+#define FISHING_POLICY_RANDOM 0     /* a ~ U[-1,1] (v0: uniform int in [0, n_actions)) from Philox word 2 */
+#define FISHING_POLICY_CONSTANT 1   /* a = policy_param (v0: (int)policy_param)                           */
+#define FISHING_POLICY_ESCAPEMENT 2 /* quota = max(x - policy_param, 0), action = get_action(quota)      */
+#define FISHING_POLICY_MSY 3        /* quota = policy_param (constant), action = get_action(quota)       */
+
+int fishing_abi_version(void);
+const char* fishing_error_string(int code);
+/* number of doubles a return_partials buffer must hold (zero-initialised by the caller) */
+int64_t fishing_partials_len(void);
+
+/* BaseFishingEnv.step (envs/base_fishing_env.py:60-81) for envs [0, n) of this shard;
+ * env i is global env (env_offset + i) for the noise stream.  step_counter = number of
+ * step() calls made so far on this vec-env (keys the noise with the env index). */
+int fishing_step_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                     uint64_t seed, uint64_t step_counter, fishing_stream_t stream);
+int fishing_step_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                     uint64_t seed, uint64_t step_counter, fishing_stream_t stream);
+
+/* n_steps consecutive step() calls enqueued from C; step k reads its actions at
+ * action + (k % ring_len) * action_stride elements.  Same results as n_steps calls. */
+int fishing_step_many_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                          int64_t action_stride, int32_t ring_len, int32_t n_steps, uint64_t seed,
+                          uint64_t step_counter, fishing_stream_t stream);
+int fishing_step_many_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                          int64_t action_stride, int32_t ring_len, int32_t n_steps, uint64_t seed,
+                          uint64_t step_counter, fishing_stream_t stream);
+
+/* BaseFishingEnv.reset (envs/base_fishing_env.py:83-91) / FishingModelError.reset
+ * (envs/fishing_model_error.py:41-48).  mask: u8[n], nullable => reset every env.
+ * Writes obs, t = 0, ep_return = 0 (and K, r for v4). */
+int fishing_reset_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                      const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream);
+int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                      const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream);
+
+/* Fused T-step rollout with an in-kernel policy (state stays in registers; no action
+ * traffic).  Equivalent to T fishing_step_* calls with auto-reset and the policy's
+ * actions.  Updates obs, t, (r, K), ep_return, return_partials; writes the LAST step's
+ * reward/done if those pointers are set.  Without FISHING_FLAG_AUTO_RESET a finished env is
+ * frozen (its episode is over, as in simulate_mdp's `break`, shared_env.py:51-52).
+ * traj (nullable): real[T][4][n] recording per step {obs before acting, action, reward,
+ * done} -- the raw material of the simulate_mdp table (shared_env.py:37-49); needs n % 4 == 0. */
+int fishing_rollout_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                        int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
+                        uint64_t step_counter, fishing_stream_t stream);
+int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                        int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
+                        uint64_t step_counter, fishing_stream_t stream);
+
+/* Sum the per-workgroup partials in slot order (deterministic) into out4 =
+ * {sum R, sum R^2, n_episodes, sum length}.  out4 is then all-reduced across GPUs by
+ * the host (RCCL). */
+int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream);
+
+/* Test/diagnostic: the generator itself.  For env (env_offset + i): words[4*i..4*i+3] =
+ * Philox4x32-10 block, z0/z1 = the two Box-Muller normals (z0 is the step noise).
+ * Any output pointer may be NULL. */
+int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
+                      uint32_t* words, float* z0, float* z1, fishing_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISHING_HIP_H */

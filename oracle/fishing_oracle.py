@@ -55,8 +55,10 @@ def quota_from_action(model, action, K, n_actions, dtype=np.float64):
     if model == MODEL_V0:
         a = np.asarray(action).astype(dtype)       # exact for |a| < 2**24 (f32) / 2**53 (f64)
         return (a / dt(n_actions)) * K
-    a = np.asarray(action, dtype=np.float32).astype(dtype)
-    a = np.clip(a, dt(-1.0), dt(1.0))
+    a = np.asarray(action)
+    if a.dtype != np.float64:                      # a float64 action (the escapement / MSY
+        a = a.astype(np.float32)                   # policies pass Python floats) is used as is
+    a = np.clip(a.astype(dtype), dt(-1.0), dt(1.0))
     return (a + dt(1.0)) * K
 
 
@@ -146,8 +148,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def philox_words(seed, env_index, step_counter, stream):
-    """Counter layout shared with csrc/fishing_common.h:
-    c0 = env[31:0], c1 = stream<<24 | env[55:32], c2 = step[31:0], c3 = step[63:32];
+    """Counter layout shared with csrc/fishing_common.h (`env_index` = the Philox index:
+    the env PAIR index on the noise stream, the env index on the reset streams):
+    c0 = index[31:0], c1 = stream<<24 | index[55:32], c2 = step[31:0], c3 = step[63:32];
     key = (seed[31:0], seed[63:32])."""
     env = np.asarray(env_index, dtype=np.uint64)
     step_counter = int(step_counter)
@@ -182,18 +185,25 @@ def box_muller(w0, w1):
 
 
 def noise_normal(seed, env_index, step_counter):
-    """Process-noise z (float32) of env `env_index` at global step `step_counter`."""
-    w0, w1, _, _ = philox_words(seed, env_index, step_counter, STREAM_NOISE)
-    return box_muller(w0, w1)[0]
+    """Process-noise z (float32) of global env `env_index` at global step `step_counter`.
+    One Philox block serves an env PAIR (index env >> 1): the even env takes the cos leg
+    of the Box-Muller pair, the odd env the sin leg."""
+    env = np.asarray(env_index, dtype=np.uint64)
+    w0, w1, _, _ = philox_words(seed, env >> np.uint64(1), step_counter, STREAM_NOISE)
+    zc, zs = box_muller(w0, w1)
+    return np.where((env & np.uint64(1)).astype(bool), zs, zc).astype(np.float32)
 
 
 def policy_random_action(model, seed, env_index, step_counter, n_actions=100):
-    """Random policy sampled in-kernel from word 2 of the noise block: continuous
-    a = float32(w2) * 2**-31 - 1 in [-1, 1]; discrete a = (w2 * n_actions) >> 32."""
-    _, _, w2, _ = philox_words(seed, env_index, step_counter, STREAM_NOISE)
+    """Random policy sampled in-kernel from word 2 (even env) / word 3 (odd env) of the
+    pair's noise block: continuous a = float32(w) * 2**-31 - 1 in [-1, 1]; discrete
+    a = (w * n_actions) >> 32."""
+    env = np.asarray(env_index, dtype=np.uint64)
+    _, _, w2, w3 = philox_words(seed, env >> np.uint64(1), step_counter, STREAM_NOISE)
+    w = np.where((env & np.uint64(1)).astype(bool), w3, w2).astype(np.uint32)
     if model == MODEL_V0:
-        return ((w2.astype(np.uint64) * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int32)
-    return w2.astype(np.float32) * np.float32(2.0 ** -31) - np.float32(1.0)
+        return ((w.astype(np.uint64) * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int32)
+    return w.astype(np.float32) * np.float32(2.0 ** -31) - np.float32(1.0)
 
 
 def reset_normals(seed, env_index, counter, stream):

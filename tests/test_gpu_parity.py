@@ -1,0 +1,471 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the pinned oracle.
+
+Bars (tolerances written here, per the north star):
+  * fp64 parity layout, v0/v1/v4: BIT-EXACT against the golden vectors captured from the
+    reference and against the oracle on seeded inputs (same noise z supplied to both).
+  * fp64 v2: the device exp() is not NumPy's exp(): <= 4 ulp on obs per step.
+  * fp32 fast layout, v0/v1/v4: BIT-EXACT against the oracle evaluated in float32 (IEEE ops,
+    no contraction on either side); v2: <= 8 float32 ulp on the population (hardware v_exp_f32).
+  * fp32 vs the float64 reference arithmetic: |obs| and |reward| within 1e-6 per step.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden_cases
+from oracle import fishing_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_golden_cases()
+V2_F64_ULP = 4
+V2_F32_ULP = 8
+
+
+@pytest.fixture(scope="module")
+def hh():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; none visible")
+    import hip_harness
+    return hip_harness
+
+
+def assert_same_bits(a, b, what):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.dtype == b.dtype, (a.dtype, b.dtype)
+    it = {4: np.int32, 8: np.int64, 1: np.uint8}[a.dtype.itemsize]
+    same = a.view(it) == b.view(it)
+    if a.dtype.kind == "f":
+        same |= np.isnan(a) & np.isnan(b)
+    assert same.all(), "%s: %d/%d differ; first idx %s: %r vs %r" % (
+        what, (~same).sum(), same.size, np.argwhere(~same)[0], a[~same][0], b[~same][0])
+
+
+def pop_close(obs_dev, obs_ref, ulps, eps):
+    """v2 tolerance on the POPULATION x = (obs + 1) K (obs = x/K - 1 cancels near -1, so an
+    ulp count on obs would overstate a 1-ulp error of exp)."""
+    a = np.asarray(obs_dev, dtype=np.float64) + 1.0
+    b = np.asarray(obs_ref, dtype=np.float64) + 1.0
+    return bool(np.all(np.abs(a - b) <= ulps * eps * np.maximum(np.abs(b), 1e-3) + 2 * eps))
+
+
+def case_kw(c):
+    return dict(sigma=c.param("sigma"), C=c.param("C"), x0=c.param("init_state"), Tmax=c.param("Tmax"),
+                n_actions=c.param("n_actions"), K_mean=c.param("K_mean"), r_mean=c.param("r_mean"),
+                sigma_p=c.param("sigma_p"))
+
+
+# ------------------------------------------------------------------ golden vectors (reference)
+@pytest.mark.parametrize("c", CASES, ids=[c.name for c in CASES])
+def test_golden_single_steps_f64(hh, c):
+    """Every recorded reference step, fed the reference's own input state, all (env, step)
+    pairs flattened into one batch."""
+    model = fo.MODEL_OF_ID[c.id]
+    t_in = np.where(np.arange(c.nsteps)[None, :] == 0, 0, np.roll(c.t, 1, axis=1))
+    if c.auto_reset:
+        prev_done = np.roll(c.done, 1, axis=1).astype(bool)
+        prev_done[:, 0] = False
+        t_in = np.where(prev_done, 0, t_in)
+    n = c.obs.size
+    per_env = model == fo.MODEL_V4
+    kw = case_kw(c)
+    p = hh.params(model, r=float(c.param("r")), K=float(c.param("K")), **kw)
+    st = hh.State(n, np.float64, model, c.obs_in.reshape(-1), t=t_in.reshape(-1),
+                  r=c.r.reshape(-1) if per_env else None, K=c.K.reshape(-1) if per_env else None)
+    obs, rew, done, t = st.step(p, c.action.reshape(-1), z=c.z.reshape(-1))
+    if model == fo.MODEL_V2:
+        assert pop_close(obs, c.obs.reshape(-1), V2_F64_ULP, 2.3e-16)
+    else:
+        assert_same_bits(obs, c.obs.reshape(-1), c.name + " obs")
+    assert_same_bits(rew, c.reward.reshape(-1), c.name + " reward")
+    assert (done == c.done.reshape(-1)).all()
+    assert (t == c.t.reshape(-1)).all()
+
+
+@pytest.mark.parametrize("c", [c for c in CASES if c.init_reset], ids=[c.name for c in CASES if c.init_reset])
+def test_golden_free_running_f64(hh, c):
+    """Carry the kernel's own state across the whole recorded trajectory.  v0/v1/v2: the
+    kernel's fused auto-reset must land on the reference's reset observation.  v4: the redraw
+    of (K, r) uses the reference's recorded normals, applied by the test between steps."""
+    model = fo.MODEL_OF_ID[c.id]
+    E = c.obs.shape[0]
+    per_env = model == fo.MODEL_V4
+    kw = case_kw(c)
+    kernel_reset = c.auto_reset and not per_env
+    p = hh.params(model, r=float(c.param("r")), K=float(c.param("K")), auto_reset=kernel_reset, **kw)
+    st = hh.State(E, np.float64, model, c.reset_obs[:, 0], r=c.r[:, 0] if per_env else None,
+                  K=c.K[:, 0] if per_env else None, terminal=True)
+    import torch
+    for s in range(c.nsteps):
+        obs, rew, done, t = st.step(p, c.action[:, s], z=c.z[:, s])
+        term = st.terminal.cpu().numpy()
+        if model == fo.MODEL_V2:
+            assert pop_close(term, c.obs[:, s], V2_F64_ULP, 2.3e-16), (c.name, s)
+            # keep following the reference's trajectory exactly so errors do not compound
+            st.obs.copy_(torch.as_tensor(np.where(done.astype(bool) & kernel_reset, obs, c.obs[:, s])).cuda())
+        else:
+            assert_same_bits(term, c.obs[:, s], "%s obs step %d" % (c.name, s))
+        assert_same_bits(rew, c.reward[:, s], "%s reward step %d" % (c.name, s))
+        assert (done == c.done[:, s]).all(), (c.name, s)
+        m = done.astype(bool)
+        if kernel_reset and m.any():
+            assert_same_bits(obs[m], c.reset_obs[m, s + 1], "%s reset obs step %d" % (c.name, s))
+            assert (t[m] == 0).all()
+        if per_env and c.auto_reset and m.any() and s + 1 < c.nsteps:
+            # host-side reset with the reference's own draws
+            st.obs.copy_(torch.as_tensor(np.where(m, c.reset_obs[:, s + 1], obs)).cuda())
+            st.t.copy_(torch.as_tensor(np.where(m, 0, t).astype(np.int32)).cuda())
+            st.K.copy_(torch.as_tensor(c.K[:, s + 1]).cuda())
+            st.r.copy_(torch.as_tensor(c.r[:, s + 1]).cuda())
+
+
+# ------------------------------------------------------------------ seeded batches vs the oracle
+def random_batch(model, n, rng, dtype):
+    obs = rng.uniform(-1.0, 0.6, n).astype(dtype)
+    obs[::97] = -1.0                      # extinct stock
+    t = rng.integers(0, 101, n).astype(np.int32)
+    t[::53] = 100                         # about to hit Tmax
+    if model == fo.MODEL_V0:
+        a = rng.integers(0, 100, n).astype(np.int32)
+        a[::31] = 150                     # out of the Discrete range: not validated (quirk B11)
+    else:
+        a = rng.uniform(-1.2, 1.2, n).astype(np.float32)   # includes values the clip must catch
+        a[::29] = np.float32(1.0)
+    z = rng.standard_normal(n).astype(dtype)
+    return obs, t, a, z
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 255, 1027, (1 << 16) + 3])
+def test_step_matches_oracle_ext_noise(hh, model, dtype, n):
+    rng = np.random.default_rng(1000 * model + n)
+    obs, t, a, z = random_batch(model, n, rng, dtype)
+    per_env = model == fo.MODEL_V4
+    r = rng.uniform(0.1, 0.6, n).astype(dtype) if per_env else dtype(0.3)
+    K = rng.uniform(0.5, 2.0, n).astype(dtype) if per_env else dtype(1.25)
+    sigma = 0.1
+    p = hh.params(model, r=0.3, K=1.25, sigma=sigma, C=0.4, Tmax=100)
+    st = hh.State(n, dtype, model, obs, t=t, r=r if per_env else None, K=K if per_env else None, done_bits=True)
+    o, rew, done, t2 = st.step(p, a, z=z)
+    eo, er, ed, et, ex = fo.step(model, obs, t, a, z, r, K, sigma, C=0.4, Tmax=100, dtype=dtype)
+    if model == fo.MODEL_V2:
+        assert pop_close(o, eo, *((V2_F64_ULP, 2.3e-16) if dtype == np.float64 else (V2_F32_ULP, 1.2e-7)))
+    else:
+        assert_same_bits(o, eo, "obs")
+    assert_same_bits(rew, er, "reward")
+    assert (done == ed).all() and (t2 == et).all()
+    # wave-ballot bit mask == byte mask
+    bits = st.done_bits.cpu().numpy().view(np.uint64)
+    unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).reshape(-1)[:n]
+    assert (unpacked.astype(np.uint8) == done).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
+def test_multi_step_auto_reset_philox(hh, model, dtype):
+    """30 steps with in-kernel Philox noise and fused auto-reset (incl. the v4 redraw) at
+    N = 4099, env_offset = 8: the oracle is fed the normals dumped from the device
+    generator and must reproduce every step bit-for-bit (v2: tolerance)."""
+    n, off, seed, T = 4099, 8, 0xC0FFEE1234, 30
+    rng = np.random.default_rng(7 + model)
+    per_env = model == fo.MODEL_V4
+    kw = dict(sigma=0.15, C=0.5, x0=0.75, Tmax=9, K_mean=1.0, r_mean=0.3, sigma_p=0.2)
+    p = hh.params(model, r=0.3, K=1.0, auto_reset=True, **kw)
+    K = np.full(n, 1.0, dtype)
+    r = np.full(n, 0.3, dtype)
+    st = hh.State(n, dtype, model, np.zeros(n), r=r if per_env else None, K=K if per_env else None,
+                  ep_return=True, terminal=True)
+    st.reset(p, seed=seed, counter=0, env_offset=off)
+    if per_env:
+        _, zK, zr = hh.device_noise(n, seed, 0, fo.STREAM_RESET, off)
+        K, r = fo.draw_model_error_params(zK, zr, 1.0, 0.3, 0.2, dtype)
+        assert_same_bits(st.K.cpu().numpy(), K, "reset K")
+        assert_same_bits(st.r.cpu().numpy(), r, "reset r")
+    obs = fo.reset_obs(model, 0.75, K, dtype)
+    assert_same_bits(st.obs.cpu().numpy(), obs, "reset obs")
+    t = np.zeros(n, np.int32)
+    ep = np.zeros(n, dtype)
+    rec = np.zeros(4)
+    for s in range(T):
+        a = (rng.integers(0, 100, n).astype(np.int32) if model == fo.MODEL_V0
+             else rng.uniform(-1, -0.2, n).astype(np.float32))
+        o, rew, done, t2 = st.step(p, a, seed=seed, step_counter=s, env_offset=off)
+        z = hh.device_step_noise(n, seed, s, off).astype(dtype)
+        eo, er, ed, et, ex = fo.step(model, obs, t, a, z, r, K, 0.15, C=0.5, Tmax=9, dtype=dtype)
+        term = st.terminal.cpu().numpy()
+        if model == fo.MODEL_V2:
+            assert pop_close(term, eo, *((V2_F64_ULP, 2.3e-16) if dtype == np.float64 else (V2_F32_ULP, 1.2e-7)))
+            eo = term      # follow the device so the comparison stays per-step
+            ed = ((et > 9) | ((term.astype(np.float64) + 1.0) <= 0)).astype(np.uint8)
+        else:
+            assert_same_bits(term, eo, "terminal obs step %d" % s)
+        assert_same_bits(rew, er, "reward step %d" % s)
+        assert (done == ed).all() and True
+        ep = (ep + er).astype(dtype)
+        m = ed.astype(bool)
+        rec += [ep[m].astype(np.float64).sum(), (ep[m].astype(np.float64) ** 2).sum(), m.sum(), et[m].sum()]
+        ep = np.where(m, dtype(0), ep)
+        zK = zr = None
+        if per_env:
+            _, zK, zr = hh.device_noise(n, seed, s, fo.STREAM_AUTORESET, off)
+        obs, t, K, r = fo.auto_reset(model, eo, ed, et, K, r, 0.75, zK=zK, zr=zr, K_mean=1.0, r_mean=0.3,
+                                     sigma_p=0.2, dtype=dtype)
+        assert_same_bits(o, obs, "obs after auto-reset step %d" % s)
+        assert (t2 == t).all()
+        if per_env:
+            assert_same_bits(st.K.cpu().numpy(), K, "K step %d" % s)
+            assert_same_bits(st.r.cpu().numpy(), r, "r step %d" % s)
+        assert_same_bits(st.ep_return.cpu().numpy(), ep, "ep_return step %d" % s)
+    got = st.record()
+    assert got[2] == rec[2] and got[3] == rec[3] and rec[2] > n   # every env finished >= 1 episode
+    assert np.allclose(got[:2], rec[:2], rtol=1e-12)
+
+
+def test_f32_within_1e6_of_f64_reference_arithmetic(hh):
+    """north star: reward/obs within 1e-6 in fp32.  Same state, action and noise through the
+    fp32 kernel and through the float64 oracle (the reference's arithmetic)."""
+    n = 1 << 16
+    rng = np.random.default_rng(5)
+    for model in (fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2):
+        obs, t, a, z = random_batch(model, n, rng, np.float32)
+        a = np.clip(a, -1, 1) if model != fo.MODEL_V0 else np.minimum(a, 99)
+        p = hh.params(model, r=0.3, K=1.0, sigma=0.1)
+        st = hh.State(n, np.float32, model, obs, t=t)
+        o, rew, done, _ = st.step(p, a, z=z)
+        eo, er, ed, _, _ = fo.step(model, obs.astype(np.float64), t, a, z.astype(np.float64), 0.3, 1.0, 0.1)
+        assert np.abs(o - eo).max() <= 1e-6, (model, np.abs(o - eo).max())
+        assert np.abs(rew - er).max() <= 1e-6
+
+
+# ------------------------------------------------------------------ the generator
+def test_device_philox_words_bit_exact_and_normals_close(hh):
+    n, seed = 1 << 16, 0x1234567890ABCDEF
+    for counter, tag, off in ((0, 0, 0), (12345678901, 1, 4096), (7, 2, (1 << 33) + 12)):
+        words, z0, z1 = hh.device_noise(n, seed, counter, tag, off)
+        w = fo.philox_words(seed, np.arange(off, off + n, dtype=np.uint64), counter, tag)
+        for k in range(4):
+            assert (words[:, k] == w[k]).all(), "philox word %d" % k
+        e0, e1 = fo.box_muller(w[0], w[1])
+        # hardware log2/sqrt/sin/cos vs libm in float64: absolute error of a few 1e-6
+        assert np.abs(z0 - e0).max() < 2e-5, np.abs(z0 - e0).max()
+        assert np.abs(z1 - e1).max() < 2e-5, np.abs(z1 - e1).max()
+        assert np.isfinite(z0).all() and np.isfinite(z1).all()
+    z = hh.device_step_noise(n, seed, 3).astype(np.float64)
+    assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.var() - 1) < 0.03
+    from scipy import stats
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    assert (hh.device_step_noise(64, seed, 3, env_offset=1000) == z[1000:1064].astype(np.float32)).all()
+
+
+# ------------------------------------------------------------------ rollout == step-by-step
+def _policy_action(policy, param, model, dtype, obs, K, seed, env, s):
+    """The action the in-kernel policy takes (models/policies.py:16-19, :27-31)."""
+    n = obs.shape[0]
+    if policy == "random":
+        return fo.policy_random_action(model, seed, env, s)
+    if policy == "constant":
+        return np.full(n, param, np.int32 if model == fo.MODEL_V0 else np.float32)
+    x = (obs + dtype(1)) * K
+    d = x - dtype(param)
+    q = np.where(dtype(0) > d, dtype(0), d) if policy == "escapement" else np.full(n, param, dtype)
+    if model == fo.MODEL_V0:
+        return np.rint((q * dtype(100) / K).astype(np.float64)).astype(np.int32)
+    return (q / K - dtype(1)).astype(dtype)       # NOT rounded to float32 (reference passes the float)
+
+
+def _policy_setup(hh, policy, model):
+    from gym_fishing_amd import _capi
+    pol = {"random": _capi.POLICY_RANDOM, "constant": _capi.POLICY_CONSTANT,
+           "escapement": _capi.POLICY_ESCAPEMENT, "msy": _capi.POLICY_MSY}[policy]
+    param = {"random": 0.0, "constant": 12.0 if model == fo.MODEL_V0 else -0.8125, "escapement": 0.5,
+             "msy": 0.075}[policy]
+    return pol, param
+
+
+ROLLOUT_KW = dict(sigma=0.1, C=0.5, x0=0.75, Tmax=7, sigma_p=0.15)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
+@pytest.mark.parametrize("policy", ["random", "constant", "escapement", "msy"])
+def test_fused_rollout_equals_stepwise(hh, model, dtype, policy):
+    """T steps inside one kernel == T step() calls fed the policy's actions (bit-exact: both
+    run the same device arithmetic and the same Philox blocks)."""
+    if dtype == np.float64 and model != fo.MODEL_V0 and policy in ("escapement", "msy"):
+        pytest.skip("float64 action: not expressible through the float32 action stream; "
+                    "covered by test_fused_rollout_f64_policy_vs_oracle")
+    n, off, seed, T = 2052, 4, 99, 25
+    per_env = model == fo.MODEL_V4
+    p = hh.params(model, r=0.3, K=1.0, auto_reset=True, **ROLLOUT_KW)
+    pol, param = _policy_setup(hh, policy, model)
+    mk = lambda: hh.State(n, dtype, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
+                          K=np.full(n, 1.0) if per_env else None, ep_return=True)
+    A, B = mk(), mk()
+    A.reset(p, seed=seed, env_offset=off)
+    B.reset(p, seed=seed, env_offset=off)
+    traj = A.rollout(p, pol, param, T, seed=seed, step_counter=0, env_offset=off, record=True)
+    env = np.arange(off, off + n)
+    for s in range(T):
+        obs = B.obs.cpu().numpy()
+        Kh = B.K.cpu().numpy() if per_env else dtype(1.0)
+        a = _policy_action(policy, param, model, dtype, obs, Kh, seed, env, s)
+        assert_same_bits(traj[s, 0], obs, "obs_in step %d" % s)
+        assert_same_bits(traj[s, 1], a.astype(dtype), "action step %d" % s)
+        _, rew, done, _ = B.step(p, a, seed=seed, step_counter=s, env_offset=off)
+        assert_same_bits(traj[s, 2], rew, "reward step %d" % s)
+        assert (traj[s, 3].astype(np.uint8) == done).all()
+    assert_same_bits(A.obs.cpu().numpy(), B.obs.cpu().numpy(), "final obs")
+    assert (A.t.cpu().numpy() == B.t.cpu().numpy()).all()
+    assert_same_bits(A.ep_return.cpu().numpy(), B.ep_return.cpu().numpy(), "ep_return")
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] and ra[2] >= n and np.allclose(ra, rb, rtol=1e-12)
+    if per_env:
+        assert_same_bits(A.K.cpu().numpy(), B.K.cpu().numpy(), "K")
+
+
+@pytest.mark.parametrize("model", [fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
+@pytest.mark.parametrize("policy", ["escapement", "msy"])
+def test_fused_rollout_f64_policy_vs_oracle(hh, model, policy):
+    """fp64 rollout under the escapement / MSY rules against a full oracle replay (the
+    policy's float64 action goes straight into get_quota, as in the reference)."""
+    dtype = np.float64
+    n, off, seed, T = 2052, 4, 99, 25
+    per_env = model == fo.MODEL_V4
+    p = hh.params(model, r=0.3, K=1.0, auto_reset=True, **ROLLOUT_KW)
+    pol, param = _policy_setup(hh, policy, model)
+    A = hh.State(n, dtype, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,
+                 K=np.full(n, 1.0) if per_env else None, ep_return=True)
+    A.reset(p, seed=seed, env_offset=off)
+    K = A.K.cpu().numpy() if per_env else np.full(n, 1.0)
+    r = A.r.cpu().numpy() if per_env else np.full(n, 0.3)
+    obs = A.obs.cpu().numpy()
+    t = np.zeros(n, np.int32)
+    traj = A.rollout(p, pol, param, T, seed=seed, step_counter=0, env_offset=off, record=True)
+    env = np.arange(off, off + n)
+    for s in range(T):
+        if model == fo.MODEL_V2:
+            assert np.allclose(traj[s, 0] + 1, obs + 1, rtol=1e-13, atol=1e-13)
+            obs = traj[s, 0]            # follow the device (exp differs in the last ulps)
+        else:
+            assert_same_bits(traj[s, 0], obs, "obs_in step %d" % s)
+        a = _policy_action(policy, param, model, dtype, obs, K, seed, env, s)
+        assert_same_bits(traj[s, 1], a, "action step %d" % s)
+        z = hh.device_step_noise(n, seed, s, off).astype(dtype)
+        eo, er, ed, et, _ = fo.step(model, obs, t, a, z, r, K, 0.1, C=0.5, Tmax=7)
+        assert_same_bits(traj[s, 2], er, "reward step %d" % s)
+        if model != fo.MODEL_V2:
+            assert (traj[s, 3].astype(np.uint8) == ed).all()
+        ed = traj[s, 3].astype(np.uint8)
+        zK = zr = None
+        if per_env:
+            _, zK, zr = hh.device_noise(n, seed, s, fo.STREAM_AUTORESET, off)
+        obs, t, K, r = fo.auto_reset(model, eo, ed, et, K, r, 0.75, zK=zK, zr=zr, K_mean=1.0, r_mean=0.3,
+                                     sigma_p=0.15)
+    if model != fo.MODEL_V2:
+        assert_same_bits(A.obs.cpu().numpy(), obs, "final obs")
+    assert (A.t.cpu().numpy() == t).all()
+
+
+def test_rollout_without_auto_reset_freezes_and_exits(hh):
+    """Wave-ballot exit: with no auto-reset every env is frozen at its first done."""
+    from gym_fishing_amd import _capi
+    n, T = 1024, 40
+    p = hh.params(fo.MODEL_V1, sigma=0.0, Tmax=5)
+    st = hh.State(n, np.float32, fo.MODEL_V1, np.full(n, -0.25), ep_return=True)
+    traj = st.rollout(p, _capi.POLICY_CONSTANT, -0.9375, T, record=True)
+    obs, rew, done, t = st.host()
+    assert (t == 6).all() and done.all()          # Tmax + 1 steps (quirk B1), then frozen
+    assert traj[5, 3].all() and not traj[4, 3].any()
+    rec = st.record()
+    assert rec[2] == n and rec[3] == 6 * n
+
+
+# ------------------------------------------------------------------ full-size properties
+FULL_N = 1 << 22   # BASELINE.json metric size
+
+
+def test_full_size_sharding_invariance_and_determinism(hh):
+    """N = 2^22, fishing-v1 sigma=0.1 (the bench workload): stepping the whole batch in one
+    call == stepping four shards with env_offset (noise keyed by the global env index), and a
+    repeat run is bitwise identical."""
+    import torch
+    n, seed = FULL_N, 1234
+    p = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = (torch.rand((3, n), device="cuda", generator=g) * 2 - 1).float()
+
+    def run(shards):
+        st = hh.State(n, np.float32, fo.MODEL_V1, np.float32(-0.25))
+        lib = __import__("gym_fishing_amd")._capi.lib()
+        for s in range(3):
+            for k in range(shards):
+                lo, hi = k * n // shards, (k + 1) * n // shards
+                b = st.buffers(acts[s])
+                for f in ("obs", "action", "reward", "t"):
+                    setattr(b, f, getattr(b, f) + 4 * lo)
+                b.done = b.done + lo
+                rc = lib.fishing_step_f32(p, hi - lo, lo, b, seed, s, None)
+                assert rc == 0
+        torch.cuda.synchronize()
+        return st
+    a, b4, a2 = run(1), run(4), run(1)
+    assert torch.equal(a.obs, b4.obs) and torch.equal(a.reward, b4.reward) and torch.equal(a.done, b4.done)
+    assert torch.equal(a.obs, a2.obs)
+    # oracle spot-check of a 4096-env window in the middle of the batch, step 0
+    lo = n // 2 + 4096
+    z = hh.device_step_noise(4096, seed, 0, lo)
+    eo, er, _, _, _ = fo.step(fo.MODEL_V1, np.full(4096, -0.25, np.float32), np.zeros(4096, np.int32),
+                              acts[0, lo:lo + 4096].cpu().numpy(), z, 0.3, 1.0, 0.1, dtype=np.float32)
+    st = hh.State(n, np.float32, fo.MODEL_V1, np.float32(-0.25))
+    o, rew, _, _ = st.step(p, acts[0].cpu().numpy(), seed=seed, step_counter=0)
+    assert_same_bits(o[lo:lo + 4096], eo, "window obs")
+    assert_same_bits(rew[lo:lo + 4096], er, "window reward")
+
+
+def test_full_size_sigma0_lockstep_properties(hh):
+    """Size-independent properties at N = 2^22: with sigma = 0 and one shared action every
+    env follows the A.4 known-answer trajectory; all envs finish on step 101 exactly; the
+    episodic-return record counts N episodes of return 6.3125."""
+    n = FULL_N
+    p = hh.params(fo.MODEL_V1, sigma=0.0, auto_reset=True)
+    st = hh.State(n, np.float64, fo.MODEL_V1, -0.25, ep_return=True)
+    a = np.full(n, -0.9375, np.float32)
+    import torch
+    at = st.action_tensor(a)
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    want = [float.fromhex(h) for h in ("-0x1.fc00000000000p-3", "-0x1.f873cccccccccp-3", "-0x1.f54f4f0b576c8p-3")]
+    for s in range(101):
+        rc = lib.fishing_step_f64(p, n, 0, st.buffers(at), 0, s, None)
+        assert rc == 0
+        if s < 3:
+            torch.cuda.synchronize()
+            assert bool((st.obs == want[s]).all())
+        if s == 99:
+            torch.cuda.synchronize()
+            assert not bool(st.done.any())
+    torch.cuda.synchronize()
+    assert bool(st.done.all()) and bool((st.t == 0).all()) and bool((st.obs == -0.25).all())
+    rec = st.record()
+    assert rec[2] == n and rec[3] == 101 * n and rec[0] == 6.3125 * n
+
+
+# ------------------------------------------------------------------ ABI argument checking
+def test_abi_rejects_bad_arguments(hh):
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    st = hh.State(64, np.float32, fo.MODEL_V1, 0.0)
+    a = st.action_tensor(np.zeros(64, np.float32))
+    p = hh.params(fo.MODEL_V1)
+    assert lib.fishing_step_f32(p, 0, 0, st.buffers(a), 0, 0, None) == 0          # n = 0: no-op
+    assert lib.fishing_step_f32(p, -1, 0, st.buffers(a), 0, 0, None) == -4
+    assert lib.fishing_step_f32(p, 64, 2, st.buffers(a), 0, 0, None) == -4         # env_offset % 4
+    assert lib.fishing_step_f32(p, 64, 0, st.buffers(None), 0, 0, None) == -1      # no action
+    b = st.buffers(a)
+    b.obs = b.obs + 4
+    assert lib.fishing_step_f32(p, 60, 0, b, 0, 0, None) == -3                     # misaligned
+    assert lib.fishing_step_f32(hh.params(3), 64, 0, st.buffers(a), 0, 0, None) == -2
+    assert lib.fishing_step_f32(hh.params(fo.MODEL_V4), 64, 0, st.buffers(a), 0, 0, None) == -1  # v4 needs r, K
+    assert lib.fishing_rollout_f32(p, 64, 0, st.buffers(a), 9, 0.0, 1, None, 0, 0, None) == -5
+    assert b"aligned" in lib.fishing_error_string(-3)
