@@ -12,7 +12,7 @@ TORCH_OF = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.flo
 
 
 def dev(a, dtype=None):
-    t = torch.as_tensor(np.ascontiguousarray(a))
+    t = torch.as_tensor(np.array(a))   # copy: inputs may be read-only broadcasts
     if dtype is not None:
         t = t.to(dtype)
     return t.cuda().contiguous()
