@@ -202,12 +202,14 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
 
 __global__ void __launch_bounds__(256)
 reduce_returns_kernel(const double* __restrict__ partials, double* __restrict__ out4) {
-    // one workgroup; thread k < 4 sums field k over the slots in slot order
-    if (threadIdx.x < kPartialFields) {
-        double s = 0.0;
-        for (int slot = 0; slot < kMaxBlocks; ++slot) s += partials[slot * kPartialFields + threadIdx.x];
-        out4[threadIdx.x] = s;
-    }
+    // one workgroup of 4 waves: wave f sums field f.  Lane l adds slots l, l+64, ... in slot
+    // order, then a fixed shuffle tree combines the 64 lanes: same bits on every run.
+    const int field = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    double s = 0.0;
+    for (int slot = lane; slot < kMaxBlocks; slot += kWave) s += partials[slot * kPartialFields + field];
+    s = wave_sum(s);
+    if (lane == 0) out4[field] = s;
 }
 
 __global__ void __launch_bounds__(256)
@@ -406,7 +408,7 @@ int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, con
 
 int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream) {
     if (!return_partials || !out4) return FISHING_ERR_NULL;
-    fishing::reduce_returns_kernel<<<1, 64, 0, (hipStream_t)stream>>>(return_partials, out4);
+    fishing::reduce_returns_kernel<<<1, 256, 0, (hipStream_t)stream>>>(return_partials, out4);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,88 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/fishing_hip.h
+declares; argument errors are reported without touching a GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from gym_fishing_amd import _capi, build
+
+HEADER = os.path.join(ROOT, "include", "fishing_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fishing_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(build.LIB_PATH):
+        build.build()
+    return _capi.lib()
+
+
+def test_header_and_binding_list_the_same_functions():
+    assert declared_functions() == sorted(_capi.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    raw = ctypes.CDLL(build.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(raw, name), name
+
+
+def test_abi_version_and_struct_layout(lib):
+    assert lib.fishing_abi_version() == _capi.ABI_VERSION
+    # FishingParams: 4 x i32, 8 x f64, 2 x i32  -> 88 bytes; FishingBuffers: 13 pointers
+    assert ctypes.sizeof(_capi.FishingParams) == 88
+    assert ctypes.sizeof(_capi.FishingBuffers) == 13 * ctypes.sizeof(ctypes.c_void_p)
+    hdr = open(HEADER).read()
+    body = hdr[hdr.index("typedef struct FishingBuffers {"):hdr.index("} FishingBuffers;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(\w+)\s*;", body)
+    assert tuple(fields) == _capi.BUFFER_FIELDS
+    assert lib.fishing_partials_len() == 4096 * 4
+
+
+def test_error_strings(lib):
+    assert lib.fishing_error_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, -6):
+        assert lib.fishing_error_string(code) not in (b"ok", b"unknown error")
+
+
+def test_argument_errors_need_no_gpu(lib):
+    """Validation happens before any launch, so it is checkable on a CPU-only host."""
+    p = _capi.FishingParams()
+    p.model, p.n_actions, p.Tmax = _capi.MODEL_V1, 100, 100
+    b = _capi.FishingBuffers()
+    assert lib.fishing_step_f32(None, 4, 0, b, 0, 0, None) == -1          # NULL params
+    assert lib.fishing_step_f32(p, 4, 0, b, 0, 0, None) == -1             # NULL obs / t
+    b = _capi.make_buffers(obs=4096, t=8192, action=12288)
+    assert lib.fishing_step_f32(p, -3, 0, b, 0, 0, None) == -4            # n < 0
+    assert lib.fishing_step_f32(p, 4, 6, b, 0, 0, None) == -4             # env_offset % 4 != 0
+    assert lib.fishing_step_f32(p, 0, 0, b, 0, 0, None) == 0              # n == 0: nothing to do
+    b = _capi.make_buffers(obs=4100, t=8192, action=12288)
+    assert lib.fishing_step_f64(p, 4, 0, b, 0, 0, None) == -3             # misaligned obs
+    p.model = 7
+    b = _capi.make_buffers(obs=4096, t=8192, action=12288)
+    assert lib.fishing_step_f32(p, 4, 0, b, 0, 0, None) == -2             # unknown model
+    p.model = _capi.MODEL_V4
+    assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -1      # v4 needs r, K arrays
+    p.model = _capi.MODEL_V1
+    assert lib.fishing_rollout_f32(p, 4, 0, b, 17, 0.0, 3, None, 0, 0, None) == -5
+    assert lib.fishing_rollout_f32(p, 4, 0, b, 0, 0.0, -1, None, 0, 0, None) == -4
+    assert lib.fishing_reduce_returns(None, None, None) == -1
+    assert lib.fishing_noise_f32(-1, 0, 0, 0, 0, None, None, None, None) == -4
+    p.launch_threads = 100
+    assert lib.fishing_step_f32(p, 4, 0, b, 0, 0, None) == -4             # threads not a multiple of 64
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setenv("FISHING_HIP_LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_capi, "_lib", None)
+    with pytest.raises(_capi.FishingLibraryError, match="no CPU fallback"):
+        _capi.lib()

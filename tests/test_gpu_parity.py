@@ -420,10 +420,11 @@ def test_full_size_sharding_invariance_and_determinism(hh):
     # oracle spot-check of a 4096-env window in the middle of the batch, step 0
     lo = n // 2 + 4096
     z = hh.device_step_noise(4096, seed, 0, lo)
-    eo, er, _, _, _ = fo.step(fo.MODEL_V1, np.full(4096, -0.25, np.float32), np.zeros(4096, np.int32),
+    eo, er, ed, _, _ = fo.step(fo.MODEL_V1, np.full(4096, -0.25, np.float32), np.zeros(4096, np.int32),
                               acts[0, lo:lo + 4096].cpu().numpy(), z, 0.3, 1.0, 0.1, dtype=np.float32)
     st = hh.State(n, np.float32, fo.MODEL_V1, np.float32(-0.25))
     o, rew, _, _ = st.step(p, acts[0].cpu().numpy(), seed=seed, step_counter=0)
+    eo = np.where(ed.astype(bool), np.float32(-0.25), eo)        # fused auto-reset
     assert_same_bits(o[lo:lo + 4096], eo, "window obs")
     assert_same_bits(rew[lo:lo + 4096], er, "window reward")
 

@@ -1,0 +1,112 @@
+"""Host-side logic that needs no GPU: registry, kwargs, spaces, sharding arithmetic, and the
+rule that the product never reaches into oracle/ or falls back to a CPU path."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gym_fishing_amd as gf
+from conftest import ROOT
+from gym_fishing_amd import sharding, spaces
+
+
+def test_registry_matches_reference_ids():
+    # gym_fishing/envs/__init__.py:17-35 (ids v5..v11 are out of scope)
+    assert gf.ENV_IDS == ("fishing-v0", "fishing-v1", "fishing-v2", "fishing-v4")
+    assert gf.env_class("fishing-v0").__name__ == "FishingEnv"
+    assert gf.env_class("fishing-v1").__name__ == "FishingCtsEnv"
+    assert gf.env_class("fishing-v2").__name__ == "FishingTippingEnv"
+    assert gf.env_class("fishing-v4").__name__ == "FishingModelError"
+    with pytest.raises(KeyError):
+        gf.env_class("fishing-v5")
+
+
+def test_constructor_kwargs_match_reference_signatures():
+    import inspect
+    want = {
+        "fishing-v0": dict(r=0.3, K=1, sigma=0.0, n_actions=100, init_state=0.75, Tmax=100, file=None),
+        "fishing-v1": dict(r=0.3, K=1, sigma=0.0, init_state=0.75, Tmax=100, file=None),
+        "fishing-v2": dict(r=0.3, K=1, C=0.5, sigma=0.0, init_state=0.75, Tmax=100, file=None),
+        "fishing-v4": dict(K_mean=1.0, r_mean=0.3, price=1.0, sigma=0.0, sigma_p=0.1, init_state=0.75, Tmax=100,
+                           file=None),
+    }
+    for env_id, kw in want.items():
+        sig = inspect.signature(gf.env_class(env_id).__init__)
+        got = {k: v.default for k, v in sig.parameters.items() if v.kind == v.POSITIONAL_OR_KEYWORD and k != "self"}
+        assert got == kw, env_id
+        assert list(got) == list(kw), "positional order differs for " + env_id
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(gf.FishingLibraryError, match="no CPU backend"):
+        gf.make("fishing-v1", num_envs=8)
+    with pytest.raises(gf.FishingLibraryError):
+        gf.make("fishing-v0")
+
+
+def test_product_never_imports_the_oracle_or_numpy_math_fallbacks():
+    pkg = os.path.join(ROOT, "gym_fishing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".h")):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            code = "\n".join(line.split("#")[0] for line in src.splitlines())
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", code, flags=re.M), f
+            assert "scalar_env" not in code and "c_oracle" not in code, f
+
+
+def test_spaces():
+    b = spaces.Box(np.array([-1], dtype=np.float32), np.array([1], dtype=np.float32), dtype=np.float32)
+    assert b.shape == (1,) and b.dtype == np.float32 and b.low[0] == -1 and b.high[0] == 1
+    b.seed(0)
+    s = b.sample()
+    assert s.shape == (1,) and s.dtype == np.float32 and b.contains(s)
+    assert not b.contains(np.array([1.5], dtype=np.float32))
+    d = spaces.Discrete(100)
+    d.seed(0)
+    assert d.n == 100 and d.contains(d.sample()) and not d.contains(100) and not d.contains(-1)
+    assert spaces.is_discrete(d) and not spaces.is_discrete(b)
+    Box, Discrete = spaces.space_classes()
+    assert Box is not None and Discrete is not None
+
+
+@pytest.mark.parametrize("total,world", [(1 << 22, 1), (1 << 22, 8), (1 << 24, 8), (1000003, 8), (10, 4), (3, 2),
+                                         (0, 3), (4, 8)])
+def test_shard_range_tiles_the_batch(total, world):
+    covered = 0
+    prev_end = 0
+    for rank in range(world):
+        off, cnt = sharding.shard_range(total, rank, world)
+        assert off % 4 == 0 or cnt == 0
+        assert off == prev_end or cnt == 0
+        assert cnt >= 0
+        prev_end = off + cnt if cnt else prev_end
+        covered += cnt
+    assert covered == total
+    counts = [sharding.shard_range(total, r, world)[1] for r in range(world)]
+    assert max(counts) - min(counts) <= 7      # one 4-env unit + the trimmed tail of the last shard
+
+
+def test_shard_range_rejects_bad_ranks():
+    with pytest.raises(ValueError):
+        sharding.shard_range(16, 2, 2)
+    with pytest.raises(ValueError):
+        sharding.shard_range(-1, 0, 1)
+
+
+def test_summarize_record():
+    import torch
+    rec = torch.tensor([10.0, 30.0, 4.0, 400.0], dtype=torch.float64)
+    s = sharding.summarize_record(rec)
+    assert s["mean_return"] == 2.5 and s["mean_length"] == 100.0
+    assert abs(s["std_return"] - np.sqrt(30 / 4 - 2.5 ** 2)) < 1e-12
+    assert "mean_return" not in sharding.summarize_record(torch.zeros(4, dtype=torch.float64))
+
+
+def test_register_with_gym_is_optional():
+    assert isinstance(gf.register_with_gym(), list)     # [] when neither gym nor gymnasium exists
