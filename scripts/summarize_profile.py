@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 CSVs of scripts/profile_bench.sh into the committed summaries:
+
+    python scripts/summarize_profile.py gpurun_out/<tag> profiles/<name> [--n-envs N] [--with-returns 0|1] [--latest]
+
+Writes <name>_kernel_stats.csv (rocprofv3 --stats table, our kernels + top others),
+<name>_summary.json (avg duration, PMC bytes per launch with the gfx950 correction:
+FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports exactly half of a wide coalesced
+read stream on gfx950 -- MI355X_MICROARCH.md section HBM -- so read bytes = 2 * FETCH_SIZE * 1024;
+WRITE_SIZE is exact for 16-byte-per-lane stores), and with --latest profiles/pmc_latest.json
+(read by bench.py for roofline.traffic).
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import statistics
+
+
+def find(d, pattern):
+    hits = glob.glob(os.path.join(d, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:100]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("raw")
+    ap.add_argument("out")
+    ap.add_argument("--kernel", default="step_kernel")
+    ap.add_argument("--n-envs", type=int, default=1 << 22)
+    ap.add_argument("--with-returns", type=int, default=1)
+    ap.add_argument("--latest", action="store_true")
+    a = ap.parse_args()
+    summ = {"raw_dir": a.raw, "kernel_filter": a.kernel, "n_envs": a.n_envs, "with_returns": bool(a.with_returns)}
+
+    stats = find(os.path.join(a.raw, "trace"), "*kernel_stats.csv")
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        with open(a.out + "_kernel_stats.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows[:12]:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+        for r in rows:
+            if a.kernel in r["Name"]:
+                summ["kernel"] = short(r["Name"])
+                summ["calls"] = int(r["Calls"])
+                summ["avg_ns"] = float(r["AverageNs"])
+                summ["min_ns"] = float(r["MinNs"])
+                summ["max_ns"] = float(r["MaxNs"])
+                break
+    trace = find(os.path.join(a.raw, "trace"), "*kernel_trace.csv")
+    if trace:
+        rows = [r for r in csv.DictReader(open(trace)) if a.kernel in r["Kernel_Name"]]
+        if rows:
+            d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+            summ["trace_median_ns"] = statistics.median(d)
+            summ["grid"] = int(rows[0]["Grid_Size_X"])
+            summ["workgroup"] = int(rows[0]["Workgroup_Size_X"])
+            summ["vgpr"] = int(rows[0]["VGPR_Count"])
+            summ["sgpr"] = int(rows[0]["SGPR_Count"])
+            summ["lds_bytes"] = int(rows[0]["LDS_Block_Size"])
+    for key, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        f = find(os.path.join(a.raw, key), "*counter_collection.csv")
+        if not f:
+            continue
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+                if a.kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        if vals:
+            summ[counter + "_KiB_median"] = statistics.median(vals)
+            summ[counter + "_launches"] = len(vals)
+    if "FETCH_SIZE_KiB_median" in summ and "WRITE_SIZE_KiB_median" in summ:
+        rd = 2.0 * summ["FETCH_SIZE_KiB_median"] * 1024.0      # gfx950: FETCH_SIZE = half the coalesced read bytes
+        wr = summ["WRITE_SIZE_KiB_median"] * 1024.0
+        summ["read_bytes_per_launch_corrected"] = rd
+        summ["write_bytes_per_launch"] = wr
+        summ["hbm_bytes_per_launch"] = rd + wr
+        per = 25 + (8 if a.with_returns else 0)
+        summ["algorithmic_bytes_per_launch"] = per * a.n_envs
+        summ["traffic_over_algorithmic"] = (rd + wr) / (per * a.n_envs)
+    bj = os.path.join(a.raw, "bench_trace.json")
+    if os.path.exists(bj):
+        try:
+            summ["bench_line_under_profiler"] = json.loads(open(bj).read().strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001
+            pass
+    with open(a.out + "_summary.json", "w") as f:
+        json.dump(summ, f, indent=1)
+    if a.latest and "hbm_bytes_per_launch" in summ:
+        with open(os.path.join(os.path.dirname(a.out), "pmc_latest.json"), "w") as f:
+            json.dump({"n_envs": a.n_envs, "with_returns": bool(a.with_returns),
+                       "hbm_bytes_per_launch": summ["hbm_bytes_per_launch"],
+                       "source": os.path.basename(a.out) + "_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                 "separate passes; FETCH_SIZE x2 gfx950 correction)"}, f, indent=1)
+    print(json.dumps({k: v for k, v in summ.items() if k != "bench_line_under_profiler"}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
