@@ -46,14 +46,22 @@ def hipcc_path():
     return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every csrc/*.hip into one shared library.  Returns its path."""
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    """Compile every csrc/*.hip into one shared library.  Returns its path.
+    `out` + `extra_flags` build an experimental variant next to the default library
+    (used by scripts/tune_variants.py; the product always loads LIB_PATH)."""
+    if out is not None:
+        return _compile(out, verbose, extra_flags)
     if not force and not is_stale():
         return LIB_PATH
+    return _compile(LIB_PATH, verbose, extra_flags)
+
+
+def _compile(LIB_PATH, verbose, extra_flags):
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libfishing_hip.so")
-    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     tmp = LIB_PATH + ".tmp.%d" % os.getpid()
     cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + sources() + ["-o", tmp]
     if verbose:

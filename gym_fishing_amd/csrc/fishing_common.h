@@ -248,13 +248,23 @@ __device__ __forceinline__ void load4(const T* p, int64_t base, int64_t n, bool 
     }
 }
 
-template <typename T>
+// NT = 1: nontemporal (streaming) store -- an experiment knob (scripts/tune_variants.py);
+// measured no faster than plain stores on gfx950 for this kernel, so the default is 0.
+template <typename T, int NT = 0>
 __device__ __forceinline__ void store4(T* p, int64_t base, int64_t n, bool full, const T (&in)[4]) {
     if (full) {
-        Vec4<T> q;
+        if (NT) {
+            typedef T VecT __attribute__((ext_vector_type(4)));
+            VecT q;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q.v[j] = in[j];
-        *reinterpret_cast<Vec4<T>*>(p + base) = q;
+            for (int j = 0; j < 4; ++j) q[j] = in[j];
+            __builtin_nontemporal_store(q, reinterpret_cast<VecT*>(p + base));
+        } else {
+            Vec4<T> q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q.v[j] = in[j];
+            *reinterpret_cast<Vec4<T>*>(p + base) = q;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)

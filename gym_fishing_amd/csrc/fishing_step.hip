@@ -15,8 +15,15 @@
 
 namespace fishing {
 
+#ifndef FISHING_STEP_ATTRS
+#define FISHING_STEP_ATTRS
+#endif
+#ifndef FISHING_NT_STORE
+#define FISHING_NT_STORE 0
+#endif
+
 template <typename T, int MODEL, int NOISE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) FISHING_STEP_ATTRS
 step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
             const uint64_t seed, const uint64_t step_counter) {
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
@@ -90,13 +97,14 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         const bool wave_done = __any(lane_done);
 
         if (active) {
-            if (b.reward) store4<T>(b.reward, base, n, full, rew);
-            if (b.terminal_obs) store4<T>(b.terminal_obs, base, n, full, obs_next);
+            if (b.reward) store4<T, FISHING_NT_STORE>(b.reward, base, n, full, rew);
+            if (b.terminal_obs) store4<T, FISHING_NT_STORE>(b.terminal_obs, base, n, full, obs_next);
             if (b.done) {
                 if (full) {
                     const uint32_t packed = (uint32_t)dn[0] | ((uint32_t)dn[1] << 8) |
                                             ((uint32_t)dn[2] << 16) | ((uint32_t)dn[3] << 24);
-                    *reinterpret_cast<uint32_t*>(b.done + base) = packed;
+                    if (FISHING_NT_STORE) __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(b.done + base));
+                    else *reinterpret_cast<uint32_t*>(b.done + base) = packed;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)

@@ -1,0 +1,226 @@
+"""GPU tests of the host-side mirror (gym_fishing_amd/envs.py): the reference's gym.Env
+protocol, scalar and vectorised, driven through the Python API a user of the reference
+would call.  Numerics are checked against the golden vectors / the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden_cases
+from oracle import fishing_oracle as fo
+
+pytestmark = pytest.mark.gpu
+CASES = {c.name: c for c in load_golden_cases()}
+
+
+@pytest.fixture(scope="module")
+def gf():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; none visible")
+    import gym_fishing_amd
+    return gym_fishing_amd
+
+
+def bits(x):
+    return np.asarray(x, dtype=np.float64).view(np.int64)
+
+
+@pytest.mark.parametrize("name", ["v1_sigma0_const", "v1_sigma01_random", "v1_params", "v1_edge_noreset",
+                                  "v0_sigma01_random", "v0_edge", "v2_sigma0_zeroquota", "v4_sigma005",
+                                  "v4_noinitreset"])
+def test_scalar_protocol_reproduces_reference(gf, name):
+    """make(id, **kw) with no num_envs: the reference's scalar protocol, types included
+    (base_fishing_env.py:60-91).  Noise = the reference's recorded normals (external-noise
+    mode); for fishing-v4 the recorded (K, r) are installed after each reset."""
+    c = CASES[name]
+    is_v2 = c.id == "fishing-v2"
+    for e in range(min(3, c.obs.shape[0])):
+        env = gf.make(c.id, **c.kwargs)
+        assert env.observation_space.shape == (1,) and env.num_envs == 1
+        if c.init_reset:
+            obs = env.reset()
+            assert isinstance(obs, np.ndarray) and obs.shape == (1,) and obs.dtype == np.float64
+        if c.id == "fishing-v4":
+            env.K, env.r = c.K[e, 0], c.r[e, 0]
+            if c.init_reset:
+                assert env.state[0] == c.reset_obs[e, 0]
+        for s in range(c.nsteps):
+            a = int(c.action[e, s]) if c.id == "fishing-v0" else np.array([c.action[e, s]], dtype=np.float32)
+            obs, rew, done, info = env.step(a, noise=[c.z[e, s]])
+            assert isinstance(obs, np.ndarray) and obs.shape == (1,) and obs.dtype == np.float64
+            assert isinstance(rew, float) and isinstance(done, bool) and info == {}
+            if is_v2:
+                assert abs(obs[0] - c.obs[e, s]) < 1e-15
+            else:
+                assert bits(obs[0]) == bits(c.obs[e, s]), (name, e, s)
+            assert bits(rew) == bits(c.reward[e, s]) and done == bool(c.done[e, s])
+            assert env.years_passed == c.t[e, s]
+            if done and c.auto_reset:
+                obs = env.reset()
+                assert bits(obs[0]) == bits(c.reset_obs[e, s + 1])
+                if c.id == "fishing-v4" and s + 1 < c.nsteps:
+                    env.K, env.r = c.K[e, s + 1], c.r[e, s + 1]
+        env.close()
+
+
+def test_reference_test_tipping_assertions(gf):
+    """tests/test-envs.py:93-106 verbatim against this package."""
+    env = gf.make("fishing-v2", sigma=0, init_state=0.75)
+    env.reset()
+    obs, reward, done, info = env.step(env.get_action(0))
+    assert env.get_fish_population(obs) >= 0.75
+    assert env.get_fish_population(obs) == 0.7641951637890196 or abs(env.get_fish_population(obs) - 0.7641951637890196) < 1e-15
+    env.init_state = 0.3
+    env.reset()
+    obs, reward, done, info = env.step(env.get_action(0))
+    assert env.get_fish_population(obs) <= 0.3
+
+
+def test_vectorised_protocol_shapes_dtypes_and_auto_reset(gf):
+    import torch
+    n = 1000
+    env = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=3, Tmax=4, record_terminal_obs=True, done_bits=True,
+                  track_returns=True)
+    assert env.num_envs == n and env.auto_reset and env.dtype == torch.float32
+    obs = env.reset()
+    assert obs.shape == (n, 1) and obs.dtype == torch.float32 and obs.is_cuda
+    assert bool((obs == -0.25).all())
+    total_done = 0
+    for s in range(12):
+        a = torch.full((n, 1), -0.9, device="cuda")
+        obs, rew, done, info = env.step(a)
+        assert obs.shape == (n, 1) and rew.shape == (n,) and done.shape == (n,) and done.dtype == torch.bool
+        term = info["terminal_observation"]
+        assert term.shape == (n, 1)
+        # SB3 semantics: finished envs already show the reset observation, terminal obs is kept
+        assert bool((obs[done] == -0.25).all()) and bool((obs[~done] == term[~done]).all())
+        bits_ = info["done_bits"].cpu().numpy().view(np.uint64)
+        unpacked = ((bits_[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).reshape(-1)[:n]
+        assert (unpacked.astype(bool) == done.cpu().numpy()).all()
+        total_done += int(done.sum())
+    stats = env.episode_stats()
+    assert stats["n_episodes"] == total_done and total_done >= 2 * n    # Tmax=4 -> 5-step episodes
+    assert 0 < stats["mean_length"] <= 5
+    # numpy / list actions are accepted too (copied to the device)
+    obs, rew, done, _ = env.step(np.full((n, 1), -0.9, dtype=np.float32))
+    assert obs.shape == (n, 1)
+    with pytest.raises(ValueError):
+        env.step(np.zeros(n + 1, dtype=np.float32))
+    # render() works (the reference's raises, quirk B10) and reports [t, obs, action, reward]
+    row = env.render(index=5)
+    assert len(row) == 4 and abs(row[2] + 0.9) < 1e-6
+
+
+def test_vectorised_matches_oracle_through_python_api(gf):
+    """fishing-v0 via the class API at N = 4096, in-kernel noise, vs the oracle on the
+    device's own normals (read back with the noise hook)."""
+    import torch
+    import hip_harness as hh
+    n, seed = 4096, 42
+    env = gf.make("fishing-v0", sigma=0.2, n_actions=50, num_envs=n, seed=seed, auto_reset=False)
+    obs = env.reset().clone()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    t = np.zeros(n, np.int32)
+    for s in range(5):
+        a = torch.randint(0, 50, (n,), device="cuda", generator=g)
+        o_prev = obs.cpu().numpy().reshape(-1)
+        obs, rew, done, _ = env.step(a)
+        z = hh.device_step_noise(n, seed, s)
+        eo, er, ed, t, _ = fo.step(fo.MODEL_V0, o_prev, t, a.cpu().numpy().astype(np.int32), z, 0.3, 1.0, 0.2,
+                                   n_actions=50, dtype=np.float32)
+        assert np.array_equal(obs.cpu().numpy().reshape(-1), eo) and np.array_equal(rew.cpu().numpy(), er)
+        assert np.array_equal(done.cpu().numpy(), ed.astype(bool))
+        obs = obs.clone()
+
+
+def test_masked_reset_and_seed(gf):
+    import torch
+    n = 256
+    env = gf.make("fishing-v4", sigma=0.05, num_envs=n, seed=9, auto_reset=False)
+    env.reset()
+    K0 = env.K.clone()
+    a = torch.full((n,), -0.8, device="cuda")
+    env.step(a)
+    mask = torch.zeros(n, dtype=torch.bool, device="cuda")
+    mask[::2] = True
+    before = env.state.clone()
+    env.reset(mask=mask)
+    st = env.state.reshape(-1)
+    assert bool((st[::2] == 0.75).all())                     # v4 reset obs is un-normalised x0 (quirk B8)
+    assert bool((st[1::2] == before.reshape(-1)[1::2]).all())
+    assert bool((env.K[1::2] == K0[1::2]).all()) and bool((env.K[::2] != K0[::2]).any())
+    assert bool((env.years_passed[::2] == 0).all()) and bool((env.years_passed[1::2] == 1).all())
+    # same seed -> same parameter draws
+    env2 = gf.make("fishing-v4", sigma=0.05, num_envs=n, seed=9, auto_reset=False)
+    env2.reset()
+    assert bool((env2.K == K0).all())
+    # K, r ~ N(mean, sigma_p) clipped at 0
+    big = gf.make("fishing-v4", sigma_p=0.1, num_envs=1 << 16, seed=1)
+    big.reset()
+    K = big.K.double()
+    assert abs(float(K.mean()) - 1.0) < 2e-3 and abs(float(K.std()) - 0.1) < 2e-3 and float(K.min()) >= 0
+
+
+def test_helpers_match_reference_maps(gf, anchors):
+    """get_quota / get_action / get_fish_population / get_state (base_fishing_env.py:135-164)."""
+    import torch
+    env0 = gf.make("fishing-v0")
+    env1 = gf.make("fishing-v1")
+    q = np.linspace(0.0, 1.0, 21)
+    assert [int(env0.get_action(x)) for x in q] == anchors["get_action_v0"]
+    assert [float(env1.get_action(x)) for x in q] == anchors["get_action_v1"]
+    assert [float(env0.get_quota(int(a))) for a in range(0, 101, 5)] == anchors["get_quota_v0"]
+    assert env1.get_quota(np.array([5.0])) == 2.0 and env1.get_quota(np.array([-5.0])) == 0.0
+    assert env1.get_fish_population(np.array([-0.25])) == 0.75
+    assert env1.get_state(0.75)[0] == -0.25
+    v = gf.make("fishing-v1", K=2.0, num_envs=8)
+    pop = v.get_fish_population(torch.full((8, 1), -0.5, device="cuda"))
+    assert pop.shape == (8,) and bool((pop == 1.0).all())
+    assert bool((v.get_quota(torch.full((8,), 0.5, device="cuda")) == 3.0).all())
+    assert v.get_attr("Tmax")[0] == 100 and len(v.get_attr("Tmax")) == 8
+    assert v.env_method("get_fish_population", np.array([-0.5]), indices=3)[0] == 1.0
+
+
+def test_fused_rollout_api_and_stats(gf):
+    import torch
+    n = 1 << 14
+    env = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=11, track_returns=True)
+    env.reset()
+    env.rollout(303, policy="escapement", param=0.5)          # 3 full 101-step episodes per env
+    s = env.episode_stats()
+    assert s["n_episodes"] >= 3 * n - 5 and 90 < s["mean_length"] <= 101
+    # constant-escapement is the known optimum: ~ MSY * 100 per episode for r=0.3, K=1
+    assert 6.5 < s["mean_return"] < 9.0
+    env2 = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=11, track_returns=True)
+    env2.reset()
+    env2.rollout(303, policy="random")
+    s2 = env2.episode_stats()
+    assert s2["mean_return"] < s["mean_return"]
+    traj = gf.make("fishing-v1", sigma=0.0, num_envs=8).rollout(5, policy="constant", param=-0.9375, record=True)
+    assert traj.shape == (5, 4, 8)
+    assert float(traj[1, 0, 0]) == pytest.approx(float.fromhex("-0x1.fc00000000000p-3"), abs=1e-7)
+    assert bool((traj[:, 2] == 0.0625).all())
+
+
+def test_step_many_equals_repeated_step(gf):
+    import torch
+    n = 5000
+    acts = torch.rand((4, n), device="cuda") * 2 - 1
+    a = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=5)
+    b = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=5)
+    a.reset()
+    b.reset()
+    a.step_many(acts, 10)
+    for k in range(10):
+        b.step(acts[k % 4])
+    assert torch.equal(a.state, b.state) and torch.equal(a.years_passed, b.years_passed)
+
+
+def test_render_writes_csv(gf, tmp_path):
+    f = tmp_path / "log.csv"
+    env = gf.make("fishing-v1", file=str(f))
+    env.reset()
+    env.step(np.array([-0.9375], dtype=np.float32))
+    row = env.render()
+    env.close()
+    assert row[0] == 1 and row[3] == 0.0625
+    assert f.read_text().strip().split(",")[0] == "1"
