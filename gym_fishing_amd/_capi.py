@@ -55,6 +55,8 @@ SIGNATURES = {
     "fishing_rollout_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),
     "fishing_rollout_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),
     "fishing_reduce_returns": (c_i32, [c_vp, c_vp, c_vp]),
+    "fishing_population_draw_f32": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "fishing_population_draw_f64": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "fishing_noise_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_i32, c_vp, c_vp, c_vp, c_vp]),
 }
 

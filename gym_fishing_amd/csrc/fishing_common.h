@@ -170,16 +170,33 @@ __device__ __forceinline__ T quota_int(int32_t a, int32_t n_actions, T K) {
 }
 
 // get_action (base_fishing_env.py:149-156), used by the in-kernel escapement / MSY policies
-// (models/policies.py:17-19, :29-31).  Continuous: quota / K - 1, NOT rounded to float32 (the
-// reference hands the Python float straight back to step()); discrete: Python round(),
-// i.e. round-half-even, of quota * n_actions / K.
+// (models/policies.py:17-19, :29-31).  Continuous: quota / K - 1 evaluated in T, then
+// rounded to float32 -- the dtype of the action Box the reference clips to
+// (base_fishing_env.py:143-145; with the reference's pinned NumPy 1.19 np.clip against the
+// float32 bounds returns float32), so an in-kernel policy emits exactly what a caller could
+// pass through the float32 action stream.  Discrete: Python round(), i.e. round-half-even,
+// of quota * n_actions / K.
 template <typename T>
-__device__ __forceinline__ T action_cts_from_quota(T quota, T K) {
-    return quota / K - (T)1;
+__device__ __forceinline__ float action_cts_from_quota(T quota, T K) {
+    return (float)(quota / K - (T)1);
 }
 template <typename T>
 __device__ __forceinline__ int32_t action_int_from_quota(T quota, int32_t n_actions, T K) {
     return (int32_t)__builtin_rint((double)(quota * (T)n_actions / K));
+}
+
+// population_draw(): base_fishing_env.py:121-133 (logistic), fishing_tipping_env.py:24-35
+// (tipping point; the noise sits inside the exponent, scaled by x -- quirk B9).
+template <typename T, int MODEL>
+__device__ __forceinline__ T population_draw(T x, T z, T r, T K, T sigma, T C) {
+    T g;
+    if (MODEL == FISHING_MODEL_V2) {
+        const T e = ((r * ((T)1 - (x / K))) * (x - C)) + ((x * sigma) * z);
+        g = x * exp_t<T>(e);
+    } else {
+        g = (x + ((r * x) * ((T)1 - (x / K)))) + ((x * sigma) * z);
+    }
+    return (g > (T)0) ? g : ((g != g) ? g : (T)0);   // np.maximum(g, 0.0): NaN-propagating, -0 -> +0
 }
 
 // One reference step() on one env.  Returns through refs.
@@ -191,14 +208,7 @@ __device__ __forceinline__ void env_step(T obs, int32_t t, T quota, T z, T r, T 
     const T h = (quota < x) ? quota : x;      // min(x, quota)        :117
     const T d = x - h;
     x = ((T)0 > d) ? (T)0 : d;                // max(x - h, 0.0)      :118
-    T g;
-    if (MODEL == FISHING_MODEL_V2) {          // fishing_tipping_env.py:25-34
-        const T e = ((r * ((T)1 - (x / K))) * (x - C)) + ((x * sigma) * z);
-        g = x * exp_t<T>(e);
-    } else {                                  // base_fishing_env.py:125-131
-        g = (x + ((r * x) * ((T)1 - (x / K)))) + ((x * sigma) * z);
-    }
-    x = (g > (T)0) ? g : ((g != g) ? g : (T)0);   // np.maximum(g, 0.0): NaN-propagating, -0 -> +0
+    x = population_draw<T, MODEL>(x, z, r, K, sigma, C);
     obs_next = x / K - (T)1;                  // get_state            :163
     reward = ((T)0 > h) ? (T)0 : h;           // max(harvest, 0.0)    :74
     t_next = t + 1;                           //                      :75

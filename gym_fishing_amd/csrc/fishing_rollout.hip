@@ -103,7 +103,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                         q = policy_param;
                     }
                     if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_quota<T>(q, p.n_actions, KK[j]);
-                    else a_c = action_cts_from_quota<T>(q, KK[j]);
+                    else a_c = (T)action_cts_from_quota<T>(q, KK[j]);
                 }
                 const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j])
                                                             : quota_cts<T>(a_c, KK[j]);

@@ -220,6 +220,16 @@ reduce_returns_kernel(const double* __restrict__ partials, double* __restrict__ 
     if (lane == 0) out4[field] = s;
 }
 
+// population_draw() over an array of populations, as BMSY() drives it (models/policies.py:59-63)
+template <typename T, int MODEL>
+__global__ void __launch_bounds__(256)
+population_draw_kernel(const ParamsT<T> p, const int64_t n, const T* __restrict__ x_in,
+                       const T* __restrict__ z, T* __restrict__ x_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, p.r, p.K, p.sigma, p.C);
+}
+
 __global__ void __launch_bounds__(256)
 noise_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, const uint64_t counter,
              const uint32_t stream_tag, uint32_t* __restrict__ words, float* __restrict__ z0,
@@ -364,9 +374,37 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
     return (int)hipGetLastError();
 }
 
+template <typename T>
+int population_draw_impl(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
+                         fishing_stream_t stream) {
+    if (!p || !x_in || !x_out) return FISHING_ERR_NULL;
+    if (n < 0) return FISHING_ERR_SIZE;
+    if (n == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    int64_t nb = (n + 255) / 256;
+    const int blocks = (int)(nb < 2048 ? nb : 2048);
+    hipStream_t s = (hipStream_t)stream;
+    if (p->model == FISHING_MODEL_V2)
+        population_draw_kernel<T, FISHING_MODEL_V2><<<blocks, 256, 0, s>>>(pt, n, (const T*)x_in, (const T*)z, (T*)x_out);
+    else if (p->model == FISHING_MODEL_V0 || p->model == FISHING_MODEL_V1 || p->model == FISHING_MODEL_V4)
+        population_draw_kernel<T, FISHING_MODEL_V1><<<blocks, 256, 0, s>>>(pt, n, (const T*)x_in, (const T*)z, (T*)x_out);
+    else
+        return FISHING_ERR_MODEL;
+    return (int)hipGetLastError();
+}
+
 }  // namespace fishing
 
 extern "C" {
+
+int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
+                                fishing_stream_t stream) {
+    return fishing::population_draw_impl<float>(p, n, x_in, z, x_out, stream);
+}
+int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
+                                fishing_stream_t stream) {
+    return fishing::population_draw_impl<double>(p, n, x_in, z, x_out, stream);
+}
 
 int fishing_abi_version(void) { return FISHING_ABI_VERSION; }
 

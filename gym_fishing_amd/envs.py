@@ -355,6 +355,8 @@ class BaseFishingEnv:
     def rollout(self, n_steps, policy="random", param=0.0, record=False):
         """n_steps of step() inside one kernel with an in-kernel policy (csrc/fishing_rollout.hip).
         record=True returns the [n_steps, 4, N] table {obs_in, action, reward, done}."""
+        if isinstance(policy, tuple):                 # ("constant", a) or a policies.* kernel_policy pair
+            policy, param = policy
         pol = POLICIES[policy] if isinstance(policy, str) else int(policy)
         traj = None
         if record:
@@ -402,9 +404,11 @@ class BaseFishingEnv:
             if isinstance(action, torch.Tensor):
                 return (action.to(torch.float64) / self.n_actions) * K
             return (action / self.n_actions) * K
+        # the action passes through the float32 action Box (np.clip against its float32 bounds),
+        # then the quota is formed in float64
         if isinstance(action, torch.Tensor):
-            return (action.to(torch.float64).clamp(-1.0, 1.0).reshape(-1) + 1.0) * K
-        a = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0).reshape(-1)[0]
+            return (action.to(torch.float32).to(torch.float64).clamp(-1.0, 1.0).reshape(-1) + 1.0) * K
+        a = np.clip(np.asarray(action, dtype=np.float32).astype(np.float64), -1.0, 1.0).reshape(-1)[0]
         return (a + 1) * K
 
     def get_action(self, quota):
@@ -433,6 +437,43 @@ class BaseFishingEnv:
         if isinstance(fish_population, torch.Tensor):
             return (fish_population / K - 1.0).reshape(-1, 1)
         return np.array([fish_population / K - 1])
+
+    def population_draw(self, x=None, noise=None, sigma=None):
+        """base_fishing_env.py:121-133 (v2: fishing_tipping_env.py:24-35) over an array of
+        populations -- the call BMSY() makes (models/policies.py:59-63).  `x` None uses
+        self.fish_population like the reference's zero-argument form (scalar protocol)."""
+        use_attr = x is None
+        if use_attr:
+            x = self.fish_population
+        xt = torch.as_tensor(x).to(device=self.device, dtype=self.dtype).reshape(-1).contiguous()
+        zt = None
+        if noise is not None:
+            zt = torch.as_tensor(noise).to(device=self.device, dtype=self.dtype).reshape(-1).contiguous()
+        out = torch.empty_like(xt)
+        cp = self._c_params()
+        if sigma is not None:
+            cp.sigma = float(sigma)
+        fn = getattr(self._lib, "fishing_population_draw_" + self._suffix)
+        with torch.cuda.device(self.device):
+            rc = fn(cp, xt.numel(), xt.data_ptr(), zt.data_ptr() if zt is not None else None, out.data_ptr(),
+                    self._stream())
+        _capi.check(rc, "fishing_population_draw")
+        if isinstance(x, torch.Tensor):
+            return out.reshape(x.shape)
+        res = out.cpu().numpy().astype(np.float64)
+        res = res.reshape(np.shape(x)) if np.ndim(x) else float(res[0])
+        if use_attr:
+            self.fish_population = res
+        return res
+
+    # the reference exposes its helpers as methods (base_fishing_env.py:100-110)
+    def simulate(self, model, reps=1):
+        from .rollout import simulate_mdp
+        return simulate_mdp(self, model, reps)
+
+    def policyfn(self, model, reps=1):
+        from .rollout import estimate_policyfn
+        return estimate_policyfn(self, model, reps)
 
     # ------------------------------------------------------------------ render / close
     def render(self, mode="human", index=0):

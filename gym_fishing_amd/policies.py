@@ -1,0 +1,69 @@
+"""The reference's non-learned policies (gym_fishing/models/policies.py:4-67) on top of the
+HIP env: MSY constant quota, constant escapement, and the BMSY growth-curve sweep.
+
+All three return `(action, obs)` from `predict(obs)` SB3-style, work with the scalar
+protocol and with N-env tensors, and carry `kernel_policy = (policy_id, param)` so that
+`env.simulate(model)` / `env.rollout(policy=...)` can run them inside the fused rollout
+kernel (csrc/fishing_rollout.hip) instead of calling predict() per step.
+"""
+import numpy as np
+import torch
+
+from ._capi import POLICY_ESCAPEMENT, POLICY_MSY
+from .spaces import is_discrete
+
+
+def BMSY(env, n=10001):
+    """models/policies.py:51-67: sweep n states of the observation Box through one noiseless
+    population_draw() on the device and return the population with the largest growth.
+    Like the reference, this resets the environment.  Evaluated in the env's dtype (float64
+    for the scalar protocol: S = K/2 for the logistic models; the float32 layout reproduces
+    the 0.4996 a float32 evaluation of the flat maximum gives)."""
+    grid = np.linspace(env.observation_space.low, env.observation_space.high, num=n,
+                       dtype=env.observation_space.dtype).reshape(-1)
+    state = torch.as_tensor(grid, device=env.device).to(env.dtype)
+    K = float(env.params["K"])
+    x0 = (state + 1.0) * K                                       # get_fish_population :158-160
+    growth = env.population_draw(x0, sigma=0.0) - x0
+    S = float(x0[int(torch.argmax(growth))])
+    env.reset()
+    return S
+
+
+class msy:
+    """models/policies.py:4-19: harvest the constant quota MSY = f(BMSY) - BMSY."""
+
+    def __init__(self, env, **kwargs):
+        self.env = env
+        self.S = BMSY(env)
+        x = torch.tensor([self.S], dtype=env.dtype, device=env.device)
+        self.msy = float(env.population_draw(x, sigma=0.0)[0] - x[0])
+        env.reset()
+        self.kernel_policy = (POLICY_MSY, self.msy)
+
+    def predict(self, obs, **kwargs):
+        action = self.env.get_action(self.msy)
+        if isinstance(obs, torch.Tensor) and obs.dim() >= 1 and obs.shape[0] == self.env.num_envs and not self.env._scalar:
+            dt = torch.int64 if is_discrete(self.env.action_space) else torch.float32
+            action = torch.as_tensor(action, device=obs.device).to(dt).expand(self.env.num_envs).reshape(-1, 1)
+        return action, obs
+
+
+class escapement:
+    """models/policies.py:22-31: harvest everything above the escapement level S = BMSY."""
+
+    def __init__(self, env, **kwargs):
+        self.env = env
+        self.S = BMSY(env)
+        self.kernel_policy = (POLICY_ESCAPEMENT, self.S)
+
+    def predict(self, obs, **kwargs):
+        pop = self.env.get_fish_population(obs)
+        if isinstance(pop, torch.Tensor):
+            quota = torch.clamp(pop - self.S, min=0.0)
+            action = self.env.get_action(quota)
+            if not is_discrete(self.env.action_space):
+                action = action.to(torch.float32)
+            return action.reshape(-1, 1), obs
+        quota = max(pop - self.S, 0.0)
+        return self.env.get_action(quota), obs

@@ -1,0 +1,132 @@
+"""Rollout recording = the reference's simulate helpers (gym_fishing/envs/shared_env.py:29-102)
+producing the same `[time, state, action, reward, rep]` table.
+
+* scalar protocol: the reference's loop, verbatim in behaviour (record before acting, quota
+  and reward of the previous step, break on done, at most Tmax rows per rep).
+* N-env tensor protocol: every env is one rep; a model that carries `kernel_policy`
+  (policies.msy / policies.escapement, or the strings "random" / ("constant", a)) runs inside
+  the fused rollout kernel and the table is cut from its `[T][4][N]` record; any other model
+  is driven step by step with batched predict().
+Returns a pandas DataFrame when pandas is importable, else a dict of NumPy columns.
+"""
+import numpy as np
+import torch
+
+from ._capi import POLICY_CONSTANT, POLICY_RANDOM
+
+COLUMNS = ["time", "state", "action", "reward", "rep"]
+
+
+def _table(rows):
+    arr = np.asarray(rows, dtype=np.float64).reshape(-1, 5)
+    try:
+        from pandas import DataFrame
+        df = DataFrame(arr, columns=COLUMNS)
+        df["rep"] = df["rep"].astype(int)
+        return df
+    except ImportError:
+        return {c: arr[:, i] for i, c in enumerate(COLUMNS)}
+
+
+def _kernel_policy(model):
+    if isinstance(model, str) and model == "random":
+        return POLICY_RANDOM, 0.0
+    if isinstance(model, tuple) and len(model) == 2 and model[0] == "constant":
+        return POLICY_CONSTANT, float(model[1])
+    return getattr(model, "kernel_policy", None)
+
+
+def simulate_mdp(env, model, reps=1):
+    """shared_env.py:29-54."""
+    if not env._scalar:
+        return simulate_mdp_vec(env, model, reps * env.num_envs)
+    rows = []
+    for rep in range(reps):
+        obs = env.reset()
+        quota, reward = 0.0, 0.0
+        for t in range(env.Tmax):
+            rows.append([t, env.get_fish_population(obs), quota, reward, int(rep)])
+            action, _ = model.predict(obs)
+            obs, reward, done, _ = env.step(action)
+            if isinstance(action, np.ndarray):
+                action = action.reshape(-1)[0]
+            quota = env.get_quota(action)
+            if done:
+                break
+    return _table(rows)
+
+
+def _cut_tables(env, traj, rep0):
+    """[T][4][N] record {obs_in, action, reward, done} -> rows of the simulate table."""
+    T, _, N = traj.shape
+    obs_in, act, rew, done = (traj[:, k].to(torch.float64) for k in range(4))
+    K = env._K_arr.to(torch.float64).reshape(1, N) if env._per_env else float(env.params["K"])
+    state = (obs_in + 1.0) * K                                   # get_fish_population :158-160
+    if env.MODEL == 0:
+        quota = (act / env.n_actions) * K                        # get_quota :140
+    else:
+        quota = (act.clamp(-1.0, 1.0) + 1.0) * K                 # get_quota :143-146 (act is float32-valued)
+    zeros = torch.zeros((1, N), dtype=torch.float64, device=traj.device)
+    quota_prev = torch.cat([zeros, quota[:-1]])
+    rew_prev = torch.cat([zeros, rew[:-1]])
+    ended = torch.cumsum(done, 0) - done          # > 0 on rows after the episode's last step
+    keep = ended == 0
+    t_idx = torch.arange(T, device=traj.device, dtype=torch.float64).reshape(T, 1).expand(T, N)
+    rep = (rep0 + torch.arange(N, device=traj.device, dtype=torch.float64)).reshape(1, N).expand(T, N)
+    cols = torch.stack([t_idx, state, quota_prev, rew_prev, rep], dim=-1)     # [T, N, 5]
+    cols = cols.permute(1, 0, 2)[keep.t()]                                    # rep-major, time order
+    return cols.cpu().numpy()
+
+
+def simulate_mdp_vec(env, model, n_eval_episodes):
+    """shared_env.py:57-79 in spirit: n_eval_episodes must be a multiple of num_envs; each env
+    of each batch is one rep.  Rows follow simulate_mdp's convention (at most Tmax per rep)."""
+    if n_eval_episodes % env.num_envs:
+        raise AssertionError("number of evaluations needs to be divisible by the number of parallel environments")
+    batches = n_eval_episodes // env.num_envs
+    kp = _kernel_policy(model)
+    out = []
+    saved = env.auto_reset
+    env.auto_reset = False
+    try:
+        for b in range(batches):
+            env.reset()
+            if kp is not None and env.num_envs % 4 == 0:
+                traj = env.rollout(env.Tmax, policy=kp[0], param=kp[1], record=True)
+            else:
+                traj = torch.zeros((env.Tmax, 4, env.num_envs), dtype=env.dtype, device=env.device)
+                obs = env.state
+                for t in range(env.Tmax):
+                    traj[t, 0] = obs.reshape(-1)
+                    action, _ = model.predict(obs)
+                    a = torch.as_tensor(action, device=env.device).reshape(-1)
+                    traj[t, 1] = a.to(env.dtype)
+                    obs, rew, done, _ = env.step(a)
+                    traj[t, 2], traj[t, 3] = rew, done.to(env.dtype)
+            out.append(_cut_tables(env, traj, b * env.num_envs))
+    finally:
+        env.auto_reset = saved
+    return _table(np.concatenate(out) if out else np.zeros((0, 5)))
+
+
+def estimate_policyfn(env, model, reps=1, n=50):
+    """shared_env.py:82-102: the policy's quota over a grid of n observations."""
+    grid = np.linspace(env.observation_space.low, env.observation_space.high, num=n,
+                       dtype=env.observation_space.dtype)
+    rows = []
+    for rep in range(reps):
+        for obs in grid:
+            action, _ = model.predict(obs)
+            if isinstance(action, np.ndarray):
+                action = action.reshape(-1)[0]
+            if isinstance(action, torch.Tensor):
+                action = action.reshape(-1)[0].item()
+            pop = env.get_fish_population(obs)
+            quota = env.get_quota(action)
+            rows.append([float(pop), float(quota), rep])
+    arr = np.asarray(rows, dtype=np.float64)
+    try:
+        from pandas import DataFrame
+        return DataFrame(arr, columns=["state", "action", "rep"])
+    except ImportError:
+        return {"state": arr[:, 0], "action": arr[:, 1], "rep": arr[:, 2]}

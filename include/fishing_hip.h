@@ -144,6 +144,15 @@ int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, c
  * the host (RCCL). */
 int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream);
 
+/* population_draw() (envs/base_fishing_env.py:121-133; v2: envs/fishing_tipping_env.py:24-35)
+ * over an array of populations with the scalar r, K, sigma, C of `p`: x_out[i] = growth of
+ * x_in[i] under noise z[i] (z nullable => 0).  This is how the reference's BMSY() sweeps the
+ * growth curve (models/policies.py:59-63). */
+int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
+                                fishing_stream_t stream);
+int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
+                                fishing_stream_t stream);
+
 /* Test/diagnostic: the generator itself.  For env (env_offset + i): words[4*i..4*i+3] =
  * Philox4x32-10 block, z0/z1 = the two Box-Muller normals (z0 is the step noise).
  * Any output pointer may be NULL. */

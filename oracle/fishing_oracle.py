@@ -55,10 +55,8 @@ def quota_from_action(model, action, K, n_actions, dtype=np.float64):
     if model == MODEL_V0:
         a = np.asarray(action).astype(dtype)       # exact for |a| < 2**24 (f32) / 2**53 (f64)
         return (a / dt(n_actions)) * K
-    a = np.asarray(action)
-    if a.dtype != np.float64:                      # a float64 action (the escapement / MSY
-        a = a.astype(np.float32)                   # policies pass Python floats) is used as is
-    a = np.clip(a.astype(dtype), dt(-1.0), dt(1.0))
+    a = np.asarray(action, dtype=np.float32).astype(dtype)
+    a = np.clip(a, dt(-1.0), dt(1.0))
     return (a + dt(1.0)) * K
 
 
@@ -204,6 +202,26 @@ def policy_random_action(model, seed, env_index, step_counter, n_actions=100):
     if model == MODEL_V0:
         return ((w.astype(np.uint64) * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int32)
     return w.astype(np.float32) * np.float32(2.0 ** -31) - np.float32(1.0)
+
+
+def policy_action(policy, param, model, obs, K, n_actions=100, dtype=np.float64):
+    """The reference's non-learned policies as the rollout kernel evaluates them
+    (models/policies.py:16-19 msy, :27-31 escapement): quota -> get_action (:149-156).
+    Continuous actions are float32 (the action Box dtype the reference clips to); discrete
+    ones use Python round() = round-half-even."""
+    dt = np.dtype(dtype).type
+    obs = np.asarray(obs, dtype=dtype)
+    K = np.asarray(K, dtype=dtype)
+    if policy == "escapement":
+        d = (obs + dt(1.0)) * K - dt(param)
+        q = np.where(dt(0.0) > d, dt(0.0), d)                     # max(x - S, 0.0)
+    elif policy == "msy":
+        q = np.broadcast_to(dt(param), obs.shape)
+    else:
+        raise ValueError(policy)
+    if model == MODEL_V0:
+        return np.rint((q * dt(n_actions) / K).astype(np.float64)).astype(np.int32)
+    return (q / K - dt(1.0)).astype(np.float32)
 
 
 def reset_normals(seed, env_index, counter, stream):

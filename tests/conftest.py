@@ -52,3 +52,21 @@ def golden_cases():
 def anchors():
     with open(os.path.join(GOLDEN, "reference_anchors.json")) as f:
         return json.load(f)
+
+
+def load_policy_sims():
+    """Reference env.simulate(msy / escapement) tables at sigma = 0 (tests/golden/make_golden.py)."""
+    with open(os.path.join(GOLDEN, "reference_anchors.json")) as f:
+        anchors = json.load(f)
+    sims = np.load(os.path.join(GOLDEN, "reference_policy_sims.npz"))
+    out = []
+    for key in sorted(sims.files):
+        parts = key.split("_")
+        pname, tag = parts[-1], "_".join(parts[1:-1])
+        a = anchors["policy_" + tag]
+        kw = a["kwargs"]
+        out.append(dict(key=key, env_id="fishing-" + tag[:2], policy=pname,
+                        param=a["BMSY"] if pname == "escapement" else a["msy"], table=sims[key][:, :4],
+                        K=float(kw.get("K", 1.0)), r=float(kw.get("r", 0.3)), x0=float(kw.get("init_state", 0.75)),
+                        n_actions=int(kw.get("n_actions", 100))))
+    return out

@@ -242,17 +242,33 @@ def main():
     anchors["test_tipping"] = {"from_0.75": hi, "from_0.3": lo}
     assert hi >= 0.75 and lo <= 0.3
 
-    # --- "next" rows: BMSY / msy / escapement known answers, sigma=0 simulate tables
+    # --- "next" rows: BMSY / msy / escapement known answers, sigma=0 simulate tables.
+    # The policies hand step() a Python / NumPy float; with the reference's pinned NumPy 1.19
+    # np.clip against the float32 Box bounds returns float32 and the quota is then formed in
+    # float64 (Appendix A.3).  NumPy 2 would keep float64 through the clip, so the policy is
+    # wrapped to round its continuous action to float32 and pass it on as a float64 array --
+    # the same "float32 value, float64 arithmetic" convention as the trajectory fixtures.
+    class RefEra:
+        def __init__(self, model, discrete):
+            self.model, self.discrete = model, discrete
+
+        def predict(self, obs, **kw):
+            a, st = self.model.predict(obs, **kw)
+            if not self.discrete:
+                a = np.array([a], dtype=np.float32).astype(np.float64)
+            return a, st
+
     sims = {}
     for env_id, kw in (("fishing-v0", {}), ("fishing-v1", {}), ("fishing-v2", {}),
-                       ("fishing-v1", {"r": 0.5, "K": 2.0, "init_state": 1.1})):
+                       ("fishing-v1", {"r": 0.5, "K": 2.0, "init_state": 1.1}),
+                       ("fishing-v0", {"n_actions": 37, "r": 0.4})):
         tag = env_id[-2:] + ("_params" if kw else "")
         env = gym.make(env_id, sigma=0.0, **kw)
         S = float(BMSY(env))
         m = msy(env)
-        anchors["policy_" + tag] = {"BMSY": S, "msy": float(m.msy)}
+        anchors["policy_" + tag] = {"BMSY": S, "msy": float(m.msy), "kwargs": kw}
         for pname, model in (("msy", m), ("escapement", escapement(env))):
-            df = env.simulate(model, reps=1)
+            df = env.simulate(RefEra(model, env_id == "fishing-v0"), reps=1)
             sims["sim_%s_%s" % (tag, pname)] = df.to_numpy(dtype=np.float64)
             anchors["policy_" + tag]["sum_reward_" + pname] = float(df.reward.sum())
             anchors["policy_" + tag]["rows_" + pname] = int(len(df))

@@ -224,3 +224,104 @@ def test_render_writes_csv(gf, tmp_path):
     env.close()
     assert row[0] == 1 and row[3] == 0.0625
     assert f.read_text().strip().split(",")[0] == "1"
+
+
+# ------------------------------------------------------------------ policies + simulate
+from conftest import load_policy_sims  # noqa: E402
+
+SIMS = load_policy_sims()
+
+
+@pytest.mark.parametrize("tag,env_id,kw", [("v0", "fishing-v0", {}), ("v1", "fishing-v1", {}), ("v2", "fishing-v2", {}),
+                                           ("v1_params", "fishing-v1", {"r": 0.5, "K": 2.0, "init_state": 1.1}),
+                                           ("v0_params", "fishing-v0", {"n_actions": 37, "r": 0.4})])
+def test_bmsy_and_msy_reproduce_reference_values(gf, anchors, tag, env_id, kw):
+    """models/policies.py:51-67 on the device.  In the float32 layout the sweep reproduces the
+    reference's values bit-for-bit (the reference under NumPy 2 evaluates the 10001-point
+    growth curve in float32: S = 0.4996 for the flat logistic maximum); in float64 it finds
+    the exact optimum K/2."""
+    import torch
+    from gym_fishing_amd.policies import BMSY, msy
+    env = gf.make(env_id, sigma=0.0, num_envs=4, dtype=torch.float32, **kw)
+    a = anchors["policy_" + tag]
+    m = msy(env)
+    if env_id == "fishing-v2":
+        # v_exp_f32 != np.exp in the last bits and the maximum of the growth curve is flat:
+        # the argmax may move a few cells of the 2e-4 grid; the MSY value itself barely changes
+        assert abs(m.S - a["BMSY"]) <= 1e-3 and abs(m.msy - a["msy"]) <= 1e-6
+    else:
+        assert m.S == a["BMSY"] and BMSY(env) == a["BMSY"]
+        assert m.msy == a["msy"]
+    if env_id != "fishing-v2":
+        env64 = gf.make(env_id, sigma=0.0, **kw)
+        assert BMSY(env64) == kw.get("K", 1) / 2
+
+
+@pytest.mark.parametrize("c", SIMS, ids=[c["key"] for c in SIMS])
+def test_env_simulate_reproduces_reference_tables(gf, c):
+    """env.simulate(model) (base_fishing_env.py:100-101 -> shared_env.py:29-54) through the
+    scalar protocol (Python loop + fp64 kernel) and through the N-env fused rollout; the
+    policy constants are the reference's own (tests/golden anchors)."""
+    import torch
+    from gym_fishing_amd import policies
+    kw = dict(r=c["r"], K=c["K"], init_state=c["x0"], sigma=0.0)
+    if c["env_id"] == "fishing-v0":
+        kw["n_actions"] = c["n_actions"]
+    table = c["table"]
+
+    def model_for(env):
+        m = policies.msy(env) if c["policy"] == "msy" else policies.escapement(env)
+        if c["policy"] == "msy":
+            m.msy = c["param"]
+        else:
+            m.S = c["param"]
+        m.kernel_policy = (m.kernel_policy[0], c["param"])
+        return m
+    is_v2 = c["env_id"] == "fishing-v2"
+    # scalar protocol
+    env = gf.make(c["env_id"], **kw)
+    df = env.simulate(model_for(env), reps=2)
+    got = df.to_numpy(dtype=np.float64)
+    assert got.shape[0] == 2 * table.shape[0] and list(df.columns) == ["time", "state", "action", "reward", "rep"]
+    for rep in range(2):
+        blk = got[rep * table.shape[0]:(rep + 1) * table.shape[0]]
+        assert (blk[:, 4] == rep).all()
+        if is_v2:
+            assert np.allclose(blk[:, :4], table, rtol=1e-8, atol=1e-10)   # unstable tipping run amplifies exp ulps
+        else:
+            assert np.array_equal(blk[:, :4].view(np.int64), table.view(np.int64)), c["key"]
+    # N-env fused rollout, fp64: every env is one rep and reproduces the same table
+    venv = gf.make(c["env_id"], num_envs=8, dtype=torch.float64, **kw)
+    dfv = venv.simulate(model_for(venv))
+    gv = dfv.to_numpy(dtype=np.float64)
+    assert gv.shape[0] == 8 * table.shape[0]
+    for rep in (0, 7):
+        blk = gv[gv[:, 4] == rep]
+        if is_v2:
+            assert np.allclose(blk[:, :4], table, rtol=1e-8, atol=1e-10)   # unstable tipping run amplifies exp ulps
+        else:
+            assert np.array_equal(blk[:, :4].view(np.int64), np.ascontiguousarray(table).view(np.int64)), c["key"]
+
+
+def test_simulate_with_generic_model_and_policyfn(gf):
+    """A model without kernel_policy is driven through batched predict(); policyfn gives the
+    reference's [state, action, rep] sweep (shared_env.py:82-102)."""
+    import torch
+    from gym_fishing_amd import policies
+
+    class Wrapped:      # hides kernel_policy -> step-by-step path
+        def __init__(self, inner):
+            self.inner = inner
+
+        def predict(self, obs, **kw):
+            return self.inner.predict(obs, **kw)
+    venv = gf.make("fishing-v1", sigma=0.0, num_envs=8, dtype=torch.float64)
+    esc = policies.escapement(venv)
+    a = venv.simulate(esc).to_numpy(dtype=np.float64)
+    b = venv.simulate(Wrapped(esc)).to_numpy(dtype=np.float64)
+    assert a.shape == b.shape and np.array_equal(a, b)
+    env = gf.make("fishing-v1")
+    pf = env.policyfn(policies.escapement(env))
+    assert list(pf.columns) == ["state", "action", "rep"] and len(pf) == 50
+    st, ac = pf["state"].to_numpy(), pf["action"].to_numpy()
+    assert np.allclose(ac, np.maximum(st - 0.5, 0.0), atol=1e-7)

@@ -271,12 +271,7 @@ def _policy_action(policy, param, model, dtype, obs, K, seed, env, s):
         return fo.policy_random_action(model, seed, env, s)
     if policy == "constant":
         return np.full(n, param, np.int32 if model == fo.MODEL_V0 else np.float32)
-    x = (obs + dtype(1)) * K
-    d = x - dtype(param)
-    q = np.where(dtype(0) > d, dtype(0), d) if policy == "escapement" else np.full(n, param, dtype)
-    if model == fo.MODEL_V0:
-        return np.rint((q * dtype(100) / K).astype(np.float64)).astype(np.int32)
-    return (q / K - dtype(1)).astype(dtype)       # NOT rounded to float32 (reference passes the float)
+    return fo.policy_action(policy, param, model, obs, K, 100, dtype)
 
 
 def _policy_setup(hh, policy, model):
@@ -297,9 +292,6 @@ ROLLOUT_KW = dict(sigma=0.1, C=0.5, x0=0.75, Tmax=7, sigma_p=0.15)
 def test_fused_rollout_equals_stepwise(hh, model, dtype, policy):
     """T steps inside one kernel == T step() calls fed the policy's actions (bit-exact: both
     run the same device arithmetic and the same Philox blocks)."""
-    if dtype == np.float64 and model != fo.MODEL_V0 and policy in ("escapement", "msy"):
-        pytest.skip("float64 action: not expressible through the float32 action stream; "
-                    "covered by test_fused_rollout_f64_policy_vs_oracle")
     n, off, seed, T = 2052, 4, 99, 25
     per_env = model == fo.MODEL_V4
     p = hh.params(model, r=0.3, K=1.0, auto_reset=True, **ROLLOUT_KW)
@@ -327,49 +319,6 @@ def test_fused_rollout_equals_stepwise(hh, model, dtype, policy):
     assert ra[2] == rb[2] and ra[2] >= n and np.allclose(ra, rb, rtol=1e-12)
     if per_env:
         assert_same_bits(A.K.cpu().numpy(), B.K.cpu().numpy(), "K")
-
-
-@pytest.mark.parametrize("model", [fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
-@pytest.mark.parametrize("policy", ["escapement", "msy"])
-def test_fused_rollout_f64_policy_vs_oracle(hh, model, policy):
-    """fp64 rollout under the escapement / MSY rules against a full oracle replay (the
-    policy's float64 action goes straight into get_quota, as in the reference)."""
-    dtype = np.float64
-    n, off, seed, T = 2052, 4, 99, 25
-    per_env = model == fo.MODEL_V4
-    p = hh.params(model, r=0.3, K=1.0, auto_reset=True, **ROLLOUT_KW)
-    pol, param = _policy_setup(hh, policy, model)
-    A = hh.State(n, dtype, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,
-                 K=np.full(n, 1.0) if per_env else None, ep_return=True)
-    A.reset(p, seed=seed, env_offset=off)
-    K = A.K.cpu().numpy() if per_env else np.full(n, 1.0)
-    r = A.r.cpu().numpy() if per_env else np.full(n, 0.3)
-    obs = A.obs.cpu().numpy()
-    t = np.zeros(n, np.int32)
-    traj = A.rollout(p, pol, param, T, seed=seed, step_counter=0, env_offset=off, record=True)
-    env = np.arange(off, off + n)
-    for s in range(T):
-        if model == fo.MODEL_V2:
-            assert np.allclose(traj[s, 0] + 1, obs + 1, rtol=1e-13, atol=1e-13)
-            obs = traj[s, 0]            # follow the device (exp differs in the last ulps)
-        else:
-            assert_same_bits(traj[s, 0], obs, "obs_in step %d" % s)
-        a = _policy_action(policy, param, model, dtype, obs, K, seed, env, s)
-        assert_same_bits(traj[s, 1], a, "action step %d" % s)
-        z = hh.device_step_noise(n, seed, s, off).astype(dtype)
-        eo, er, ed, et, _ = fo.step(model, obs, t, a, z, r, K, 0.1, C=0.5, Tmax=7)
-        assert_same_bits(traj[s, 2], er, "reward step %d" % s)
-        if model != fo.MODEL_V2:
-            assert (traj[s, 3].astype(np.uint8) == ed).all()
-        ed = traj[s, 3].astype(np.uint8)
-        zK = zr = None
-        if per_env:
-            _, zK, zr = hh.device_noise(n, seed, s, fo.STREAM_AUTORESET, off)
-        obs, t, K, r = fo.auto_reset(model, eo, ed, et, K, r, 0.75, zK=zK, zr=zr, K_mean=1.0, r_mean=0.3,
-                                     sigma_p=0.15)
-    if model != fo.MODEL_V2:
-        assert_same_bits(A.obs.cpu().numpy(), obs, "final obs")
-    assert (A.t.cpu().numpy() == t).all()
 
 
 def test_rollout_without_auto_reset_freezes_and_exits(hh):
@@ -474,3 +423,41 @@ def test_abi_rejects_bad_arguments(hh):
     assert lib.fishing_step_f32(hh.params(fo.MODEL_V4), 64, 0, st.buffers(a), 0, 0, None) == -1  # v4 needs r, K
     assert lib.fishing_rollout_f32(p, 64, 0, st.buffers(a), 9, 0.0, 1, None, 0, 0, None) == -5
     assert b"aligned" in lib.fishing_error_string(-3)
+
+
+# ------------------------------------------------------------------ reference simulate() tables
+from conftest import load_policy_sims  # noqa: E402
+
+SIMS = load_policy_sims()
+
+
+@pytest.mark.parametrize("c", SIMS, ids=[c["key"] for c in SIMS])
+def test_rollout_reproduces_reference_simulate_tables(hh, c):
+    """env.simulate(msy / escapement) of the reference (shared_env.py:29-54, models/policies.py)
+    at sigma = 0: the fused fp64 rollout with the in-kernel policy reproduces the reference's
+    [time, state, action, reward] table bit-for-bit (v2: exp tolerance)."""
+    from gym_fishing_amd import _capi
+    model = fo.MODEL_OF_ID[c["env_id"]]
+    K, nact, table = c["K"], c["n_actions"], c["table"]
+    p = hh.params(model, r=c["r"], K=K, sigma=0.0, x0=c["x0"], Tmax=100, n_actions=nact, auto_reset=False)
+    st = hh.State(4, np.float64, model, c["x0"] / K - 1.0)
+    pol = _capi.POLICY_ESCAPEMENT if c["policy"] == "escapement" else _capi.POLICY_MSY
+    traj = st.rollout(p, pol, c["param"], 100, record=True)[:, :, 0]          # [T, 4] of env 0
+    done_at = np.flatnonzero(traj[:, 3] > 0)
+    rows = int(done_at[0]) + 1 if done_at.size else 100
+    assert rows == table.shape[0], (rows, table.shape)
+    state = (traj[:rows, 0] + 1.0) * K
+    act = traj[:rows, 1].astype(np.int32) if model == fo.MODEL_V0 else traj[:rows, 1].astype(np.float32)
+    quota = fo.quota_from_action(model, act, K, nact)
+    quota_col = np.concatenate([[0.0], quota[:-1]])
+    reward_col = np.concatenate([[0.0], traj[:rows - 1, 2]])
+    assert (table[:, 0] == np.arange(rows)).all()
+    if model == fo.MODEL_V2:
+        # free-running tipping-point trajectory: the msy run sits on the unstable side of the
+        # threshold, so the 1-ulp exp() difference is amplified step by step (collapse in 92 steps)
+        assert np.allclose(state, table[:, 1], rtol=1e-8, atol=1e-10) and np.allclose(reward_col, table[:, 3], rtol=1e-8, atol=1e-10)
+        assert np.allclose(quota_col, table[:, 2], rtol=1e-8, atol=1e-10)
+    else:
+        assert_same_bits(state, table[:, 1], c["key"] + " state")
+        assert_same_bits(quota_col, table[:, 2], c["key"] + " action(quota)")
+        assert_same_bits(reward_col, table[:, 3], c["key"] + " reward")

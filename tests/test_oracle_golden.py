@@ -190,3 +190,27 @@ def test_scalar_env_reproduces_reference_when_seeded_identically(c):
             if done and c.auto_reset:
                 o = env.reset()
                 assert bits(o[0]) == bits(c.reset_obs[e, s + 1])
+
+
+from conftest import load_policy_sims  # noqa: E402
+
+SIMS = load_policy_sims()
+
+
+@pytest.mark.parametrize("c", SIMS, ids=[c["key"] for c in SIMS])
+def test_policy_rollouts_reproduce_reference_simulate_tables(c):
+    """the msy / escapement rules + step() reproduce env.simulate()'s table
+    [time, state, action, reward] of the reference bit-for-bit (shared_env.py:29-54)."""
+    model = fo.MODEL_OF_ID[c["env_id"]]
+    K, nact = c["K"], c["n_actions"]
+    obs = np.array([c["x0"] / K - 1.0])
+    t = np.zeros(1, np.int32)
+    rows, quota_prev, rew_prev = [], 0.0, 0.0
+    for s in range(100):
+        rows.append([s, (obs[0] + 1.0) * K, quota_prev, rew_prev])          # record BEFORE acting (:37-38)
+        act = fo.policy_action(c["policy"], c["param"], model, obs, K, nact)
+        obs, rew, done, t, _ = fo.step(model, obs, t, act, [0.0], c["r"], K, 0.0, n_actions=nact)
+        quota_prev, rew_prev = fo.quota_from_action(model, act, K, nact)[0], rew[0]
+        if done[0]:
+            break
+    assert_bit_equal(np.array(rows), c["table"], c["key"])
