@@ -105,7 +105,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created for any world size, so
+    # the single-rank launch exercises the same RCCL init / all-reduce / barrier code as N > 1
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -120,7 +123,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -137,7 +140,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)     # HIP events around the K launches
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -180,16 +183,37 @@ def main():
 
     if args.extra and rank == 0:
         extra = {}
-        # fused rollout (VALU-bound, not HBM-bound): env-steps/s only
-        env2 = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=1234, track_returns=True)
-        env2.reset()
-        env2.rollout(101)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        env2.rollout(1010)
-        torch.cuda.synchronize()
-        extra["fused_rollout_env_steps_per_s"] = n * 1010 / (time.perf_counter() - t1)
-        del env2
+        del env, actions
+        torch.cuda.empty_cache()
+        # fused T-step rollout, in-kernel policy (VALU-bound, not HBM-bound): env-steps/s only
+        for pol, param in (("random", 0.0), ("escapement", 0.5)):
+            env2 = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=1234, track_returns=True)
+            env2.reset()
+            env2.rollout(101, policy=pol, param=param)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            env2.rollout(2020, policy=pol, param=param)
+            torch.cuda.synchronize()
+            extra["fused_rollout_%s_env_steps_per_s" % pol] = n * 2020 / (time.perf_counter() - t1)
+            del env2
+        # pure 25 B step at sizes that do / do not fit the Infinity Cache (kernel-only, HIP events)
+        for ln in (20, 22, 24, 26):
+            nn = 1 << ln
+            e3 = gf.make("fishing-v1", sigma=0.1, num_envs=nn, seed=1234)
+            e3.reset()
+            acts = torch.rand((4, nn), device="cuda") * 2 - 1
+            k = max(20, min(400, (1 << 31) // nn))
+            e3.step_many(acts, k)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            e3.step_many(acts, k)
+            a1.record()
+            torch.cuda.synchronize()
+            us = a0.elapsed_time(a1) * 1e3 / k
+            extra["step_only_2^%d" % ln] = {"us_per_launch": us, "GBps": nn * BYTES_STEP / us / 1e3,
+                                            "env_steps_per_s": nn / us * 1e6}
+            del e3, acts
+            torch.cuda.empty_cache()
         out["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -198,7 +222,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
