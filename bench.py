@@ -110,7 +110,20 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout at communicator creation; stdout must carry
+        # exactly one JSON line, so fd 1 points at stderr until the communicator exists.
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(4, dtype=torch.float64, device="cuda")
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import gym_fishing_amd as gf
     n = args.n_envs

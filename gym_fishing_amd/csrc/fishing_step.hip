@@ -278,7 +278,11 @@ void launch_shape(const FishingParams* p, int64_t n, int& blocks, int& threads) 
     threads = p->launch_threads ? p->launch_threads : 256;
     const int64_t tile = (int64_t)threads * kEnvsPerThread;
     const int64_t ntiles = (n + tile - 1) / tile;
-    int cap = p->launch_blocks ? p->launch_blocks : 2048;
+    // default cap: one 1024-env tile per workgroup up to 4096 workgroups, grid-stride beyond.
+    // Measured on MI355X (profiles/r01b_sweep_blocks.txt): caps from 1024 to 4096 stay within
+    // +-4 % of each other at N = 2^21..2^24 with no consistent winner; 4096 is best or near-best
+    // in most rows.
+    int cap = p->launch_blocks ? p->launch_blocks : kMaxBlocks;
     if (cap > kMaxBlocks) cap = kMaxBlocks;
     blocks = (int)(ntiles < cap ? ntiles : cap);
     if (blocks < 1) blocks = 1;

@@ -134,6 +134,15 @@ class BaseFishingEnv:
             self._record = torch.zeros(4, dtype=torch.float64, device=dev)
         self._action_buf = None
         self._last_action = None
+        self._cparams = self._pkey = self._cbuf = None
+        self._want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
+        self._obs_view = self._obs.view(N, 1)
+        self._done_view = self._done.view(torch.bool)
+        self._info = {}
+        if self._terminal_obs is not None:
+            self._info["terminal_observation"] = self._terminal_obs.view(N, 1)
+        if self._done_bits is not None:
+            self._info["done_bits"] = self._done_bits
         self._launch = (int(launch_blocks), int(launch_threads))
 
         # reference attributes (base_fishing_env.py:27-46)
@@ -189,7 +198,18 @@ class BaseFishingEnv:
         else:
             self.params[name] = v
 
+    def _param_key(self):
+        p = self.params
+        return (self.Tmax, self.init_state, self.auto_reset, self._sigma_scalar, p["r"], p["K"], self._launch,
+                getattr(self, "n_actions", 0), getattr(self, "C", None), getattr(self, "r_mean", None),
+                getattr(self, "K_mean", None), getattr(self, "sigma_p", None))
+
     def _c_params(self):
+        """FishingParams for the next call; rebuilt only when a source attribute changed
+        (env.Tmax = ..., env.sigma = ..., env.init_state = ... are all legal in the reference)."""
+        key = self._param_key()
+        if key == self._pkey:
+            return self._cparams
         p = self.params
         cp = _capi.FishingParams()
         cp.model = self.MODEL
@@ -205,6 +225,7 @@ class BaseFishingEnv:
         cp.K_mean = float(getattr(self, "K_mean", p.get("K_mean", p["K"])))
         cp.sigma_p = float(getattr(self, "sigma_p", p.get("sigma_p", 0.0)))
         cp.launch_blocks, cp.launch_threads = self._launch
+        self._cparams, self._pkey = cp, key
         return cp
 
     def _c_buffers(self, action=None, z_ext=None, with_outputs=True):
@@ -215,6 +236,17 @@ class BaseFishingEnv:
             r=ptr(self._r_arr), K=ptr(self._K_arr), sigma=ptr(self._sigma_arr), z_ext=ptr(z_ext),
             terminal_obs=ptr(self._terminal_obs), ep_return=ptr(self._ep_return),
             return_partials=ptr(self._partials))
+
+    def _step_buffers(self, action_ptr, z_ptr):
+        """The step() FishingBuffers: built once (the env's tensors never move), only the
+        action / z_ext / sigma pointers are refreshed per call."""
+        b = self._cbuf
+        if b is None:
+            b = self._cbuf = self._c_buffers()
+        b.action = action_ptr
+        b.z_ext = z_ptr
+        b.sigma = self._sigma_arr.data_ptr() if self._sigma_arr is not None else None
+        return b
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -232,7 +264,8 @@ class BaseFishingEnv:
             self.years_passed = int(self._t[0])
             self.fish_population = float((self.state[0] + 1.0) * float(self._K_view() if self._per_env else self.params["K"]))
         else:
-            self.state = self._obs.view(self.num_envs, 1)
+            self.state = self._obs_view
+            self.reward = self._reward
             self.years_passed = self._t
 
     def seed(self, seed=None):
@@ -254,17 +287,22 @@ class BaseFishingEnv:
                                 self._seed, self._reset_count, self._stream())
         _capi.check(rc, "fishing_reset")
         self._reset_count += 1
-        self.reward = 0 if self.MODEL != MODEL_V4 else self.reward   # v4 leaves it (quirk B8)
-        self.harvest = 0
+        if self._scalar:
+            self.reward = 0 if self.MODEL != MODEL_V4 else self.reward   # v4 leaves it (quirk B8)
+            self.harvest = 0
         self._publish_scalar_state()
         return self.state
 
     # ------------------------------------------------------------------ step
     def _prepare_action(self, action):
         N = self.num_envs
-        want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
+        want = self._want
         if isinstance(action, torch.Tensor):
             a = action
+            # fast path: already the stream the kernel reads
+            if a.dtype == want and a.device == self.device and a.numel() == N and a.is_contiguous() \
+                    and not a.data_ptr() & 15:
+                return a
             if a.device != self.device:
                 a = a.to(self.device)
         else:
@@ -288,13 +326,21 @@ class BaseFishingEnv:
         z = None
         if noise is not None:
             z = torch.as_tensor(noise).to(device=self.device, dtype=self.dtype).reshape(self.num_envs).contiguous()
-        with torch.cuda.device(self.device):
-            rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(a, z),
-                               self._seed, self._step_count, self._stream())
-        _capi.check(rc, "fishing_step")
+        bufs = self._step_buffers(a.data_ptr(), z.data_ptr() if z is not None else None)
+        if torch.cuda.current_device() == self.device.index:
+            rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed,
+                               self._step_count, torch.cuda.current_stream().cuda_stream)
+        else:
+            with torch.cuda.device(self.device):
+                rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed,
+                                   self._step_count, self._stream())
+        if rc:
+            _capi.check(rc, "fishing_step")
         self._step_count += 1
         self._last_action = a
-        return self._step_result()
+        if self._scalar:
+            return self._step_result()
+        return self._obs_view, self._reward, self._done_view, self._info
 
     def _step_result(self):
         if self._scalar:
@@ -302,14 +348,7 @@ class BaseFishingEnv:
             self.reward = float(self._reward[0])
             self.harvest = self.reward
             return self.state, self.reward, bool(self._done[0]), {}
-        self.state = self._obs.view(self.num_envs, 1)
-        self.reward = self._reward
-        info = {}
-        if self._terminal_obs is not None:
-            info["terminal_observation"] = self._terminal_obs.view(self.num_envs, 1)
-        if self._done_bits is not None:
-            info["done_bits"] = self._done_bits
-        return self.state, self._reward, self._done.view(torch.bool), info
+        return self._obs_view, self._reward, self._done_view, self._info
 
     def step_many(self, actions, n_steps=None):
         """n_steps consecutive step() calls enqueued by one C call; `actions` is [R, N]
