@@ -16,7 +16,7 @@
 
 namespace fishing {
 
-template <typename T, int MODEL, int POLICY>
+template <typename T, int MODEL, int POLICY, bool AUTO>
 __global__ void __launch_bounds__(256)
 rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
                const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed,
@@ -26,7 +26,6 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
-    const bool auto_reset = (p.flags & FISHING_FLAG_AUTO_RESET) != 0;
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -36,7 +35,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
 
         T obs[4], rr[4], KK[4], sg[4], er[4], rew[4];
         int32_t t[4];
-        bool dn[4], frozen[4];
+        bool dn[4], live[4];    // live: a real env whose episode is still running
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             obs[j] = (T)0;
@@ -47,7 +46,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             er[j] = (T)0;
             rew[j] = (T)0;
             dn[j] = false;
-            frozen[j] = !(base + j < n);
+            live[j] = base + j < n;
         }
         if (active) {
             load4<T>(b.obs, base, n, full, obs, (T)0);
@@ -60,6 +59,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             if (b.ep_return) load4<T>(b.ep_return, base, n, full, er, (T)0);
         }
         const uint64_t pair = (env_offset + (uint64_t)base) >> 1;
+        const T robs_scalar = reset_obs<T, MODEL>(p.x0, p.K);   // loop-invariant unless per-env K
         bool kr_dirty = false;
 
         for (int32_t s = 0; s < Tsteps; ++s) {
@@ -80,11 +80,13 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     aw[2 * q + 1] = w.w3;
                 }
             }
+            // ---- all four envs advance branch-free (independent chains, full ILP); a finished
+            // env of a no-auto-reset rollout is frozen by selects, not by control flow
             T obs_in[4], act_rec[4];
+            bool fin[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 obs_in[j] = obs[j];
-                // ---- policy: action from the observation (models/policies.py)
                 T a_c = (T)-1;
                 int32_t a_d = 0;
                 if (POLICY == FISHING_POLICY_RANDOM) {
@@ -112,53 +114,61 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                 bool d2;
                 int32_t t2;
                 env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax, o2, r2, d2, t2);
-                if (!frozen[j]) {
+                if (AUTO) {
                     obs[j] = o2;
                     rew[j] = r2;
                     dn[j] = d2;
                     t[j] = t2;
                     er[j] = er[j] + r2;
+                    fin[j] = d2 && live[j];
                 } else {
-                    rew[j] = (T)0;
+                    const bool lv = live[j];
+                    obs[j] = lv ? o2 : obs[j];
+                    rew[j] = lv ? r2 : (T)0;
+                    dn[j] = lv ? d2 : dn[j];
+                    t[j] = lv ? t2 : t[j];
+                    er[j] = lv ? er[j] + r2 : er[j];
+                    fin[j] = d2 && lv;
                 }
             }
             if (traj && active) {
                 T* row = traj + (int64_t)s * 4 * n;
                 T dn_rec[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dn_rec[j] = (dn[j] && !frozen[j]) ? (T)1 : (T)0;
+                for (int j = 0; j < 4; ++j) dn_rec[j] = fin[j] ? (T)1 : (T)0;
                 store4<T>(row, base, n, full, obs_in);
                 store4<T>(row + n, base, n, full, act_rec);
                 store4<T>(row + 2 * n, base, n, full, rew);
                 store4<T>(row + 3 * n, base, n, full, dn_rec);
             }
-            const bool lane_done = (dn[0] && !frozen[0]) | (dn[1] && !frozen[1]) | (dn[2] && !frozen[2]) |
-                                   (dn[3] && !frozen[3]);
-            if (__any(lane_done)) {
+            // ---- wave-ballot: only waves holding a finished env do the record / reset work
+            if (__any(fin[0] | fin[1] | fin[2] | fin[3])) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (dn[j] && !frozen[j]) {
-                        const double R = (double)er[j];
-                        acc[0] += R;
-                        acc[1] += R * R;
-                        acc[2] += 1.0;
-                        acc[3] += (double)t[j];
-                        if (auto_reset) {
-                            er[j] = (T)0;
-                            if (kPerEnv) {
+                    const bool f = fin[j];
+                    const double R = (double)er[j];
+                    acc[0] += f ? R : 0.0;
+                    acc[1] += f ? R * R : 0.0;
+                    acc[2] += f ? 1.0 : 0.0;
+                    acc[3] += f ? (double)t[j] : 0.0;
+                    if (AUTO) {
+                        if (kPerEnv) {
+                            if (f) {
                                 draw_model_error<T>(seed, env_offset + (uint64_t)(base + j), step_counter,
                                                     kStreamAutoReset, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
                                 kr_dirty = true;
                             }
-                            obs[j] = reset_obs<T, MODEL>(p.x0, KK[j]);
-                            t[j] = 0;
-                            // dn[j] keeps the flag of this step for the final done output
-                        } else {
-                            frozen[j] = true;
                         }
+                        const T ro = kPerEnv ? reset_obs<T, MODEL>(p.x0, KK[j]) : robs_scalar;
+                        er[j] = f ? (T)0 : er[j];
+                        obs[j] = f ? ro : obs[j];
+                        t[j] = f ? 0 : t[j];
+                        // dn[j] keeps this step's flag for the final done output
+                    } else {
+                        live[j] = live[j] && !f;
                     }
                 }
-                if (!auto_reset && __all(frozen[0] && frozen[1] && frozen[2] && frozen[3])) break;
+                if (!AUTO && __all(!(live[0] | live[1] | live[2] | live[3]))) break;
             }
         }
 
@@ -213,9 +223,17 @@ template <typename T, int MODEL>
 int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& bt, int64_t n, uint64_t env_offset,
                           T policy_param, int32_t Tsteps, T* traj, uint64_t seed, uint64_t step_counter,
                           int noise_on, int blocks, int threads, hipStream_t s) {
-#define FISHING_LAUNCH_ROLLOUT(POL)                                                                         \
-    rollout_kernel<T, MODEL, POL><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param, Tsteps, \
-                                                             traj, seed, step_counter, noise_on)
+#define FISHING_LAUNCH_ROLLOUT(POL)                                                                                \
+    do {                                                                                                           \
+        if (pt.flags & FISHING_FLAG_AUTO_RESET)                                                                    \
+            rollout_kernel<T, MODEL, POL, true><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param,  \
+                                                                           Tsteps, traj, seed, step_counter,      \
+                                                                           noise_on);                             \
+        else                                                                                                       \
+            rollout_kernel<T, MODEL, POL, false><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param, \
+                                                                            Tsteps, traj, seed, step_counter,     \
+                                                                            noise_on);                            \
+    } while (0)
     switch (policy) {
         case FISHING_POLICY_RANDOM: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_RANDOM); break;
         case FISHING_POLICY_CONSTANT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_CONSTANT); break;
