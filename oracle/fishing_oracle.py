@@ -37,8 +37,34 @@ MODEL_V1 = 1  # logistic, continuous                    fishing_cts_env.py:4-12
 MODEL_V2 = 2  # tipping point, continuous               fishing_tipping_env.py:6-35
 MODEL_V4 = 4  # logistic, per-episode K,r uncertainty   fishing_model_error.py:6-48
 
+# growth-model zoo (growth_models.py:6-270): lognormal noise, x' = max(0, exp(mu(x) + sigma z))
+MODEL_V5 = 5    # Allen            growth_models.py:6-25,   allen() :208-217
+MODEL_V6 = 6    # Beverton-Holt    :28-40,  beverton_holt() :220-226
+MODEL_V7 = 7    # May              :75-108, may() :229-242
+MODEL_V8 = 8    # Myers            :43-70,  myers() :247-255
+MODEL_V9 = 9    # Ricker           :111-123, ricker() :258-261
+MODEL_V10 = 10  # NonStationary    :126-154 (Beverton-Holt with r += alpha every draw)
+MODEL_V11 = 11  # ModelUncertainty :157-204 (one of the five per episode)
+
 MODEL_OF_ID = {"fishing-v0": MODEL_V0, "fishing-v1": MODEL_V1,
-               "fishing-v2": MODEL_V2, "fishing-v4": MODEL_V4}
+               "fishing-v2": MODEL_V2, "fishing-v4": MODEL_V4,
+               "fishing-v5": MODEL_V5, "fishing-v6": MODEL_V6, "fishing-v7": MODEL_V7,
+               "fishing-v8": MODEL_V8, "fishing-v9": MODEL_V9, "fishing-v10": MODEL_V10,
+               "fishing-v11": MODEL_V11}
+
+# kinds of growth function, in the order of the reference's default `models` list
+# (growth_models.py:160): the index is what fishing-v11 stores per env
+KIND_ALLEN, KIND_BH, KIND_MYERS, KIND_MAY, KIND_RICKER = 0, 1, 2, 3, 4
+KIND_OF_MODEL = {MODEL_V5: KIND_ALLEN, MODEL_V6: KIND_BH, MODEL_V7: KIND_MAY, MODEL_V8: KIND_MYERS,
+                 MODEL_V9: KIND_RICKER, MODEL_V10: KIND_BH}
+# fishing-v11's per-model parameter table (growth_models.py:161-186)
+V11_TABLE = [
+    {"r": 0.3, "K": 1.0, "sigma": 0.0, "C": 0.5},                                        # allen
+    {"r": 0.3, "K": 1.0, "sigma": 0.0},                                                  # beverton_holt
+    {"r": 1.0, "K": 1.0, "M": 1.0, "theta": 3.0, "sigma": 0.0},                          # myers
+    {"r": 0.7, "K": 1.5, "M": 1.5, "q": 3.0, "b": 0.15, "sigma": 0.0, "a": 0.2},         # may
+    {"r": 0.3, "K": 1.0, "sigma": 0.0},                                                  # ricker
+]
 
 # RNG stream tags (top byte of Philox counter word 1)
 STREAM_NOISE = 0      # per-step process noise z  (+ in-kernel policy action)
@@ -92,6 +118,89 @@ def step(model, obs, t, action, z, r, K, sigma, C=0.5, Tmax=100, n_actions=100,
         done = (t_next > np.int32(Tmax)) | (x <= zero)        # :76-79
     return (obs_next.astype(dtype), reward.astype(dtype), done.astype(np.uint8),
             t_next.astype(np.int32), x.astype(dtype))
+
+
+def _libm_exp(v):
+    """exp() of the C library, element by element.  np.random.lognormal (legacy RandomState)
+    is exp(loc + scale * gauss) evaluated with libm's scalar exp(), which differs from NumPy's
+    SIMD np.exp by 1 ulp on ~2 % of inputs; float64 parity needs the libm one."""
+    import math
+    v = np.asarray(v)
+    if v.dtype != np.float64:
+        return np.exp(v)                     # float32 layout: tolerance-based anyway
+    flat = v.reshape(-1)
+    out = np.empty_like(flat)
+    for i, e in enumerate(flat):
+        try:
+            out[i] = math.exp(e)
+        except OverflowError:
+            out[i] = np.inf
+    return out.reshape(v.shape)
+
+
+def zoo_population_draw(kind, x, z, P, dtype=np.float64):
+    """The five growth functions of growth_models.py:208-261, each followed by
+    np.maximum(0, np.random.lognormal(mu, sigma)) = max(0, exp(mu + sigma z)).
+    `P`: dict of scalars / arrays (r, K, sigma and, per kind, C | M, theta | M, q, b, a)."""
+    dt = np.dtype(dtype).type
+    g = lambda k: np.asarray(P[k], dtype=dtype)   # noqa: E731
+    x = np.asarray(x, dtype=dtype)
+    z = np.asarray(z, dtype=dtype)
+    one, zero = dt(1.0), dt(0.0)
+    with np.errstate(all="ignore"):
+        if kind == KIND_ALLEN:                                  # :208-217
+            mu = np.log(x) + g("r") * (one - x / g("K")) * (one - g("C")) / g("K")
+        elif kind == KIND_BH:                                   # :220-226
+            x = np.clip(x, zero, dt(np.inf))
+            A = np.clip(g("r"), zero, dt(np.inf)) + one
+            B = np.clip(g("K"), zero, dt(np.inf)) / np.clip(g("r"), zero, dt(np.inf))
+            mu = np.log(A) + np.log(x) - np.log(one + x / B)
+        elif kind == KIND_MAY:                                  # :229-242
+            xq = np.power(x, g("q"))
+            exp_mu = x + x * g("r") * (one - x / g("M")) - g("a") * xq / (xq + np.power(g("b"), g("q")))
+            mu = np.log(exp_mu)
+        elif kind == KIND_MYERS:                                # :247-255
+            A = g("r") + one
+            mu = np.log(A) + g("theta") * np.log(x) - np.log(one + np.power(x, g("theta")) / g("M"))
+        elif kind == KIND_RICKER:                               # :258-261
+            mu = np.log(x) + g("r") * (one - x / g("K"))
+        else:
+            raise ValueError(kind)
+        return np.maximum(zero, _libm_exp(mu + g("sigma") * z)).astype(dtype)
+
+
+def step_zoo(model, obs, t, action, z, P, K_obs, Tmax=100, kind=None, dtype=np.float64):
+    """step() (base_fishing_env.py:60-81) with a zoo population_draw.  K_obs is the env's
+    self.K (obs <-> population map, quota); the growth parameters come from P
+    (self.params).  fishing-v10: P["r"] is the value AFTER this step's `r += alpha`
+    (growth_models.py:151).  fishing-v11: `kind` is the per-env model index array."""
+    dt = np.dtype(dtype).type
+    obs = np.asarray(obs, dtype=dtype)
+    K_obs = np.asarray(K_obs, dtype=dtype)
+    one, zero = dt(1.0), dt(0.0)
+    with np.errstate(all="ignore"):
+        quota = quota_from_action(MODEL_V1, action, K_obs, 0, dtype)
+        x = (obs + one) * K_obs
+        h = np.where(quota < x, quota, x)
+        d = x - h
+        x = np.where(zero > d, zero, d)
+        if model == MODEL_V11:
+            kind = np.asarray(kind)
+            xn = np.zeros_like(x)
+            for k in range(5):
+                m = kind == k
+                if m.any():
+                    Pk = dict(V11_TABLE[k]) if P is None else dict(P[k])
+                    xn[m] = zoo_population_draw(k, x[m], np.asarray(z, dtype=dtype)[m], Pk, dtype)
+            x = xn
+        else:
+            x = zoo_population_draw(KIND_OF_MODEL[model], x, z, P, dtype)
+        obs_next = x / K_obs - one
+        reward = np.where(zero > h, zero, h)
+        t_next = np.asarray(t, dtype=np.int32) + np.int32(1)
+        done = (t_next > np.int32(Tmax)) | (x <= zero)
+    return (obs_next.astype(dtype), reward.astype(dtype), done.astype(np.uint8), t_next.astype(np.int32),
+            x.astype(dtype))
 
 
 def draw_model_error_params(zK, zr, K_mean, r_mean, sigma_p, dtype=np.float64):

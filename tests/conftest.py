@@ -23,7 +23,7 @@ class GoldenCase:
         self.name = name
         self.meta = json.loads(str(npz[name + "/meta"]))
         for k in ("action", "z", "obs_in", "obs", "reward", "done", "t", "K", "r", "zK", "zr",
-                  "reset_obs"):
+                  "reset_obs", "params_r", "model_idx"):
             setattr(self, k, npz[name + "/" + k])
         self.id = self.meta["id"]
         self.kwargs = self.meta["kwargs"]
@@ -35,6 +35,12 @@ class GoldenCase:
         defaults = {"r": 0.3, "K": 1.0, "sigma": 0.0, "init_state": 0.75, "Tmax": 100,
                     "n_actions": 100, "C": 0.5, "K_mean": 1.0, "r_mean": 0.3, "sigma_p": 0.1}
         return self.kwargs.get(key, defaults[key])
+
+
+def load_zoo_cases():
+    npz = np.load(os.path.join(GOLDEN, "reference_zoo_trajectories.npz"))
+    names = sorted({k.split("/")[0] for k in npz.files})
+    return [GoldenCase(n, npz) for n in names]
 
 
 def load_golden_cases():

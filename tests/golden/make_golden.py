@@ -113,7 +113,8 @@ def main():
     import gym_fishing  # noqa: F401  (registers ids)
     from gym_fishing.models.policies import BMSY, escapement, msy
 
-    out = {}
+    out_default = {}
+    out = out_default
     anchors = {}
 
     def as_action(env_id, a):
@@ -121,8 +122,10 @@ def main():
             return int(a)
         return np.array([a], dtype=np.float32).astype(np.float64)
 
+    ZOO_MODELS = ["allen", "beverton_holt", "myers", "may", "ricker"]
+
     def run_case(name, env_id, kwargs, seeds, nsteps, action_fn, auto_reset=True,
-                 init_reset=True):
+                 init_reset=True, out=None):
         """One reference env per seed, driven `nsteps` steps.  On done the driver
         calls reset() (what SB3's DummyVecEnv does around the reference) when
         auto_reset, else keeps stepping the finished env (reference allows it)."""
@@ -141,6 +144,9 @@ def main():
         ZK = np.full((E, nsteps + 1), np.nan)  # reset draws; column 0 = initial reset
         ZR = np.full((E, nsteps + 1), np.nan)
         RESET_OBS = np.full((E, nsteps + 1), np.nan)
+        RP = np.full((E, nsteps), np.nan)                 # params["r"] in force (fishing-v10 drifts it)
+        MID = np.full((E, nsteps), -1, dtype=np.int32)    # fishing-v11: index of the model in force
+        out = out_default if out is None else out
         for e, seed in enumerate(seeds):
             np.random.seed(seed)
             env = gym.make(env_id, **kwargs)
@@ -164,6 +170,10 @@ def main():
                 OBS_IN[e, s] = env.state[0]
                 KK[e, s] = env.K
                 RR[e, s] = env.r
+                if isinstance(env.params.get("r", None), (int, float)):
+                    RP[e, s] = env.params["r"]
+                if hasattr(env, "model"):
+                    MID[e, s] = ZOO_MODELS.index(env.model)
                 obs, rew, done, info = env.step(as_action(env_id, A[e, s]))
                 OBS[e, s] = obs[0]
                 REW[e, s] = rew
@@ -177,7 +187,7 @@ def main():
              "auto_reset": auto_reset, "init_reset": init_reset}))
         for k, v in (("action", A), ("z", Z), ("obs_in", OBS_IN), ("obs", OBS), ("reward", REW),
                      ("done", DONE), ("t", T), ("K", KK), ("r", RR), ("zK", ZK), ("zr", ZR),
-                     ("reset_obs", RESET_OBS)):
+                     ("reset_obs", RESET_OBS), ("params_r", RP), ("model_idx", MID)):
             out[name + "/" + k] = v
         return OBS, REW, DONE
 
@@ -230,6 +240,26 @@ def main():
     run_case("v4_noinitreset", "fishing-v4", {"sigma": 0.05}, [97, 98], 20,
              lambda g, s, e: f32(g.uniform(-1, -0.7)), init_reset=False)
 
+    # --- growth-model zoo fishing-v5..v11 (growth_models.py), lognormal noise
+    zoo = {}
+    low = lambda g, s, e: f32(g.uniform(-1, -0.8))      # noqa: E731
+    mid = lambda g, s, e: f32(g.uniform(-1, 0.0))       # noqa: E731
+    for tag, env_id, kw, af, n in (
+            ("v5_allen", "fishing-v5", {"sigma": 0.1}, low, 120),
+            ("v5_allen_s0", "fishing-v5", {"sigma": 0.0, "C": 0.3, "r": 0.5}, mid, 40),
+            ("v6_bh", "fishing-v6", {"sigma": 0.1}, low, 120),
+            ("v6_bh_params", "fishing-v6", {"sigma": 0.05, "r": 0.6, "K": 2.0, "init_state": 1.0, "Tmax": 20}, mid, 70),
+            ("v7_may", "fishing-v7", {"sigma": 0.1}, low, 120),
+            ("v7_may_s0", "fishing-v7", {"sigma": 0.0}, mid, 60),
+            ("v8_myers", "fishing-v8", {"sigma": 0.1}, low, 120),
+            ("v8_myers_s0", "fishing-v8", {"sigma": 0.0, "theta": 2.5, "M": 1.2}, mid, 60),
+            ("v9_ricker", "fishing-v9", {"sigma": 0.1}, low, 120),
+            ("v9_ricker_params", "fishing-v9", {"sigma": 0.2, "r": 0.8, "K": 1.5, "Tmax": 15}, mid, 60),
+            ("v10_nonstat", "fishing-v10", {"sigma": 0.05, "alpha": -0.007}, low, 230),
+            ("v10_nonstat_s0", "fishing-v10", {"sigma": 0.0, "alpha": -0.02, "r": 0.5, "Tmax": 40}, low, 90),
+            ("v11_uncert", "fishing-v11", {}, low, 330),
+            ("v11_uncert_T", "fishing-v11", {"Tmax": 6}, mid, 100)):
+        run_case(tag, env_id, kw, list(range(200, 206)), n, af, out=zoo)
     # --- anchors from the reference's own test (tests/test-envs.py:93-106)
     env = gym.make("fishing-v2", sigma=0, init_state=0.75)
     env.reset()
@@ -285,6 +315,7 @@ def main():
 
     np.savez_compressed(os.path.join(HERE, "reference_trajectories.npz"), **out)
     np.savez_compressed(os.path.join(HERE, "reference_policy_sims.npz"), **sims)
+    np.savez_compressed(os.path.join(HERE, "reference_zoo_trajectories.npz"), **zoo)
     with open(os.path.join(HERE, "reference_anchors.json"), "w") as f:
         json.dump(anchors, f, indent=1, sort_keys=True)
     print("wrote %d arrays, %d sims, %d anchors" % (len(out), len(sims), len(anchors)))

@@ -214,3 +214,48 @@ def test_policy_rollouts_reproduce_reference_simulate_tables(c):
         if done[0]:
             break
     assert_bit_equal(np.array(rows), c["table"], c["key"])
+
+
+# ------------------------------------------------------------------ growth-model zoo
+from conftest import load_zoo_cases  # noqa: E402
+
+ZOO = load_zoo_cases()
+ZOO_DEFAULTS = {   # constructor defaults, growth_models.py:6-154
+    "fishing-v5": {"r": 0.3, "K": 1, "C": 0.5, "sigma": 0.0, "init_state": 0.75},
+    "fishing-v6": {"r": 0.3, "K": 1, "sigma": 0.0, "init_state": 0.75},
+    "fishing-v7": {"r": 0.7, "K": 1.5, "M": 1.5, "q": 3, "b": 0.15, "sigma": 0.0, "a": 0.2, "init_state": 0.75},
+    "fishing-v8": {"r": 1.0, "K": 1.0, "M": 1.0, "theta": 3.0, "sigma": 0.0, "init_state": 1.5},
+    "fishing-v9": {"r": 0.3, "K": 1, "sigma": 0.0, "init_state": 0.75},
+    "fishing-v10": {"r": 0.8, "K": 1, "sigma": 0.0, "alpha": -0.007, "init_state": 0.75},
+    "fishing-v11": {"K": 1, "init_state": 0.75},
+}
+
+
+def zoo_params(c):
+    P = dict(ZOO_DEFAULTS[c.id])
+    P.update({k: v for k, v in c.kwargs.items() if k != "Tmax"})
+    return P
+
+
+@pytest.mark.parametrize("c", ZOO, ids=[c.name for c in ZOO])
+def test_zoo_single_step_bit_exact(c):
+    """fishing-v5..v11: every recorded reference step replayed by the oracle (same NumPy
+    log / exp / power on the same dtype, so bit-for-bit on the CPU)."""
+    model = fo.MODEL_OF_ID[c.id]
+    P = zoo_params(c)
+    Tmax = c.kwargs.get("Tmax", 100)
+    t_in = np.where(np.arange(c.nsteps)[None, :] == 0, 0, np.roll(c.t, 1, axis=1))
+    prev_done = np.roll(c.done, 1, axis=1).astype(bool)
+    prev_done[:, 0] = False
+    t_in = np.where(prev_done, 0, t_in)
+    kind = None
+    if model == fo.MODEL_V10:
+        P["r"] = c.params_r + P["alpha"]            # the draw uses r AFTER the += alpha
+        assert np.allclose(c.params_r[:, 1:], c.params_r[:, :-1] + P["alpha"], rtol=0, atol=1e-15)
+    if model == fo.MODEL_V11:
+        kind, P = c.model_idx, None
+        assert set(np.unique(kind)) <= {0, 1, 2, 3, 4} and len(np.unique(kind)) >= 3
+    obs, rew, done, t, _ = fo.step_zoo(model, c.obs_in, t_in, c.action, c.z, P, c.K, Tmax=Tmax, kind=kind)
+    assert_bit_equal(obs, c.obs, c.name + " obs")
+    assert_bit_equal(rew, c.reward, c.name + " reward")
+    assert (done == c.done).all() and (t == c.t).all()
