@@ -2,7 +2,7 @@
 
 Drop-in for the rollout path of boettiger-lab/gym_fishing: the ids fishing-v0/v1/v2/v4,
 the gym.Env reset()/step()/render() surface and the constructor kwargs of the reference
-(gym_fishing/envs/__init__.py:17-35), with step()/reset() executed by hand-written HIP
+(gym_fishing/envs/__init__.py:17-71; v5..v11 = the growth-model zoo), with step()/reset() executed by hand-written HIP
 kernels for gfx950 behind a C ABI (include/fishing_hip.h).
 
     import gym_fishing_amd as gf
@@ -19,12 +19,19 @@ from ._capi import FishingLibraryError
 
 __version__ = "0.1.0"
 
-# id -> class name in .envs (gym_fishing/envs/__init__.py:17-35; ids v5..v11 are out of scope)
+# id -> class name in .envs (gym_fishing/envs/__init__.py:17-71)
 ENTRY_POINTS = {
     "fishing-v0": "FishingEnv",
     "fishing-v1": "FishingCtsEnv",
     "fishing-v2": "FishingTippingEnv",
     "fishing-v4": "FishingModelError",
+    "fishing-v5": "Allen",
+    "fishing-v6": "BevertonHolt",
+    "fishing-v7": "May",
+    "fishing-v8": "Myers",
+    "fishing-v9": "Ricker",
+    "fishing-v10": "NonStationary",
+    "fishing-v11": "ModelUncertainty",
 }
 ENV_IDS = tuple(ENTRY_POINTS)
 
@@ -60,7 +67,8 @@ def register_with_gym():
 
 
 def __getattr__(name):
-    if name in ("FishingEnv", "FishingCtsEnv", "FishingTippingEnv", "FishingModelError", "BaseFishingEnv"):
+    if name in ("FishingEnv", "FishingCtsEnv", "FishingTippingEnv", "FishingModelError", "BaseFishingEnv", "Allen",
+                "BevertonHolt", "May", "Myers", "Ricker", "NonStationary", "ModelUncertainty"):
         from . import envs
         return getattr(envs, name)
     raise AttributeError(name)

@@ -12,9 +12,14 @@ from . import build as _build
 c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 c_dbl, c_vp = ctypes.c_double, ctypes.c_void_p
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4 = 0, 1, 2, 4
+MODEL_V5, MODEL_V6, MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11 = 5, 6, 7, 8, 9, 10, 11
+KIND_ALLEN, KIND_BEVERTON_HOLT, KIND_MYERS, KIND_MAY, KIND_RICKER = 0, 1, 2, 3, 4
+KIND_OF_NAME = {"allen": KIND_ALLEN, "beverton_holt": KIND_BEVERTON_HOLT, "myers": KIND_MYERS, "may": KIND_MAY,
+                "ricker": KIND_RICKER}
+N_KINDS = 5
 FLAG_AUTO_RESET = 1
 POLICY_RANDOM, POLICY_CONSTANT, POLICY_ESCAPEMENT, POLICY_MSY = 0, 1, 2, 3
 STREAM_NOISE, STREAM_AUTORESET, STREAM_RESET = 0, 1, 2
@@ -24,15 +29,21 @@ class FishingLibraryError(RuntimeError):
     pass
 
 
+class FishingGrowthParams(ctypes.Structure):
+    _fields_ = [(k, c_dbl) for k in ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a")]
+
+
 class FishingParams(ctypes.Structure):
     _fields_ = [("model", c_i32), ("n_actions", c_i32), ("Tmax", c_i32), ("flags", c_u32),
                 ("r", c_dbl), ("K", c_dbl), ("sigma", c_dbl), ("C", c_dbl), ("x0", c_dbl),
                 ("r_mean", c_dbl), ("K_mean", c_dbl), ("sigma_p", c_dbl),
-                ("launch_blocks", c_i32), ("launch_threads", c_i32)]
+                ("launch_blocks", c_i32), ("launch_threads", c_i32),
+                ("M", c_dbl), ("theta", c_dbl), ("q", c_dbl), ("b", c_dbl), ("a", c_dbl), ("alpha", c_dbl),
+                ("n_models", c_i32), ("kinds", c_i32 * 5), ("zoo", FishingGrowthParams * 5)]
 
 
 BUFFER_FIELDS = ("obs", "action", "reward", "done", "done_bits", "t", "r", "K", "sigma", "z_ext",
-                 "terminal_obs", "ep_return", "return_partials")
+                 "terminal_obs", "ep_return", "return_partials", "model_idx")
 
 
 class FishingBuffers(ctypes.Structure):

@@ -81,11 +81,24 @@ __device__ __forceinline__ int32_t action_int_from_word(uint32_t w, int32_t n_ac
 }
 
 // ---------------------------------------------------------------- scalar params in T
+constexpr int kModelZoo = 100;   // template tag: fishing-v5..v11 share one instantiation, the
+                                 // growth function is picked at run time (wave-uniform switch;
+                                 // per-lane for fishing-v11)
+
+template <typename T>
+struct GrowthT {                 // FishingGrowthParams narrowed to T
+    T r, K, sigma, C, M, theta, q, b, a;
+};
+
 template <typename T>
 struct ParamsT {
     int32_t model, n_actions, Tmax;
     uint32_t flags;
     T r, K, sigma, C, x0, r_mean, K_mean, sigma_p;
+    T M, theta, q, b, a, alpha;
+    int32_t n_models;
+    int32_t kinds[FISHING_N_KINDS];
+    GrowthT<T> zoo[FISHING_N_KINDS];
 };
 
 template <typename T>
@@ -103,7 +116,32 @@ inline ParamsT<T> narrow_params(const FishingParams& p) {
     q.r_mean = (T)p.r_mean;
     q.K_mean = (T)p.K_mean;
     q.sigma_p = (T)p.sigma_p;
+    q.M = (T)p.M;
+    q.theta = (T)p.theta;
+    q.q = (T)p.q;
+    q.b = (T)p.b;
+    q.a = (T)p.a;
+    q.alpha = (T)p.alpha;
+    q.n_models = p.n_models;
+    for (int k = 0; k < FISHING_N_KINDS; ++k) {
+        q.kinds[k] = p.kinds[k];
+        const FishingGrowthParams& g = p.zoo[k];
+        q.zoo[k] = GrowthT<T>{(T)g.r, (T)g.K, (T)g.sigma, (T)g.C, (T)g.M, (T)g.theta, (T)g.q, (T)g.b, (T)g.a};
+    }
     return q;
+}
+
+inline bool is_zoo_model(int model) { return model >= FISHING_MODEL_V5 && model <= FISHING_MODEL_V11; }
+
+// growth-function kind of a single-kind zoo model (v11 carries it per env)
+inline int kind_of_model(int model) {
+    switch (model) {
+        case FISHING_MODEL_V5: return FISHING_KIND_ALLEN;
+        case FISHING_MODEL_V7: return FISHING_KIND_MAY;
+        case FISHING_MODEL_V8: return FISHING_KIND_MYERS;
+        case FISHING_MODEL_V9: return FISHING_KIND_RICKER;
+        default: return FISHING_KIND_BEVERTON_HOLT;   // v6, v10
+    }
 }
 
 template <typename T>
@@ -121,6 +159,7 @@ struct BuffersT {
     T* terminal_obs;
     T* ep_return;
     double* partials;
+    int32_t* model_idx;
 };
 
 template <typename T>
@@ -139,6 +178,7 @@ inline BuffersT<T> typed_buffers(const FishingBuffers& b) {
     q.terminal_obs = (T*)b.terminal_obs;
     q.ep_return = (T*)b.ep_return;
     q.partials = b.return_partials;
+    q.model_idx = b.model_idx;
     return q;
 }
 
@@ -183,6 +223,83 @@ __device__ __forceinline__ float action_cts_from_quota(T quota, T K) {
 template <typename T>
 __device__ __forceinline__ int32_t action_int_from_quota(T quota, int32_t n_actions, T K) {
     return (int32_t)__builtin_rint((double)(quota * (T)n_actions / K));
+}
+
+template <typename T>
+__device__ __forceinline__ T log_t(T v);
+template <>
+__device__ __forceinline__ double log_t<double>(double v) {
+    return log(v);
+}
+template <>
+__device__ __forceinline__ float log_t<float>(float v) {
+    return __logf(v);
+}
+template <typename T>
+__device__ __forceinline__ T pow_t(T v, T e);
+template <>
+__device__ __forceinline__ double pow_t<double>(double v, double e) {
+    return pow(v, e);
+}
+template <>
+__device__ __forceinline__ float pow_t<float>(float v, float e) {
+    return __powf(v, e);
+}
+
+// The five growth functions of growth_models.py:208-261; each ends in
+// np.maximum(0, np.random.lognormal(mu, sigma)) = max(0, exp(mu + sigma z)).  The reference
+// really does round-trip through log and exp (also at sigma = 0); so does this.
+template <typename T>
+__device__ __forceinline__ T zoo_population_draw(int kind, T x, T z, const GrowthT<T>& P) {
+    const T inf = (T)__builtin_huge_val();
+    T mu;
+    switch (kind) {
+        case FISHING_KIND_ALLEN:          // :208-217
+            mu = log_t<T>(x) + P.r * ((T)1 - x / P.K) * ((T)1 - P.C) / P.K;
+            break;
+        case FISHING_KIND_MYERS: {        // :247-255
+            const T A = P.r + (T)1;
+            mu = log_t<T>(A) + P.theta * log_t<T>(x) - log_t<T>((T)1 + pow_t<T>(x, P.theta) / P.M);
+            break;
+        }
+        case FISHING_KIND_MAY: {          // :229-242
+            const T xq = pow_t<T>(x, P.q);
+            const T exp_mu = x + x * P.r * ((T)1 - x / P.M) - P.a * xq / (xq + pow_t<T>(P.b, P.q));
+            mu = log_t<T>(exp_mu);
+            break;
+        }
+        case FISHING_KIND_RICKER:         // :258-261
+            mu = log_t<T>(x) + P.r * ((T)1 - x / P.K);
+            break;
+        default: {                        // Beverton-Holt :220-226 (np.clip(., 0, inf): NaN passes)
+            const T xc = (x < (T)0) ? (T)0 : ((x > inf) ? inf : x);
+            const T rc = (P.r < (T)0) ? (T)0 : P.r;
+            const T Kc = (P.K < (T)0) ? (T)0 : P.K;
+            const T A = rc + (T)1;
+            const T B = Kc / rc;
+            mu = log_t<T>(A) + log_t<T>(xc) - log_t<T>((T)1 + xc / B);
+            break;
+        }
+    }
+    const T g = exp_t<T>(mu + P.sigma * z);
+    return (g > (T)0) ? g : ((g != g) ? g : (T)0);    // np.maximum(0, g)
+}
+
+// step() with a zoo growth function: quota / obs maps use the env's K (K_obs), the growth its
+// own parameter set (self.params in the reference).
+template <typename T>
+__device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int kind, const GrowthT<T>& P,
+                                             T K_obs, int32_t Tmax, T& obs_next, T& reward, bool& done,
+                                             int32_t& t_next) {
+    T x = (obs + (T)1) * K_obs;
+    const T h = (quota < x) ? quota : x;
+    const T d = x - h;
+    x = ((T)0 > d) ? (T)0 : d;
+    x = zoo_population_draw<T>(kind, x, z, P);
+    obs_next = x / K_obs - (T)1;
+    reward = ((T)0 > h) ? (T)0 : h;
+    t_next = t + 1;
+    done = (t_next > Tmax) || (x <= (T)0);
 }
 
 // population_draw(): base_fishing_env.py:121-133 (logistic), fishing_tipping_env.py:24-35

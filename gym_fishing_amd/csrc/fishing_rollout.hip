@@ -250,6 +250,7 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
                  fishing_stream_t stream) {
     const int rc = check_common(p, n, env_offset, b);
     if (rc != FISHING_OK) return rc;
+    if (is_zoo_model(p->model)) return FISHING_ERR_MODEL;   // zoo envs roll out step by step (host loop)
     if (policy < FISHING_POLICY_RANDOM || policy > FISHING_POLICY_MSY) return FISHING_ERR_POLICY;
     if (Tsteps < 0) return FISHING_ERR_SIZE;
     if (traj && (((uintptr_t)traj) & 15u)) return FISHING_ERR_ALIGN;

@@ -27,11 +27,21 @@ __global__ void __launch_bounds__(256) FISHING_STEP_ATTRS
 step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
             const uint64_t seed, const uint64_t step_counter) {
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
+    constexpr bool kZoo = (MODEL == kModelZoo);
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
     const bool auto_reset = (p.flags & FISHING_FLAG_AUTO_RESET) != 0;
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
+    // zoo (fishing-v5..v11): wave-uniform facts about the family
+    const bool zoo_drift = kZoo && p.model == FISHING_MODEL_V10;       // r += alpha every draw
+    const bool zoo_mixed = kZoo && p.model == FISHING_MODEL_V11;       // growth kind per env
+    const int zoo_kind = (p.model == FISHING_MODEL_V5)   ? FISHING_KIND_ALLEN
+                         : (p.model == FISHING_MODEL_V7) ? FISHING_KIND_MAY
+                         : (p.model == FISHING_MODEL_V8) ? FISHING_KIND_MYERS
+                         : (p.model == FISHING_MODEL_V9) ? FISHING_KIND_RICKER
+                                                         : FISHING_KIND_BEVERTON_HOLT;
+    const GrowthT<T> zoo_base{p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a};
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
@@ -42,8 +52,10 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         int32_t t[4];
         float a_f[4];
         int32_t a_i[4];
+        int32_t kind[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            kind[j] = zoo_kind;
             obs[j] = (T)0;
             t[j] = 0;
             rr[j] = p.r;
@@ -64,6 +76,8 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                 load4<T>(b.r, base, n, full, rr, p.r);
                 load4<T>(b.K, base, n, full, KK, p.K);
             }
+            if (zoo_drift) load4<T>(b.r, base, n, full, rr, p.r);
+            if (zoo_mixed) load4<int32_t>(b.model_idx, base, n, full, kind, FISHING_KIND_BEVERTON_HOLT);
             if (b.sigma) load4<T>(b.sigma, base, n, full, sg, p.sigma);
             if (NOISE == kNoiseExt) load4<T>(b.z_ext, base, n, full, z, (T)0);
         }
@@ -88,8 +102,23 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         for (int j = 0; j < 4; ++j) {
             const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], p.n_actions, KK[j])
                                                         : quota_cts<T>((T)a_f[j], KK[j]);
-            env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax,
-                               obs_next[j], rew[j], dn[j], t_next[j]);
+            if constexpr (kZoo) {
+                GrowthT<T> P = zoo_base;
+                if (zoo_mixed) {
+                    const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+                    P = p.zoo[kk];
+                }
+                if (zoo_drift) {                     // growth_models.py:151: drift first, then draw
+                    rr[j] = rr[j] + p.alpha;
+                    P.r = rr[j];
+                }
+                if (b.sigma) P.sigma = sg[j];
+                env_step_zoo<T>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, obs_next[j], rew[j], dn[j],
+                                t_next[j]);
+            } else {
+                env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax,
+                                   obs_next[j], rew[j], dn[j], t_next[j]);
+            }
             dn[j] = dn[j] && (base + j < n);
         }
         const bool lane_done = dn[0] | dn[1] | dn[2] | dn[3];
@@ -140,8 +169,22 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
             if (active) store4<T>(b.ep_return, base, n, full, er);
         }
 
+        if (zoo_drift && active) store4<T>(b.r, base, n, full, rr);
         if (auto_reset && wave_done) {
             bool redrawn = false;
+            if (zoo_mixed) {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (dn[j]) {      // growth_models.py:200: a new model for the next episode
+                        const Words4 w = philox_block(seed, env_offset + (uint64_t)(base + j), step_counter,
+                                                      kStreamAutoReset);
+                        kind[j] = p.kinds[action_int_from_word(w.w0, p.n_models)];
+                        any = true;
+                    }
+                }
+                if (any) store4<int32_t>(b.model_idx, base, n, full, kind);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (dn[j]) {
@@ -195,6 +238,10 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
          i += (int64_t)gridDim.x * blockDim.x) {
         if (mask && !mask[i]) continue;
         T K = p.K;
+        if (MODEL == kModelZoo && p.model == FISHING_MODEL_V11) {
+            const Words4 w = philox_block(seed, env_offset + (uint64_t)i, reset_counter, kStreamReset);
+            b.model_idx[i] = p.kinds[action_int_from_word(w.w0, p.n_models)];
+        }
         if (MODEL == FISHING_MODEL_V4) {
             T r;
             draw_model_error<T>(seed, env_offset + (uint64_t)i, reset_counter, kStreamReset, p.K_mean,
@@ -225,9 +272,14 @@ template <typename T, int MODEL>
 __global__ void __launch_bounds__(256)
 population_draw_kernel(const ParamsT<T> p, const int64_t n, const T* __restrict__ x_in,
                        const T* __restrict__ z, T* __restrict__ x_out) {
+    const GrowthT<T> P{p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, p.r, p.K, p.sigma, p.C);
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if constexpr (MODEL == kModelZoo)
+            x_out[i] = zoo_population_draw<T>(p.n_models /* kind passed by the host */, x_in[i], z ? z[i] : (T)0, P);
+        else
+            x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, p.r, p.K, p.sigma, p.C);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -256,8 +308,15 @@ static inline bool misaligned(const void* p) { return p && (((uintptr_t)p) & 15u
 int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b) {
     if (!p || !b) return FISHING_ERR_NULL;
     if (p->model != FISHING_MODEL_V0 && p->model != FISHING_MODEL_V1 && p->model != FISHING_MODEL_V2 &&
-        p->model != FISHING_MODEL_V4)
+        p->model != FISHING_MODEL_V4 && !is_zoo_model(p->model))
         return FISHING_ERR_MODEL;
+    if (p->model == FISHING_MODEL_V10 && !b->r) return FISHING_ERR_NULL;
+    if (p->model == FISHING_MODEL_V11) {
+        if (!b->model_idx) return FISHING_ERR_NULL;
+        if (p->n_models < 1 || p->n_models > FISHING_N_KINDS) return FISHING_ERR_SIZE;
+        for (int k = 0; k < p->n_models; ++k)
+            if (p->kinds[k] < 0 || p->kinds[k] >= FISHING_N_KINDS) return FISHING_ERR_SIZE;
+    }
     if (n < 0 || env_offset < 0 || (env_offset & 3)) return FISHING_ERR_SIZE;
     if (p->model == FISHING_MODEL_V0 && p->n_actions <= 0) return FISHING_ERR_SIZE;
     if (p->launch_threads != 0 &&
@@ -268,7 +327,8 @@ int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     if (p->model == FISHING_MODEL_V4 && (!b->r || !b->K)) return FISHING_ERR_NULL;
     if (b->return_partials && !b->ep_return) return FISHING_ERR_NULL;
     const void* ptrs[] = {b->obs,  b->action, b->reward, b->done,         b->done_bits, b->t,           b->r,
-                          b->K,    b->sigma,  b->z_ext,  b->terminal_obs, b->ep_return, b->return_partials};
+                          b->K,    b->sigma,  b->z_ext,  b->terminal_obs, b->ep_return, b->return_partials,
+                          b->model_idx};
     for (const void* q : ptrs)
         if (misaligned(q)) return FISHING_ERR_ALIGN;
     return FISHING_OK;
@@ -316,7 +376,12 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
     const BuffersT<T> bt = typed_buffers<T>(*b);
     // the reference draws a normal even at sigma == 0 (quirk B3) but multiplies it by 0:
     // skipping the generator there changes no result bit.
-    const int noise = b->z_ext ? kNoiseExt : ((p->sigma == 0.0 && !b->sigma) ? kNoiseNone : kNoisePhilox);
+    bool quiet = (p->sigma == 0.0 && !b->sigma);
+    if (p->model == FISHING_MODEL_V11) {
+        quiet = !b->sigma;
+        for (int k = 0; k < FISHING_N_KINDS; ++k) quiet = quiet && p->zoo[k].sigma == 0.0;
+    }
+    const int noise = b->z_ext ? kNoiseExt : (quiet ? kNoiseNone : kNoisePhilox);
     int blocks, threads;
     launch_shape(p, n, blocks, threads);
     hipStream_t s = (hipStream_t)stream;
@@ -327,8 +392,10 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
             return launch_step_noise<T, FISHING_MODEL_V1>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
         case FISHING_MODEL_V2:
             return launch_step_noise<T, FISHING_MODEL_V2>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-        default:
+        case FISHING_MODEL_V4:
             return launch_step_noise<T, FISHING_MODEL_V4>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+        default:   // fishing-v5..v11
+            return launch_step_noise<T, kModelZoo>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
     }
 }
 
@@ -371,8 +438,11 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
         case FISHING_MODEL_V2:
             reset_kernel<T, FISHING_MODEL_V2><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
             break;
-        default:
+        case FISHING_MODEL_V4:
             reset_kernel<T, FISHING_MODEL_V4><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
+            break;
+        default:
+            reset_kernel<T, kModelZoo><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
             break;
     }
     return (int)hipGetLastError();
@@ -384,10 +454,15 @@ int population_draw_impl(const FishingParams* p, int64_t n, const void* x_in, co
     if (!p || !x_in || !x_out) return FISHING_ERR_NULL;
     if (n < 0) return FISHING_ERR_SIZE;
     if (n == 0) return FISHING_OK;
-    const ParamsT<T> pt = narrow_params<T>(*p);
+    ParamsT<T> pt = narrow_params<T>(*p);
     int64_t nb = (n + 255) / 256;
     const int blocks = (int)(nb < 2048 ? nb : 2048);
     hipStream_t s = (hipStream_t)stream;
+    if (is_zoo_model(p->model) && p->model != FISHING_MODEL_V11) {
+        pt.n_models = kind_of_model(p->model);     // the kernel reads the growth kind from here
+        population_draw_kernel<T, kModelZoo><<<blocks, 256, 0, s>>>(pt, n, (const T*)x_in, (const T*)z, (T*)x_out);
+        return (int)hipGetLastError();
+    }
     if (p->model == FISHING_MODEL_V2)
         population_draw_kernel<T, FISHING_MODEL_V2><<<blocks, 256, 0, s>>>(pt, n, (const T*)x_in, (const T*)z, (T*)x_out);
     else if (p->model == FISHING_MODEL_V0 || p->model == FISHING_MODEL_V1 || p->model == FISHING_MODEL_V4)

@@ -22,8 +22,9 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import (FLAG_AUTO_RESET, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, POLICY_CONSTANT,
-                    POLICY_ESCAPEMENT, POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
+from ._capi import (FLAG_AUTO_RESET, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
+                    MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11, POLICY_CONSTANT, POLICY_ESCAPEMENT,
+                    POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
 from .spaces import is_discrete, space_classes
 
 POLICIES = {"random": POLICY_RANDOM, "constant": POLICY_CONSTANT, "escapement": POLICY_ESCAPEMENT,
@@ -125,6 +126,9 @@ class BaseFishingEnv:
         if self._per_env:
             self._r_arr = torch.full((N,), float(params["r"]), dtype=dtype, device=dev)
             self._K_arr = torch.full((N,), float(params["K"]), dtype=dtype, device=dev)
+        if self.MODEL == MODEL_V10:      # the drifting growth rate is per-env state (growth_models.py:151)
+            self._r_arr = torch.full((N,), float(params["r"]), dtype=dtype, device=dev)
+        self._model_idx = torch.zeros(N, dtype=torch.int32, device=dev) if self.MODEL == MODEL_V11 else None
         self._terminal_obs = torch.empty(N, dtype=dtype, device=dev) if record_terminal_obs else None
         self._done_bits = (torch.zeros((N + 63) // 64, dtype=torch.int64, device=dev) if done_bits else None)
         self._ep_return = self._partials = self._record = None
@@ -202,7 +206,8 @@ class BaseFishingEnv:
         p = self.params
         return (self.Tmax, self.init_state, self.auto_reset, self._sigma_scalar, p["r"], p["K"], self._launch,
                 getattr(self, "n_actions", 0), getattr(self, "C", None), getattr(self, "r_mean", None),
-                getattr(self, "K_mean", None), getattr(self, "sigma_p", None))
+                getattr(self, "K_mean", None), getattr(self, "sigma_p", None),
+                tuple(p.get(k) for k in ("C", "M", "theta", "q", "b", "a", "alpha")))
 
     def _c_params(self):
         """FishingParams for the next call; rebuilt only when a source attribute changed
@@ -225,6 +230,16 @@ class BaseFishingEnv:
         cp.K_mean = float(getattr(self, "K_mean", p.get("K_mean", p["K"])))
         cp.sigma_p = float(getattr(self, "sigma_p", p.get("sigma_p", 0.0)))
         cp.launch_blocks, cp.launch_threads = self._launch
+        for k in ("M", "theta", "q", "b", "a", "alpha"):
+            setattr(cp, k, float(p.get(k, 0.0) or 0.0))
+        if self.MODEL == MODEL_V11:
+            cp.n_models = len(self.models)
+            for i, name in enumerate(self.models):
+                cp.kinds[i] = KIND_OF_NAME[name]
+            for name, d in self.model_params.items():
+                g = cp.zoo[KIND_OF_NAME[name]]
+                for k in ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a"):
+                    setattr(g, k, float(d.get(k, 0.0) or 0.0))
         self._cparams, self._pkey = cp, key
         return cp
 
@@ -235,7 +250,7 @@ class BaseFishingEnv:
             done=ptr(self._done) if with_outputs else None, done_bits=ptr(self._done_bits), t=ptr(self._t),
             r=ptr(self._r_arr), K=ptr(self._K_arr), sigma=ptr(self._sigma_arr), z_ext=ptr(z_ext),
             terminal_obs=ptr(self._terminal_obs), ep_return=ptr(self._ep_return),
-            return_partials=ptr(self._partials))
+            return_partials=ptr(self._partials), model_idx=ptr(self._model_idx))
 
     def _step_buffers(self, action_ptr, z_ptr):
         """The step() FishingBuffers: built once (the env's tensors never move), only the
@@ -582,3 +597,123 @@ class FishingModelError(BaseFishingEnv):
         self._reset_count += 1
         self._obs.fill_(float(self.init_state) / float(self.K_mean) - 1.0)
         self._publish_scalar_state()
+
+
+# ---------------------------------------------------------------------------------------------
+# Growth-model zoo, fishing-v5..v11 (gym_fishing/envs/growth_models.py:6-204): same env core,
+# lognormal process noise, growth function selected by MODEL (wave-uniform in the kernel;
+# per-env for fishing-v11).  Fused rollouts are not built for these: env.rollout() raises and
+# env.simulate() drives them step by step.
+# ---------------------------------------------------------------------------------------------
+class Allen(BaseFishingEnv):
+    """fishing-v5 (growth_models.py:6-25; allen() :208-217)."""
+    MODEL = MODEL_V5
+
+    def __init__(self, r=0.3, K=1, C=0.5, sigma=0.0, init_state=0.75, Tmax=100, file=None, **vec):
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "C": C, "x0": init_state}, Tmax=Tmax, file=file, **vec)
+
+
+class BevertonHolt(BaseFishingEnv):
+    """fishing-v6 (growth_models.py:28-40; beverton_holt() :220-226)."""
+    MODEL = MODEL_V6
+
+    def __init__(self, r=0.3, K=1, sigma=0.0, init_state=0.75, Tmax=100, file=None, **vec):
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "x0": init_state}, Tmax=Tmax, file=file, **vec)
+
+
+class Myers(BaseFishingEnv):
+    """fishing-v8 (growth_models.py:43-70; myers() :247-255)."""
+    MODEL = MODEL_V8
+
+    def __init__(self, r=1.0, K=1.0, M=1.0, theta=3.0, sigma=0.0, init_state=1.5, Tmax=100, file=None, **vec):
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "theta": theta, "M": M, "x0": init_state},
+                         Tmax=Tmax, file=file, **vec)
+
+
+class May(BaseFishingEnv):
+    """fishing-v7 (growth_models.py:75-108; may() :229-242)."""
+    MODEL = MODEL_V7
+
+    def __init__(self, r=0.7, K=1.5, M=1.5, q=3, b=0.15, sigma=0.0, a=0.2, init_state=0.75, Tmax=100, file=None,
+                 **vec):
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "q": q, "b": b, "a": a, "M": M, "x0": init_state},
+                         Tmax=Tmax, file=file, **vec)
+
+
+class Ricker(BaseFishingEnv):
+    """fishing-v9 (growth_models.py:111-123; ricker() :258-261)."""
+    MODEL = MODEL_V9
+
+    def __init__(self, r=0.3, K=1, sigma=0.0, init_state=0.75, Tmax=100, file=None, **vec):
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "x0": init_state}, Tmax=Tmax, file=file, **vec)
+
+
+class NonStationary(BaseFishingEnv):
+    """fishing-v10 (growth_models.py:126-154): Beverton-Holt whose r drifts by alpha at every
+    population draw and is never restored by reset() -- r is per-env state here."""
+    MODEL = MODEL_V10
+
+    def __init__(self, r=0.8, K=1, sigma=0.0, alpha=-0.007, init_state=0.75, Tmax=100, file=None, **vec):
+        super().__init__(params={"r": r, "K": K, "sigma": sigma, "alpha": alpha, "x0": init_state}, Tmax=Tmax,
+                         file=file, **vec)
+
+    @property
+    def r(self):
+        return float(self._r_arr[0]) if self._scalar else self._r_arr
+
+    @r.setter
+    def r(self, v):
+        if isinstance(v, (torch.Tensor, np.ndarray, list, tuple)):
+            self._r_arr.copy_(torch.as_tensor(v).to(device=self.device, dtype=self.dtype).reshape(self.num_envs))
+        else:
+            self._r_arr.fill_(float(v))
+
+
+_V11_DEFAULT_PARAMS = {
+    "allen": {"r": 0.3, "K": 1.0, "sigma": 0.0, "C": 0.5, "x0": 0.75},
+    "beverton_holt": {"r": 0.3, "K": 1, "sigma": 0.0, "x0": 0.75},
+    "myers": {"r": 1.0, "K": 1.0, "M": 1.0, "theta": 3.0, "sigma": 0.0, "x0": 1.5},
+    "may": {"r": 0.7, "K": 1.5, "M": 1.5, "q": 3, "b": 0.15, "sigma": 0.0, "a": 0.2, "x0": 0.75},
+    "ricker": {"r": 0.3, "K": 1, "sigma": 0.0, "x0": 0.75},
+}
+
+
+class ModelUncertainty(BaseFishingEnv):
+    """fishing-v11 (growth_models.py:157-204): the growth function is one of `models`, redrawn
+    per env at every reset.  The env core keeps the base defaults (K = 1, x0 = 0.75) for the
+    obs / quota maps, as the reference does; `model_params` holds the per-model dicts (the
+    reference's `self.params`), `model` / `model_idx` the kind in force."""
+    MODEL = MODEL_V11
+
+    def __init__(self, models=("allen", "beverton_holt", "myers", "may", "ricker"), params=None, Tmax=100,
+                 file=None, **vec):
+        self.models = list(models)
+        if not 1 <= len(self.models) <= 5 or any(m not in KIND_OF_NAME for m in self.models):
+            raise ValueError("models must be 1..5 of %s" % sorted(KIND_OF_NAME))
+        self.model_params = {k: dict(v) for k, v in (_V11_DEFAULT_PARAMS if params is None else params).items()}
+        super().__init__(Tmax=Tmax, file=file, **vec)
+
+    def _param_key(self):
+        return super()._param_key() + (tuple(self.models), tuple(sorted((k, tuple(sorted(v.items())))
+                                                                        for k, v in self.model_params.items())))
+
+    def _set_initial_state(self):
+        # constructor: choose a model (growth_models.py:187); obs as the base class sets it
+        with torch.cuda.device(self.device):
+            rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
+                                self._c_buffers(with_outputs=False), None, self._seed, self._reset_count,
+                                self._stream())
+        _capi.check(rc, "fishing_reset")
+        self._reset_count += 1
+        self._publish_scalar_state()
+
+    @property
+    def model_idx(self):
+        return self._model_idx
+
+    @property
+    def model(self):
+        names = {v: k for k, v in KIND_OF_NAME.items()}
+        if self._scalar:
+            return names[int(self._model_idx[0])]
+        return [names[int(k)] for k in self._model_idx.tolist()]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FISHING_ABI_VERSION 1
+#define FISHING_ABI_VERSION 2
 
 typedef void* fishing_stream_t; /* hipStream_t */
 
@@ -39,6 +39,22 @@ typedef void* fishing_stream_t; /* hipStream_t */
 #define FISHING_MODEL_V1 1 /* fishing-v1: logistic, continuous            envs/fishing_cts_env.py:4-12    */
 #define FISHING_MODEL_V2 2 /* fishing-v2: tipping point, continuous       envs/fishing_tipping_env.py:6-35*/
 #define FISHING_MODEL_V4 4 /* fishing-v4: per-episode (K, r) uncertainty  envs/fishing_model_error.py:6-48*/
+/* growth-model zoo (envs/growth_models.py): lognormal noise, x' = max(0, exp(mu(x) + sigma z)) */
+#define FISHING_MODEL_V5 5   /* fishing-v5  Allen            growth_models.py:6-25,   allen()  :208-217        */
+#define FISHING_MODEL_V6 6   /* fishing-v6  Beverton-Holt    growth_models.py:28-40,  beverton_holt() :220-226 */
+#define FISHING_MODEL_V7 7   /* fishing-v7  May              growth_models.py:75-108, may()    :229-242        */
+#define FISHING_MODEL_V8 8   /* fishing-v8  Myers            growth_models.py:43-70,  myers()  :247-255        */
+#define FISHING_MODEL_V9 9   /* fishing-v9  Ricker           growth_models.py:111-123, ricker() :258-261       */
+#define FISHING_MODEL_V10 10 /* fishing-v10 NonStationary    growth_models.py:126-154 (r += alpha every draw)  */
+#define FISHING_MODEL_V11 11 /* fishing-v11 ModelUncertainty growth_models.py:157-204 (one of five per episode)*/
+
+/* growth-function kinds = positions in the reference's default model list (growth_models.py:160) */
+#define FISHING_KIND_ALLEN 0
+#define FISHING_KIND_BEVERTON_HOLT 1
+#define FISHING_KIND_MYERS 2
+#define FISHING_KIND_MAY 3
+#define FISHING_KIND_RICKER 4
+#define FISHING_N_KINDS 5
 
 /* FishingParams.flags */
 #define FISHING_FLAG_AUTO_RESET 1u /* SB3-VecEnv semantics: a finished env is reset inside step() */
@@ -55,6 +71,11 @@ typedef void* fishing_stream_t; /* hipStream_t */
 /* Scalar parameters of one env family: the constructor kwargs of the reference
  * (envs/fishing_env.py:7-16, fishing_cts_env.py:5-7, fishing_tipping_env.py:7-16,
  * fishing_model_error.py:9-19). */
+/* parameters of one growth function (the per-model dicts of growth_models.py:161-186) */
+typedef struct FishingGrowthParams {
+    double r, K, sigma, C, M, theta, q, b, a;
+} FishingGrowthParams;
+
 typedef struct FishingParams {
     int32_t model;     /* FISHING_MODEL_*                                               */
     int32_t n_actions; /* fishing-v0 only (default 100)                                 */
@@ -65,7 +86,13 @@ typedef struct FishingParams {
     double x0;         /* init_state                                                    */
     double r_mean, K_mean, sigma_p; /* fishing-v4 redraw at reset                       */
     int32_t launch_blocks;  /* 0 = auto; else cap on workgroups (tuning knob)           */
-    int32_t launch_threads; /* 0 = auto (256); 64..1024, multiple of 64                 */
+    int32_t launch_threads; /* 0 = auto (256); 64..256, multiple of 64                  */
+    /* zoo extras (fishing-v5..v11) */
+    double M, theta, q, b, a; /* May / Myers shape parameters (growth_models.py:43-108) */
+    double alpha;             /* fishing-v10: r += alpha before every draw (:151)       */
+    int32_t n_models;         /* fishing-v11: length of the model list (1..5)           */
+    int32_t kinds[FISHING_N_KINDS]; /* fishing-v11: FISHING_KIND_* of each list entry   */
+    FishingGrowthParams zoo[FISHING_N_KINDS]; /* fishing-v11: parameters per KIND       */
 } FishingParams;
 
 /* Device buffers, all of length n unless noted.  "real" = float (_f32) or double (_f64). */
@@ -76,7 +103,7 @@ typedef struct FishingBuffers {
     uint8_t* done;       /* u8    out     nullable                                                */
     uint64_t* done_bits; /* u64[ceil(n/64)] out, bit (i%64) of word i/64 = done[i]; nullable      */
     int32_t* t;          /* i32   in/out  years_passed (base_fishing_env.py:75)                   */
-    void* r;             /* real  in/out  per-env growth rate; required for v4, else nullable     */
+    void* r;             /* real  in/out  per-env growth rate; required for v4 and v10 (drift)    */
     void* K;             /* real  in/out  per-env carrying capacity; required for v4              */
     const void* sigma;   /* real  in      per-env noise scale; nullable => FishingParams.sigma    */
     const void* z_ext;   /* real  in      externally supplied standard normals; nullable =>
@@ -86,6 +113,8 @@ typedef struct FishingBuffers {
     double* return_partials; /* f64[fishing_partials_len()] in/out: per-workgroup partial sums of
                                 {sum R, sum R^2, n_episodes, sum length} over finished episodes;
                                 needs ep_return; nullable                                         */
+    int32_t* model_idx;  /* i32   in/out  fishing-v11: FISHING_KIND_* in force per env (redrawn
+                                          at reset, growth_models.py:187,200); else nullable      */
 } FishingBuffers;
 
 /* In-kernel policies for the fused rollout (callers of step(): shared_env.py:29-54,

@@ -19,8 +19,17 @@ def dev(a, dtype=None):
 
 
 def params(model, r=0.3, K=1.0, sigma=0.0, C=0.5, x0=0.75, Tmax=100, n_actions=100, K_mean=1.0, r_mean=0.3,
-           sigma_p=0.1, auto_reset=False, launch_blocks=0, launch_threads=0):
+           sigma_p=0.1, auto_reset=False, launch_blocks=0, launch_threads=0, M=0.0, theta=0.0, q=0.0, b=0.0, a=0.0,
+           alpha=0.0, models=None, zoo_table=None):
     p = _capi.FishingParams()
+    p.M, p.theta, p.q, p.b, p.a, p.alpha = M, theta, q, b, a, alpha
+    if models is not None:                      # fishing-v11: list of kind indices + per-kind dicts
+        p.n_models = len(models)
+        for i, k in enumerate(models):
+            p.kinds[i] = k
+        for k, d in enumerate(zoo_table):
+            for name in ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a"):
+                setattr(p.zoo[k], name, float(d.get(name, 0.0)))
     p.model, p.n_actions, p.Tmax = model, n_actions, Tmax
     p.flags = _capi.FLAG_AUTO_RESET if auto_reset else 0
     p.r, p.K, p.sigma, p.C, p.x0 = r, K, sigma, C, x0
@@ -33,7 +42,7 @@ class State:
     """Device buffers of one shard, created from host arrays."""
 
     def __init__(self, n, dtype, model, obs, t=None, r=None, K=None, sigma=None, ep_return=False,
-                 terminal=False, done_bits=False):
+                 terminal=False, done_bits=False, model_idx=None):
         self.n, self.np_dtype, self.model = n, np.dtype(dtype), model
         td = TORCH_OF[self.np_dtype]
         self.obs = dev(np.broadcast_to(np.asarray(obs, dtype=dtype), (n,)))
@@ -48,14 +57,16 @@ class State:
         self.partials = (torch.zeros(int(_capi.lib().fishing_partials_len()), dtype=torch.float64, device="cuda")
                          if ep_return else None)
         self.done_bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda") if done_bits else None
-        self._keep = []
+        self.model_idx = (dev(np.broadcast_to(np.asarray(model_idx, dtype=np.int32), (n,)))
+                          if model_idx is not None else None)
 
     def buffers(self, action=None, z_ext=None):
         p = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
         return _capi.make_buffers(obs=p(self.obs), action=p(action), reward=p(self.reward), done=p(self.done),
                                   done_bits=p(self.done_bits), t=p(self.t), r=p(self.r), K=p(self.K),
                                   sigma=p(self.sigma), z_ext=p(z_ext), terminal_obs=p(self.terminal),
-                                  ep_return=p(self.ep_return), return_partials=p(self.partials))
+                                  ep_return=p(self.ep_return), return_partials=p(self.partials),
+                                  model_idx=p(self.model_idx))
 
     @property
     def suffix(self):

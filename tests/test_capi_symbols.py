@@ -37,9 +37,9 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_struct_layout(lib):
     assert lib.fishing_abi_version() == _capi.ABI_VERSION
-    # FishingParams: 4 x i32, 8 x f64, 2 x i32  -> 88 bytes; FishingBuffers: 13 pointers
-    assert ctypes.sizeof(_capi.FishingParams) == 88
-    assert ctypes.sizeof(_capi.FishingBuffers) == 13 * ctypes.sizeof(ctypes.c_void_p)
+    # FishingParams: 4 x i32, 8 x f64, 2 x i32 (88) + 6 x f64 + 6 x i32 (160) + 5 x 9 x f64 -> 520 bytes
+    assert ctypes.sizeof(_capi.FishingParams) == 520
+    assert ctypes.sizeof(_capi.FishingBuffers) == 14 * ctypes.sizeof(ctypes.c_void_p)
     hdr = open(HEADER).read()
     body = hdr[hdr.index("typedef struct FishingBuffers {"):hdr.index("} FishingBuffers;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
@@ -67,7 +67,7 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.fishing_step_f32(p, 0, 0, b, 0, 0, None) == 0              # n == 0: nothing to do
     b = _capi.make_buffers(obs=4100, t=8192, action=12288)
     assert lib.fishing_step_f64(p, 4, 0, b, 0, 0, None) == -3             # misaligned obs
-    p.model = 7
+    p.model = 3                                                           # there is no fishing-v3
     b = _capi.make_buffers(obs=4096, t=8192, action=12288)
     assert lib.fishing_step_f32(p, 4, 0, b, 0, 0, None) == -2             # unknown model
     p.model = _capi.MODEL_V4

@@ -12,14 +12,17 @@ from gym_fishing_amd import sharding, spaces
 
 
 def test_registry_matches_reference_ids():
-    # gym_fishing/envs/__init__.py:17-35 (ids v5..v11 are out of scope)
-    assert gf.ENV_IDS == ("fishing-v0", "fishing-v1", "fishing-v2", "fishing-v4")
+    # gym_fishing/envs/__init__.py:17-71 (there is no fishing-v3)
+    assert gf.ENV_IDS == ("fishing-v0", "fishing-v1", "fishing-v2", "fishing-v4", "fishing-v5", "fishing-v6",
+                          "fishing-v7", "fishing-v8", "fishing-v9", "fishing-v10", "fishing-v11")
+    assert [gf.env_class("fishing-v%d" % k).__name__ for k in range(5, 12)] == [
+        "Allen", "BevertonHolt", "May", "Myers", "Ricker", "NonStationary", "ModelUncertainty"]
     assert gf.env_class("fishing-v0").__name__ == "FishingEnv"
     assert gf.env_class("fishing-v1").__name__ == "FishingCtsEnv"
     assert gf.env_class("fishing-v2").__name__ == "FishingTippingEnv"
     assert gf.env_class("fishing-v4").__name__ == "FishingModelError"
     with pytest.raises(KeyError):
-        gf.env_class("fishing-v5")
+        gf.env_class("fishing-v3")
 
 
 def test_constructor_kwargs_match_reference_signatures():
@@ -30,6 +33,13 @@ def test_constructor_kwargs_match_reference_signatures():
         "fishing-v2": dict(r=0.3, K=1, C=0.5, sigma=0.0, init_state=0.75, Tmax=100, file=None),
         "fishing-v4": dict(K_mean=1.0, r_mean=0.3, price=1.0, sigma=0.0, sigma_p=0.1, init_state=0.75, Tmax=100,
                            file=None),
+        # growth_models.py:6-154
+        "fishing-v5": dict(r=0.3, K=1, C=0.5, sigma=0.0, init_state=0.75, Tmax=100, file=None),
+        "fishing-v6": dict(r=0.3, K=1, sigma=0.0, init_state=0.75, Tmax=100, file=None),
+        "fishing-v7": dict(r=0.7, K=1.5, M=1.5, q=3, b=0.15, sigma=0.0, a=0.2, init_state=0.75, Tmax=100, file=None),
+        "fishing-v8": dict(r=1.0, K=1.0, M=1.0, theta=3.0, sigma=0.0, init_state=1.5, Tmax=100, file=None),
+        "fishing-v9": dict(r=0.3, K=1, sigma=0.0, init_state=0.75, Tmax=100, file=None),
+        "fishing-v10": dict(r=0.8, K=1, sigma=0.0, alpha=-0.007, init_state=0.75, Tmax=100, file=None),
     }
     for env_id, kw in want.items():
         sig = inspect.signature(gf.env_class(env_id).__init__)
