@@ -461,3 +461,164 @@ def test_rollout_reproduces_reference_simulate_tables(hh, c):
         assert_same_bits(state, table[:, 1], c["key"] + " state")
         assert_same_bits(quota_col, table[:, 2], c["key"] + " action(quota)")
         assert_same_bits(reward_col, table[:, 3], c["key"] + " reward")
+
+
+# ------------------------------------------------------------------ the other BASELINE configs at full size
+@pytest.mark.parametrize("cfg", ["config3_v0_2^22", "config4_v2_2^22", "config5_v4_2^21_shard"])
+def test_full_size_baseline_configs(hh, cfg):
+    """BASELINE.json configs 3-5 at their real per-GPU sizes: 3 steps with in-kernel noise and
+    fused auto-reset; (i) a 4096-env window in the middle of the batch against the oracle fed
+    the device's normals -- bit-exact (v2: tolerance), (ii) stepping the batch as 1 shard ==
+    as 8 env_offset shards (the multi-GPU decomposition of configs 4 and 5), (iii) counts."""
+    import torch
+    seed = 20240
+    if cfg.startswith("config3"):
+        model, n, kw = fo.MODEL_V0, 1 << 22, dict(sigma=0.1, n_actions=100)
+    elif cfg.startswith("config4"):
+        model, n, kw = fo.MODEL_V2, 1 << 22, dict(sigma=0.1, C=0.5)
+    else:
+        model, n, kw = fo.MODEL_V4, 1 << 21, dict(sigma=0.05, K_mean=1.0, r_mean=0.3, sigma_p=0.1)
+    per_env = model == fo.MODEL_V4
+    dtype = np.float32
+    p = hh.params(model, auto_reset=True, **kw)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    if model == fo.MODEL_V0:
+        acts = torch.randint(0, 100, (3, n), device="cuda", generator=g, dtype=torch.int32)
+    elif model == fo.MODEL_V2:
+        acts = (torch.rand((3, n), device="cuda", generator=g) * 0.2 - 1.0).float()        # U[-1, -0.8)
+    else:
+        acts = (torch.rand((3, n), device="cuda", generator=g) * 2 - 1).float()
+    lib = __import__("gym_fishing_amd")._capi.lib()
+
+    def run(shards):
+        st = hh.State(n, dtype, model, np.float32(0), r=np.float32(0.3) if per_env else None,
+                      K=np.float32(1) if per_env else None, sigma=np.float32(0.05) if per_env else None,
+                      ep_return=True)
+        snaps = []
+        for k in range(shards):
+            lo, hi = k * n // shards, (k + 1) * n // shards
+            b = st.buffers()
+            for f in ("obs", "t", "r", "K", "sigma", "ep_return"):
+                if getattr(b, f):
+                    setattr(b, f, getattr(b, f) + 4 * lo)
+            assert lib.fishing_reset_f32(p, hi - lo, lo, b, None, seed, 0, None) == 0
+        torch.cuda.synchronize()
+        snaps.append((st.obs.clone(), st.K.clone() if per_env else None, st.r.clone() if per_env else None))
+        for s in range(3):
+            for k in range(shards):
+                lo, hi = k * n // shards, (k + 1) * n // shards
+                b = st.buffers(acts[s])
+                for f in ("obs", "action", "reward", "t", "r", "K", "sigma", "ep_return"):
+                    if getattr(b, f):
+                        setattr(b, f, getattr(b, f) + 4 * lo)
+                b.done = b.done + lo
+                # each shard keeps its own return_partials in a real multi-GPU run; here the 8
+                # shards share one buffer, which only changes the order of the (commutative) sums
+                assert lib.fishing_step_f32(p, hi - lo, lo, b, seed, s, None) == 0
+            torch.cuda.synchronize()
+            snaps.append((st.obs.clone(), st.reward.clone(), st.done.clone(), st.t.clone()))
+        return st, snaps
+    one, s1 = run(1)
+    eight, s8 = run(8)
+    for a, b in zip(s1, s8):
+        for x, y in zip(a, b):
+            assert x is None or torch.equal(x, y)
+    r1, r8 = one.record(), eight.record()
+    assert r1[2] == r8[2] and r1[3] == r8[3] and np.allclose(r1[:2], r8[:2], rtol=1e-12)
+    assert r1[2] == sum(int(s[2].sum()) for s in s1[1:])
+    # oracle window
+    lo, w = n // 2 + 8192, 4096
+    env = np.arange(lo, lo + w)
+    if per_env:
+        _, zK, zr = hh.device_noise(w, seed, 0, fo.STREAM_RESET, lo)
+        K, r = fo.draw_model_error_params(zK, zr, 1.0, 0.3, 0.1, dtype)
+        assert np.array_equal(s1[0][1][lo:lo + w].cpu().numpy(), K)
+        sig = np.float32(0.05)
+    else:
+        K, r, sig = np.full(w, 1.0, dtype), np.full(w, 0.3, dtype), np.float32(kw["sigma"])
+    obs = fo.reset_obs(model, 0.75, K, dtype)
+    assert np.array_equal(s1[0][0][lo:lo + w].cpu().numpy(), obs)
+    t = np.zeros(w, np.int32)
+    for s in range(3):
+        a = acts[s, lo:lo + w].cpu().numpy()
+        z = hh.device_step_noise(w, seed, s, lo).astype(dtype)
+        eo, er, ed, et, _ = fo.step(model, obs, t, a, z, r, K, sig, C=0.5, n_actions=100, dtype=dtype)
+        zK = zr = None
+        if per_env:
+            _, zK, zr = hh.device_noise(w, seed, s, fo.STREAM_AUTORESET, lo)
+        dev_obs, dev_rew, dev_done, dev_t = (x[lo:lo + w].cpu().numpy() for x in s1[s + 1])
+        if model == fo.MODEL_V2:
+            ed = dev_done
+        obs, t, K, r = fo.auto_reset(model, eo, ed, et, K, r, 0.75, zK=zK, zr=zr, K_mean=1.0, r_mean=0.3,
+                                     sigma_p=0.1, dtype=dtype)
+        if model == fo.MODEL_V2:
+            assert pop_close(dev_obs, obs, V2_F32_ULP, 1.2e-7)
+            obs = dev_obs
+        else:
+            assert_same_bits(dev_obs, obs, "%s window obs step %d" % (cfg, s))
+        assert_same_bits(dev_rew, er, "window reward")
+        assert (dev_done == ed).all() and (dev_t == t).all()
+
+
+# ------------------------------------------------------------------ randomised parameter sweep
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
+def test_random_parameter_sets_match_oracle(hh, model, dtype):
+    """30 random constructor-parameter sets per model (r, K, sigma, C, x0, Tmax, n_actions far
+    from the defaults, incl. K = 0 reachable in fishing-v4 and sigma large enough to drive
+    stocks extinct), 6 steps each with fused auto-reset and external noise: every output of
+    every step against the oracle -- bit-exact (v2: population tolerance)."""
+    rng = np.random.default_rng(900 + model)
+    n = 1003
+    per_env = model == fo.MODEL_V4
+    for trial in range(30):
+        r0 = float(rng.uniform(0.0, 2.0))
+        K0 = float(rng.choice([0.1, 0.5, 1.0, 1.0, 3.0, 10.0, 123.456]))
+        sigma = float(rng.choice([0.0, 0.05, 0.3, 0.8]))
+        C = float(rng.uniform(0.0, 1.0)) * K0
+        x0 = float(rng.uniform(0.05, 1.5)) * K0
+        if model == fo.MODEL_V2:
+            # the tipping model exponentiates x*sigma*z: keep the exponent O(1) so that the comparison
+            # measures exp() accuracy, not float32 overflow behaviour
+            r0, sigma = min(r0, 1.0), min(sigma, 0.3)
+        Tmax = int(rng.integers(1, 9))
+        nact = int(rng.choice([2, 7, 100, 1000]))
+        p = hh.params(model, r=r0, K=K0, sigma=sigma, C=C, x0=x0, Tmax=Tmax, n_actions=nact, auto_reset=True,
+                      K_mean=K0, r_mean=r0, sigma_p=0.4)
+        if per_env:
+            K = np.clip(rng.normal(K0, 0.4 * K0, n), 0, 1e6).astype(dtype)
+            K[::101] = 0.0                                   # clip floor: 0/0 -> NaN must propagate
+            r = np.clip(rng.normal(r0, 0.4, n), 0, 1e6).astype(dtype)
+            obs = np.full(n, x0, dtype)
+        else:
+            K, r = np.full(n, K0, dtype), np.full(n, r0, dtype)
+            obs = fo.reset_obs(model, x0, K, dtype)
+        t = np.zeros(n, np.int32)
+        st = hh.State(n, dtype, model, obs, r=r if per_env else None, K=K if per_env else None, terminal=True)
+        for s in range(6):
+            a = (rng.integers(0, nact + 3, n).astype(np.int32) if model == fo.MODEL_V0
+                 else rng.uniform(-1.3, 1.3, n).astype(np.float32))
+            z = rng.standard_normal(n).astype(dtype)
+            o, rew, done, t2 = st.step(p, a, z=z, seed=trial, step_counter=s)
+            eo, er, ed, et, ex = fo.step(model, obs, t, a, z, r, K, sigma, C=C, Tmax=Tmax, n_actions=nact, dtype=dtype)
+            term = st.terminal.cpu().numpy()
+            if model == fo.MODEL_V2:
+                ok = pop_close(term, eo, *((V2_F64_ULP, 2.3e-16) if dtype == np.float64 else (V2_F32_ULP, 1.2e-7)))
+                if not ok:      # populations far above K have |obs| >> 1: compare relatively there
+                    big = np.isfinite(eo) & (np.abs(eo) < 1e6)
+                    assert np.allclose(term[big].astype(np.float64), eo[big].astype(np.float64),
+                                       rtol=1e-13 if dtype == np.float64 else 5e-6, atol=1e-6, equal_nan=True)
+                eo = term
+                ed = done
+            else:
+                assert_same_bits(term, eo, "trial %d step %d terminal obs" % (trial, s))
+                assert (done == ed).all()
+            assert_same_bits(rew, er, "trial %d step %d reward" % (trial, s))
+            zK = zr = None
+            if per_env:
+                import hip_harness
+                _, zK, zr = hip_harness.device_noise(n, trial, s, fo.STREAM_AUTORESET, 0)
+            obs, t, K, r = fo.auto_reset(model, eo, ed, et, K, r, x0, zK=zK, zr=zr, K_mean=K0, r_mean=r0,
+                                         sigma_p=0.4, dtype=dtype)
+            assert_same_bits(o, obs, "trial %d step %d obs" % (trial, s))
+            assert (t2 == t).all()
