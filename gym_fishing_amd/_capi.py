@@ -43,7 +43,7 @@ class FishingParams(ctypes.Structure):
 
 
 BUFFER_FIELDS = ("obs", "action", "reward", "done", "done_bits", "t", "r", "K", "sigma", "z_ext",
-                 "terminal_obs", "ep_return", "return_partials", "model_idx")
+                 "terminal_obs", "ep_return", "return_partials", "model_idx", "counter")
 
 
 class FishingBuffers(ctypes.Structure):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "fishing_rollout_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),
     "fishing_rollout_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),
     "fishing_reduce_returns": (c_i32, [c_vp, c_vp, c_vp]),
+    "fishing_counter_add": (c_i32, [c_vp, c_u64, c_vp]),
     "fishing_population_draw_f32": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "fishing_population_draw_f64": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "fishing_noise_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_i32, c_vp, c_vp, c_vp, c_vp]),

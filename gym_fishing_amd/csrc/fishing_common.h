@@ -160,6 +160,7 @@ struct BuffersT {
     T* ep_return;
     double* partials;
     int32_t* model_idx;
+    const uint64_t* counter;
 };
 
 template <typename T>
@@ -179,6 +180,7 @@ inline BuffersT<T> typed_buffers(const FishingBuffers& b) {
     q.ep_return = (T*)b.ep_return;
     q.partials = b.return_partials;
     q.model_idx = b.model_idx;
+    q.counter = b.counter;
     return q;
 }
 

@@ -20,7 +20,8 @@ template <typename T, int MODEL, int POLICY, bool AUTO>
 __global__ void __launch_bounds__(256)
 rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
                const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed,
-               const uint64_t step_counter0, const int noise_on) {
+               const uint64_t step_counter_arg, const int noise_on) {
+    const uint64_t step_counter0 = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     constexpr bool kNeedWords = (POLICY == FISHING_POLICY_RANDOM);
     const int lane = threadIdx.x & (kWave - 1);

@@ -25,7 +25,10 @@ namespace fishing {
 template <typename T, int MODEL, int NOISE>
 __global__ void __launch_bounds__(256) FISHING_STEP_ATTRS
 step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
-            const uint64_t seed, const uint64_t step_counter) {
+            const uint64_t seed, const uint64_t step_counter_arg) {
+    // graph-replay safety: with a device-resident counter the launch arguments can stay frozen
+    // in a captured hipGraph while the noise key still advances (wave-uniform scalar load)
+    const uint64_t step_counter = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     constexpr bool kZoo = (MODEL == kModelZoo);
     const int lane = threadIdx.x & (kWave - 1);
@@ -282,6 +285,8 @@ population_draw_kernel(const ParamsT<T> p, const int64_t n, const T* __restrict_
     }
 }
 
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t delta) { *counter += delta; }
+
 __global__ void __launch_bounds__(256)
 noise_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, const uint64_t counter,
              const uint32_t stream_tag, uint32_t* __restrict__ words, float* __restrict__ z0,
@@ -326,6 +331,7 @@ int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     if (!b->obs || !b->t) return FISHING_ERR_NULL;
     if (p->model == FISHING_MODEL_V4 && (!b->r || !b->K)) return FISHING_ERR_NULL;
     if (b->return_partials && !b->ep_return) return FISHING_ERR_NULL;
+    if (b->counter && (((uintptr_t)b->counter) & 7u)) return FISHING_ERR_ALIGN;
     const void* ptrs[] = {b->obs,  b->action, b->reward, b->done,         b->done_bits, b->t,           b->r,
                           b->K,    b->sigma,  b->z_ext,  b->terminal_obs, b->ep_return, b->return_partials,
                           b->model_idx};
@@ -529,6 +535,13 @@ int fishing_reset_f32(const FishingParams* p, int64_t n, int64_t env_offset, con
 int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                       const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream) {
     return fishing::reset_impl<double>(p, n, env_offset, b, mask, seed, reset_counter, stream);
+}
+
+int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stream) {
+    if (!counter) return FISHING_ERR_NULL;
+    if (((uintptr_t)counter) & 7u) return FISHING_ERR_ALIGN;
+    fishing::counter_add_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter, delta);
+    return (int)hipGetLastError();
 }
 
 int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream) {

@@ -139,6 +139,7 @@ class BaseFishingEnv:
         self._action_buf = None
         self._last_action = None
         self._cparams = self._pkey = self._cbuf = None
+        self._counter = None          # device-resident step counter (graph-replay mode), else host int
         self._want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
         self._obs_view = self._obs.view(N, 1)
         self._done_view = self._done.view(torch.bool)
@@ -250,7 +251,7 @@ class BaseFishingEnv:
             done=ptr(self._done) if with_outputs else None, done_bits=ptr(self._done_bits), t=ptr(self._t),
             r=ptr(self._r_arr), K=ptr(self._K_arr), sigma=ptr(self._sigma_arr), z_ext=ptr(z_ext),
             terminal_obs=ptr(self._terminal_obs), ep_return=ptr(self._ep_return),
-            return_partials=ptr(self._partials), model_idx=ptr(self._model_idx))
+            return_partials=ptr(self._partials), model_idx=ptr(self._model_idx), counter=ptr(self._counter))
 
     def _step_buffers(self, action_ptr, z_ptr):
         """The step() FishingBuffers: built once (the env's tensors never move), only the
@@ -288,7 +289,19 @@ class BaseFishingEnv:
         self._seed = int(0 if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self._step_count = 0
         self._reset_count = 0
+        if self._counter is not None:
+            self._counter.zero_()
         return [self._seed]
+
+    def enable_graph_replay(self):
+        """Keep the step counter in device memory from now on.  step() / step_many() / rollout()
+        then launch with frozen arguments plus a one-thread counter bump, so a hipGraph that
+        captured them (torch.cuda.CUDAGraph, or gym_fishing_amd.graphs.GraphedSteps) draws
+        fresh noise on every replay.  Same noise stream as the host-counter mode."""
+        if self._counter is None:
+            self._counter = torch.tensor([self._step_count], dtype=torch.int64, device=self.device)
+            self._cbuf = None
+        return self
 
     def reset(self, mask=None):
         """base_fishing_env.py:83-91 (v4: fishing_model_error.py:41-48).  `mask` (bool[N]) resets
@@ -342,13 +355,20 @@ class BaseFishingEnv:
         if noise is not None:
             z = torch.as_tensor(noise).to(device=self.device, dtype=self.dtype).reshape(self.num_envs).contiguous()
         bufs = self._step_buffers(a.data_ptr(), z.data_ptr() if z is not None else None)
+        on_device = self._counter is not None
+        host_count = 0 if on_device else self._step_count
         if torch.cuda.current_device() == self.device.index:
-            rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed,
-                               self._step_count, torch.cuda.current_stream().cuda_stream)
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed, host_count, stream)
+            if on_device and not rc:
+                rc = self._lib.fishing_counter_add(self._counter.data_ptr(), 1, stream)
         else:
             with torch.cuda.device(self.device):
-                rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed,
-                                   self._step_count, self._stream())
+                stream = self._stream()
+                rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed, host_count,
+                                   stream)
+                if on_device and not rc:
+                    rc = self._lib.fishing_counter_add(self._counter.data_ptr(), 1, stream)
         if rc:
             _capi.check(rc, "fishing_step")
         self._step_count += 1
@@ -376,7 +396,10 @@ class BaseFishingEnv:
         n_steps = R if n_steps is None else int(n_steps)
         with torch.cuda.device(self.device):
             rc = self._fn_step_many(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(actions),
-                                    self.num_envs, R, n_steps, self._seed, self._step_count, self._stream())
+                                    self.num_envs, R, n_steps, self._seed,
+                                    0 if self._counter is not None else self._step_count, self._stream())
+            if self._counter is not None and not rc:
+                rc = self._lib.fishing_counter_add(self._counter.data_ptr(), n_steps, self._stream())
         _capi.check(rc, "fishing_step_many")
         self._step_count += n_steps
         self._last_action = actions[(n_steps - 1) % R] if n_steps else self._last_action
@@ -420,7 +443,9 @@ class BaseFishingEnv:
         with torch.cuda.device(self.device):
             rc = self._fn_rollout(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(),
                                   pol, float(param), int(n_steps), traj.data_ptr() if traj is not None else None,
-                                  self._seed, self._step_count, self._stream())
+                                  self._seed, 0 if self._counter is not None else self._step_count, self._stream())
+            if self._counter is not None and not rc:
+                rc = self._lib.fishing_counter_add(self._counter.data_ptr(), int(n_steps), self._stream())
         _capi.check(rc, "fishing_rollout")
         self._step_count += int(n_steps)
         if self._scalar:

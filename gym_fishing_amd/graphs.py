@@ -1,0 +1,53 @@
+"""hipGraph capture of env steps (torch.cuda.CUDAGraph is the capture/replay plumbing).
+
+The kernels are launched on torch's current stream, so they are captured like any torch
+op.  What needs care is the noise key: a captured launch freezes its arguments, so the
+step counter moves to device memory first (BaseFishingEnv.enable_graph_replay); every
+replay then advances it with a captured one-thread kernel.
+
+    g = GraphedSteps(env, actions)      # actions: static [R, N] (or [N]) device tensor
+    for _ in range(iters):
+        actions.copy_(policy(...))      # write new actions into the static buffer
+        obs, reward, done, info = g.replay()
+"""
+import torch
+
+
+class GraphedSteps:
+    def __init__(self, env, actions, n_steps=None, warmup=1):
+        if env._scalar:
+            raise ValueError("graph capture is for the N-env tensor protocol")
+        self.env = env.enable_graph_replay()
+        self.actions = actions
+        many = actions.dim() == 2
+        self.n_steps = (actions.shape[0] if n_steps is None else int(n_steps)) if many else 1
+        run = (lambda: env.step_many(actions, self.n_steps)) if many else (lambda: env.step(actions))
+        # warm up on a side stream (torch's capture rule), then restore the counter so the
+        # captured sequence continues where the caller left off
+        start = env._counter.clone()
+        side = torch.cuda.Stream(device=env.device)
+        side.wait_stream(torch.cuda.current_stream(env.device))
+        with torch.cuda.stream(side):
+            snap = (env._obs.clone(), env._t.clone())
+            extra = [t.clone() if t is not None else None for t in (env._ep_return, env._partials, env._r_arr,
+                                                                     env._K_arr, env._model_idx)]
+            for _ in range(warmup):
+                run()
+            env._obs.copy_(snap[0])
+            env._t.copy_(snap[1])
+            for t, c in zip((env._ep_return, env._partials, env._r_arr, env._K_arr, env._model_idx), extra):
+                if t is not None:
+                    t.copy_(c)
+            env._counter.copy_(start)
+        torch.cuda.current_stream(env.device).wait_stream(side)
+        env._step_count -= warmup * self.n_steps
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = run()
+        # capture does not execute: the env state and counter are still at `start`
+        env._step_count -= self.n_steps
+
+    def replay(self):
+        self.graph.replay()
+        self.env._step_count += self.n_steps
+        return self.out

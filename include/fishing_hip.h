@@ -115,6 +115,11 @@ typedef struct FishingBuffers {
                                 needs ep_return; nullable                                         */
     int32_t* model_idx;  /* i32   in/out  fishing-v11: FISHING_KIND_* in force per env (redrawn
                                           at reset, growth_models.py:187,200); else nullable      */
+    const uint64_t* counter; /* u64[1] in  device-resident step counter, nullable.  When set, the
+                                noise of fishing_step_* / fishing_rollout_* is keyed by
+                                *counter + step_counter instead of step_counter alone, so a
+                                hipGraph that captured the launch draws fresh noise on every
+                                replay; advance it with fishing_counter_add (also capturable).  */
 } FishingBuffers;
 
 /* In-kernel policies for the fused rollout (callers of step(): shared_env.py:29-54,
@@ -167,6 +172,10 @@ int fishing_rollout_f32(const FishingParams* p, int64_t n, int64_t env_offset, c
 int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                         int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
                         uint64_t step_counter, fishing_stream_t stream);
+
+/* *counter += delta on `stream` (one thread).  Pair with FishingBuffers.counter to make a
+ * captured step() / rollout() replayable: capture {step, counter_add(1)} once, replay K times. */
+int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stream);
 
 /* Sum the per-workgroup partials in slot order (deterministic) into out4 =
  * {sum R, sum R^2, n_episodes, sum length}.  out4 is then all-reduced across GPUs by

@@ -325,3 +325,39 @@ def test_simulate_with_generic_model_and_policyfn(gf):
     assert list(pf.columns) == ["state", "action", "rep"] and len(pf) == 50
     st, ac = pf["state"].to_numpy(), pf["action"].to_numpy()
     assert np.allclose(ac, np.maximum(st - 0.5, 0.0), atol=1e-7)
+
+
+def test_graph_replay_draws_fresh_noise_and_matches_eager(gf):
+    """A captured step() replays with advancing noise keys (device-resident counter) and
+    gives exactly what eager stepping gives; same for a captured 5-step step_many."""
+    import torch
+    from gym_fishing_amd.graphs import GraphedSteps
+    n = 4096
+    acts = torch.rand((5, n), device="cuda") * 2 - 1
+    eager = gf.make("fishing-v1", sigma=0.2, num_envs=n, seed=21)
+    eager.reset()
+    graphed = gf.make("fishing-v1", sigma=0.2, num_envs=n, seed=21)
+    graphed.reset()
+    static = acts[0].clone()
+    g = GraphedSteps(graphed, static)
+    assert int(graphed._counter) == 0 and torch.equal(graphed.state, eager.state)
+    prev = None
+    for k in range(7):
+        static.copy_(acts[k % 5])
+        obs, rew, done, _ = g.replay()
+        eo, er, ed, _ = eager.step(acts[k % 5])
+        assert torch.equal(obs, eo) and torch.equal(rew, er) and torch.equal(done, ed), k
+        if prev is not None:
+            assert not torch.equal(prev, rew)
+        prev = rew.clone()
+    assert int(graphed._counter) == 7
+    # multi-step graph
+    g2 = GraphedSteps(graphed, acts)
+    for _ in range(3):
+        g2.replay()
+        eager.step_many(acts, 5)
+    assert torch.equal(graphed.state, eager.state) and int(graphed._counter) == 7 + 15
+    # eager calls on a graph-mode env keep the same stream of noise
+    graphed.step(acts[1])
+    eager.step(acts[1])
+    assert torch.equal(graphed.state, eager.state)
