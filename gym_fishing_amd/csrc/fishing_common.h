@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
+
 #include "../../include/fishing_hip.h"
 
 namespace fishing {
@@ -81,14 +83,37 @@ __device__ __forceinline__ int32_t action_int_from_word(uint32_t w, int32_t n_ac
 }
 
 // ---------------------------------------------------------------- scalar params in T
-constexpr int kModelZoo = 100;   // template tag: fishing-v5..v11 share one instantiation, the
-                                 // growth function is picked at run time (wave-uniform switch;
-                                 // per-lane for fishing-v11)
+// template tags of the zoo (fishing-v5..v11): kModelZoo + FISHING_KIND_* = one instantiation per
+// growth function (v5..v10: the kind is a compile-time constant, so each kernel carries only
+// its own log/exp/pow chain); kModelZooMixed = fishing-v11, kind per env (per-lane switch)
+constexpr int kModelZoo = 100;
+constexpr int kModelZooMixed = kModelZoo + FISHING_N_KINDS;
+constexpr bool is_zoo_tag(int model_tag) { return model_tag >= kModelZoo && model_tag <= kModelZooMixed; }
 
 template <typename T>
 struct GrowthT {                 // FishingGrowthParams narrowed to T
     T r, K, sigma, C, M, theta, q, b, a;
+    // per-launch constants of the growth functions, evaluated once on the host in double
+    // (libm) instead of once per env on the device:
+    T bq;      // May:            b ** q                       (growth_models.py:238)
+    T logA;    // B-H / Myers:    log(clip(r, 0, inf) + 1) / log(r + 1)   (:222,:225 / :248,:251)
+    T B;       // Beverton-Holt:  clip(K, 0, inf) / clip(r, 0, inf)       (:224)
 };
+
+template <typename T>
+inline GrowthT<T> make_growth(double r, double K, double sigma, double C, double M, double theta, double q,
+                              double b, double a, bool beverton_holt) {
+    GrowthT<T> g{(T)r, (T)K, (T)sigma, (T)C, (T)M, (T)theta, (T)q, (T)b, (T)a, (T)0, (T)0, (T)0};
+    g.bq = (T)std::pow(b, q);
+    if (beverton_holt) {
+        const double rc = r < 0 ? 0 : r, Kc = K < 0 ? 0 : K;
+        g.logA = (T)std::log(rc + 1.0);
+        g.B = (T)(Kc / rc);
+    } else {
+        g.logA = (T)std::log(r + 1.0);
+    }
+    return g;
+}
 
 template <typename T>
 struct ParamsT {
@@ -96,6 +121,7 @@ struct ParamsT {
     uint32_t flags;
     T r, K, sigma, C, x0, r_mean, K_mean, sigma_p;
     T M, theta, q, b, a, alpha;
+    GrowthT<T> growth;           // the single growth function of fishing-v5..v10 (+ host constants)
     int32_t n_models;
     int32_t kinds[FISHING_N_KINDS];
     GrowthT<T> zoo[FISHING_N_KINDS];
@@ -123,10 +149,12 @@ inline ParamsT<T> narrow_params(const FishingParams& p) {
     q.a = (T)p.a;
     q.alpha = (T)p.alpha;
     q.n_models = p.n_models;
+    q.growth = make_growth<T>(p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a,
+                              p.model == FISHING_MODEL_V6 || p.model == FISHING_MODEL_V10);
     for (int k = 0; k < FISHING_N_KINDS; ++k) {
         q.kinds[k] = p.kinds[k];
         const FishingGrowthParams& g = p.zoo[k];
-        q.zoo[k] = GrowthT<T>{(T)g.r, (T)g.K, (T)g.sigma, (T)g.C, (T)g.M, (T)g.theta, (T)g.q, (T)g.b, (T)g.a};
+        q.zoo[k] = make_growth<T>(g.r, g.K, g.sigma, g.C, g.M, g.theta, g.q, g.b, g.a, k == FISHING_KIND_BEVERTON_HOLT);
     }
     return q;
 }
@@ -235,38 +263,43 @@ __device__ __forceinline__ double log_t<double>(double v) {
 }
 template <>
 __device__ __forceinline__ float log_t<float>(float v) {
-    return __logf(v);
+    return __builtin_amdgcn_logf(v) * 0.6931471805599453f;          // v_log_f32 is log2
 }
+// x ** e for x >= 0 as exp(e * log x): one log + one exp instead of the library pow (which
+// carries full special-case handling and is ~4x the instructions); pow(0, e > 0) = exp(-inf) = 0,
+// inf and NaN propagate.  Error ~ |e log x| ulp, far inside the zoo's parity tolerance.
 template <typename T>
 __device__ __forceinline__ T pow_t(T v, T e);
 template <>
 __device__ __forceinline__ double pow_t<double>(double v, double e) {
-    return pow(v, e);
+    return exp(e * log(v));
 }
 template <>
 __device__ __forceinline__ float pow_t<float>(float v, float e) {
-    return __powf(v, e);
+    return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(v));    // v_exp_f32 is 2**x
 }
 
 // The five growth functions of growth_models.py:208-261; each ends in
 // np.maximum(0, np.random.lognormal(mu, sigma)) = max(0, exp(mu + sigma z)).  The reference
 // really does round-trip through log and exp (also at sigma = 0); so does this.
-template <typename T>
-__device__ __forceinline__ T zoo_population_draw(int kind, T x, T z, const GrowthT<T>& P) {
+// RECOMPUTE: P.r changed on the device (fishing-v10 drift) -> logA / B are evaluated here
+template <typename T, int KIND = -1, bool RECOMPUTE = false>
+__device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const GrowthT<T>& P) {
     const T inf = (T)__builtin_huge_val();
+    const int kind = (KIND >= 0) ? KIND : kind_rt;      // compile-time kind folds the switch away
     T mu;
     switch (kind) {
         case FISHING_KIND_ALLEN:          // :208-217
             mu = log_t<T>(x) + P.r * ((T)1 - x / P.K) * ((T)1 - P.C) / P.K;
             break;
-        case FISHING_KIND_MYERS: {        // :247-255
-            const T A = P.r + (T)1;
-            mu = log_t<T>(A) + P.theta * log_t<T>(x) - log_t<T>((T)1 + pow_t<T>(x, P.theta) / P.M);
+        case FISHING_KIND_MYERS: {        // :247-255   (log(A), A = r + 1, comes from the host)
+            const T lx = log_t<T>(x);
+            mu = P.logA + P.theta * lx - log_t<T>((T)1 + exp_t<T>(P.theta * lx) / P.M);   // x**theta
             break;
         }
-        case FISHING_KIND_MAY: {          // :229-242
+        case FISHING_KIND_MAY: {          // :229-242   (b**q comes from the host)
             const T xq = pow_t<T>(x, P.q);
-            const T exp_mu = x + x * P.r * ((T)1 - x / P.M) - P.a * xq / (xq + pow_t<T>(P.b, P.q));
+            const T exp_mu = x + x * P.r * ((T)1 - x / P.M) - P.a * xq / (xq + P.bq);
             mu = log_t<T>(exp_mu);
             break;
         }
@@ -275,11 +308,14 @@ __device__ __forceinline__ T zoo_population_draw(int kind, T x, T z, const Growt
             break;
         default: {                        // Beverton-Holt :220-226 (np.clip(., 0, inf): NaN passes)
             const T xc = (x < (T)0) ? (T)0 : ((x > inf) ? inf : x);
-            const T rc = (P.r < (T)0) ? (T)0 : P.r;
-            const T Kc = (P.K < (T)0) ? (T)0 : P.K;
-            const T A = rc + (T)1;
-            const T B = Kc / rc;
-            mu = log_t<T>(A) + log_t<T>(xc) - log_t<T>((T)1 + xc / B);
+            T logA = P.logA, B = P.B;
+            if (RECOMPUTE) {
+                const T rc = (P.r < (T)0) ? (T)0 : P.r;
+                const T Kc = (P.K < (T)0) ? (T)0 : P.K;
+                logA = log_t<T>(rc + (T)1);
+                B = Kc / rc;
+            }
+            mu = logA + log_t<T>(xc) - log_t<T>((T)1 + xc / B);
             break;
         }
     }
@@ -289,7 +325,7 @@ __device__ __forceinline__ T zoo_population_draw(int kind, T x, T z, const Growt
 
 // step() with a zoo growth function: quota / obs maps use the env's K (K_obs), the growth its
 // own parameter set (self.params in the reference).
-template <typename T>
+template <typename T, int KIND = -1, bool RECOMPUTE = false>
 __device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int kind, const GrowthT<T>& P,
                                              T K_obs, int32_t Tmax, T& obs_next, T& reward, bool& done,
                                              int32_t& t_next) {
@@ -297,7 +333,7 @@ __device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int
     const T h = (quota < x) ? quota : x;
     const T d = x - h;
     x = ((T)0 > d) ? (T)0 : d;
-    x = zoo_population_draw<T>(kind, x, z, P);
+    x = zoo_population_draw<T, KIND, RECOMPUTE>(kind, x, z, P);
     obs_next = x / K_obs - (T)1;
     reward = ((T)0 > h) ? (T)0 : h;
     t_next = t + 1;

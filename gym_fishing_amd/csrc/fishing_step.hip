@@ -30,7 +30,8 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
     // in a captured hipGraph while the noise key still advances (wave-uniform scalar load)
     const uint64_t step_counter = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
-    constexpr bool kZoo = (MODEL == kModelZoo);
+    constexpr bool kZoo = is_zoo_tag(MODEL);
+    constexpr int kZooKind = (kZoo && MODEL != kModelZooMixed) ? (MODEL - kModelZoo) : -1;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
@@ -38,13 +39,9 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
     // zoo (fishing-v5..v11): wave-uniform facts about the family
     const bool zoo_drift = kZoo && p.model == FISHING_MODEL_V10;       // r += alpha every draw
-    const bool zoo_mixed = kZoo && p.model == FISHING_MODEL_V11;       // growth kind per env
-    const int zoo_kind = (p.model == FISHING_MODEL_V5)   ? FISHING_KIND_ALLEN
-                         : (p.model == FISHING_MODEL_V7) ? FISHING_KIND_MAY
-                         : (p.model == FISHING_MODEL_V8) ? FISHING_KIND_MYERS
-                         : (p.model == FISHING_MODEL_V9) ? FISHING_KIND_RICKER
-                                                         : FISHING_KIND_BEVERTON_HOLT;
-    const GrowthT<T> zoo_base{p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a};
+    constexpr bool zoo_mixed = (MODEL == kModelZooMixed);              // growth kind per env
+    constexpr int zoo_kind = (kZooKind >= 0) ? kZooKind : FISHING_KIND_BEVERTON_HOLT;
+    const GrowthT<T> zoo_base = p.growth;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
@@ -116,8 +113,12 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                     P.r = rr[j];
                 }
                 if (b.sigma) P.sigma = sg[j];
-                env_step_zoo<T>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, obs_next[j], rew[j], dn[j],
-                                t_next[j]);
+                if (zoo_drift)
+                    env_step_zoo<T, kZooKind, true>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, obs_next[j],
+                                                    rew[j], dn[j], t_next[j]);
+                else
+                    env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, obs_next[j],
+                                                     rew[j], dn[j], t_next[j]);
             } else {
                 env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax,
                                    obs_next[j], rew[j], dn[j], t_next[j]);
@@ -241,7 +242,7 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
          i += (int64_t)gridDim.x * blockDim.x) {
         if (mask && !mask[i]) continue;
         T K = p.K;
-        if (MODEL == kModelZoo && p.model == FISHING_MODEL_V11) {
+        if (is_zoo_tag(MODEL) && p.model == FISHING_MODEL_V11) {
             const Words4 w = philox_block(seed, env_offset + (uint64_t)i, reset_counter, kStreamReset);
             b.model_idx[i] = p.kinds[action_int_from_word(w.w0, p.n_models)];
         }
@@ -275,10 +276,10 @@ template <typename T, int MODEL>
 __global__ void __launch_bounds__(256)
 population_draw_kernel(const ParamsT<T> p, const int64_t n, const T* __restrict__ x_in,
                        const T* __restrict__ z, T* __restrict__ x_out) {
-    const GrowthT<T> P{p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a};
+    const GrowthT<T> P = p.growth;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
-        if constexpr (MODEL == kModelZoo)
+        if constexpr (is_zoo_tag(MODEL))
             x_out[i] = zoo_population_draw<T>(p.n_models /* kind passed by the host */, x_in[i], z ? z[i] : (T)0, P);
         else
             x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, p.r, p.K, p.sigma, p.C);
@@ -400,8 +401,21 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
             return launch_step_noise<T, FISHING_MODEL_V2>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
         case FISHING_MODEL_V4:
             return launch_step_noise<T, FISHING_MODEL_V4>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-        default:   // fishing-v5..v11
-            return launch_step_noise<T, kModelZoo>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+        case FISHING_MODEL_V11:
+            return launch_step_noise<T, kModelZooMixed>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+        default:   // fishing-v5..v10: one instantiation per growth function
+            switch (kind_of_model(p->model)) {
+                case FISHING_KIND_ALLEN:
+                    return launch_step_noise<T, kModelZoo + FISHING_KIND_ALLEN>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+                case FISHING_KIND_MYERS:
+                    return launch_step_noise<T, kModelZoo + FISHING_KIND_MYERS>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+                case FISHING_KIND_MAY:
+                    return launch_step_noise<T, kModelZoo + FISHING_KIND_MAY>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+                case FISHING_KIND_RICKER:
+                    return launch_step_noise<T, kModelZoo + FISHING_KIND_RICKER>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+                default:
+                    return launch_step_noise<T, kModelZoo + FISHING_KIND_BEVERTON_HOLT>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
+            }
     }
 }
 
@@ -448,7 +462,7 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
             reset_kernel<T, FISHING_MODEL_V4><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
             break;
         default:
-            reset_kernel<T, kModelZoo><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
+            reset_kernel<T, kModelZooMixed><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
             break;
     }
     return (int)hipGetLastError();

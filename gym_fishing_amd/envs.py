@@ -530,7 +530,8 @@ class BaseFishingEnv:
             zt = torch.as_tensor(noise).to(device=self.device, dtype=self.dtype).reshape(-1).contiguous()
         out = torch.empty_like(xt)
         cp = self._c_params()
-        if sigma is not None:
+        if sigma is not None:                       # never edit the cached struct step() uses
+            cp = _capi.FishingParams.from_buffer_copy(cp)
             cp.sigma = float(sigma)
         fn = getattr(self._lib, "fishing_population_draw_" + self._suffix)
         with torch.cuda.device(self.device):

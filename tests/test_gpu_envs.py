@@ -361,3 +361,19 @@ def test_graph_replay_draws_fresh_noise_and_matches_eager(gf):
     graphed.step(acts[1])
     eager.step(acts[1])
     assert torch.equal(graphed.state, eager.state)
+
+
+def test_bmsy_does_not_disturb_the_env_noise_level(gf):
+    """BMSY()/msy() evaluate population_draw at sigma = 0 (models/policies.py:61-65) and must
+    leave the env's own sigma in force afterwards."""
+    import torch
+    from gym_fishing_amd import policies
+    a = gf.make("fishing-v1", sigma=0.3, num_envs=256, seed=2)
+    b = gf.make("fishing-v1", sigma=0.3, num_envs=256, seed=2)
+    policies.msy(a)
+    a.reset()
+    b.reset()
+    act = torch.full((256,), -0.9, device="cuda")
+    oa, _, _, _ = a.step(act)
+    ob, _, _, _ = b.step(act)
+    assert torch.equal(oa, ob) and float(oa.std()) > 0.01
