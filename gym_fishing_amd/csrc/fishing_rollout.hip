@@ -20,10 +20,17 @@ template <typename T, int MODEL, int POLICY, bool AUTO>
 __global__ void __launch_bounds__(256)
 rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
                const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed,
-               const uint64_t step_counter_arg, const int noise_on) {
+               const uint64_t step_counter_arg, const int noise_on, const int policy_rt) {
     const uint64_t step_counter0 = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
-    constexpr bool kNeedWords = (POLICY == FISHING_POLICY_RANDOM);
+    // POLICY >= 0: compile-time policy (v0/v1/v2/v4); POLICY < 0: wave-uniform run-time policy (zoo,
+    // to keep the number of instantiations of the transcendental-heavy bodies small)
+    const int policy = (POLICY >= 0) ? POLICY : policy_rt;
+    const bool kNeedWords = (policy == FISHING_POLICY_RANDOM);
+    constexpr bool kZoo = is_zoo_tag(MODEL);
+    constexpr int kZooKind = (kZoo && MODEL != kModelZooMixed) ? (MODEL - kModelZoo) : -1;
+    constexpr bool zoo_mixed = (MODEL == kModelZooMixed);
+    const bool zoo_drift = kZoo && p.model == FISHING_MODEL_V10;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
@@ -37,8 +44,10 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         T obs[4], rr[4], KK[4], sg[4], er[4], rew[4];
         int32_t t[4];
         bool dn[4], live[4];    // live: a real env whose episode is still running
+        int32_t kind[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            kind[j] = (kZooKind >= 0) ? kZooKind : FISHING_KIND_BEVERTON_HOLT;
             obs[j] = (T)0;
             t[j] = 0;
             rr[j] = p.r;
@@ -56,9 +65,12 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                 load4<T>(b.r, base, n, full, rr, p.r);
                 load4<T>(b.K, base, n, full, KK, p.K);
             }
+            if (zoo_drift) load4<T>(b.r, base, n, full, rr, p.r);
+            if (zoo_mixed) load4<int32_t>(b.model_idx, base, n, full, kind, FISHING_KIND_BEVERTON_HOLT);
             if (b.sigma) load4<T>(b.sigma, base, n, full, sg, p.sigma);
             if (b.ep_return) load4<T>(b.ep_return, base, n, full, er, (T)0);
         }
+        bool kind_dirty = false;
         const uint64_t pair = (env_offset + (uint64_t)base) >> 1;
         const T robs_scalar = reset_obs<T, MODEL>(p.x0, p.K);   // loop-invariant unless per-env K
         bool kr_dirty = false;
@@ -90,15 +102,15 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                 obs_in[j] = obs[j];
                 T a_c = (T)-1;
                 int32_t a_d = 0;
-                if (POLICY == FISHING_POLICY_RANDOM) {
+                if (policy == FISHING_POLICY_RANDOM) {
                     if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_word(aw[j], p.n_actions);
                     else a_c = (T)action_cts_from_word(aw[j]);
-                } else if (POLICY == FISHING_POLICY_CONSTANT) {
+                } else if (policy == FISHING_POLICY_CONSTANT) {
                     if (MODEL == FISHING_MODEL_V0) a_d = (int32_t)policy_param;
                     else a_c = (T)(float)policy_param;
                 } else {
                     T q;
-                    if (POLICY == FISHING_POLICY_ESCAPEMENT) {   // policies.py:27-31
+                    if (policy == FISHING_POLICY_ESCAPEMENT) {   // policies.py:27-31
                         const T x = (obs[j] + (T)1) * KK[j];
                         const T dq = x - policy_param;
                         q = ((T)0 > dq) ? (T)0 : dq;             // max(x - S, 0.0)
@@ -114,7 +126,24 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                 T o2, r2;
                 bool d2;
                 int32_t t2;
-                env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax, o2, r2, d2, t2);
+                if constexpr (kZoo) {
+                    GrowthT<T> P = p.growth;
+                    if (zoo_mixed) {
+                        const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+                        P = p.zoo[kk];
+                    }
+                    if (b.sigma) P.sigma = sg[j];
+                    if (zoo_drift) {                 // growth_models.py:151: r += alpha before every draw;
+                        const T r_new = rr[j] + p.alpha;   // a frozen env makes no draw, so its r stays
+                        P.r = r_new;
+                        rr[j] = (AUTO || live[j]) ? r_new : rr[j];
+                        env_step_zoo<T, kZooKind, true>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, o2, r2, d2, t2);
+                    } else {
+                        env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, o2, r2, d2, t2);
+                    }
+                } else {
+                    env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax, o2, r2, d2, t2);
+                }
                 if (AUTO) {
                     obs[j] = o2;
                     rew[j] = r2;
@@ -160,6 +189,14 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                                 kr_dirty = true;
                             }
                         }
+                        if (zoo_mixed) {
+                            if (f) {      // growth_models.py:200: a new model for the next episode
+                                const Words4 w = philox_block(seed, env_offset + (uint64_t)(base + j), step_counter,
+                                                              kStreamAutoReset);
+                                kind[j] = p.kinds[action_int_from_word(w.w0, p.n_models)];
+                                kind_dirty = true;
+                            }
+                        }
                         const T ro = kPerEnv ? reset_obs<T, MODEL>(p.x0, KK[j]) : robs_scalar;
                         er[j] = f ? (T)0 : er[j];
                         obs[j] = f ? ro : obs[j];
@@ -182,6 +219,8 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                 store4<T>(b.K, base, n, full, KK);
                 store4<T>(b.r, base, n, full, rr);
             }
+            if (zoo_drift) store4<T>(b.r, base, n, full, rr);
+            if (zoo_mixed && kind_dirty) store4<int32_t>(b.model_idx, base, n, full, kind);
             if (b.done) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -229,17 +268,21 @@ int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& b
         if (pt.flags & FISHING_FLAG_AUTO_RESET)                                                                    \
             rollout_kernel<T, MODEL, POL, true><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param,  \
                                                                            Tsteps, traj, seed, step_counter,      \
-                                                                           noise_on);                             \
+                                                                           noise_on, policy);                     \
         else                                                                                                       \
             rollout_kernel<T, MODEL, POL, false><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param, \
                                                                             Tsteps, traj, seed, step_counter,     \
-                                                                            noise_on);                            \
+                                                                            noise_on, policy);                    \
     } while (0)
-    switch (policy) {
-        case FISHING_POLICY_RANDOM: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_RANDOM); break;
-        case FISHING_POLICY_CONSTANT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_CONSTANT); break;
-        case FISHING_POLICY_ESCAPEMENT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_ESCAPEMENT); break;
-        default: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_MSY); break;
+    if constexpr (is_zoo_tag(MODEL)) {
+        FISHING_LAUNCH_ROLLOUT(-1);          // run-time policy switch
+    } else {
+        switch (policy) {
+            case FISHING_POLICY_RANDOM: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_RANDOM); break;
+            case FISHING_POLICY_CONSTANT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_CONSTANT); break;
+            case FISHING_POLICY_ESCAPEMENT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_ESCAPEMENT); break;
+            default: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_MSY); break;
+        }
     }
 #undef FISHING_LAUNCH_ROLLOUT
     return (int)hipGetLastError();
@@ -251,7 +294,6 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
                  fishing_stream_t stream) {
     const int rc = check_common(p, n, env_offset, b);
     if (rc != FISHING_OK) return rc;
-    if (is_zoo_model(p->model)) return FISHING_ERR_MODEL;   // zoo envs roll out step by step (host loop)
     if (policy < FISHING_POLICY_RANDOM || policy > FISHING_POLICY_MSY) return FISHING_ERR_POLICY;
     if (Tsteps < 0) return FISHING_ERR_SIZE;
     if (traj && (((uintptr_t)traj) & 15u)) return FISHING_ERR_ALIGN;
@@ -259,7 +301,12 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     if (n == 0 || Tsteps == 0) return FISHING_OK;
     const ParamsT<T> pt = narrow_params<T>(*p);
     const BuffersT<T> bt = typed_buffers<T>(*b);
-    const int noise_on = !(p->sigma == 0.0 && !b->sigma);
+    bool quiet = (p->sigma == 0.0 && !b->sigma);
+    if (p->model == FISHING_MODEL_V11) {
+        quiet = !b->sigma;
+        for (int k = 0; k < FISHING_N_KINDS; ++k) quiet = quiet && p->zoo[k].sigma == 0.0;
+    }
+    const int noise_on = !quiet;
     int blocks, threads;
     launch_shape(p, n, blocks, threads);
     hipStream_t s = (hipStream_t)stream;
@@ -271,8 +318,23 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
             return launch_rollout_policy<T, FISHING_MODEL_V1>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
         case FISHING_MODEL_V2:
             return launch_rollout_policy<T, FISHING_MODEL_V2>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-        default:
+        case FISHING_MODEL_V4:
             return launch_rollout_policy<T, FISHING_MODEL_V4>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+        case FISHING_MODEL_V11:
+            return launch_rollout_policy<T, kModelZooMixed>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+        default:
+            switch (kind_of_model(p->model)) {
+                case FISHING_KIND_ALLEN:
+                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_ALLEN>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+                case FISHING_KIND_MYERS:
+                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_MYERS>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+                case FISHING_KIND_MAY:
+                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_MAY>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+                case FISHING_KIND_RICKER:
+                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_RICKER>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+                default:
+                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_BEVERTON_HOLT>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
+            }
     }
 }
 

@@ -627,9 +627,8 @@ class FishingModelError(BaseFishingEnv):
 
 # ---------------------------------------------------------------------------------------------
 # Growth-model zoo, fishing-v5..v11 (gym_fishing/envs/growth_models.py:6-204): same env core,
-# lognormal process noise, growth function selected by MODEL (wave-uniform in the kernel;
-# per-env for fishing-v11).  Fused rollouts are not built for these: env.rollout() raises and
-# env.simulate() drives them step by step.
+# lognormal process noise; one kernel instantiation per growth function (per-env switch for
+# fishing-v11).  step(), reset(), rollout() and simulate() all work as for fishing-v0..v4.
 # ---------------------------------------------------------------------------------------------
 class Allen(BaseFishingEnv):
     """fishing-v5 (growth_models.py:6-25; allen() :208-217)."""

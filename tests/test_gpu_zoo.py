@@ -204,5 +204,69 @@ def test_zoo_bmsy_and_policies_run(hh):
         assert len(df) == 100 and df["reward"].sum() > 0
         df2 = env.simulate(policies.msy(env))
         assert 1 <= len(df2) <= 100
-    with pytest.raises(gf.FishingLibraryError):
-        gf.make("fishing-v9", num_envs=8).rollout(3)       # no fused rollout for the zoo (documented)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("policy", ["random", "constant", "escapement", "msy"])
+@pytest.mark.parametrize("env_id", ["fishing-v5", "fishing-v6", "fishing-v7", "fishing-v8", "fishing-v9", "fishing-v10",
+                                    "fishing-v11"])
+def test_zoo_fused_rollout_equals_stepwise(hh, env_id, policy, dtype):
+    """The fused rollout of a zoo env == T step() calls fed the policy's float32 actions:
+    both run the same device arithmetic and Philox blocks, so bit-for-bit (incl. the
+    fishing-v10 drift of r and the fishing-v11 model redraws)."""
+    from gym_fishing_amd import _capi
+    model = fo.MODEL_OF_ID[env_id]
+    n, off, seed, T = 2052, 4, 31, 22
+    P = dict(ZOO_DEFAULTS[env_id])
+    K, x0 = float(P["K"]), float(P["init_state"])
+    kw = dict(r=float(P.get("r", 0.3)), K=K, sigma=0.1, C=float(P.get("C", 0.5)), x0=x0, Tmax=6,
+              M=float(P.get("M", 0.0)), theta=float(P.get("theta", 0.0)), q=float(P.get("q", 0.0)),
+              b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)), alpha=float(P.get("alpha", 0.0)), auto_reset=True)
+    if model == fo.MODEL_V11:
+        kw.update(models=[0, 1, 2, 3, 4], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE])
+    p = hh.params(model, **kw)
+    pol = {"random": _capi.POLICY_RANDOM, "constant": _capi.POLICY_CONSTANT, "escapement": _capi.POLICY_ESCAPEMENT,
+           "msy": _capi.POLICY_MSY}[policy]
+    param = {"random": 0.0, "constant": -0.8125, "escapement": 0.5 * K, "msy": 0.05 * K}[policy]
+    mk = lambda: hh.State(n, dtype, model, np.zeros(n), r=np.full(n, P.get("r", 0.3)) if model == fo.MODEL_V10 else None,   # noqa: E731
+                          model_idx=np.zeros(n, np.int32) if model == fo.MODEL_V11 else None, ep_return=True)
+    A, B = mk(), mk()
+    A.reset(p, seed=seed, env_offset=off)
+    B.reset(p, seed=seed, env_offset=off)
+    traj = A.rollout(p, pol, param, T, seed=seed, env_offset=off, record=True)
+    env = np.arange(off, off + n)
+    for s in range(T):
+        obs = B.obs.cpu().numpy()
+        if policy == "random":
+            a = fo.policy_random_action(fo.MODEL_V1, seed, env, s)
+        elif policy == "constant":
+            a = np.full(n, param, np.float32)
+        else:
+            a = fo.policy_action(policy, param, fo.MODEL_V1, obs, dtype(K), 100, dtype)
+        assert np.array_equal(traj[s, 0], obs), (s, "obs_in")
+        assert np.array_equal(traj[s, 1], a.astype(dtype)), (s, "action")
+        _, rew, done, _ = B.step(p, a, seed=seed, step_counter=s, env_offset=off)
+        assert np.array_equal(traj[s, 2], rew) and (traj[s, 3].astype(np.uint8) == done).all(), s
+    assert np.array_equal(A.obs.cpu().numpy(), B.obs.cpu().numpy())
+    assert (A.t.cpu().numpy() == B.t.cpu().numpy()).all()
+    if model == fo.MODEL_V10:
+        assert np.array_equal(A.r.cpu().numpy(), B.r.cpu().numpy())
+    if model == fo.MODEL_V11:
+        assert np.array_equal(A.model_idx.cpu().numpy(), B.model_idx.cpu().numpy())
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] and ra[2] >= n and np.allclose(ra, rb, rtol=1e-12)
+
+
+def test_zoo_simulate_uses_the_fused_rollout(hh):
+    import torch
+    import gym_fishing_amd as gf
+    from gym_fishing_amd import policies
+    venv = gf.make("fishing-v9", sigma=0.0, num_envs=8, dtype=torch.float64)
+    esc = policies.escapement(venv)
+    fused = venv.simulate(esc).to_numpy(dtype=np.float64)
+
+    class Plain:      # no kernel_policy -> step-by-step path
+        def predict(self, obs, **kw):
+            return esc.predict(obs, **kw)
+    stepwise = venv.simulate(Plain()).to_numpy(dtype=np.float64)
+    assert fused.shape == stepwise.shape == (800, 5) and np.array_equal(fused, stepwise)
