@@ -461,13 +461,10 @@ class BaseFishingEnv:
         with torch.cuda.device(self.device):
             rc = self._lib.fishing_reduce_returns(self._partials.data_ptr(), self._record.data_ptr(), self._stream())
         _capi.check(rc, "fishing_reduce_returns")
+        from .sharding import all_reduce_record, summarize_record
         rec = self._record
         if all_reduce:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                rec = rec.clone()
-                dist.all_reduce(rec, op=dist.ReduceOp.SUM)
-        from .sharding import summarize_record
+            rec = all_reduce_record(rec.clone())
         return summarize_record(rec)
 
     # ------------------------------------------------------------------ helpers (base_fishing_env.py:135-164)

@@ -52,10 +52,18 @@ def summarize_record(rec):
 
 
 def all_reduce_record(rec, group=None):
-    """Sum the 4-double record across ranks in place (RCCL on GPUs, gloo on CPU tensors)."""
+    """Sum the 4-double record across ranks (returns the reduced tensor).  RCCL ("nccl")
+    reduces the device tensor in place; any other backend (gloo in CPU tests, or gloo ranks
+    sharing one GPU) goes through a host copy -- 32 bytes."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return rec
+    if rec.is_cuda and dist.get_backend(group) != "nccl":
+        host = rec.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        rec.copy_(host)
+        return rec
+    dist.all_reduce(rec, op=dist.ReduceOp.SUM, group=group)
     return rec
 
 
