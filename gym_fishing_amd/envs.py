@@ -552,6 +552,14 @@ class BaseFishingEnv:
         from .rollout import estimate_policyfn
         return estimate_policyfn(self, model, reps)
 
+    def plot(self, df, output="results.png"):
+        from .plotting import plot_mdp
+        return plot_mdp(df, output)
+
+    def plot_policy(self, df, output="results.png"):
+        from .plotting import plot_policyfn
+        return plot_policyfn(df, output)
+
     # ------------------------------------------------------------------ render / close
     def render(self, mode="human", index=0):
         """base_fishing_env.py:93-94 -> shared_env.py:8-12.  The reference's version raises

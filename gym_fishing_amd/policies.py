@@ -67,3 +67,15 @@ class escapement:
             return action.reshape(-1, 1), obs
         quota = max(pop - self.S, 0.0)
         return self.env.get_action(quota), obs
+
+
+class user_action:
+    """models/policies.py:34-47: ask the person at the terminal for this step's quota."""
+
+    def __init__(self, env, **kwargs):
+        self.env = env
+
+    def predict(self, obs, **kwargs):
+        pop = self.env.get_fish_population(obs)
+        quota = float(input("fish population: %s. Your harvest quota: " % (pop,)))
+        return self.env.get_action(quota), obs

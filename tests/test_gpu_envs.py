@@ -377,3 +377,37 @@ def test_bmsy_does_not_disturb_the_env_noise_level(gf):
     oa, _, _, _ = a.step(act)
     ob, _, _, _ = b.step(act)
     assert torch.equal(oa, ob) and float(oa.std()) > 0.01
+
+
+@pytest.mark.parametrize("env_id,kw", [("fishing-v0", {}), ("fishing-v1", {}), ("fishing-v5", {"sigma": 0}),
+                                       ("fishing-v6", {"sigma": 0}), ("fishing-v7", {"sigma": 0}),
+                                       ("fishing-v8", {"sigma": 0}), ("fishing-v9", {"sigma": 0}),
+                                       ("fishing-v2", {"sigma": 0, "init_state": 0.75}),
+                                       ("fishing-v10", {"sigma": 0, "alpha": -0.007}), ("fishing-v11", {})])
+def test_reference_test_suite_flow(gf, tmp_path, env_id, kw):
+    """The body of every test in the reference's tests/test-envs.py (:11-139), minus SB3's
+    check_env (not installed): make -> msy -> simulate -> plot -> escapement -> simulate -> plot,
+    plus the API-conformance facts check_env would assert."""
+    from gym_fishing_amd.policies import escapement, msy, user_action
+    env = gf.make(env_id, **kw)
+    obs = env.reset()
+    assert obs.shape == env.observation_space.shape and isinstance(obs, np.ndarray)
+    a = env.action_space.sample()
+    o, r, d, info = env.step(a)
+    assert o.shape == (1,) and isinstance(r, float) and isinstance(d, bool) and isinstance(info, dict)
+    user_action(env)                                       # constructed, never prompted (as in the reference)
+    reps = 3 if env_id == "fishing-v11" else 1
+    if env_id == "fishing-v11":
+        env2 = gf.make("fishing-v6", sigma=0)              # BMSY needs one growth curve: use a member model's
+        model, model2 = msy(env2), escapement(env2)
+        model.env = model2.env = env
+    else:
+        model, model2 = msy(env), escapement(env)
+    for tag, m in (("msy", model), ("escapement", model2)):
+        df = env.simulate(m, reps=reps)
+        assert list(df.columns) == ["time", "state", "action", "reward", "rep"] and 1 <= len(df) <= 100 * reps
+        out = env.plot(df, str(tmp_path / ("%s_%s.png" % (env_id, tag))))
+        assert (tmp_path / ("%s_%s.png" % (env_id, tag))).stat().st_size > 1000 and out.endswith(".png")
+    pf = env.policyfn(model2)
+    env.plot_policy(pf, str(tmp_path / "policy.png"))
+    assert (tmp_path / "policy.png").exists()
