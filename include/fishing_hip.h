@@ -58,6 +58,7 @@ typedef void* fishing_stream_t; /* hipStream_t */
 
 /* FishingParams.flags */
 #define FISHING_FLAG_AUTO_RESET 1u /* SB3-VecEnv semantics: a finished env is reset inside step() */
+#define FISHING_FLAG_GENERAL_KERNEL 2u /* test knob: never take the lean fp32 fast path of step()  */
 
 /* error codes */
 #define FISHING_OK 0

@@ -1,0 +1,92 @@
+// Experiment (not product): fishing-v1 f32 step with EPT envs per thread, to see whether wider
+// per-lane accesses move the 2^22-env step closer to the copy rate.
+#include "../../gym_fishing_amd/csrc/fishing_common.h"
+using namespace fishing;
+
+template <int EPT>
+__global__ void __launch_bounds__(256)
+exp_step_kernel(int64_t n, float* __restrict__ obs, const float* __restrict__ action, float* __restrict__ reward,
+                uint8_t* __restrict__ done, int32_t* __restrict__ t, uint64_t seed, uint64_t step_counter,
+                float r, float K, float sigma, float x0, int32_t Tmax) {
+    const int64_t tile_envs = (int64_t)blockDim.x * EPT;
+    const int64_t ntiles = n / tile_envs;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = (tile * blockDim.x + threadIdx.x) * EPT;
+        float o[EPT], a[EPT], z[EPT], on[EPT], rw[EPT];
+        int32_t tt[EPT], tn[EPT];
+        bool dn[EPT];
+#pragma unroll
+        for (int v = 0; v < EPT / 4; ++v) {
+            const Vec4<float> q = *reinterpret_cast<const Vec4<float>*>(obs + base + 4 * v);
+            const Vec4<float> qa = *reinterpret_cast<const Vec4<float>*>(action + base + 4 * v);
+            const Vec4<int32_t> qt = *reinterpret_cast<const Vec4<int32_t>*>(t + base + 4 * v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[4 * v + j] = q.v[j]; a[4 * v + j] = qa.v[j]; tt[4 * v + j] = qt.v[j]; }
+        }
+        const uint64_t pair = (uint64_t)base >> 1;
+#pragma unroll
+        for (int q = 0; q < EPT / 2; ++q) {
+            const Words4 w = philox_block(seed, pair + q, step_counter, kStreamNoise);
+            box_muller(w.w0, w.w1, z[2 * q], z[2 * q + 1]);
+        }
+        const float ro = x0 / K - 1.0f;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            env_step<float, FISHING_MODEL_V1>(o[j], tt[j], quota_cts<float>(a[j], K), z[j], r, K, sigma, 0.5f, Tmax, on[j],
+                                              rw[j], dn[j], tn[j]);
+            on[j] = dn[j] ? ro : on[j];
+            tn[j] = dn[j] ? 0 : tn[j];
+        }
+#pragma unroll
+        for (int v = 0; v < EPT / 4; ++v) {
+            Vec4<float> q, qr;
+            Vec4<int32_t> qt;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                q.v[j] = on[4 * v + j]; qr.v[j] = rw[4 * v + j]; qt.v[j] = tn[4 * v + j];
+                packed |= (uint32_t)dn[4 * v + j] << (8 * j);
+            }
+            *reinterpret_cast<Vec4<float>*>(obs + base + 4 * v) = q;
+            *reinterpret_cast<Vec4<float>*>(reward + base + 4 * v) = qr;
+            *reinterpret_cast<Vec4<int32_t>*>(t + base + 4 * v) = qt;
+            *reinterpret_cast<uint32_t*>(done + base + 4 * v) = packed;
+        }
+    }
+}
+
+// copy with the same stream shape: 3 x 4-byte inputs -> 3 x 4-byte outputs + 1 byte
+template <int EPT>
+__global__ void __launch_bounds__(256)
+exp_copy_kernel(int64_t n, float* __restrict__ obs, const float* __restrict__ action, float* __restrict__ reward,
+                uint8_t* __restrict__ done, int32_t* __restrict__ t) {
+    const int64_t tile_envs = (int64_t)blockDim.x * EPT;
+    const int64_t ntiles = n / tile_envs;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = (tile * blockDim.x + threadIdx.x) * EPT;
+#pragma unroll
+        for (int v = 0; v < EPT / 4; ++v) {
+            Vec4<float> q = *reinterpret_cast<const Vec4<float>*>(obs + base + 4 * v);
+            const Vec4<float> qa = *reinterpret_cast<const Vec4<float>*>(action + base + 4 * v);
+            Vec4<int32_t> qt = *reinterpret_cast<const Vec4<int32_t>*>(t + base + 4 * v);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { q.v[j] += qa.v[j]; qt.v[j] += 1; packed |= (uint32_t)(qt.v[j] & 1) << (8 * j); }
+            *reinterpret_cast<Vec4<float>*>(obs + base + 4 * v) = q;
+            *reinterpret_cast<Vec4<float>*>(reward + base + 4 * v) = qa;
+            *reinterpret_cast<Vec4<int32_t>*>(t + base + 4 * v) = qt;
+            *reinterpret_cast<uint32_t*>(done + base + 4 * v) = packed;
+        }
+    }
+}
+
+extern "C" int exp_step(int ept, int copy, int blocks, int64_t n, float* obs, const float* action, float* reward,
+                        uint8_t* done, int32_t* t, uint64_t seed, uint64_t counter, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define RUN(E)                                                                                                  \
+    if (copy) exp_copy_kernel<E><<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t);                       \
+    else exp_step_kernel<E><<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t, seed, counter, 0.3f, 1.0f,  \
+                                                   0.1f, 0.75f, 100)
+    if (ept == 4) { RUN(4); } else if (ept == 8) { RUN(8); } else { RUN(16); }
+    return (int)hipGetLastError();
+}

@@ -624,3 +624,36 @@ def test_random_parameter_sets_match_oracle(hh, model, dtype):
                                          sigma_p=0.4, dtype=dtype)
             assert_same_bits(o, obs, "trial %d step %d obs" % (trial, s))
             assert (t2 == t).all()
+
+
+# ------------------------------------------------------------------ lean fast path == general kernel
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
+@pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
+@pytest.mark.parametrize("n", [1024, 1024 * 7 + 5, (1 << 18) + 1027])
+def test_lean_and_general_kernels_agree(hh, model, ret, n):
+    """step() takes a lean fp32 kernel for whole 1024-env tiles (+ a general launch for the
+    ragged tail); FISHING_FLAG_GENERAL_KERNEL forces the general kernel everywhere.  Both must
+    give the same bits for every stream over 12 auto-resetting steps (sigma > 0 and sigma = 0)."""
+    import torch
+    per_env = model == fo.MODEL_V4
+    for sigma in (0.1, 0.0):
+        kw = dict(sigma=sigma, C=0.5, Tmax=4, sigma_p=0.2, auto_reset=True)
+        pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
+        mk = lambda: hh.State(n, np.float32, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
+                              K=np.full(n, 1.0) if per_env else None, ep_return=ret)
+        A, B = mk(), mk()
+        A.reset(pa, seed=5, env_offset=12)
+        B.reset(pb, seed=5, env_offset=12)
+        g = torch.Generator(device="cuda").manual_seed(n)
+        lib = __import__("gym_fishing_amd")._capi.lib()
+        for s in range(12):
+            a = (torch.randint(0, 100, (n,), device="cuda", generator=g, dtype=torch.int32) if model == fo.MODEL_V0
+                 else (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float())
+            for st, p in ((A, pa), (B, pb)):
+                assert lib.fishing_step_f32(p, n, 12, st.buffers(a), 5, s, None) == 0
+            torch.cuda.synchronize()
+            for name in ("obs", "reward", "done", "t") + (("K", "r") if per_env else ()) + (("ep_return",) if ret else ()):
+                assert torch.equal(getattr(A, name), getattr(B, name)), (name, s, sigma)
+        if ret:
+            ra, rb = A.record(), B.record()
+            assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12) and ra[2] > 0
