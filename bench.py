@@ -132,7 +132,11 @@ def main():
                   track_returns=with_returns, auto_reset=True)
     env.reset()
     g = torch.Generator(device="cuda").manual_seed(4321 + rank)
-    actions = torch.rand((RING, n), device="cuda", generator=g, dtype=torch.float32) * 2 - 1
+    # ring rows are 12 KiB longer than N so consecutive batches do not start at power-of-two-spaced
+    # addresses (same reason the env staggers its own streams)
+    ring = torch.empty((RING, n + 3072), device="cuda", dtype=torch.float32)
+    actions = ring[:, :n]
+    actions.copy_(torch.rand((RING, n), device="cuda", generator=g, dtype=torch.float32) * 2 - 1)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -162,7 +166,7 @@ def main():
     bytes_per = BYTES_STEP + (BYTES_RETURN_ACC if with_returns else 0)
     achieved = n * bytes_per / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(n, with_returns)
-    resident = n * (4 + 4 + 4 + 1 + (4 if with_returns else 0)) + RING * n * 4
+    resident = n * (4 + 4 + 4 + 1 + (4 if with_returns else 0)) + RING * (n + 3072) * 4
     out = {
         "metric": "env-steps/sec at N=2^22, fishing-v1",
         "value": total_env_steps / elapsed,

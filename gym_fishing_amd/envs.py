@@ -112,10 +112,21 @@ class BaseFishingEnv:
 
         N, dev = self.num_envs, self.device
         self._per_env = self.MODEL == MODEL_V4
-        self._obs = torch.empty(N, dtype=dtype, device=dev)
-        self._t = torch.zeros(N, dtype=torch.int32, device=dev)
-        self._reward = torch.zeros(N, dtype=dtype, device=dev)
-        self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
+        # The four streams every step touches live in one arena, each start staggered by a further
+        # 12 KiB: streams that are walked in lockstep from power-of-two-spaced bases collide in the
+        # HBM channel hash (measured at N = 2^22: 16.6 us unstaggered -> 16.1 us; profiles/
+        # r01c_stream_stagger_experiment.jsonl).
+        esz = torch.empty(0, dtype=dtype).element_size()
+        sizes = [(dtype, N * esz), (torch.int32, N * 4), (dtype, N * esz), (torch.uint8, N)]
+        if track_returns:
+            sizes.append((dtype, N * esz))
+        offs, off = [], 0
+        for k, (_, nbytes) in enumerate(sizes):
+            offs.append(off)
+            off = (off + nbytes + 12288 * (k + 1) + 255) & ~255
+        self._arena = torch.zeros(off, dtype=torch.uint8, device=dev)
+        views = [self._arena[o:o + nb].view(dt) for o, (dt, nb) in zip(offs, sizes)]
+        self._obs, self._t, self._reward, self._done = views[:4]
         self._r_arr = self._K_arr = self._sigma_arr = None
         sigma = params["sigma"]
         if isinstance(sigma, (torch.Tensor, np.ndarray, list, tuple)):
@@ -133,7 +144,7 @@ class BaseFishingEnv:
         self._done_bits = (torch.zeros((N + 63) // 64, dtype=torch.int64, device=dev) if done_bits else None)
         self._ep_return = self._partials = self._record = None
         if track_returns:
-            self._ep_return = torch.zeros(N, dtype=dtype, device=dev)
+            self._ep_return = views[4]
             self._partials = torch.zeros(int(self._lib.fishing_partials_len()), dtype=torch.float64, device=dev)
             self._record = torch.zeros(4, dtype=torch.float64, device=dev)
         self._action_buf = None
@@ -390,13 +401,16 @@ class BaseFishingEnv:
         (a ring of R action batches, cycled).  Returns the last step's result."""
         want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
         if not (isinstance(actions, torch.Tensor) and actions.device == self.device and actions.dtype == want
-                and actions.is_contiguous() and actions.dim() == 2 and actions.shape[1] == self.num_envs):
-            raise ValueError("actions must be a contiguous [R, %d] %s tensor on %s" % (self.num_envs, want, self.device))
+                and actions.dim() == 2 and actions.shape[1] == self.num_envs and actions.stride(1) == 1
+                and actions.stride(0) >= self.num_envs and actions.stride(0) % 4 == 0 and actions.data_ptr() % 16 == 0):
+            raise ValueError("actions must be a [R, %d] %s tensor on %s with unit inner stride and a row stride "
+                             "that is a multiple of 4 elements" % (self.num_envs, want, self.device))
         R = actions.shape[0]
+        row_stride = actions.stride(0) if R > 1 else self.num_envs
         n_steps = R if n_steps is None else int(n_steps)
         with torch.cuda.device(self.device):
             rc = self._fn_step_many(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(actions),
-                                    self.num_envs, R, n_steps, self._seed,
+                                    row_stride, R, n_steps, self._seed,
                                     0 if self._counter is not None else self._step_count, self._stream())
             if self._counter is not None and not rc:
                 rc = self._lib.fishing_counter_add(self._counter.data_ptr(), n_steps, self._stream())
