@@ -3,14 +3,22 @@
 #include "../../gym_fishing_amd/csrc/fishing_common.h"
 using namespace fishing;
 
-template <int EPT>
+template <int EPT, int MAP = 0>
 __global__ void __launch_bounds__(256)
 exp_step_kernel(int64_t n, float* __restrict__ obs, const float* __restrict__ action, float* __restrict__ reward,
                 uint8_t* __restrict__ done, int32_t* __restrict__ t, uint64_t seed, uint64_t step_counter,
                 float r, float K, float sigma, float x0, int32_t Tmax) {
     const int64_t tile_envs = (int64_t)blockDim.x * EPT;
     const int64_t ntiles = n / tile_envs;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    for (int64_t it = 0; it < per; ++it) {
+        // MAP 0: tile = block + it * grid (strided);  MAP 1: contiguous run of tiles per block;
+        // MAP 2: XCD-contiguous: blocks that share an XCD (b % 8) walk one contiguous eighth
+        int64_t tile;
+        if (MAP == 0) tile = blockIdx.x + it * gridDim.x;
+        else if (MAP == 1) tile = (int64_t)blockIdx.x * per + it;
+        else tile = (int64_t)(blockIdx.x & 7) * (ntiles / 8) + (int64_t)(blockIdx.x >> 3) * per + it;
+        if (tile >= ntiles) break;
         const int64_t base = (tile * blockDim.x + threadIdx.x) * EPT;
         float o[EPT], a[EPT], z[EPT], on[EPT], rw[EPT];
         int32_t tt[EPT], tn[EPT];
@@ -87,6 +95,8 @@ extern "C" int exp_step(int ept, int copy, int blocks, int64_t n, float* obs, co
     if (copy) exp_copy_kernel<E><<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t);                       \
     else exp_step_kernel<E><<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t, seed, counter, 0.3f, 1.0f,  \
                                                    0.1f, 0.75f, 100)
-    if (ept == 4) { RUN(4); } else if (ept == 8) { RUN(8); } else { RUN(16); }
+    if (ept == 4) { RUN(4); } else if (ept == 8) { RUN(8); } else if (ept == 16) { RUN(16); }
+    else if (ept == 41) exp_step_kernel<4, 1><<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t, seed, counter, 0.3f, 1.0f, 0.1f, 0.75f, 100);
+    else if (ept == 42) exp_step_kernel<4, 2><<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t, seed, counter, 0.3f, 1.0f, 0.1f, 0.75f, 100);
     return (int)hipGetLastError();
 }

@@ -10,7 +10,7 @@ base = arena.data_ptr()
 base = (base + (1 << 21) - 1) & ~((1 << 21) - 1)
 acts = torch.rand((8, n), device="cuda") * 2 - 1
 st = torch.cuda.current_stream().cuda_stream
-pads = [0, 256, 4096 + 256, 65536 + 4096 + 256, 3 * 4096, (1 << 20) + 4096]
+pads = [0, 4096, 8192, 12288, 16384, 20480, 24576, 49152, 12288 + 256]
 def place(pad):
     sizes = [4 * n, 4 * n, 4 * n, n]     # obs, reward, t, done
     ptrs, off = [], 0
@@ -34,5 +34,22 @@ for rnd in range(6):
             lib.exp_step(4, 0, 2048, n, obs, acts[k % 8].data_ptr(), rew, done, t, 1, k, st)
         e1.record(); torch.cuda.synchronize()
         res[p].append(e0.elapsed_time(e1) * 5.0)
+# tile -> workgroup mapping at the best-known stagger
+maps = {4: "strided", 41: "contiguous per block", 42: "contiguous per XCD group"}
+resm = {m: [] for m in maps}
+obs, rew, t, done = place(12288)
+for rnd in range(6):
+    for m in maps:
+        for blocks in (2048,):
+            for k in range(20):
+                lib.exp_step(m, 0, blocks, n, obs, acts[k % 8].data_ptr(), rew, done, t, 1, k, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(200):
+                lib.exp_step(m, 0, blocks, n, obs, acts[k % 8].data_ptr(), rew, done, t, 1, k, st)
+            e1.record(); torch.cuda.synchronize()
+            resm[m].append(e0.elapsed_time(e1) * 5.0)
+for m, name in maps.items():
+    print(json.dumps({"map": name, "med_us": round(statistics.median(resm[m]), 2), "min_us": round(min(resm[m]), 2)}), flush=True)
 for p in pads:
     print(json.dumps({"pad_bytes": p, "med_us": round(statistics.median(res[p]), 2), "min_us": round(min(res[p]), 2)}), flush=True)
