@@ -104,6 +104,11 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    # rehearsal knobs (not used by the driver): several ranks on ONE device over gloo, to run the
+    # multi-rank control flow on a single-GPU box
+    backend = os.environ.get("FISHING_BENCH_BACKEND", "nccl")
+    if os.environ.get("FISHING_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (RANK set) the process group is created for any world size, so
     # the single-rank launch exercises the same RCCL init / all-reduce / barrier code as N > 1
@@ -116,8 +121,11 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(4, dtype=torch.float64, device="cuda")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            warm = torch.zeros(4, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(warm)
             torch.cuda.synchronize()
         finally:
@@ -158,7 +166,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)     # HIP events around the K launches
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
