@@ -657,3 +657,52 @@ def test_lean_and_general_kernels_agree(hh, model, ret, n):
         if ret:
             ra, rb = A.record(), B.record()
             assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12) and ra[2] > 0
+
+
+def test_huge_batch_64bit_indexing(hh):
+    """Maximum sizes: N = 2^29 + 1029 envs (2 GiB per float32 stream, byte offsets past 2^31 and
+    element counts past 2^29; ragged tail behind the lean launch).  sigma = 0 and one shared
+    action make every env follow the A.4 known-answer trajectory, so min == max == the known
+    value certifies every element was read and written exactly once."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    n = (1 << 29) + 1029
+    if free < 14 * (1 << 30):
+        pytest.skip("needs ~10 GiB of free HBM")
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    p = hh.params(fo.MODEL_V1, sigma=0.0, auto_reset=True)
+    obs = torch.full((n,), -0.25, dtype=torch.float32, device="cuda")
+    t = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rew = torch.empty(n, dtype=torch.float32, device="cuda")
+    done = torch.empty(n, dtype=torch.uint8, device="cuda")
+    act = torch.full((n,), -0.9375, dtype=torch.float32, device="cuda")
+    from gym_fishing_amd import _capi
+    b = _capi.make_buffers(obs=obs.data_ptr(), action=act.data_ptr(), reward=rew.data_ptr(), done=done.data_ptr(),
+                           t=t.data_ptr())
+    eo = np.float32(-0.25)
+    et = np.zeros(1, np.int32)
+    for s in range(3):
+        assert lib.fishing_step_f32(p, n, 0, b, 0, s, None) == 0
+        eo_arr, er, ed, et, _ = fo.step(fo.MODEL_V1, np.array([eo], np.float32), et, np.float32([-0.9375]), [0.0], 0.3, 1.0,
+                                        0.0, dtype=np.float32)
+        eo = eo_arr[0]
+        torch.cuda.synchronize()
+        assert float(obs.min()) == float(obs.max()) == float(eo), s
+        assert float(rew.min()) == float(rew.max()) == 0.0625
+        assert int(t.min()) == int(t.max()) == s + 1 and int(done.max()) == 0
+    # spot bytes at the far end, beyond the last whole tile
+    assert float(obs[-1]) == float(eo) and float(obs[n - 1030]) == float(eo)
+    # in-kernel noise at indices past 2^29: the tail window against the oracle
+    p2 = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=False)
+    obs.fill_(-0.25)
+    t.zero_()
+    assert lib.fishing_step_f32(p2, n, 0, b, 77, 5, None) == 0
+    torch.cuda.synchronize()
+    w = 2053                      # n is odd: an even window start keeps the noise pairs aligned
+    lo = n - w
+    z = hh.device_step_noise(w, 77, 5, lo)
+    eo2, _, _, _, _ = fo.step(fo.MODEL_V1, np.full(w, -0.25, np.float32), np.zeros(w, np.int32),
+                              np.full(w, -0.9375, np.float32), z, 0.3, 1.0, 0.1, dtype=np.float32)
+    assert_same_bits(obs[lo:].cpu().numpy(), eo2, "tail window past 2^29")
+    del obs, t, rew, done, act
+    torch.cuda.empty_cache()
