@@ -86,3 +86,20 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_capi, "_lib", None)
     with pytest.raises(_capi.FishingLibraryError, match="no CPU fallback"):
         _capi.lib()
+
+
+def test_header_is_valid_c_and_cxx(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 and as C++ with no HIP headers."""
+    import shutil
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    src_c = tmp_path / "t.c"
+    src_c.write_text('#include "fishing_hip.h"\nint main(void){FishingParams p; FishingBuffers b; (void)p; (void)b; '
+                     'return sizeof(FishingParams) == 520 ? 0 : 1;}\n')
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src_c), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+    if shutil.which("g++"):
+        src_cc = tmp_path / "t.cc"
+        src_cc.write_text('#include "fishing_hip.h"\nint main(){return fishing_abi_version == nullptr;}\n')
+        subprocess.run(["g++", "-std=c++11", "-Wall", "-fsyntax-only", "-I", inc, str(src_cc)], check=True)

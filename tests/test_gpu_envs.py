@@ -411,3 +411,22 @@ def test_reference_test_suite_flow(gf, tmp_path, env_id, kw):
     pf = env.policyfn(model2)
     env.plot_policy(pf, str(tmp_path / "policy.png"))
     assert (tmp_path / "policy.png").exists()
+
+
+def test_c_api_demo_runs_without_python_side_state(gf, tmp_path):
+    """examples/c_api_demo.cpp: the library driven from plain C++ (hipMalloc + a stream)."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    import os
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not on this box")
+    exe = tmp_path / "c_api_demo"
+    libdir = os.path.join(ROOT, "gym_fishing_amd", "_lib")
+    subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "c_api_demo.cpp"), "-L", libdir, "-lfishing_hip",
+                    "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout
+    assert "mean return 6.312500" in out.stdout and "episodes 1048576" in out.stdout
