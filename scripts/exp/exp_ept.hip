@@ -63,6 +63,65 @@ exp_step_kernel(int64_t n, float* __restrict__ obs, const float* __restrict__ ac
     }
 }
 
+// software-pipelined variant: the next tile's loads are issued before the current tile is computed
+__global__ void __launch_bounds__(256)
+exp_step_pipelined(int64_t n, float* __restrict__ obs, const float* __restrict__ action, float* __restrict__ reward,
+                   uint8_t* __restrict__ done, int32_t* __restrict__ t, uint64_t seed, uint64_t step_counter,
+                   float r, float K, float sigma, float x0, int32_t Tmax) {
+    const int64_t ntiles = n / 1024;
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int64_t base = (tile * 256 + threadIdx.x) * 4;
+    Vec4<float> qo = *reinterpret_cast<const Vec4<float>*>(obs + base);
+    Vec4<float> qa = *reinterpret_cast<const Vec4<float>*>(action + base);
+    Vec4<int32_t> qt = *reinterpret_cast<const Vec4<int32_t>*>(t + base);
+    const float ro = x0 / K - 1.0f;
+    while (true) {
+        const int64_t next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        const int64_t nbase = (next * 256 + threadIdx.x) * 4;
+        Vec4<float> no, na;
+        Vec4<int32_t> nt;
+        if (has_next) {
+            no = *reinterpret_cast<const Vec4<float>*>(obs + nbase);
+            na = *reinterpret_cast<const Vec4<float>*>(action + nbase);
+            nt = *reinterpret_cast<const Vec4<int32_t>*>(t + nbase);
+        }
+        float z[4];
+        const uint64_t pair = (uint64_t)base >> 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const Words4 w = philox_block(seed, pair + q, step_counter, kStreamNoise);
+            box_muller(w.w0, w.w1, z[2 * q], z[2 * q + 1]);
+        }
+        Vec4<float> wo, wr;
+        Vec4<int32_t> wt;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float on, rw;
+            bool dn;
+            int32_t tn;
+            env_step<float, FISHING_MODEL_V1>(qo.v[j], qt.v[j], quota_cts<float>(qa.v[j], K), z[j], r, K, sigma, 0.5f, Tmax, on,
+                                              rw, dn, tn);
+            wo.v[j] = dn ? ro : on;
+            wt.v[j] = dn ? 0 : tn;
+            wr.v[j] = rw;
+            packed |= (uint32_t)dn << (8 * j);
+        }
+        *reinterpret_cast<Vec4<float>*>(obs + base) = wo;
+        *reinterpret_cast<Vec4<float>*>(reward + base) = wr;
+        *reinterpret_cast<Vec4<int32_t>*>(t + base) = wt;
+        *reinterpret_cast<uint32_t*>(done + base) = packed;
+        if (!has_next) break;
+        tile = next;
+        base = nbase;
+        qo = no;
+        qa = na;
+        qt = nt;
+    }
+}
+
 // copy with the same stream shape: 3 x 4-byte inputs -> 3 x 4-byte outputs + 1 byte
 template <int EPT>
 __global__ void __launch_bounds__(256)
@@ -97,6 +156,7 @@ extern "C" int exp_step(int ept, int copy, int blocks, int64_t n, float* obs, co
                                                    0.1f, 0.75f, 100)
     if (ept == 4) { RUN(4); } else if (ept == 8) { RUN(8); } else if (ept == 16) { RUN(16); }
     else if (ept == 41) exp_step_kernel<4, 1><<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t, seed, counter, 0.3f, 1.0f, 0.1f, 0.75f, 100);
+    else if (ept == 43) exp_step_pipelined<<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t, seed, counter, 0.3f, 1.0f, 0.1f, 0.75f, 100);
     else if (ept == 42) exp_step_kernel<4, 2><<<blocks, 256, 0, s>>>(n, obs, action, reward, done, t, seed, counter, 0.3f, 1.0f, 0.1f, 0.75f, 100);
     return (int)hipGetLastError();
 }
