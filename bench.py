@@ -59,6 +59,22 @@ def cpu_baseline(seconds):
     out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": "oracle/scalar_env.py (per-env NumPy step(), same op sequence as the reference): "
                      "%d env-steps of fishing-v1 sigma=0.1, random policy, reset on done, 1 core" % n}
+    try:    # the same Python port on every core of the box's CPU share;
+        # independent `python -c` workers: nothing here depends on how this file was started
+        import subprocess
+        procs = max(1, min(os.cpu_count() or 1, 16))
+        per = max(20_000, n // 8)
+        code = ("import sys; sys.path.insert(0, %r); from oracle.scalar_env import time_random_rollout; "
+                "print(time_random_rollout('fishing-v1', %d, seed=int(sys.argv[1]), sigma=0.1)[0])" % (ROOT, per))
+        kids = [subprocess.Popen([sys.executable, "-c", code, str(100 + i)], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
+        rates = [float(k.communicate(timeout=180)[0].strip().splitlines()[-1]) for k in kids]
+        if all(k.returncode == 0 for k in kids):
+            out["python_port_all_cores"] = {"value": sum(rates), "unit": "env-steps/s", "cores": procs,
+                                            "sample": "%d concurrent processes x %d env-steps each; sum of the "
+                                                      "per-process rates" % (procs, per)}
+    except Exception as e:  # noqa: BLE001
+        out["python_port_all_cores_error"] = repr(e)[:200]
     try:    # stronger CPU figure for context: the plain-C oracle over all host cores
         from oracle import c_oracle
         threads = min(os.cpu_count() or 1, 64)
