@@ -122,6 +122,70 @@ exp_step_pipelined(int64_t n, float* __restrict__ obs, const float* __restrict__
     }
 }
 
+// stateful-generator comparison (north star: "LDS-staged Philox/xoshiro RNG state per wavefront"):
+// xoshiro128++ with its 16-byte state per env in HBM, read and written every step.  One draw gives
+// 32 bits; a normal needs two -> two state advances per env-step.  The state stream is already
+// 16 B/lane coalesced, so staging it through LDS would add a round trip and buy nothing.
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+__device__ __forceinline__ uint32_t xoshiro_next(uint4& s) {
+    const uint32_t result = rotl32(s.x + s.w, 7) + s.x;
+    const uint32_t tt = s.y << 9;
+    s.z ^= s.x;
+    s.w ^= s.y;
+    s.y ^= s.z;
+    s.x ^= s.w;
+    s.z ^= tt;
+    s.w = rotl32(s.w, 11);
+    return result;
+}
+__global__ void __launch_bounds__(256)
+exp_step_xoshiro(int64_t n, float* __restrict__ obs, const float* __restrict__ action, float* __restrict__ reward,
+                 uint8_t* __restrict__ done, int32_t* __restrict__ t, uint4* __restrict__ state, float r, float K,
+                 float sigma, float x0, int32_t Tmax) {
+    const int64_t ntiles = n / 1024;
+    const float ro = x0 / K - 1.0f;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = (tile * 256 + threadIdx.x) * 4;
+        const Vec4<float> qo = *reinterpret_cast<const Vec4<float>*>(obs + base);
+        const Vec4<float> qa = *reinterpret_cast<const Vec4<float>*>(action + base);
+        const Vec4<int32_t> qt = *reinterpret_cast<const Vec4<int32_t>*>(t + base);
+        uint4 st[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st[j] = state[base + j];
+        Vec4<float> wo, wr;
+        Vec4<int32_t> wt;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float zc, zs, on, rw;
+            bool dn;
+            int32_t tn;
+            const uint32_t w0 = xoshiro_next(st[j]);
+            const uint32_t w1 = xoshiro_next(st[j]);
+            box_muller(w0, w1, zc, zs);
+            env_step<float, FISHING_MODEL_V1>(qo.v[j], qt.v[j], quota_cts<float>(qa.v[j], K), zc, r, K, sigma, 0.5f, Tmax, on, rw,
+                                              dn, tn);
+            wo.v[j] = dn ? ro : on;
+            wt.v[j] = dn ? 0 : tn;
+            wr.v[j] = rw;
+            packed |= (uint32_t)dn << (8 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) state[base + j] = st[j];
+        *reinterpret_cast<Vec4<float>*>(obs + base) = wo;
+        *reinterpret_cast<Vec4<float>*>(reward + base) = wr;
+        *reinterpret_cast<Vec4<int32_t>*>(t + base) = wt;
+        *reinterpret_cast<uint32_t*>(done + base) = packed;
+    }
+}
+
+extern "C" int exp_step_xo(int blocks, int64_t n, float* obs, const float* action, float* reward, uint8_t* done, int32_t* t,
+                           void* state, void* stream) {
+    exp_step_xoshiro<<<blocks, 256, 0, (hipStream_t)stream>>>(n, obs, action, reward, done, t, (uint4*)state, 0.3f, 1.0f, 0.1f,
+                                                             0.75f, 100);
+    return (int)hipGetLastError();
+}
+
 // copy with the same stream shape: 3 x 4-byte inputs -> 3 x 4-byte outputs + 1 byte
 template <int EPT>
 __global__ void __launch_bounds__(256)
