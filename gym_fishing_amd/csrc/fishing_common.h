@@ -453,11 +453,33 @@ __device__ __forceinline__ uint64_t ballot_tile_words(uint32_t nibble, int lane)
     return mine;
 }
 
-// Block-wide sum of kPartialFields doubles: wave shuffle tree, then one LDS hop.
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
     return v;
+}
+
+// Episodic-return record: add this workgroup's partial {sum R, sum R^2, n, sum length} to its own
+// slot of `partials`.  Wave shuffle tree -> one LDS hop across waves -> thread k adds field k.
+// One owner thread per slot and no atomics, so the sums are bitwise reproducible for a fixed
+// launch shape.  Must be reached by every thread of the workgroup (it contains a barrier).
+template <int MAX_WAVES>
+__device__ __forceinline__ void add_block_partials(const double (&acc)[kPartialFields], double* partials) {
+    __shared__ double red[MAX_WAVES][kPartialFields];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kPartialFields; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[wid][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartialFields) {
+        double s = 0.0;
+        const int nw = blockDim.x >> 6;
+        for (int w = 0; w < nw; ++w) s += red[w][threadIdx.x];
+        if (s != 0.0) partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x] += s;
+    }
 }
 
 }  // namespace fishing

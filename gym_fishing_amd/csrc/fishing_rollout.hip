@@ -238,22 +238,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         }
     }
 
-    if (b.partials) {
-        __shared__ double red[4][kPartialFields];
-        const int wid = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < kPartialFields; ++k) {
-            const double s = wave_sum(acc[k]);
-            if (lane == 0) red[wid][k] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < kPartialFields) {
-            double s = 0.0;
-            const int nw = blockDim.x >> 6;
-            for (int w = 0; w < nw; ++w) s += red[w][threadIdx.x];
-            if (s != 0.0) b.partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x] += s;
-        }
-    }
+    if (b.partials) add_block_partials<4>(acc, b.partials);
 }
 
 int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b);

@@ -215,25 +215,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         }
     }
 
-    if (b.partials) {
-        // per-workgroup partial of the episodic-return record: shuffle tree per wave, one
-        // LDS hop across waves, then the workgroup's own slot (no atomics: bitwise
-        // reproducible for a fixed launch shape).
-        __shared__ double red[FISHING_STEP_MAXTHREADS / kWave][kPartialFields];
-        const int wid = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < kPartialFields; ++k) {
-            const double s = wave_sum(acc[k]);
-            if (lane == 0) red[wid][k] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < kPartialFields) {
-            double s = 0.0;
-            const int nw = blockDim.x >> 6;
-            for (int w = 0; w < nw; ++w) s += red[w][threadIdx.x];
-            if (s != 0.0) b.partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x] += s;
-        }
-    }
+    if (b.partials) add_block_partials<FISHING_STEP_MAXTHREADS / kWave>(acc, b.partials);
 }
 
 // ---------------------------------------------------------------- lean fast path
@@ -409,21 +391,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
     }
 
     if (RET) {
-        if (a.partials) {
-            __shared__ double red[4][kPartialFields];
-            const int lane = threadIdx.x & (kWave - 1);
-            const int wid = threadIdx.x >> 6;
-#pragma unroll
-            for (int k = 0; k < kPartialFields; ++k) {
-                const double s = wave_sum(acc[k]);
-                if (lane == 0) red[wid][k] = s;
-            }
-            __syncthreads();
-            if (threadIdx.x < kPartialFields) {
-                const double s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-                if (s != 0.0) a.partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x] += s;
-            }
-        }
+        if (a.partials) add_block_partials<4>(acc, a.partials);
     }
 }
 
@@ -468,13 +436,13 @@ reduce_returns_kernel(const double* __restrict__ partials, double* __restrict__ 
 // population_draw() over an array of populations, as BMSY() drives it (models/policies.py:59-63)
 template <typename T, int MODEL>
 __global__ void __launch_bounds__(256)
-population_draw_kernel(const ParamsT<T> p, const int64_t n, const T* __restrict__ x_in,
+population_draw_kernel(const ParamsT<T> p, const int kind, const int64_t n, const T* __restrict__ x_in,
                        const T* __restrict__ z, T* __restrict__ x_out) {
     const GrowthT<T> P = p.growth;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         if constexpr (is_zoo_tag(MODEL))
-            x_out[i] = zoo_population_draw<T>(p.n_models /* kind passed by the host */, x_in[i], z ? z[i] : (T)0, P);
+            x_out[i] = zoo_population_draw<T>(kind, x_in[i], z ? z[i] : (T)0, P);
         else
             x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, p.r, p.K, p.sigma, p.C);
     }
@@ -737,19 +705,19 @@ int population_draw_impl(const FishingParams* p, int64_t n, const void* x_in, co
     if (!p || !x_in || !x_out) return FISHING_ERR_NULL;
     if (n < 0) return FISHING_ERR_SIZE;
     if (n == 0) return FISHING_OK;
-    ParamsT<T> pt = narrow_params<T>(*p);
+    const ParamsT<T> pt = narrow_params<T>(*p);
     int64_t nb = (n + 255) / 256;
     const int blocks = (int)(nb < 2048 ? nb : 2048);
     hipStream_t s = (hipStream_t)stream;
     if (is_zoo_model(p->model) && p->model != FISHING_MODEL_V11) {
-        pt.n_models = kind_of_model(p->model);     // the kernel reads the growth kind from here
-        population_draw_kernel<T, kModelZoo><<<blocks, 256, 0, s>>>(pt, n, (const T*)x_in, (const T*)z, (T*)x_out);
+        population_draw_kernel<T, kModelZoo><<<blocks, 256, 0, s>>>(pt, kind_of_model(p->model), n, (const T*)x_in,
+                                                                    (const T*)z, (T*)x_out);
         return (int)hipGetLastError();
     }
     if (p->model == FISHING_MODEL_V2)
-        population_draw_kernel<T, FISHING_MODEL_V2><<<blocks, 256, 0, s>>>(pt, n, (const T*)x_in, (const T*)z, (T*)x_out);
+        population_draw_kernel<T, FISHING_MODEL_V2><<<blocks, 256, 0, s>>>(pt, 0, n, (const T*)x_in, (const T*)z, (T*)x_out);
     else if (p->model == FISHING_MODEL_V0 || p->model == FISHING_MODEL_V1 || p->model == FISHING_MODEL_V4)
-        population_draw_kernel<T, FISHING_MODEL_V1><<<blocks, 256, 0, s>>>(pt, n, (const T*)x_in, (const T*)z, (T*)x_out);
+        population_draw_kernel<T, FISHING_MODEL_V1><<<blocks, 256, 0, s>>>(pt, 0, n, (const T*)x_in, (const T*)z, (T*)x_out);
     else
         return FISHING_ERR_MODEL;
     return (int)hipGetLastError();
