@@ -7,8 +7,6 @@ product raises FishingLibraryError -- no CPU fallback exists anywhere in this pa
 import ctypes
 import os
 
-from . import build as _build
-
 c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 c_dbl, c_vp = ctypes.c_double, ctypes.c_void_p
 
@@ -77,6 +75,7 @@ _lib = None
 
 
 def library_path():
+    from . import build as _build       # lazy: keeps `python -m gym_fishing_amd.build` warning-free
     return os.environ.get("FISHING_HIP_LIB", _build.LIB_PATH)
 
 

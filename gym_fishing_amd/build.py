@@ -57,12 +57,12 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     return _compile(LIB_PATH, verbose, extra_flags)
 
 
-def _compile(LIB_PATH, verbose, extra_flags):
+def _compile(out_path, verbose, extra_flags):
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libfishing_hip.so")
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    tmp = out_path + ".tmp.%d" % os.getpid()
     cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + sources() + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -73,8 +73,8 @@ def _compile(LIB_PATH, verbose, extra_flags):
         raise RuntimeError("hipcc failed (%d):\n%s" % (proc.returncode, proc.stdout))
     if verbose and proc.stdout.strip():
         print(proc.stdout)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    os.replace(tmp, out_path)
+    return out_path
 
 
 if __name__ == "__main__":
