@@ -246,9 +246,16 @@ __device__ __forceinline__ T quota_int(int32_t a, int32_t n_actions, T K) {
 // float32 bounds returns float32), so an in-kernel policy emits exactly what a caller could
 // pass through the float32 action stream.  Discrete: Python round(), i.e. round-half-even,
 // of quota * n_actions / K.
+struct DivK;   // exact power-of-two shortcut for x / K, defined below
+template <typename T>
+__device__ __forceinline__ T div_K(T x, T K, const DivK& d);
 template <typename T>
 __device__ __forceinline__ float action_cts_from_quota(T quota, T K) {
     return (float)(quota / K - (T)1);
+}
+template <typename T>
+__device__ __forceinline__ float action_cts_from_quota(T quota, T K, const DivK& dk) {
+    return (float)(div_K<T>(quota, K, dk) - (T)1);
 }
 template <typename T>
 __device__ __forceinline__ int32_t action_int_from_quota(T quota, int32_t n_actions, T K) {
@@ -340,16 +347,42 @@ __device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int
     done = (t_next > Tmax) || (x <= (T)0);
 }
 
+// x / K.  When K is a power of two (the default K = 1 included) the quotient is exact up to the
+// final rounding, and x * (1/K) with the exactly representable 1/K rounds to the same bits, so the
+// ~12-instruction IEEE division sequence can be one multiply.  KP2 is decided on the host
+// (is_pow2) and is wave-uniform; every other K keeps the correctly rounded division.
+struct DivK {
+    bool pow2;
+    float inv_f;
+    double inv_d;
+};
+inline DivK make_divk(double K) {
+    int e = 0;
+    const bool p2 = K > 0 && std::isfinite(K) && std::frexp(K, &e) == 0.5 && e > -120 && e < 120;
+    return DivK{p2, p2 ? (float)(1.0 / K) : 0.0f, p2 ? 1.0 / K : 0.0};
+}
+template <typename T>
+__device__ __forceinline__ T div_K(T x, T K, const DivK& d);
+template <>
+__device__ __forceinline__ float div_K<float>(float x, float K, const DivK& d) {
+    return d.pow2 ? x * d.inv_f : x / K;
+}
+template <>
+__device__ __forceinline__ double div_K<double>(double x, double K, const DivK& d) {
+    return d.pow2 ? x * d.inv_d : x / K;
+}
+
 // population_draw(): base_fishing_env.py:121-133 (logistic), fishing_tipping_env.py:24-35
 // (tipping point; the noise sits inside the exponent, scaled by x -- quirk B9).
 template <typename T, int MODEL>
-__device__ __forceinline__ T population_draw(T x, T z, T r, T K, T sigma, T C) {
+__device__ __forceinline__ T population_draw(T x, T z, T r, T K, T sigma, T C, const DivK& dk = DivK{false, 0.0f, 0.0}) {
     T g;
+    const T xk = div_K<T>(x, K, dk);
     if (MODEL == FISHING_MODEL_V2) {
-        const T e = ((r * ((T)1 - (x / K))) * (x - C)) + ((x * sigma) * z);
+        const T e = ((r * ((T)1 - xk)) * (x - C)) + ((x * sigma) * z);
         g = x * exp_t<T>(e);
     } else {
-        g = (x + ((r * x) * ((T)1 - (x / K)))) + ((x * sigma) * z);
+        g = (x + ((r * x) * ((T)1 - xk))) + ((x * sigma) * z);
     }
     return (g > (T)0) ? g : ((g != g) ? g : (T)0);   // np.maximum(g, 0.0): NaN-propagating, -0 -> +0
 }
@@ -358,13 +391,13 @@ __device__ __forceinline__ T population_draw(T x, T z, T r, T K, T sigma, T C) {
 template <typename T, int MODEL>
 __device__ __forceinline__ void env_step(T obs, int32_t t, T quota, T z, T r, T K, T sigma, T C,
                                          int32_t Tmax, T& obs_next, T& reward, bool& done,
-                                         int32_t& t_next) {
+                                         int32_t& t_next, const DivK& dk = DivK{false, 0.0f, 0.0}) {
     T x = (obs + (T)1) * K;                   // get_fish_population  :159
     const T h = (quota < x) ? quota : x;      // min(x, quota)        :117
     const T d = x - h;
     x = ((T)0 > d) ? (T)0 : d;                // max(x - h, 0.0)      :118
-    x = population_draw<T, MODEL>(x, z, r, K, sigma, C);
-    obs_next = x / K - (T)1;                  // get_state            :163
+    x = population_draw<T, MODEL>(x, z, r, K, sigma, C, dk);
+    obs_next = div_K<T>(x, K, dk) - (T)1;     // get_state            :163
     reward = ((T)0 > h) ? (T)0 : h;           // max(harvest, 0.0)    :74
     t_next = t + 1;                           //                      :75
     done = (t_next > Tmax) || (x <= (T)0);    //                      :76-79

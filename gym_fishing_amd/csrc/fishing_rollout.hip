@@ -20,9 +20,10 @@ template <typename T, int MODEL, int POLICY, bool AUTO>
 __global__ void __launch_bounds__(256)
 rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
                const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed,
-               const uint64_t step_counter_arg, const int noise_on, const int policy_rt) {
+               const uint64_t step_counter_arg, const int noise_on, const int policy_rt, const DivK dk_arg) {
     const uint64_t step_counter0 = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
+    const DivK dk = kPerEnv ? DivK{false, 0.0f, 0.0} : dk_arg;      // per-env K keeps the true division
     // POLICY >= 0: compile-time policy (v0/v1/v2/v4); POLICY < 0: wave-uniform run-time policy (zoo,
     // to keep the number of instantiations of the transcendental-heavy bodies small)
     const int policy = (POLICY >= 0) ? POLICY : policy_rt;
@@ -118,7 +119,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                         q = policy_param;
                     }
                     if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_quota<T>(q, p.n_actions, KK[j]);
-                    else a_c = (T)action_cts_from_quota<T>(q, KK[j]);
+                    else a_c = (T)action_cts_from_quota<T>(q, KK[j], dk);
                 }
                 const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j])
                                                             : quota_cts<T>(a_c, KK[j]);
@@ -142,7 +143,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                         env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, o2, r2, d2, t2);
                     }
                 } else {
-                    env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax, o2, r2, d2, t2);
+                    env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax, o2, r2, d2, t2, dk);
                 }
                 if (AUTO) {
                     obs[j] = o2;
@@ -248,16 +249,17 @@ template <typename T, int MODEL>
 int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& bt, int64_t n, uint64_t env_offset,
                           T policy_param, int32_t Tsteps, T* traj, uint64_t seed, uint64_t step_counter,
                           int noise_on, int blocks, int threads, hipStream_t s) {
+    const DivK dk = make_divk((double)pt.K);
 #define FISHING_LAUNCH_ROLLOUT(POL)                                                                                \
     do {                                                                                                           \
         if (pt.flags & FISHING_FLAG_AUTO_RESET)                                                                    \
             rollout_kernel<T, MODEL, POL, true><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param,  \
                                                                            Tsteps, traj, seed, step_counter,      \
-                                                                           noise_on, policy);                     \
+                                                                           noise_on, policy, dk);                 \
         else                                                                                                       \
             rollout_kernel<T, MODEL, POL, false><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param, \
                                                                             Tsteps, traj, seed, step_counter,     \
-                                                                            noise_on, policy);                    \
+                                                                            noise_on, policy, dk);                \
     } while (0)
     if constexpr (is_zoo_tag(MODEL)) {
         FISHING_LAUNCH_ROLLOUT(-1);          // run-time policy switch
