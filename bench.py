@@ -40,8 +40,8 @@ HBM_COPY_GBS = 6290.0       # measured float4 copy on the same table
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1010)
-    ap.add_argument("--warmup", type=int, default=101)
+    ap.add_argument("--steps", type=int, default=5050)
+    ap.add_argument("--warmup", type=int, default=505)
     ap.add_argument("--n-envs", type=int, default=N_ENVS, help="envs per GPU (default 2^22, the metric's N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-returns", action="store_true", help="pure 25 B step (no episodic-return accumulator)")
