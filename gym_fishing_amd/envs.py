@@ -64,7 +64,19 @@ class _Repeat:
         return (self.value for _ in range(self.n))
 
 
-class BaseFishingEnv:
+def _gym_env_base():
+    """`gym.Env` when the (optional) gym package is importable, so isinstance checks of tooling
+    built on the reference's gym 0.17 API (SB3's DummyVecEnv / check_env) accept these classes;
+    plain `object` otherwise.  gymnasium is not used as a base: its 5-tuple step API differs
+    from the reference's 4-tuple one, which this package keeps."""
+    try:
+        import gym
+        return gym.Env
+    except Exception:  # noqa: BLE001 - optional dependency
+        return object
+
+
+class BaseFishingEnv(_gym_env_base()):
     """base_fishing_env.py:16-164, vectorised.  See the module docstring."""
 
     metadata = {"render.modes": ["human"]}
