@@ -37,6 +37,7 @@ import types
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE      # overridden by `--out DIR` (tests/test_golden_provenance.py regenerates into a temp dir)
 
 
 def _install_gym_stand_in():
@@ -313,14 +314,16 @@ def main():
     anchors["versions"] = {"numpy": np.__version__, "python": sys.version.split()[0],
                            "reference_version": open(os.path.join(REF, "gym_fishing/version.txt")).read().strip()}
 
-    np.savez_compressed(os.path.join(HERE, "reference_trajectories.npz"), **out)
-    np.savez_compressed(os.path.join(HERE, "reference_policy_sims.npz"), **sims)
-    np.savez_compressed(os.path.join(HERE, "reference_zoo_trajectories.npz"), **zoo)
-    with open(os.path.join(HERE, "reference_anchors.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, "reference_trajectories.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "reference_policy_sims.npz"), **sims)
+    np.savez_compressed(os.path.join(OUT, "reference_zoo_trajectories.npz"), **zoo)
+    with open(os.path.join(OUT, "reference_anchors.json"), "w") as f:
         json.dump(anchors, f, indent=1, sort_keys=True)
     print("wrote %d arrays, %d sims, %d anchors" % (len(out), len(sims), len(anchors)))
     return 0
 
 
 if __name__ == "__main__":
+    if "--out" in sys.argv:
+        OUT = sys.argv[sys.argv.index("--out") + 1]
     sys.exit(main())
