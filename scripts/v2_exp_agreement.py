@@ -6,7 +6,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden_cases
 import hip_harness as hh
-from oracle import fishing_oracle as fo
 tot = same = 0
 worst = 0
 for c in load_golden_cases():
