@@ -120,3 +120,21 @@ def test_summarize_record():
 
 def test_register_with_gym_is_optional():
     assert isinstance(gf.register_with_gym(), list)     # [] when neither gym nor gymnasium exists
+
+
+def test_only_tests_smoke_and_bench_touch_the_oracle():
+    """The oracle is the checker, never the thing shipped: outside tests/ and oracle/ itself, only
+    bench.py (cpu_baseline leg) and __graft_entry__.py (build of the C restatement, smoke check)
+    may import it."""
+    allowed = {os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    offenders = []
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "tests", "oracle", "gpurun_out", "__pycache__", ".pytest_cache")]
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, f)
+            code = "\n".join(line.split("#")[0] for line in open(path).read().splitlines())
+            if re.search(r"^\s*(from|import)\s+oracle\b", code, flags=re.M) and path not in allowed:
+                offenders.append(os.path.relpath(path, ROOT))
+    assert not offenders, offenders
