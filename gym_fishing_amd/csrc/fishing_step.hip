@@ -239,12 +239,13 @@ struct LeanArgs {
     T* ep_return;
     double* partials;
     const uint64_t* counter;
+    const T* sigma_arr;      // per-env noise scale (fishing-v4 with parameter arrays, SIGARR)
     T pr, pK, sigma, C, x0, r_mean, K_mean, sigma_p;
     int32_t Tmax, n_actions;
     uint32_t auto_reset;
 };
 
-template <typename T, int MODEL, int NOISE, bool RET>
+template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false>
 __global__ void __launch_bounds__(256)
 step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_offset, const uint64_t seed,
                  const uint64_t step_counter_arg) {
@@ -256,10 +257,17 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * 256 + threadIdx.x) * kEnvsPerThread;
-        T obs[4], rr[4], KK[4], z[4], er[4];
+        T obs[4], rr[4], KK[4], z[4], er[4], sg[4];
         int32_t t[4], a_i[4];
         float a_f[4];
         {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sg[j] = a.sigma;
+            if (SIGARR) {
+                const Vec4<T> qs = *reinterpret_cast<const Vec4<T>*>(a.sigma_arr + base);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sg[j] = qs.v[j];
+            }
             const Vec4<T> q = *reinterpret_cast<const Vec4<T>*>(a.obs + base);
             const Vec4<int32_t> qt = *reinterpret_cast<const Vec4<int32_t>*>(a.t + base);
 #pragma unroll
@@ -314,7 +322,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         for (int j = 0; j < 4; ++j) {
             const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
                                                         : quota_cts<T>((T)a_f[j], KK[j]);
-            env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], a.sigma, a.C, a.Tmax, obs_next[j], rew[j],
+            env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
                                dn[j], t_next[j]);
         }
         {
@@ -556,6 +564,13 @@ BuffersT<T> offset_buffers(const BuffersT<T>& b, int64_t off) {
 template <typename T, int MODEL>
 int launch_lean(const LeanArgs<T>& a, int noise, bool ret, int64_t ntiles, uint64_t env_offset, uint64_t seed,
                 uint64_t step_counter, int blocks, hipStream_t s) {
+    if constexpr (MODEL == FISHING_MODEL_V4) {
+        if (a.sigma_arr) {      // BASELINE config 5: per-env (r, K, sigma) arrays; always noisy
+            if (ret) step_kernel_lean<T, MODEL, kNoisePhilox, true, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
+            else step_kernel_lean<T, MODEL, kNoisePhilox, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
+            return (int)hipGetLastError();
+        }
+    }
 #define FISHING_LEAN(NZ, RT) step_kernel_lean<T, MODEL, NZ, RT><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter)
     if (noise == kNoiseNone) {
         if (ret) FISHING_LEAN(kNoiseNone, true); else FISHING_LEAN(kNoiseNone, false);
@@ -593,12 +608,12 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
                           p->model == FISHING_MODEL_V2 || p->model == FISHING_MODEL_V4;
         const int64_t tile = 256 * kEnvsPerThread;
         if (core && noise != kNoiseExt && !(p->flags & FISHING_FLAG_GENERAL_KERNEL) && b->reward && b->done &&
-            !b->done_bits && !b->terminal_obs && !b->sigma && (p->launch_threads == 0 || p->launch_threads == 256) &&
-            n >= tile) {
+            !b->done_bits && !b->terminal_obs && (!b->sigma || (p->model == FISHING_MODEL_V4 && noise == kNoisePhilox)) &&
+            (p->launch_threads == 0 || p->launch_threads == 256) && n >= tile) {
             const int64_t ntiles = n / tile;
             const int64_t n_full = ntiles * tile;
             LeanArgs<T> a{bt.obs,      bt.action,  bt.reward,  bt.done,     bt.t,        bt.r,
-                          bt.K,        bt.ep_return, bt.partials, bt.counter, pt.r,      pt.K,
+                          bt.K,        bt.ep_return, bt.partials, bt.counter, bt.sigma,  pt.r,      pt.K,
                           pt.sigma,    pt.C,       pt.x0,      pt.r_mean,   pt.K_mean,   pt.sigma_p,
                           pt.Tmax,     pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET)};
             int cap = p->launch_blocks ? p->launch_blocks : 2048;

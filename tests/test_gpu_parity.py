@@ -639,8 +639,9 @@ def test_lean_and_general_kernels_agree(hh, model, ret, n):
     for sigma in (0.1, 0.0):
         kw = dict(sigma=sigma, C=0.5, Tmax=4, sigma_p=0.2, auto_reset=True)
         pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
+        sig_arr = np.random.default_rng(n).uniform(0.0, 0.3, n) if (per_env and sigma > 0) else None   # config 5
         mk = lambda: hh.State(n, np.float32, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
-                              K=np.full(n, 1.0) if per_env else None, ep_return=ret)
+                              K=np.full(n, 1.0) if per_env else None, sigma=sig_arr, ep_return=ret)
         A, B = mk(), mk()
         A.reset(pa, seed=5, env_offset=12)
         B.reset(pb, seed=5, env_offset=12)
