@@ -132,10 +132,12 @@ class BaseFishingEnv(_gym_env_base()):
         sizes = [(dtype, N * esz), (torch.int32, N * 4), (dtype, N * esz), (torch.uint8, N)]
         if track_returns:
             sizes.append((dtype, N * esz))
+        stagger = 0 if self._scalar else 12288       # one env: keep the arena one small D2H copy
         offs, off = [], 0
         for k, (_, nbytes) in enumerate(sizes):
             offs.append(off)
-            off = (off + nbytes + 12288 * (k + 1) + 255) & ~255
+            off = (off + nbytes + stagger * (k + 1) + 255) & ~255
+        self._arena_offs = offs
         self._arena = torch.zeros(off, dtype=torch.uint8, device=dev)
         views = [self._arena[o:o + nb].view(dt) for o, (dt, nb) in zip(offs, sizes)]
         self._obs, self._t, self._reward, self._done = views[:4]
@@ -297,10 +299,20 @@ class BaseFishingEnv(_gym_env_base()):
         self._t.zero_()
         self._publish_scalar_state()
 
+    def _read_scalar(self):
+        """obs, t, reward, done of the single env with ONE device-to-host copy (the arena is a few
+        hundred bytes in the scalar protocol)."""
+        host = self._arena.cpu().numpy()
+        o_obs, o_t, o_rew, o_done = self._arena_offs[:4]
+        ftype = np.float64 if self.dtype == torch.float64 else np.float32
+        obs = host[o_obs:o_obs + np.dtype(ftype).itemsize].view(ftype).astype(np.float64)
+        t = int(host[o_t:o_t + 4].view(np.int32)[0])
+        rew = float(host[o_rew:o_rew + np.dtype(ftype).itemsize].view(ftype)[0])
+        return obs, t, rew, bool(host[o_done])
+
     def _publish_scalar_state(self):
         if self._scalar:
-            self.state = self._obs.cpu().numpy().astype(np.float64)
-            self.years_passed = int(self._t[0])
+            self.state, self.years_passed, self._last_reward, self._last_done = self._read_scalar()
             self.fish_population = float((self.state[0] + 1.0) * float(self._K_view() if self._per_env else self.params["K"]))
         else:
             self.state = self._obs_view
@@ -403,9 +415,9 @@ class BaseFishingEnv(_gym_env_base()):
     def _step_result(self):
         if self._scalar:
             self._publish_scalar_state()
-            self.reward = float(self._reward[0])
+            self.reward = self._last_reward
             self.harvest = self.reward
-            return self.state, self.reward, bool(self._done[0]), {}
+            return self.state, self.reward, self._last_done, {}
         return self._obs_view, self._reward, self._done_view, self._info
 
     def step_many(self, actions, n_steps=None):
