@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <type_traits>
 
 #include "../../include/fishing_hip.h"
 
@@ -160,6 +161,9 @@ inline ParamsT<T> narrow_params(const FishingParams& p) {
 }
 
 inline bool is_zoo_model(int model) { return model >= FISHING_MODEL_V5 && model <= FISHING_MODEL_V11; }
+inline bool is_core_model(int model) {
+    return model == FISHING_MODEL_V0 || model == FISHING_MODEL_V1 || model == FISHING_MODEL_V2 || model == FISHING_MODEL_V4;
+}
 
 // growth-function kind of a single-kind zoo model (v11 carries it per env)
 inline int kind_of_model(int model) {
@@ -210,6 +214,32 @@ inline BuffersT<T> typed_buffers(const FishingBuffers& b) {
     q.model_idx = b.model_idx;
     q.counter = b.counter;
     return q;
+}
+
+// Host-side tag dispatch: calls f(std::integral_constant<int, TAG>{}) with the kernel template tag
+// of `model` (the model id itself for fishing-v0/v1/v2/v4; kModelZoo + kind for v5..v10;
+// kModelZooMixed for v11).  Keeps the run-time -> compile-time switch in one place.
+template <int TAG>
+using ModelTag = std::integral_constant<int, TAG>;
+
+template <typename F>
+inline int with_model_tag(int model, F&& f) {
+    switch (model) {
+        case FISHING_MODEL_V0: return f(ModelTag<FISHING_MODEL_V0>{});
+        case FISHING_MODEL_V1: return f(ModelTag<FISHING_MODEL_V1>{});
+        case FISHING_MODEL_V2: return f(ModelTag<FISHING_MODEL_V2>{});
+        case FISHING_MODEL_V4: return f(ModelTag<FISHING_MODEL_V4>{});
+        case FISHING_MODEL_V11: return f(ModelTag<kModelZooMixed>{});
+        default: break;
+    }
+    if (!is_zoo_model(model)) return FISHING_ERR_MODEL;
+    switch (kind_of_model(model)) {
+        case FISHING_KIND_ALLEN: return f(ModelTag<kModelZoo + FISHING_KIND_ALLEN>{});
+        case FISHING_KIND_MYERS: return f(ModelTag<kModelZoo + FISHING_KIND_MYERS>{});
+        case FISHING_KIND_MAY: return f(ModelTag<kModelZoo + FISHING_KIND_MAY>{});
+        case FISHING_KIND_RICKER: return f(ModelTag<kModelZoo + FISHING_KIND_RICKER>{});
+        default: return f(ModelTag<kModelZoo + FISHING_KIND_BEVERTON_HOLT>{});
+    }
 }
 
 // ---------------------------------------------------------------- the env arithmetic

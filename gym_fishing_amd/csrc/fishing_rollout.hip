@@ -298,31 +298,10 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     launch_shape(p, n, blocks, threads);
     hipStream_t s = (hipStream_t)stream;
     const T pp = (T)policy_param;
-    switch (p->model) {
-        case FISHING_MODEL_V0:
-            return launch_rollout_policy<T, FISHING_MODEL_V0>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-        case FISHING_MODEL_V1:
-            return launch_rollout_policy<T, FISHING_MODEL_V1>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-        case FISHING_MODEL_V2:
-            return launch_rollout_policy<T, FISHING_MODEL_V2>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-        case FISHING_MODEL_V4:
-            return launch_rollout_policy<T, FISHING_MODEL_V4>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-        case FISHING_MODEL_V11:
-            return launch_rollout_policy<T, kModelZooMixed>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-        default:
-            switch (kind_of_model(p->model)) {
-                case FISHING_KIND_ALLEN:
-                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_ALLEN>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-                case FISHING_KIND_MYERS:
-                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_MYERS>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-                case FISHING_KIND_MAY:
-                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_MAY>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-                case FISHING_KIND_RICKER:
-                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_RICKER>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-                default:
-                    return launch_rollout_policy<T, kModelZoo + FISHING_KIND_BEVERTON_HOLT>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed, step_counter, noise_on, blocks, threads, s);
-            }
-    }
+    return with_model_tag(p->model, [&](auto tag) {
+        return launch_rollout_policy<T, decltype(tag)::value>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed,
+                                                              step_counter, noise_on, blocks, threads, s);
+    });
 }
 
 }  // namespace fishing

@@ -483,9 +483,7 @@ static inline bool misaligned(const void* p) { return p && (((uintptr_t)p) & 15u
 
 int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b) {
     if (!p || !b) return FISHING_ERR_NULL;
-    if (p->model != FISHING_MODEL_V0 && p->model != FISHING_MODEL_V1 && p->model != FISHING_MODEL_V2 &&
-        p->model != FISHING_MODEL_V4 && !is_zoo_model(p->model))
-        return FISHING_ERR_MODEL;
+    if (!is_core_model(p->model) && !is_zoo_model(p->model)) return FISHING_ERR_MODEL;
     if (p->model == FISHING_MODEL_V10 && !b->r) return FISHING_ERR_NULL;
     if (p->model == FISHING_MODEL_V11) {
         if (!b->model_idx) return FISHING_ERR_NULL;
@@ -604,8 +602,7 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
 
     // lean fast path (fp32, v0/v1/v2/v4, no optional stream but the return accumulator)
     if constexpr (sizeof(T) == 4) {
-        const bool core = p->model == FISHING_MODEL_V0 || p->model == FISHING_MODEL_V1 ||
-                          p->model == FISHING_MODEL_V2 || p->model == FISHING_MODEL_V4;
+        const bool core = is_core_model(p->model);
         const int64_t tile = 256 * kEnvsPerThread;
         if (core && noise != kNoiseExt && !(p->flags & FISHING_FLAG_GENERAL_KERNEL) && b->reward && b->done &&
             !b->done_bits && !b->terminal_obs && (!b->sigma || (p->model == FISHING_MODEL_V4 && noise == kNoisePhilox)) &&
@@ -620,49 +617,27 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
             if (cap > kMaxBlocks) cap = kMaxBlocks;
             const int lb = (int)(ntiles < cap ? ntiles : cap);
             const bool ret = b->ep_return != nullptr;
-            int rc2;
-            switch (p->model) {
-                case FISHING_MODEL_V0: rc2 = launch_lean<T, FISHING_MODEL_V0>(a, noise, ret, ntiles, env_offset, seed, step_counter, lb, s); break;
-                case FISHING_MODEL_V1: rc2 = launch_lean<T, FISHING_MODEL_V1>(a, noise, ret, ntiles, env_offset, seed, step_counter, lb, s); break;
-                case FISHING_MODEL_V2: rc2 = launch_lean<T, FISHING_MODEL_V2>(a, noise, ret, ntiles, env_offset, seed, step_counter, lb, s); break;
-                default: rc2 = launch_lean<T, FISHING_MODEL_V4>(a, noise, ret, ntiles, env_offset, seed, step_counter, lb, s); break;
-            }
+            const int rc2 = with_model_tag(p->model, [&](auto tag) {
+                constexpr int kTag = decltype(tag)::value;
+                if constexpr (kTag == FISHING_MODEL_V0 || kTag == FISHING_MODEL_V1 || kTag == FISHING_MODEL_V2 ||
+                              kTag == FISHING_MODEL_V4)
+                    return launch_lean<T, kTag>(a, noise, ret, ntiles, env_offset, seed, step_counter, lb, s);
+                else
+                    return (int)FISHING_ERR_MODEL;
+            });
             if (rc2 != 0 || n_full == n) return rc2;
             // ragged tail (< 1024 envs): one workgroup of the general kernel
             const BuffersT<T> tb = offset_buffers<T>(bt, n_full);
-            switch (p->model) {
-                case FISHING_MODEL_V0: return launch_step_noise<T, FISHING_MODEL_V0>(pt, tb, noise, n - n_full, env_offset + n_full, seed, step_counter, 1, 256, s);
-                case FISHING_MODEL_V1: return launch_step_noise<T, FISHING_MODEL_V1>(pt, tb, noise, n - n_full, env_offset + n_full, seed, step_counter, 1, 256, s);
-                case FISHING_MODEL_V2: return launch_step_noise<T, FISHING_MODEL_V2>(pt, tb, noise, n - n_full, env_offset + n_full, seed, step_counter, 1, 256, s);
-                default: return launch_step_noise<T, FISHING_MODEL_V4>(pt, tb, noise, n - n_full, env_offset + n_full, seed, step_counter, 1, 256, s);
-            }
+            return with_model_tag(p->model, [&](auto tag) {
+                return launch_step_noise<T, decltype(tag)::value>(pt, tb, noise, n - n_full, env_offset + n_full, seed,
+                                                                  step_counter, 1, 256, s);
+            });
         }
     }
-    switch (p->model) {
-        case FISHING_MODEL_V0:
-            return launch_step_noise<T, FISHING_MODEL_V0>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-        case FISHING_MODEL_V1:
-            return launch_step_noise<T, FISHING_MODEL_V1>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-        case FISHING_MODEL_V2:
-            return launch_step_noise<T, FISHING_MODEL_V2>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-        case FISHING_MODEL_V4:
-            return launch_step_noise<T, FISHING_MODEL_V4>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-        case FISHING_MODEL_V11:
-            return launch_step_noise<T, kModelZooMixed>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-        default:   // fishing-v5..v10: one instantiation per growth function
-            switch (kind_of_model(p->model)) {
-                case FISHING_KIND_ALLEN:
-                    return launch_step_noise<T, kModelZoo + FISHING_KIND_ALLEN>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-                case FISHING_KIND_MYERS:
-                    return launch_step_noise<T, kModelZoo + FISHING_KIND_MYERS>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-                case FISHING_KIND_MAY:
-                    return launch_step_noise<T, kModelZoo + FISHING_KIND_MAY>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-                case FISHING_KIND_RICKER:
-                    return launch_step_noise<T, kModelZoo + FISHING_KIND_RICKER>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-                default:
-                    return launch_step_noise<T, kModelZoo + FISHING_KIND_BEVERTON_HOLT>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s);
-            }
-    }
+    return with_model_tag(p->model, [&](auto tag) {
+        return launch_step_noise<T, decltype(tag)::value>(pt, bt, noise, n, env_offset, seed, step_counter, blocks,
+                                                          threads, s);
+    });
 }
 
 template <typename T>
@@ -694,23 +669,15 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
     int64_t nb = (n + threads - 1) / threads;
     const int blocks = (int)(nb < 2048 ? nb : 2048);
     hipStream_t s = (hipStream_t)stream;
-    switch (p->model) {
-        case FISHING_MODEL_V0:
-            reset_kernel<T, FISHING_MODEL_V0><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
-            break;
-        case FISHING_MODEL_V1:
-            reset_kernel<T, FISHING_MODEL_V1><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
-            break;
-        case FISHING_MODEL_V2:
-            reset_kernel<T, FISHING_MODEL_V2><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
-            break;
-        case FISHING_MODEL_V4:
-            reset_kernel<T, FISHING_MODEL_V4><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
-            break;
-        default:
-            reset_kernel<T, kModelZooMixed><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
-            break;
-    }
+    with_model_tag(p->model, [&](auto tag) {
+        // reset only distinguishes v4 (parameter redraw, un-normalised obs) and v11 (model draw)
+        constexpr int kTag = decltype(tag)::value;
+        constexpr int kResetTag = (kTag == FISHING_MODEL_V4) ? FISHING_MODEL_V4
+                                  : is_zoo_tag(kTag)         ? kModelZooMixed
+                                                             : FISHING_MODEL_V1;
+        reset_kernel<T, kResetTag><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, mask, seed, reset_counter);
+        return 0;
+    });
     return (int)hipGetLastError();
 }
 
