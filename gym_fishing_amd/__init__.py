@@ -66,6 +66,14 @@ def register_with_gym():
     return done
 
 
+# like the reference (gym_fishing/__init__.py:2), importing the package registers the ids -- but
+# only if a gym is there to register with; never a hard dependency
+try:
+    register_with_gym()
+except Exception:  # noqa: BLE001
+    pass
+
+
 def __getattr__(name):
     if name in ("FishingEnv", "FishingCtsEnv", "FishingTippingEnv", "FishingModelError", "BaseFishingEnv", "Allen",
                 "BevertonHolt", "May", "Myers", "Ricker", "NonStationary", "ModelUncertainty"):
