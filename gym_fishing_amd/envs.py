@@ -339,6 +339,37 @@ class BaseFishingEnv(_gym_env_base()):
             self._counter.zero_()
         return [self._seed]
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    _STATE_TENSORS = ("_obs", "_t", "_reward", "_done", "_r_arr", "_K_arr", "_sigma_arr", "_ep_return", "_partials",
+                      "_model_idx", "_counter")
+
+    def state_dict(self):
+        """Everything a rollout needs to resume bit-for-bit: the per-env streams, the counters that
+        key the noise, the seed.  (The reference has no checkpointing; its env is a few scalars.)"""
+        if self._scalar:
+            torch.cuda.current_stream(self.device).synchronize()
+        sd = {k: getattr(self, k).clone() for k in self._STATE_TENSORS if getattr(self, k) is not None}
+        sd.update(seed=self._seed, step_count=self._step_count, reset_count=self._reset_count,
+                  params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state)
+        return sd
+
+    def load_state_dict(self, sd):
+        if self._scalar:
+            torch.cuda.current_stream(self.device).synchronize()
+        for k in self._STATE_TENSORS:
+            if k in sd:
+                if getattr(self, k) is None:
+                    if k == "_counter":
+                        self.enable_graph_replay()
+                    else:
+                        raise ValueError("state has %s but this env was built without it" % k)
+                getattr(self, k).copy_(sd[k])
+        self._seed, self._step_count, self._reset_count = sd["seed"], sd["step_count"], sd["reset_count"]
+        self.params.update(sd["params"])
+        self.Tmax, self.init_state = sd["Tmax"], sd["init_state"]
+        self._publish_scalar_state()
+        return self
+
     def enable_graph_replay(self):
         """Keep the step counter in device memory from now on.  step() / step_many() / rollout()
         then launch with frozen arguments plus a one-thread counter bump, so a hipGraph that

@@ -430,3 +430,32 @@ def test_c_api_demo_runs_without_python_side_state(gf, tmp_path):
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, timeout=120)
     assert out.returncode == 0, out.stdout
     assert "mean return 6.312500" in out.stdout and "episodes 1048576" in out.stdout
+
+
+def test_state_dict_resume_is_bit_exact(gf):
+    """Checkpoint / resume: a restored env continues exactly like the one that kept running
+    (streams, counters and seed are all that is needed; the noise is counter-based)."""
+    import torch
+    n = 3000
+    acts = torch.rand((6, n), device="cuda") * 2 - 1
+    a = gf.make("fishing-v4", sigma=0.1, num_envs=n, seed=8, Tmax=5, track_returns=True)
+    a.reset()
+    a.step_many(acts, 9)
+    sd = a.state_dict()
+    a.step_many(acts, 11)
+    a.rollout(7, policy="random")
+    b = gf.make("fishing-v4", sigma=0.1, num_envs=n, seed=123, Tmax=5, track_returns=True)
+    b.load_state_dict(sd)
+    b.step_many(acts, 11)
+    b.rollout(7, policy="random")
+    assert torch.equal(a.state, b.state) and torch.equal(a.K, b.K) and torch.equal(a.years_passed, b.years_passed)
+    assert a.episode_stats() == b.episode_stats()
+    s = gf.make("fishing-v1", sigma=0.3, seed=4)
+    s.reset()
+    for _ in range(5):
+        s.step(np.array([-0.9], dtype=np.float32))
+    sd = s.state_dict()
+    want = [s.step(np.array([-0.8], dtype=np.float32))[0][0] for _ in range(4)]
+    s2 = gf.make("fishing-v1", sigma=0.3, seed=999).load_state_dict(sd)
+    got = [s2.step(np.array([-0.8], dtype=np.float32))[0][0] for _ in range(4)]
+    assert want == got
