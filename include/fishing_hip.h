@@ -192,9 +192,12 @@ int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x
 int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
                                 fishing_stream_t stream);
 
-/* Test/diagnostic: the generator itself.  For env (env_offset + i): words[4*i..4*i+3] =
- * Philox4x32-10 block, z0/z1 = the two Box-Muller normals (z0 is the step noise).
- * Any output pointer may be NULL. */
+/* Test/diagnostic: the generator itself.  For Philox index (env_offset + i): words[4*i..4*i+3] =
+ * the Philox4x32-10 block, z0 / z1 = the cos / sin legs of its Box-Muller pair.  On the step-noise
+ * stream (stream_tag 0) the index is the env PAIR (global env >> 1): z0 is the noise of env 2*index,
+ * z1 of env 2*index + 1, words 2 / 3 their random-policy actions.  On the reset streams (tags 1, 2)
+ * the index is the global env: (z0, z1) = the (K, r) normals of fishing-v4, word 0 the fishing-v11
+ * model draw.  Any output pointer may be NULL. */
 int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
                       uint32_t* words, float* z0, float* z1, fishing_stream_t stream);
 
