@@ -459,3 +459,29 @@ def test_state_dict_resume_is_bit_exact(gf):
     s2 = gf.make("fishing-v1", sigma=0.3, seed=999).load_state_dict(sd)
     got = [s2.step(np.array([-0.8], dtype=np.float32))[0][0] for _ in range(4)]
     assert want == got
+
+
+def test_bench_contract_json_line(gf):
+    """bench.py prints exactly ONE JSON line with the contract's keys (small run, no CPU baseline)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import os
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "8",
+                          "--n-envs", str(1 << 18), "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 8 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert abs(d["value"] - (1 << 18) * 40 / (d["ms_per_step"] * 40 / 1e3)) / d["value"] < 1e-9
