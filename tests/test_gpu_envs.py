@@ -315,11 +315,12 @@ def test_simulate_with_generic_model_and_policyfn(gf):
 
         def predict(self, obs, **kw):
             return self.inner.predict(obs, **kw)
-    venv = gf.make("fishing-v1", sigma=0.0, num_envs=8, dtype=torch.float64)
-    esc = policies.escapement(venv)
-    a = venv.simulate(esc).to_numpy(dtype=np.float64)
-    b = venv.simulate(Wrapped(esc)).to_numpy(dtype=np.float64)
-    assert a.shape == b.shape and np.array_equal(a, b)
+    for env_id, dt in (("fishing-v1", torch.float64), ("fishing-v0", torch.float64), ("fishing-v2", torch.float32)):
+        venv = gf.make(env_id, sigma=0.0, num_envs=8, dtype=dt)
+        for pol in (policies.escapement(venv), policies.msy(venv)):
+            a = venv.simulate(pol).to_numpy(dtype=np.float64)
+            b = venv.simulate(Wrapped(pol)).to_numpy(dtype=np.float64)
+            assert a.shape == b.shape and np.array_equal(a, b), (env_id, type(pol).__name__)
     env = gf.make("fishing-v1")
     pf = env.policyfn(policies.escapement(env))
     assert list(pf.columns) == ["state", "action", "rep"] and len(pf) == 50
