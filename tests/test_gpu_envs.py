@@ -486,3 +486,18 @@ def test_bench_contract_json_line(gf):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert abs(d["value"] - (1 << 18) * 40 / (d["ms_per_step"] * 40 / 1e3)) / d["value"] < 1e-9
+
+
+@pytest.mark.parametrize("script", ["const_escapement.py", "random_rollout.py"])
+def test_examples_run(gf, script):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import os
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    if script == "const_escapement.py":
+        assert "scalar protocol: 100 steps, return 7.675000" in out.stdout and "mean_return" in out.stdout
+    else:
+        assert "env-steps/s" in out.stdout
