@@ -32,6 +32,7 @@ RING = 8
 # algorithmic bytes per env-step: fp32 layout 25 B (R obs 4 + action 4 + t 4,
 # W obs 4 + reward 4 + done 1 + t 4) + 8 B for the per-env episodic-return accumulator (R+W 4)
 BYTES_STEP = 25
+BYTES_STEP_COMPACT = 19     # --compact: years_passed as uint8 (R 1 + W 1 instead of R 4 + W 4)
 BYTES_RETURN_ACC = 8
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 HBM_COPY_GBS = 6290.0       # measured float4 copy on the same table
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-returns", action="store_true", help="pure 25 B step (no episodic-return accumulator)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--compact", action="store_true",
+                    help="opt-in compact layout (uint8 year counter, 19 B/env-step); NOT the BASELINE layout")
     ap.add_argument("--extra", action="store_true", help="also time the fused rollout and an L3-spilling N")
     return ap.parse_args()
 
@@ -153,7 +156,7 @@ def main():
     n = args.n_envs
     with_returns = not args.no_returns
     env = gf.make("fishing-v1", sigma=0.1, num_envs=n, env_offset=rank * n, seed=1234,
-                  track_returns=with_returns, auto_reset=True)
+                  track_returns=with_returns, auto_reset=True, compact=args.compact)
     env.reset()
     g = torch.Generator(device="cuda").manual_seed(4321 + rank)
     # ring rows are 12 KiB longer than N so consecutive batches do not start at power-of-two-spaced
@@ -187,10 +190,10 @@ def main():
         elapsed = float(tt.item())
 
     total_env_steps = float(n) * world * args.steps
-    bytes_per = BYTES_STEP + (BYTES_RETURN_ACC if with_returns else 0)
+    bytes_per = (BYTES_STEP_COMPACT if args.compact else BYTES_STEP) + (BYTES_RETURN_ACC if with_returns else 0)
     achieved = n * bytes_per / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(n, with_returns)
-    resident = n * (4 + 4 + 4 + 1 + (4 if with_returns else 0)) + RING * (n + 3072) * 4
+    resident = n * (4 + (1 if args.compact else 4) + 4 + 1 + (4 if with_returns else 0)) + RING * (n + 3072) * 4
     out = {
         "metric": "env-steps/sec at N=2^22, fishing-v1",
         "value": total_env_steps / elapsed,
@@ -206,14 +209,16 @@ def main():
         "data": "synthetic",
         "config": {"workload": "fishing-v1 sigma=0.1 r=0.3 K=1 x0=0.75 Tmax=100, N=2^%d envs per GPU, random-policy "
                                "float32 actions read from HBM (ring of %d batches), in-kernel Philox4x32-10 noise, "
-                               "fused auto-reset%s; one fishing_step_f32 launch per step" % (
+                               "fused auto-reset%s%s; one fishing_step_f32 launch per step" % (
                                    n.bit_length() - 1, RING,
-                                   ", per-env episodic-return accumulator + return record" if with_returns else ""),
+                                   ", per-env episodic-return accumulator + return record" if with_returns else "",
+                                   "; COMPACT layout (uint8 year counter)" if args.compact else ""),
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-shard x%d" % world,
                    "collective": "1 all-reduce of 4 doubles per rollout" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "fishing::step_kernel_lean<float, 1, 2, %s, false>" % ("true" if with_returns else "false"),
+                     "kernel": "fishing::step_kernel_lean<float, 1, 2, %s, false, %s>" % (
+                         "true" if with_returns else "false", "true" if args.compact else "false"),
                      "bytes_per_env_step": bytes_per,
                      "avg_launch_us": kernel_ms * 1e3, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                      "note": "resident arrays %.0f MB (obs, t, reward, done%s + %d action batches): %s the 256 MiB "

@@ -20,6 +20,7 @@ KIND_OF_NAME = {"allen": KIND_ALLEN, "beverton_holt": KIND_BEVERTON_HOLT, "myers
 N_KINDS = 5
 FLAG_AUTO_RESET = 1
 FLAG_GENERAL_KERNEL = 2
+FLAG_T_U8 = 4
 POLICY_RANDOM, POLICY_CONSTANT, POLICY_ESCAPEMENT, POLICY_MSY = 0, 1, 2, 3
 STREAM_NOISE, STREAM_AUTORESET, STREAM_RESET = 0, 1, 2
 

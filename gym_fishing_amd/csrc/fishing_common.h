@@ -500,6 +500,47 @@ __device__ __forceinline__ void store4(T* p, int64_t base, int64_t n, bool full,
     }
 }
 
+// years_passed stream: int32 (SURVEY layout) or, under FISHING_FLAG_T_U8, one byte per env (4 envs =
+// one dword per lane).  Counters saturate at 255 in the byte form (Tmax <= 254 is enforced on the
+// host, so `t' > Tmax` never needs a larger value).
+__device__ __forceinline__ void load_t4(const int32_t* tp, bool u8, int64_t base, int64_t n, bool full,
+                                        int32_t (&t)[4]) {
+    if (!u8) {
+        load4<int32_t>(tp, base, n, full, t, 0);
+        return;
+    }
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(tp);
+    if (full) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(p + base);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (int32_t)((w >> (8 * j)) & 255u);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (base + j < n) ? (int32_t)p[base + j] : 0;
+    }
+}
+__device__ __forceinline__ uint32_t pack_t4(const int32_t (&t)[4]) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w |= (uint32_t)(t[j] > 255 ? 255 : t[j]) << (8 * j);
+    return w;
+}
+__device__ __forceinline__ void store_t4(int32_t* tp, bool u8, int64_t base, int64_t n, bool full,
+                                         const int32_t (&t)[4]) {
+    if (!u8) {
+        store4<int32_t>(tp, base, n, full, t);
+        return;
+    }
+    uint8_t* p = reinterpret_cast<uint8_t*>(tp);
+    if (full) {
+        *reinterpret_cast<uint32_t*>(p + base) = pack_t4(t);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (base + j < n) p[base + j] = (uint8_t)(t[j] > 255 ? 255 : t[j]);
+    }
+}
+
 // Wave-ballot done mask in the natural layout (bit i%64 of word i/64 = done[i]).
 // Lane l holds the flags of envs 4l..4l+3 of its wave's 256-env tile as a nibble; word k of
 // the tile collects lanes 16k..16k+15.  Lane L fetches the nibble of lane 16k + L/4 with a

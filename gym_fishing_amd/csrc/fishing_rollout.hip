@@ -61,7 +61,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         }
         if (active) {
             load4<T>(b.obs, base, n, full, obs, (T)0);
-            load4<int32_t>(b.t, base, n, full, t, 0);
+            load_t4(b.t, (p.flags & FISHING_FLAG_T_U8) != 0, base, n, full, t);
             if (kPerEnv) {
                 load4<T>(b.r, base, n, full, rr, p.r);
                 load4<T>(b.K, base, n, full, KK, p.K);
@@ -213,7 +213,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
 
         if (active) {
             store4<T>(b.obs, base, n, full, obs);
-            store4<int32_t>(b.t, base, n, full, t);
+            store_t4(b.t, (p.flags & FISHING_FLAG_T_U8) != 0, base, n, full, t);
             if (b.ep_return) store4<T>(b.ep_return, base, n, full, er);
             if (b.reward) store4<T>(b.reward, base, n, full, rew);
             if (kPerEnv && kr_dirty) {

@@ -70,7 +70,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         }
         if (active) {
             load4<T>(b.obs, base, n, full, obs, (T)0);
-            load4<int32_t>(b.t, base, n, full, t, 0);
+            load_t4(b.t, (p.flags & FISHING_FLAG_T_U8) != 0, base, n, full, t);
             if (MODEL == FISHING_MODEL_V0)
                 load4<int32_t>((const int32_t*)b.action, base, n, full, a_i, 0);
             else
@@ -211,7 +211,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         }
         if (active) {
             store4<T>(b.obs, base, n, full, obs_next);
-            store4<int32_t>(b.t, base, n, full, t_next);
+            store_t4(b.t, (p.flags & FISHING_FLAG_T_U8) != 0, base, n, full, t_next);
         }
     }
 
@@ -245,7 +245,7 @@ struct LeanArgs {
     uint32_t auto_reset;
 };
 
-template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false>
+template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false, bool T8 = false>
 __global__ void __launch_bounds__(256)
 step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_offset, const uint64_t seed,
                  const uint64_t step_counter_arg) {
@@ -269,7 +269,14 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                 for (int j = 0; j < 4; ++j) sg[j] = qs.v[j];
             }
             const Vec4<T> q = *reinterpret_cast<const Vec4<T>*>(a.obs + base);
-            const Vec4<int32_t> qt = *reinterpret_cast<const Vec4<int32_t>*>(a.t + base);
+            Vec4<int32_t> qt;
+            if (T8) {
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(a.t) + base);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qt.v[j] = (int32_t)((w >> (8 * j)) & 255u);
+            } else {
+                qt = *reinterpret_cast<const Vec4<int32_t>*>(a.t + base);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 obs[j] = q.v[j];
@@ -394,7 +401,8 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                 qt.v[j] = t_next[j];
             }
             *reinterpret_cast<Vec4<T>*>(a.obs + base) = qo;
-            *reinterpret_cast<Vec4<int32_t>*>(a.t + base) = qt;
+            if (T8) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.t) + base) = pack_t4(t_next);
+            else *reinterpret_cast<Vec4<int32_t>*>(a.t + base) = qt;
         }
     }
 
@@ -424,7 +432,8 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
             b.r[i] = r;
         }
         b.obs[i] = reset_obs<T, MODEL>(p.x0, K);
-        b.t[i] = 0;
+        if (p.flags & FISHING_FLAG_T_U8) reinterpret_cast<uint8_t*>(b.t)[i] = 0;
+        else b.t[i] = 0;
         if (b.ep_return) b.ep_return[i] = (T)0;
     }
 }
@@ -497,6 +506,7 @@ int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
         (p->launch_threads < 64 || p->launch_threads > FISHING_STEP_MAXTHREADS || (p->launch_threads & 63)))
         return FISHING_ERR_SIZE;
     if (p->launch_blocks < 0) return FISHING_ERR_SIZE;
+    if ((p->flags & FISHING_FLAG_T_U8) && (p->Tmax < 0 || p->Tmax > 254)) return FISHING_ERR_SIZE;
     if (!b->obs || !b->t) return FISHING_ERR_NULL;
     if (p->model == FISHING_MODEL_V4 && (!b->r || !b->K)) return FISHING_ERR_NULL;
     if (b->return_partials && !b->ep_return) return FISHING_ERR_NULL;
@@ -542,13 +552,13 @@ int launch_step_noise(const ParamsT<T>& pt, const BuffersT<T>& bt, int noise, in
 
 // ---- lean-path dispatch
 template <typename T>
-BuffersT<T> offset_buffers(const BuffersT<T>& b, int64_t off) {
+BuffersT<T> offset_buffers(const BuffersT<T>& b, int64_t off, bool t_u8) {
     BuffersT<T> q = b;
     q.obs = b.obs + off;
     q.action = b.action ? (const void*)((const char*)b.action + 4 * off) : nullptr;
     q.reward = b.reward ? b.reward + off : nullptr;
     q.done = b.done ? b.done + off : nullptr;
-    q.t = b.t + off;
+    q.t = t_u8 ? reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(b.t) + off) : b.t + off;
     q.r = b.r ? b.r + off : nullptr;
     q.K = b.K ? b.K + off : nullptr;
     q.sigma = b.sigma ? b.sigma + off : nullptr;
@@ -560,8 +570,19 @@ BuffersT<T> offset_buffers(const BuffersT<T>& b, int64_t off) {
 }
 
 template <typename T, int MODEL>
-int launch_lean(const LeanArgs<T>& a, int noise, bool ret, int64_t ntiles, uint64_t env_offset, uint64_t seed,
+int launch_lean(const LeanArgs<T>& a, int noise, bool ret, bool t8, int64_t ntiles, uint64_t env_offset, uint64_t seed,
                 uint64_t step_counter, int blocks, hipStream_t s) {
+    if (t8) {       // compact layout: one-byte year counters
+#define FISHING_LEAN8(NZ, RT) \
+    step_kernel_lean<T, MODEL, NZ, RT, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter)
+        if (noise == kNoiseNone) {
+            if (ret) FISHING_LEAN8(kNoiseNone, true); else FISHING_LEAN8(kNoiseNone, false);
+        } else {
+            if (ret) FISHING_LEAN8(kNoisePhilox, true); else FISHING_LEAN8(kNoisePhilox, false);
+        }
+#undef FISHING_LEAN8
+        return (int)hipGetLastError();
+    }
     if constexpr (MODEL == FISHING_MODEL_V4) {
         if (a.sigma_arr) {      // BASELINE config 5: per-env (r, K, sigma) arrays; always noisy
             if (ret) step_kernel_lean<T, MODEL, kNoisePhilox, true, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
@@ -605,7 +626,8 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
         const bool core = is_core_model(p->model);
         const int64_t tile = 256 * kEnvsPerThread;
         if (core && noise != kNoiseExt && !(p->flags & FISHING_FLAG_GENERAL_KERNEL) && b->reward && b->done &&
-            !b->done_bits && !b->terminal_obs && (!b->sigma || (p->model == FISHING_MODEL_V4 && noise == kNoisePhilox)) &&
+            !b->done_bits && !b->terminal_obs &&
+            (!b->sigma || (p->model == FISHING_MODEL_V4 && noise == kNoisePhilox && !(p->flags & FISHING_FLAG_T_U8))) &&
             (p->launch_threads == 0 || p->launch_threads == 256) && n >= tile) {
             const int64_t ntiles = n / tile;
             const int64_t n_full = ntiles * tile;
@@ -617,17 +639,18 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
             if (cap > kMaxBlocks) cap = kMaxBlocks;
             const int lb = (int)(ntiles < cap ? ntiles : cap);
             const bool ret = b->ep_return != nullptr;
+            const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
             const int rc2 = with_model_tag(p->model, [&](auto tag) {
                 constexpr int kTag = decltype(tag)::value;
                 if constexpr (kTag == FISHING_MODEL_V0 || kTag == FISHING_MODEL_V1 || kTag == FISHING_MODEL_V2 ||
                               kTag == FISHING_MODEL_V4)
-                    return launch_lean<T, kTag>(a, noise, ret, ntiles, env_offset, seed, step_counter, lb, s);
+                    return launch_lean<T, kTag>(a, noise, ret, t8, ntiles, env_offset, seed, step_counter, lb, s);
                 else
                     return (int)FISHING_ERR_MODEL;
             });
             if (rc2 != 0 || n_full == n) return rc2;
             // ragged tail (< 1024 envs): one workgroup of the general kernel
-            const BuffersT<T> tb = offset_buffers<T>(bt, n_full);
+            const BuffersT<T> tb = offset_buffers<T>(bt, n_full, (p->flags & FISHING_FLAG_T_U8) != 0);
             return with_model_tag(p->model, [&](auto tag) {
                 return launch_step_noise<T, decltype(tag)::value>(pt, tb, noise, n - n_full, env_offset + n_full, seed,
                                                                   step_counter, 1, 256, s);

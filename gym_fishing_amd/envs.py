@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import (FLAG_AUTO_RESET, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
+from ._capi import (FLAG_AUTO_RESET, FLAG_T_U8, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
                     MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11, POLICY_CONSTANT, POLICY_ESCAPEMENT,
                     POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
 from .spaces import is_discrete, space_classes
@@ -84,7 +84,7 @@ class BaseFishingEnv(_gym_env_base()):
 
     def __init__(self, params=None, Tmax=100, file=None, *, num_envs=None, device=None, seed=0,
                  dtype=None, auto_reset=None, env_offset=0, record_terminal_obs=False,
-                 track_returns=False, done_bits=False, launch_blocks=0, launch_threads=0):
+                 track_returns=False, done_bits=False, launch_blocks=0, launch_threads=0, compact=False):
         params = dict({"r": 0.3, "K": 1, "sigma": 0.0, "x0": 0.75} if params is None else params)
         self.params = params
         self.Tmax = int(Tmax)
@@ -97,6 +97,11 @@ class BaseFishingEnv(_gym_env_base()):
         if env_offset % 4 or env_offset < 0:
             raise ValueError("env_offset must be a non-negative multiple of 4 (noise pairs / 16-byte rows)")
         self.env_offset = int(env_offset)
+        # compact layout: years_passed as one byte per env instead of four (19 instead of 25 bytes per
+        # env-step in the fp32 layout); needs Tmax <= 254
+        self.compact = bool(compact)
+        if self.compact and (num_envs is None or int(Tmax) > 254):
+            raise ValueError("compact=True is for the N-env protocol with Tmax <= 254")
         if dtype is None:
             dtype = torch.float64 if self._scalar else torch.float32
         if dtype not in (torch.float32, torch.float64):
@@ -129,7 +134,8 @@ class BaseFishingEnv(_gym_env_base()):
         # HBM channel hash (measured at N = 2^22: 16.6 us unstaggered -> 16.1 us; profiles/
         # r01c_stream_stagger_experiment.jsonl).
         esz = torch.empty(0, dtype=dtype).element_size()
-        sizes = [(dtype, N * esz), (torch.int32, N * 4), (dtype, N * esz), (torch.uint8, N)]
+        sizes = [(dtype, N * esz), (torch.uint8, N) if self.compact else (torch.int32, N * 4), (dtype, N * esz),
+                 (torch.uint8, N)]
         if track_returns:
             sizes.append((dtype, N * esz))
         stagger = 0 if self._scalar else 12288       # one env: keep the arena one small D2H copy
@@ -241,6 +247,8 @@ class BaseFishingEnv(_gym_env_base()):
 
     def _param_key(self):
         p = self.params
+        if self.compact and self.Tmax > 254:
+            raise ValueError("compact layout needs Tmax <= 254")
         return (self.Tmax, self.init_state, self.auto_reset, self._sigma_scalar, p["r"], p["K"], self._launch,
                 getattr(self, "n_actions", 0), getattr(self, "C", None), getattr(self, "r_mean", None),
                 getattr(self, "K_mean", None), getattr(self, "sigma_p", None),
@@ -257,7 +265,7 @@ class BaseFishingEnv(_gym_env_base()):
         cp.model = self.MODEL
         cp.n_actions = int(getattr(self, "n_actions", 0) or 0)
         cp.Tmax = int(self.Tmax)
-        cp.flags = FLAG_AUTO_RESET if self.auto_reset else 0
+        cp.flags = (FLAG_AUTO_RESET if self.auto_reset else 0) | (FLAG_T_U8 if self.compact else 0)
         cp.r = float(p["r"])
         cp.K = float(p["K"])
         cp.sigma = self._sigma_scalar

@@ -59,6 +59,9 @@ typedef void* fishing_stream_t; /* hipStream_t */
 /* FishingParams.flags */
 #define FISHING_FLAG_AUTO_RESET 1u /* SB3-VecEnv semantics: a finished env is reset inside step() */
 #define FISHING_FLAG_GENERAL_KERNEL 2u /* test knob: never take the lean fp32 fast path of step()  */
+#define FISHING_FLAG_T_U8 4u /* compact layout: FishingBuffers.t is uint8_t[n] instead of int32_t[n]
+                                (needs Tmax <= 254; a counter that would pass 255 stays at 255).
+                                Saves 6 of the 25 bytes per env-step of the fp32 layout.          */
 
 /* error codes */
 #define FISHING_OK 0
@@ -103,7 +106,8 @@ typedef struct FishingBuffers {
     void* reward;        /* real  out     max(harvest, 0) (base_fishing_env.py:74); nullable      */
     uint8_t* done;       /* u8    out     nullable                                                */
     uint64_t* done_bits; /* u64[ceil(n/64)] out, bit (i%64) of word i/64 = done[i]; nullable      */
-    int32_t* t;          /* i32   in/out  years_passed (base_fishing_env.py:75)                   */
+    int32_t* t;          /* i32   in/out  years_passed (base_fishing_env.py:75); uint8_t[n] under
+                                          FISHING_FLAG_T_U8                                        */
     void* r;             /* real  in/out  per-env growth rate; required for v4 and v10 (drift)    */
     void* K;             /* real  in/out  per-env carrying capacity; required for v4              */
     const void* sigma;   /* real  in      per-env noise scale; nullable => FishingParams.sigma    */

@@ -20,7 +20,7 @@ def dev(a, dtype=None):
 
 def params(model, r=0.3, K=1.0, sigma=0.0, C=0.5, x0=0.75, Tmax=100, n_actions=100, K_mean=1.0, r_mean=0.3,
            sigma_p=0.1, auto_reset=False, launch_blocks=0, launch_threads=0, M=0.0, theta=0.0, q=0.0, b=0.0, a=0.0,
-           alpha=0.0, models=None, zoo_table=None, general=False):
+           alpha=0.0, models=None, zoo_table=None, general=False, t_u8=False):
     p = _capi.FishingParams()
     p.M, p.theta, p.q, p.b, p.a, p.alpha = M, theta, q, b, a, alpha
     if models is not None:                      # fishing-v11: list of kind indices + per-kind dicts
@@ -31,7 +31,8 @@ def params(model, r=0.3, K=1.0, sigma=0.0, C=0.5, x0=0.75, Tmax=100, n_actions=1
             for name in ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a"):
                 setattr(p.zoo[k], name, float(d.get(name, 0.0)))
     p.model, p.n_actions, p.Tmax = model, n_actions, Tmax
-    p.flags = (_capi.FLAG_AUTO_RESET if auto_reset else 0) | (_capi.FLAG_GENERAL_KERNEL if general else 0)
+    p.flags = ((_capi.FLAG_AUTO_RESET if auto_reset else 0) | (_capi.FLAG_GENERAL_KERNEL if general else 0)
+               | (_capi.FLAG_T_U8 if t_u8 else 0))
     p.r, p.K, p.sigma, p.C, p.x0 = r, K, sigma, C, x0
     p.r_mean, p.K_mean, p.sigma_p = r_mean, K_mean, sigma_p
     p.launch_blocks, p.launch_threads = launch_blocks, launch_threads
@@ -42,11 +43,11 @@ class State:
     """Device buffers of one shard, created from host arrays."""
 
     def __init__(self, n, dtype, model, obs, t=None, r=None, K=None, sigma=None, ep_return=False,
-                 terminal=False, done_bits=False, model_idx=None):
+                 terminal=False, done_bits=False, model_idx=None, t_u8=False):
         self.n, self.np_dtype, self.model = n, np.dtype(dtype), model
         td = TORCH_OF[self.np_dtype]
         self.obs = dev(np.broadcast_to(np.asarray(obs, dtype=dtype), (n,)))
-        self.t = dev(np.broadcast_to(np.asarray(0 if t is None else t, dtype=np.int32), (n,)))
+        self.t = dev(np.broadcast_to(np.asarray(0 if t is None else t, dtype=np.uint8 if t_u8 else np.int32), (n,)))
         self.reward = torch.zeros(n, dtype=td, device="cuda")
         self.done = torch.zeros(n, dtype=torch.uint8, device="cuda")
         self.r = dev(np.broadcast_to(np.asarray(r, dtype=dtype), (n,))) if r is not None else None

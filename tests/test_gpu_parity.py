@@ -707,3 +707,47 @@ def test_huge_batch_64bit_indexing(hh):
     assert_same_bits(obs[lo:].cpu().numpy(), eo2, "tail window past 2^29")
     del obs, t, rew, done, act
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ compact layout (one-byte year counter)
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4, fo.MODEL_V9])
+@pytest.mark.parametrize("general", [False, True], ids=["lean", "general"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_compact_t_u8_layout_equals_standard(hh, model, general, dtype):
+    """FISHING_FLAG_T_U8 stores years_passed as uint8: same obs / reward / done bits and the same
+    counter values as the int32 layout over 40 steps (auto-reset and no auto-reset, where the
+    counter saturates at 255), through the lean kernel, the general kernel and the fused rollout."""
+    import torch
+    from gym_fishing_amd import _capi
+    n = 1024 * 3 + 7
+    per_env = model == fo.MODEL_V4
+    lib = _capi.lib()
+    for auto, Tmax, steps in ((True, 6, 40), (False, 254, 300)):
+        kw = dict(sigma=0.1, C=0.5, Tmax=Tmax, sigma_p=0.2, auto_reset=auto, r=0.3, K=1.0)
+        pa, pb = hh.params(model, general=general, **kw), hh.params(model, general=general, t_u8=True, **kw)
+        mk = lambda u8: hh.State(n, dtype, model, np.full(n, -0.25), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
+                                 K=np.full(n, 1.0) if per_env else None, ep_return=True, t_u8=u8)
+        A, B = mk(False), mk(True)
+        A.reset(pa, seed=3)
+        B.reset(pb, seed=3)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        fn = lib.fishing_step_f32 if dtype == np.float32 else lib.fishing_step_f64
+        for s in range(steps):
+            a = (torch.randint(0, 30, (n,), device="cuda", generator=g, dtype=torch.int32) if model == fo.MODEL_V0
+                 else (torch.rand(n, device="cuda", generator=g) * 0.3 - 1.0).float())
+            assert fn(pa, n, 0, A.buffers(a), 3, s, None) == 0 and fn(pb, n, 0, B.buffers(a), 3, s, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(A.obs, B.obs) and torch.equal(A.reward, B.reward) and torch.equal(A.done, B.done)
+        assert torch.equal(A.ep_return, B.ep_return)
+        assert torch.equal(A.t.clamp(max=255), B.t.to(torch.int32))
+        if not auto:
+            assert int(B.t.max()) == 255 and int(A.t.max()) == 300 and bool(B.done.all())
+        # fused rollout on top of the same state
+        A.rollout(pa, _capi.POLICY_RANDOM, 0.0, 9, seed=3, step_counter=steps)
+        B.rollout(pb, _capi.POLICY_RANDOM, 0.0, 9, seed=3, step_counter=steps)
+        assert torch.equal(A.obs, B.obs) and torch.equal(A.t.clamp(max=255), B.t.to(torch.int32))
+        ra, rb = A.record(), B.record()
+        # sum-of-lengths differs by construction once a finished env is stepped past 255 years
+        # (the byte counter saturates); every other field, and everything under auto-reset, agrees
+        assert np.allclose(ra[:3], rb[:3], rtol=1e-12) and (not auto or np.isclose(ra[3], rb[3], rtol=1e-12))
+    assert lib.fishing_step_f32(hh.params(fo.MODEL_V1, t_u8=True, Tmax=255), 4, 0, B.buffers(a), 0, 0, None) == -4
