@@ -812,3 +812,40 @@ def test_optional_streams_in_any_combination(hh, model, dtype):
                     assert torch.equal(getattr(got, attr), getattr(ref, attr)), (n, name, sorted(subset))
             if per_env:
                 assert torch.equal(got.K, ref.K) and torch.equal(got.r, ref.r)
+
+
+# ------------------------------------------------------------------ ensemble statistics vs the reference's generator
+@pytest.mark.parametrize("model,policy,param", [(fo.MODEL_V1, "escapement", 0.5), (fo.MODEL_V1, "msy", 0.07),
+                                                (fo.MODEL_V2, "escapement", 0.79), (fo.MODEL_V0, "escapement", 0.5)])
+def test_philox_ensemble_matches_numpy_ensemble(hh, model, policy, param):
+    """The production noise path (Philox + Box-Muller on the device) against the oracle driven by
+    NumPy's legacy MT19937 normals (the reference's generator): full 101-step episodes at
+    sigma = 0.1, 2^16 device envs vs 2^14 oracle envs.  Mean and variance of the episodic return
+    and the distribution of the final stock agree within sampling error."""
+    from gym_fishing_amd import _capi
+    from scipy import stats
+    n_dev, n_ref, T = 1 << 16, 1 << 14, 101
+    p = hh.params(model, sigma=0.1, auto_reset=False, Tmax=100)
+    st = hh.State(n_dev, np.float32, model, np.full(n_dev, -0.25), ep_return=True)
+    pol = _capi.POLICY_ESCAPEMENT if policy == "escapement" else _capi.POLICY_MSY
+    traj = st.rollout(p, pol, param, T, seed=2026, record=True)
+    ret_dev = st.ep_return.cpu().numpy().astype(np.float64)
+    final_dev = (st.obs.cpu().numpy().astype(np.float64) + 1.0)
+    rs = np.random.RandomState(7)
+    obs = np.full(n_ref, -0.25)
+    t = np.zeros(n_ref, np.int32)
+    ret_ref = np.zeros(n_ref)
+    alive = np.ones(n_ref, bool)
+    for s in range(T):
+        a = fo.policy_action(policy, param, model, obs, 1.0, 100)
+        o2, rew, done, t2, _ = fo.step(model, obs, t, a, rs.normal(0, 1, n_ref), 0.3, 1.0, 0.1)
+        ret_ref += np.where(alive, rew, 0.0)
+        obs = np.where(alive, o2, obs)
+        t = np.where(alive, t2, t)
+        alive &= ~done.astype(bool)
+    final_ref = obs + 1.0
+    se = np.sqrt(ret_dev.var() / n_dev + ret_ref.var() / n_ref)
+    assert abs(ret_dev.mean() - ret_ref.mean()) < 5 * se, (ret_dev.mean(), ret_ref.mean(), se)
+    assert abs(ret_dev.std() / ret_ref.std() - 1.0) < 0.05
+    assert stats.ks_2samp(final_dev[::4], final_ref).pvalue > 1e-4
+    assert abs((traj[:, 3].sum(axis=0) > 0).mean() - (~alive).mean()) < 0.02     # same fraction of finished episodes
