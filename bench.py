@@ -228,6 +228,28 @@ def main():
     if stats:
         out["episode_stats"] = {k: stats[k] for k in ("n_episodes", "mean_return", "std_return", "mean_length") if k in stats}
 
+    if with_returns and rank == 0 and world == 1 and not args.compact:
+        # for reference on the same line: the bare 25-byte step (no return accumulator), i.e. exactly
+        # SURVEY 8(d)'s per-unit figure, measured right after the headline region on the same device
+        bare = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=1234, auto_reset=True)
+        bare.reset()
+        bare.step_many(actions, min(args.warmup, 200))
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kb = max(1, min(args.steps, 2020))
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        b0.record()
+        bare.step_many(actions, kb)
+        b1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - tb
+        us = b0.elapsed_time(b1) * 1e3 / kb
+        out["bare_step"] = {"value": n * kb / wall, "unit": "env-steps/s", "steps": kb, "bytes_per_env_step": BYTES_STEP,
+                            "avg_launch_us": us, "achieved_GBps": n * BYTES_STEP / us / 1e3,
+                            "frac": n * BYTES_STEP / us / 1e3 / HBM_PEAK_GBS,
+                            "note": "same env family without the per-env episodic-return accumulator"}
+        del bare
+
     if args.extra and rank == 0:
         extra = {}
         del env, actions
