@@ -45,7 +45,7 @@ def env_class(env_id):
 
 def make(env_id, **kwargs):
     """gym.make(id, **ctor_kwargs) equivalent.  Extra kwargs: num_envs, device, seed, dtype,
-    auto_reset, env_offset, record_terminal_obs, track_returns, done_bits."""
+    auto_reset, env_offset, record_terminal_obs, track_returns, done_bits, compact."""
     return env_class(env_id)(**kwargs)
 
 
