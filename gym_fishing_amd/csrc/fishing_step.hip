@@ -21,6 +21,13 @@ namespace fishing {
 #ifndef FISHING_NT_STORE
 #define FISHING_NT_STORE 0
 #endif
+#ifndef FISHING_LEAN_FENCE
+#define FISHING_LEAN_FENCE 0     // experiment knob (bit 0: sched fence after the loads, bit 1: after the Philox
+                                 // block); measured neutral for the bare step, +1 % time with returns -> off
+#endif
+#ifndef FISHING_LEAN_BATCH_ARGS
+#define FISHING_LEAN_BATCH_ARGS 1
+#endif
 #ifndef FISHING_STEP_MAXTHREADS
 #define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
 #endif
@@ -245,11 +252,26 @@ struct LeanArgs {
     uint32_t auto_reset;
 };
 
+#ifndef FISHING_LEAN_ATTRS
+#define FISHING_LEAN_ATTRS
+#endif
 template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false, bool T8 = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
 step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_offset, const uint64_t seed,
                  const uint64_t step_counter_arg) {
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
+    // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
+    // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
+    // trips in front of the first global load of every wave.  Measured (scripts/exp/ab_lean_variants.py,
+    // N = 2^22): bare step 16.9 -> 16.5 us; with the return accumulator the three extra SGPRs cost
+    // more than the batch saves (23.0 -> 23.15 us), so only the RET = false variants do it.
+    if constexpr (FISHING_LEAN_BATCH_ARGS && !RET) {
+        asm volatile("" ::"s"(a.obs), "s"(a.action), "s"(a.reward), "s"(a.done), "s"(a.t), "s"(a.counter), "s"(a.pr),
+                     "s"(a.pK), "s"(a.sigma), "s"(a.C), "s"(a.x0), "s"(a.Tmax), "s"(a.n_actions), "s"(a.auto_reset),
+                     "s"(ntiles), "s"(env_offset), "s"(seed), "s"(step_counter_arg));
+        if constexpr (kPerEnv) asm volatile("" ::"s"(a.r), "s"(a.K), "s"(a.r_mean), "s"(a.K_mean), "s"(a.sigma_p));
+        if constexpr (SIGARR) asm volatile("" ::"s"(a.sigma_arr));
+    }
     const uint64_t step_counter = a.counter ? (*a.counter + step_counter_arg) : step_counter_arg;
     const bool auto_reset = a.auto_reset != 0;
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
@@ -311,6 +333,9 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                 for (int j = 0; j < 4; ++j) er[j] = qe.v[j];
             }
         }
+        // the loads above must be in flight BEFORE the ~200-instruction Philox block starts: without
+        // this fence the scheduler hoists the (independent) generator above them in some variants
+        if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
         if (NOISE == kNoisePhilox) {
             const uint64_t pair = (env_offset + (uint64_t)base) >> 1;
 #pragma unroll
@@ -321,6 +346,9 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                 z[2 * q] = (T)zc;
                 z[2 * q + 1] = (T)zs;
             }
+            // ... and the generator (which needs none of the loaded data) runs under their latency:
+            // the first s_waitcnt vmcnt lands after it, at the first use of a loaded register
+            if (FISHING_LEAN_FENCE & 2) __builtin_amdgcn_sched_barrier(0);
         }
         T obs_next[4], rew[4];
         int32_t t_next[4];
