@@ -582,7 +582,10 @@ __device__ __forceinline__ void add_block_partials(const double (&acc)[kPartialF
         double s = 0.0;
         const int nw = blockDim.x >> 6;
         for (int w = 0; w < nw; ++w) s += red[w][threadIdx.x];
-        if (s != 0.0) partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x] += s;
+        // The slot belongs to this workgroup alone, so a hardware no-return atomic add gives the same
+        // bits as a read-modify-write (one add per slot per launch, launches are stream-ordered) without
+        // the dependent load -> add -> store round trip at the very end of the kernel.
+        if (s != 0.0) unsafeAtomicAdd(&partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x], s);
     }
 }
 
