@@ -21,6 +21,9 @@ namespace fishing {
 #ifndef FISHING_NT_STORE
 #define FISHING_NT_STORE 0
 #endif
+#ifndef FISHING_GENERAL_BATCH_ARGS
+#define FISHING_GENERAL_BATCH_ARGS 0
+#endif
 #ifndef FISHING_LEAN_FENCE
 #define FISHING_LEAN_FENCE 0     // experiment knob (bit 0: sched fence after the loads, bit 1: after the Philox
                                  // block); measured neutral for the bare step, +1 % time with returns -> off
@@ -36,6 +39,12 @@ template <typename T, int MODEL, int NOISE>
 __global__ void __launch_bounds__(FISHING_STEP_MAXTHREADS) FISHING_STEP_ATTRS
 step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
             const uint64_t seed, const uint64_t step_counter_arg) {
+#if FISHING_GENERAL_BATCH_ARGS
+    // same one-batch kernel-argument load as the lean kernel (the always-used arguments only)
+    asm volatile("" ::"s"(b.obs), "s"(b.action), "s"(b.reward), "s"(b.done), "s"(b.t), "s"(b.counter), "s"(b.sigma),
+                 "s"(b.ep_return), "s"(b.partials), "s"(b.done_bits), "s"(b.terminal_obs), "s"(p.r), "s"(p.K), "s"(p.sigma),
+                 "s"(p.C), "s"(p.x0), "s"(p.Tmax), "s"(p.flags), "s"(n), "s"(env_offset), "s"(seed), "s"(step_counter_arg));
+#endif
     // graph-replay safety: with a device-resident counter the launch arguments can stay frozen
     // in a captured hipGraph while the noise key still advances (wave-uniform scalar load)
     const uint64_t step_counter = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
