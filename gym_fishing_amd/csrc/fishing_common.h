@@ -563,29 +563,84 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Episodic-return record of one thread's 4-env tile.  The tile's finished returns and their squares
+// are summed in T (four values) and widened once, episode count and length are integer adds: four
+// double operations per tile instead of sixteen, which is 7 % of the fp32 step kernel's launch time
+// on the random-policy workload where every wave finishes an env every step.  Every kernel uses
+// this routine, so step-wise, fused-rollout and general-kernel records agree to double rounding.
+template <typename T>
+__device__ __forceinline__ void record_tile(const bool (&fin)[4], const T (&er)[4], const int32_t (&len)[4],
+                                            double (&acc)[4]) {
+    T s1 = (T)0, s2 = (T)0;
+    int32_t cnt = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s1 += fin[j] ? er[j] : (T)0;
+        s2 += fin[j] ? er[j] * er[j] : (T)0;
+        cnt += fin[j] ? 1 : 0;
+        tot += fin[j] ? len[j] : 0;
+    }
+    acc[0] += (double)s1;
+    acc[1] += (double)s2;
+    acc[2] += (double)cnt;
+    acc[3] += (double)tot;
+}
+
+// One DPP lane permutation of a double (two 32-bit v_mov_dpp, no LDS traffic).  Every lane of the
+// wave must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kDppQuadXor1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int kDppRowRor4 = 0x124;   // row_ror:4
+constexpr int kDppRowRor8 = 0x128;   // row_ror:8
+
+// Sum the four record fields over each 16-lane DPP row.  A packed butterfly: the xor-2 exchange
+// leaves every lane with two fields, the xor-1 exchange with one (field = lane & 3), and two row
+// rotations add the row's four lanes of that field -- 7 double adds and 14 DPP moves per lane where
+// four independent 64-lane shuffle trees cost 24 adds and 48 ds_bpermute.  On return lane l holds
+// field (l & 3) summed over its row; the order of the additions is fixed.
+__device__ __forceinline__ double row_sum_fields(const double (&acc)[kPartialFields], int lane) {
+    const bool up2 = (lane & 2) != 0;
+    double k0 = up2 ? acc[2] : acc[0], k1 = up2 ? acc[3] : acc[1];
+    const double s0 = up2 ? acc[0] : acc[2], s1 = up2 ? acc[1] : acc[3];
+    k0 += dpp_f64<kDppQuadXor2>(s0);
+    k1 += dpp_f64<kDppQuadXor2>(s1);
+    const bool up1 = (lane & 1) != 0;
+    double k = up1 ? k1 : k0;
+    const double s = up1 ? k0 : k1;
+    k += dpp_f64<kDppQuadXor1>(s);
+    k += dpp_f64<kDppRowRor4>(k);
+    k += dpp_f64<kDppRowRor8>(k);
+    return k;
+}
+
 // Episodic-return record: add this workgroup's partial {sum R, sum R^2, n, sum length} to its own
-// slot of `partials`.  Wave shuffle tree -> one LDS hop across waves -> thread k adds field k.
-// One owner thread per slot and no atomics, so the sums are bitwise reproducible for a fixed
-// launch shape.  Must be reached by every thread of the workgroup (it contains a barrier).
+// slot of `partials`.  DPP butterfly inside each 16-lane row -> one LDS hop across the rows of all
+// waves -> thread k adds field k.  One owner thread per slot and a fixed addition order, so the sums
+// are bitwise reproducible for a fixed launch shape.  Must be reached by every thread of the
+// workgroup with all lanes active (it contains a barrier and whole-wave DPP moves).
 template <int MAX_WAVES>
 __device__ __forceinline__ void add_block_partials(const double (&acc)[kPartialFields], double* partials) {
-    __shared__ double red[MAX_WAVES][kPartialFields];
+    constexpr int kRows = kWave / 16;
+    __shared__ double red[MAX_WAVES * kRows][kPartialFields];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kPartialFields; ++k) {
-        const double s = wave_sum(acc[k]);
-        if (lane == 0) red[wid][k] = s;
-    }
+    const double s = row_sum_fields(acc, lane);
+    if ((lane & 15) < kPartialFields) red[threadIdx.x >> 4][lane & 3] = s;
     __syncthreads();
     if (threadIdx.x < kPartialFields) {
-        double s = 0.0;
-        const int nw = blockDim.x >> 6;
-        for (int w = 0; w < nw; ++w) s += red[w][threadIdx.x];
+        double tot = 0.0;
+        const int nrows = blockDim.x >> 4;
+        for (int w = 0; w < nrows; ++w) tot += red[w][threadIdx.x];
         // The slot belongs to this workgroup alone, so a hardware no-return atomic add gives the same
         // bits as a read-modify-write (one add per slot per launch, launches are stream-ordered) without
         // the dependent load -> add -> store round trip at the very end of the kernel.
-        if (s != 0.0) unsafeAtomicAdd(&partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x], s);
+        if (tot != 0.0) unsafeAtomicAdd(&partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x], tot);
     }
 }
 

@@ -174,14 +174,10 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             }
             // ---- wave-ballot: only waves holding a finished env do the record / reset work
             if (__any(fin[0] | fin[1] | fin[2] | fin[3])) {
+                record_tile<T>(fin, er, t, acc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool f = fin[j];
-                    const double R = (double)er[j];
-                    acc[0] += f ? R : 0.0;
-                    acc[1] += f ? R * R : 0.0;
-                    acc[2] += f ? 1.0 : 0.0;
-                    acc[3] += f ? (double)t[j] : 0.0;
                     if (AUTO) {
                         if (kPerEnv) {
                             if (f) {

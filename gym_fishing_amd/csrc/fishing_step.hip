@@ -178,16 +178,11 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
             T er[4] = {(T)0, (T)0, (T)0, (T)0};
             if (active) load4<T>(b.ep_return, base, n, full, er, (T)0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                er[j] = er[j] + rew[j];
-                if (dn[j]) {
-                    const double R = (double)er[j];
-                    acc[0] += R;
-                    acc[1] += R * R;
-                    acc[2] += 1.0;
-                    acc[3] += (double)t_next[j];
-                    if (auto_reset) er[j] = (T)0;
-                }
+            for (int j = 0; j < 4; ++j) er[j] = er[j] + rew[j];
+            if (wave_done) {
+                record_tile<T>(dn, er, t_next, acc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
             }
             if (active) store4<T>(b.ep_return, base, n, full, er);
         }
@@ -382,15 +377,9 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
 #pragma unroll
             for (int j = 0; j < 4; ++j) er[j] = er[j] + rew[j];
             if (__any(lane_done)) {          // wave-ballot: only waves with a finished env record
+                record_tile<T>(dn, er, t_next, acc);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double R = (double)er[j];
-                    acc[0] += dn[j] ? R : 0.0;
-                    acc[1] += dn[j] ? R * R : 0.0;
-                    acc[2] += dn[j] ? 1.0 : 0.0;
-                    acc[3] += dn[j] ? (double)t_next[j] : 0.0;
-                    er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
-                }
+                for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
             }
             Vec4<T> qe;
 #pragma unroll

@@ -222,7 +222,10 @@ def test_multi_step_auto_reset_philox(hh, model, dtype):
         assert_same_bits(st.ep_return.cpu().numpy(), ep, "ep_return step %d" % s)
     got = st.record()
     assert got[2] == rec[2] and got[3] == rec[3] and rec[2] > n   # every env finished >= 1 episode
-    assert np.allclose(got[:2], rec[:2], rtol=1e-12)
+    # the record sums each thread's four finished returns (and squares) in the state dtype before
+    # widening to double (fishing_common.h record_tile): exact to double rounding for float64, to a
+    # few float32 ulps of a tile's partial for float32
+    assert np.allclose(got[:2], rec[:2], rtol=1e-12 if dtype == np.float64 else 5e-7)
 
 
 def test_f32_within_1e6_of_f64_reference_arithmetic(hh):
