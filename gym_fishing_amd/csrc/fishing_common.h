@@ -440,22 +440,66 @@ __device__ __forceinline__ T clip_param(T v) {
     v = (v > (T)1e6) ? (T)1e6 : v;
     return v;
 }
-template <typename T>
-__device__ __forceinline__ void draw_model_error(uint64_t seed, uint64_t env, uint64_t counter,
-                                                 uint32_t stream, T K_mean, T r_mean, T sigma_p,
-                                                 T& K, T& r) {
-    const Words4 w = philox_block(seed, env, counter, stream);
-    float zK, zr;
-    box_muller(w.w0, w.w1, zK, zr);
-    K = clip_param<T>(K_mean + sigma_p * (T)zK);
-    r = clip_param<T>(r_mean + sigma_p * (T)zr);
-}
-
 // reset observation: x0 / K - 1 (base_fishing_env.py:84); v4 returns x0 un-normalised
 // (fishing_model_error.py:44, quirk B8).
 template <typename T, int MODEL>
 __device__ __forceinline__ T reset_obs(T x0, T K) {
     return (MODEL == FISHING_MODEL_V4) ? x0 : (x0 / K - (T)1);
+}
+
+// fishing-v4 (K, r) redraw for the env pair {2 * pair, 2 * pair + 1}: ONE Philox block per pair on the
+// reset streams -- (w0, w1) -> Box-Muller (zK, zr) of the even env, (w2, w3) -> of the odd env; K is
+// drawn before r (fishing_model_error.py:42-43).  Halves the generator work of the auto-reset path,
+// which runs in practically every wave (256 envs: some env finishes almost every step).
+template <typename T>
+__device__ __forceinline__ void draw_model_error_pair(uint64_t seed, uint64_t pair, uint64_t counter,
+                                                      uint32_t stream, T K_mean, T r_mean, T sigma_p,
+                                                      T (&K)[2], T (&r)[2]) {
+    const Words4 w = philox_block(seed, pair, counter, stream);
+    float zK, zr;
+    box_muller(w.w0, w.w1, zK, zr);
+    K[0] = clip_param<T>(K_mean + sigma_p * (T)zK);
+    r[0] = clip_param<T>(r_mean + sigma_p * (T)zr);
+    box_muller(w.w2, w.w3, zK, zr);
+    K[1] = clip_param<T>(K_mean + sigma_p * (T)zK);
+    r[1] = clip_param<T>(r_mean + sigma_p * (T)zr);
+}
+
+// the same draw for one env (reset kernel, ragged tails)
+template <typename T>
+__device__ __forceinline__ void draw_model_error(uint64_t seed, uint64_t env, uint64_t counter,
+                                                 uint32_t stream, T K_mean, T r_mean, T sigma_p,
+                                                 T& K, T& r) {
+    T K2[2], r2[2];
+    draw_model_error_pair<T>(seed, env >> 1, counter, stream, K_mean, r_mean, sigma_p, K2, r2);
+    K = (env & 1) ? K2[1] : K2[0];
+    r = (env & 1) ? r2[1] : r2[0];
+}
+
+// Redraw (K, r) and restart the finished envs of one thread's 4-env tile (`base` = global index of
+// its first env, a multiple of 4): two pair blocks at most.  Returns whether anything was redrawn.
+template <typename T, int MODEL>
+__device__ __forceinline__ bool redraw_tile(uint64_t seed, uint64_t base, uint64_t counter, uint32_t stream,
+                                            T K_mean, T r_mean, T sigma_p, T x0, const bool (&fin)[4],
+                                            T (&KK)[4], T (&rr)[4], T (&obs)[4], int32_t (&t)[4]) {
+    bool redrawn = false;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (fin[2 * q] | fin[2 * q + 1]) {
+            T K2[2], r2[2];
+            draw_model_error_pair<T>(seed, (base >> 1) + q, counter, stream, K_mean, r_mean, sigma_p, K2, r2);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * q + h;
+                KK[j] = fin[j] ? K2[h] : KK[j];
+                rr[j] = fin[j] ? r2[h] : rr[j];
+                obs[j] = fin[j] ? reset_obs<T, MODEL>(x0, KK[j]) : obs[j];
+                t[j] = fin[j] ? 0 : t[j];
+            }
+            redrawn = true;
+        }
+    }
+    return redrawn;
 }
 
 // ---------------------------------------------------------------- 4-wide access helpers

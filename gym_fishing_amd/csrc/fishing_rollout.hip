@@ -175,17 +175,15 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             // ---- wave-ballot: only waves holding a finished env do the record / reset work
             if (__any(fin[0] | fin[1] | fin[2] | fin[3])) {
                 record_tile<T>(fin, er, t, acc);
+                if (AUTO && kPerEnv) {
+                    if (redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
+                                              p.K_mean, p.r_mean, p.sigma_p, p.x0, fin, KK, rr, obs, t))
+                        kr_dirty = true;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool f = fin[j];
                     if (AUTO) {
-                        if (kPerEnv) {
-                            if (f) {
-                                draw_model_error<T>(seed, env_offset + (uint64_t)(base + j), step_counter,
-                                                    kStreamAutoReset, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
-                                kr_dirty = true;
-                            }
-                        }
                         if (zoo_mixed) {
                             if (f) {      // growth_models.py:200: a new model for the next episode
                                 const Words4 w = philox_block(seed, env_offset + (uint64_t)(base + j), step_counter,

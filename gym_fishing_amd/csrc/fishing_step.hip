@@ -203,16 +203,16 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                 }
                 if (any) store4<int32_t>(b.model_idx, base, n, full, kind);
             }
+            if (kPerEnv) {
+                redrawn = redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
+                                                p.K_mean, p.r_mean, p.sigma_p, p.x0, dn, KK, rr, obs_next, t_next);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (dn[j]) {
-                    if (kPerEnv) {
-                        draw_model_error<T>(seed, env_offset + (uint64_t)(base + j), step_counter,
-                                            kStreamAutoReset, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
-                        redrawn = true;
+                for (int j = 0; j < 4; ++j) {
+                    if (dn[j]) {
+                        obs_next[j] = reset_obs<T, MODEL>(p.x0, KK[j]);
+                        t_next[j] = 0;
                     }
-                    obs_next[j] = reset_obs<T, MODEL>(p.x0, KK[j]);
-                    t_next[j] = 0;
                 }
             }
             if (kPerEnv && redrawn) {
@@ -388,17 +388,9 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         }
         if (kPerEnv) {
             if (auto_reset && __any(lane_done)) {
-                bool redrawn = false;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (dn[j]) {
-                        draw_model_error<T>(seed, env_offset + (uint64_t)(base + j), step_counter, kStreamAutoReset,
-                                            a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
-                        redrawn = true;
-                        obs_next[j] = reset_obs<T, MODEL>(a.x0, KK[j]);
-                        t_next[j] = 0;
-                    }
-                }
+                const bool redrawn =
+                    redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, a.K_mean,
+                                          a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs_next, t_next);
                 if (redrawn) {
                     Vec4<T> qk, qr;
 #pragma unroll
@@ -510,6 +502,21 @@ noise_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, co
         }
         if (z0) z0[i] = zc;
         if (z1) z1[i] = zs;
+    }
+}
+
+// test hook: the (zK, zr) normals of the fishing-v4 redraw, pair scheme of draw_model_error_pair
+__global__ void __launch_bounds__(256)
+reset_normals_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, const uint64_t counter,
+                     const uint32_t stream_tag, float* __restrict__ zK, float* __restrict__ zr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t env = env_offset + (uint64_t)i;
+        const Words4 w = philox_block(seed, env >> 1, counter, stream_tag);
+        float a, c;
+        box_muller((env & 1) ? w.w2 : w.w0, (env & 1) ? w.w3 : w.w1, a, c);
+        if (zK) zK[i] = a;
+        if (zr) zr[i] = c;
     }
 }
 
@@ -834,6 +841,16 @@ int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t cou
     const int blocks = (int)(nb < 2048 ? nb : 2048);
     fishing::noise_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(n, (uint64_t)env_offset, seed, counter,
                                                                  (uint32_t)stream_tag, words, z0, z1);
+    return (int)hipGetLastError();
+}
+
+int fishing_reset_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
+                              float* zK, float* zr, fishing_stream_t stream) {
+    if (n < 0 || env_offset < 0) return FISHING_ERR_SIZE;
+    if (n == 0) return FISHING_OK;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, fishing::kMaxBlocks);
+    fishing::reset_normals_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(n, (uint64_t)env_offset, seed, counter,
+                                                                         (uint32_t)stream_tag, zK, zr);
     return (int)hipGetLastError();
 }
 

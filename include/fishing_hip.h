@@ -200,10 +200,17 @@ int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x
  * the Philox4x32-10 block, z0 / z1 = the cos / sin legs of its Box-Muller pair.  On the step-noise
  * stream (stream_tag 0) the index is the env PAIR (global env >> 1): z0 is the noise of env 2*index,
  * z1 of env 2*index + 1, words 2 / 3 their random-policy actions.  On the reset streams (tags 1, 2)
- * the index is the global env: (z0, z1) = the (K, r) normals of fishing-v4, word 0 the fishing-v11
- * model draw.  Any output pointer may be NULL. */
+ * fishing-v11 indexes by global env (word 0 = the model draw) and fishing-v4 by env PAIR, see
+ * fishing_reset_normals_f32.  Any output pointer may be NULL. */
 int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
                       uint32_t* words, float* z0, float* z1, fishing_stream_t stream);
+
+/* Test/diagnostic: the standard normals behind fishing-v4's (K, r) redraw (fishing_model_error.py:42-43)
+ * for envs env_offset .. env_offset + n - 1 on reset stream `stream_tag` (1 = auto-reset inside step,
+ * counter = that step's counter; 2 = reset(), counter = the reset counter).  One Philox block per env
+ * pair: Box-Muller of (w0, w1) -> (zK, zr) of the even env, of (w2, w3) -> the odd env. */
+int fishing_reset_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
+                              float* zK, float* zr, fishing_stream_t stream);
 
 #ifdef __cplusplus
 }

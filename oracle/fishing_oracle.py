@@ -256,7 +256,8 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def philox_words(seed, env_index, step_counter, stream):
     """Counter layout shared with csrc/fishing_common.h (`env_index` = the Philox index:
-    the env PAIR index on the noise stream, the env index on the reset streams):
+    the env PAIR index on the noise stream and for fishing-v4's redraw on the reset streams
+    (reset_normals), the env index for fishing-v11's model draw):
     c0 = index[31:0], c1 = stream<<24 | index[55:32], c2 = step[31:0], c3 = step[63:32];
     key = (seed[31:0], seed[63:32])."""
     env = np.asarray(env_index, dtype=np.uint64)
@@ -335,9 +336,13 @@ def policy_action(policy, param, model, obs, K, n_actions=100, dtype=np.float64)
 
 def reset_normals(seed, env_index, counter, stream):
     """(zK, zr) float32 for a fishing-v4 parameter redraw: the cos and sin legs of
-    ONE Box-Muller pair, K first then r (fishing_model_error.py:42-43 order)."""
-    w0, w1, _, _ = philox_words(seed, env_index, counter, stream)
-    return box_muller(w0, w1)
+    ONE Box-Muller pair, K first then r (fishing_model_error.py:42-43 order).  The reset streams
+    are indexed by env PAIR: words (0, 1) of block env_index >> 1 serve the even env, words (2, 3)
+    the odd env (fishing_common.h: draw_model_error_pair)."""
+    env_index = np.asarray(env_index, dtype=np.uint64)
+    w0, w1, w2, w3 = philox_words(seed, env_index >> np.uint64(1), counter, stream)
+    odd = (env_index & np.uint64(1)).astype(bool)
+    return box_muller(np.where(odd, w2, w0), np.where(odd, w3, w1))
 
 
 def auto_reset(model, obs_next, done, t_next, K, r, x0, zK=None, zr=None, K_mean=1.0,

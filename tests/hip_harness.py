@@ -113,7 +113,8 @@ class State:
 
 
 def device_noise(n, seed, counter, stream_tag=0, env_offset=0):
-    """(words[n,4], z0[n], z1[n]) of Philox index env_offset + i from the device generator."""
+    """(words[n,4], z0[n], z1[n]) of Philox index env_offset + i from the device generator; on the reset
+    streams z0 / z1 are the (zK, zr) normals of ENV env_offset + i (pair scheme), words stay per index."""
     words = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
     z0 = torch.zeros(n, dtype=torch.float32, device="cuda")
     z1 = torch.zeros(n, dtype=torch.float32, device="cuda")
@@ -121,6 +122,12 @@ def device_noise(n, seed, counter, stream_tag=0, env_offset=0):
                                       z1.data_ptr(), None)
     assert rc == 0, rc
     torch.cuda.synchronize()
+    if stream_tag != _capi.STREAM_NOISE:
+        # fishing-v4 (K, r) normals: one block per env PAIR on the reset streams (fishing_hip.h)
+        rc = _capi.lib().fishing_reset_normals_f32(n, env_offset, seed, counter, stream_tag, z0.data_ptr(),
+                                                  z1.data_ptr(), None)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
     return words.cpu().numpy().view(np.uint32), z0.cpu().numpy(), z1.cpu().numpy()
 
 
