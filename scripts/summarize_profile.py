@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--with-returns", type=int, default=1)
     ap.add_argument("--latest", action="store_true")
     a = ap.parse_args()
+    full = None
     summ = {"raw_dir": a.raw, "kernel_filter": a.kernel, "n_envs": a.n_envs, "with_returns": bool(a.with_returns)}
 
     stats = find(os.path.join(a.raw, "trace"), "*kernel_stats.csv")
@@ -50,15 +51,20 @@ def main():
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
         for r in rows:
             if a.kernel in r["Name"]:
+                full = r["Name"]       # the most expensive match: every later filter uses THIS kernel only
                 summ["kernel"] = short(r["Name"])
                 summ["calls"] = int(r["Calls"])
                 summ["avg_ns"] = float(r["AverageNs"])
                 summ["min_ns"] = float(r["MinNs"])
                 summ["max_ns"] = float(r["MaxNs"])
                 break
+
+    def same(name):
+        return short(name) == short(full) if full else a.kernel in name
+
     trace = find(os.path.join(a.raw, "trace"), "*kernel_trace.csv")
     if trace:
-        rows = [r for r in csv.DictReader(open(trace)) if a.kernel in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(trace)) if same(r["Kernel_Name"])]
         if rows:
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
             summ["trace_median_ns"] = statistics.median(d)
@@ -72,7 +78,7 @@ def main():
         if not f:
             continue
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if a.kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                if same(r["Kernel_Name"]) and r["Counter_Name"] == counter]
         if vals:
             summ[counter + "_KiB_median"] = statistics.median(vals)
             summ[counter + "_launches"] = len(vals)
