@@ -22,7 +22,7 @@ FLAG_AUTO_RESET = 1
 FLAG_GENERAL_KERNEL = 2
 FLAG_T_U8 = 4
 POLICY_RANDOM, POLICY_CONSTANT, POLICY_ESCAPEMENT, POLICY_MSY = 0, 1, 2, 3
-STREAM_NOISE, STREAM_AUTORESET, STREAM_RESET = 0, 1, 2
+STREAM_NOISE, STREAM_AUTORESET, STREAM_RESET, STREAM_POLICY = 0, 1, 2, 3
 
 
 class FishingLibraryError(RuntimeError):
@@ -70,6 +70,7 @@ SIGNATURES = {
     "fishing_population_draw_f32": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "fishing_population_draw_f64": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "fishing_noise_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "fishing_step_normals_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_vp, c_vp]),
     "fishing_reset_normals_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_i32, c_vp, c_vp, c_vp]),
 }
 

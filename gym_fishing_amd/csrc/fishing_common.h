@@ -22,9 +22,10 @@ constexpr int kEnvsPerThread = 4;   // 16-byte accesses on the f32 streams
 constexpr int kMaxBlocks = 4096;    // slots of the return_partials buffer
 constexpr int kPartialFields = 4;   // {sum R, sum R^2, n_episodes, sum length}
 
-constexpr uint32_t kStreamNoise = 0;      // step noise (+ in-kernel policy action)
+constexpr uint32_t kStreamNoise = 0;      // step noise
 constexpr uint32_t kStreamAutoReset = 1;  // v4 (K, r) redraw inside step()
 constexpr uint32_t kStreamReset = 2;      // v4 (K, r) redraw in reset()
+constexpr uint32_t kStreamPolicy = 3;     // random-policy actions of the fused rollout
 
 enum NoiseMode { kNoiseNone = 0, kNoiseExt = 1, kNoisePhilox = 2 };
 
@@ -56,9 +57,11 @@ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32
 
 // Counter layout (mirrored in oracle/fishing_oracle.py: philox_words):
 //   c0 = index[31:0], c1 = stream << 24 | index[55:32], c2 = counter[31:0], c3 = counter[63:32]
-// `index` is the global env PAIR index (env >> 1) on the noise stream -- one block feeds
-// two envs: (w0, w1) -> Box-Muller cos leg for the even env, sin leg for the odd env,
-// w2 / w3 -> their random-policy actions -- and the global env index on the reset streams.
+// `index` is the global env QUAD index (env >> 2) on the noise and policy streams -- one block
+// feeds the four envs of a thread tile: noise (w0, w1) -> Box-Muller cos / sin legs = z of envs
+// 4q, 4q+1, (w2, w3) -> z of envs 4q+2, 4q+3; policy word j -> the random action of env 4q+j --,
+// the env PAIR index for fishing-v4's redraw on the reset streams (draw_model_error_pair) and the
+// env index for fishing-v11's model draw.
 __device__ __forceinline__ Words4 philox_block(uint64_t seed, uint64_t index, uint64_t counter,
                                                uint32_t stream) {
     return philox4x32_10((uint32_t)index, (stream << 24) | ((uint32_t)(index >> 32) & 0xFFFFFFu),
@@ -75,6 +78,15 @@ __device__ __forceinline__ void box_muller(uint32_t w0, uint32_t w1, float& zc, 
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
     zc = rad * __builtin_amdgcn_cosf(u2);
     zs = rad * __builtin_amdgcn_sinf(u2);
+}
+
+// Process noise of the env quad {4 * quad .. 4 * quad + 3} at step `counter`: ONE Philox block and
+// two Box-Muller pairs for a thread's four envs (env_offset and tile bases are multiples of 4, so a
+// quad never straddles threads or shards).
+__device__ __forceinline__ void noise_quad(uint64_t seed, uint64_t quad, uint64_t counter, float (&z)[4]) {
+    const Words4 w = philox_block(seed, quad, counter, kStreamNoise);
+    box_muller(w.w0, w.w1, z[0], z[1]);
+    box_muller(w.w2, w.w3, z[2], z[3]);
 }
 
 // random-policy action from one word: continuous a in [-1, 1]; discrete in [0, n_actions)

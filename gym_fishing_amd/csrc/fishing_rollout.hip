@@ -72,7 +72,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             if (b.ep_return) load4<T>(b.ep_return, base, n, full, er, (T)0);
         }
         bool kind_dirty = false;
-        const uint64_t pair = (env_offset + (uint64_t)base) >> 1;
+        const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
         const T robs_scalar = reset_obs<T, MODEL>(p.x0, p.K);   // loop-invariant unless per-env K
         bool kr_dirty = false;
 
@@ -80,19 +80,18 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             const uint64_t step_counter = step_counter0 + (uint64_t)s;
             T z[4] = {(T)0, (T)0, (T)0, (T)0};
             uint32_t aw[4] = {0u, 0u, 0u, 0u};
-            if (noise_on || kNeedWords) {
+            if (noise_on) {         // one block for the tile's four normals
+                float zq[4];
+                noise_quad(seed, quad, step_counter, zq);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const Words4 w = philox_block(seed, pair + q, step_counter, kStreamNoise);
-                    if (noise_on) {
-                        float zc, zs;
-                        box_muller(w.w0, w.w1, zc, zs);
-                        z[2 * q] = (T)zc;
-                        z[2 * q + 1] = (T)zs;
-                    }
-                    aw[2 * q] = w.w2;
-                    aw[2 * q + 1] = w.w3;
-                }
+                for (int j = 0; j < 4; ++j) z[j] = (T)zq[j];
+            }
+            if (kNeedWords) {       // random policy: one more block, a word per env
+                const Words4 w = philox_block(seed, quad, step_counter, kStreamPolicy);
+                aw[0] = w.w0;
+                aw[1] = w.w1;
+                aw[2] = w.w2;
+                aw[3] = w.w3;
             }
             // ---- all four envs advance branch-free (independent chains, full ILP); a finished
             // env of a no-auto-reset rollout is frozen by selects, not by control flow

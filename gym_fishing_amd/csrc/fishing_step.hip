@@ -25,8 +25,10 @@ namespace fishing {
 #define FISHING_GENERAL_BATCH_ARGS 0
 #endif
 #ifndef FISHING_LEAN_FENCE
-#define FISHING_LEAN_FENCE 0     // experiment knob (bit 0: sched fence after the loads, bit 1: after the Philox
-                                 // block); measured neutral for the bare step, +1 % time with returns -> off
+#define FISHING_LEAN_FENCE 1     // bit 0: scheduling fence after the tile's loads, bit 1: after the Philox block.
+                                 // With one Philox block per tile (quad noise) the compiler otherwise sinks
+                                 // loads behind the generator: 16.6 -> 16.3 us bare, 21.6 -> 21.5 us with
+                                 // returns (bits 1, 2, 3 measure the same; profiles/r01f_lean_fence_ab.txt)
 #endif
 #ifndef FISHING_LEAN_BATCH_ARGS
 #define FISHING_LEAN_BATCH_ARGS 1
@@ -101,17 +103,10 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
             if (NOISE == kNoiseExt) load4<T>(b.z_ext, base, n, full, z, (T)0);
         }
         if (NOISE == kNoisePhilox) {
-            // 4 consecutive envs = 2 env pairs = 2 Philox blocks (env_offset and base are
-            // multiples of 4, so the pairs never straddle threads or shards).
-            const uint64_t pair = (env_offset + (uint64_t)base) >> 1;
+            float zq[4];
+            noise_quad(seed, (env_offset + (uint64_t)base) >> 2, step_counter, zq);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const Words4 w = philox_block(seed, pair + q, step_counter, kStreamNoise);
-                float zc, zs;
-                box_muller(w.w0, w.w1, zc, zs);
-                z[2 * q] = (T)zc;
-                z[2 * q + 1] = (T)zs;
-            }
+            for (int j = 0; j < 4; ++j) z[j] = (T)zq[j];
         }
 
         T obs_next[4], rew[4];
@@ -337,19 +332,14 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                 for (int j = 0; j < 4; ++j) er[j] = qe.v[j];
             }
         }
-        // the loads above must be in flight BEFORE the ~200-instruction Philox block starts: without
+        // the loads above must be in flight BEFORE the ~100-instruction Philox block starts: without
         // this fence the scheduler hoists the (independent) generator above them in some variants
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
         if (NOISE == kNoisePhilox) {
-            const uint64_t pair = (env_offset + (uint64_t)base) >> 1;
+            float zq[4];
+            noise_quad(seed, (env_offset + (uint64_t)base) >> 2, step_counter, zq);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const Words4 w = philox_block(seed, pair + q, step_counter, kStreamNoise);
-                float zc, zs;
-                box_muller(w.w0, w.w1, zc, zs);
-                z[2 * q] = (T)zc;
-                z[2 * q + 1] = (T)zs;
-            }
+            for (int j = 0; j < 4; ++j) z[j] = (T)zq[j];
             // ... and the generator (which needs none of the loaded data) runs under their latency:
             // the first s_waitcnt vmcnt lands after it, at the first use of a loaded register
             if (FISHING_LEAN_FENCE & 2) __builtin_amdgcn_sched_barrier(0);
@@ -502,6 +492,20 @@ noise_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, co
         }
         if (z0) z0[i] = zc;
         if (z1) z1[i] = zs;
+    }
+}
+
+// test hook: the per-env process noise the step / rollout kernels draw (quad scheme of noise_quad)
+__global__ void __launch_bounds__(256)
+step_normals_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, const uint64_t counter,
+                    float* __restrict__ z) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t env = env_offset + (uint64_t)i;
+        float zq[4];
+        noise_quad(seed, env >> 2, counter, zq);
+        const int leg = (int)(env & 3);
+        z[i] = leg == 0 ? zq[0] : leg == 1 ? zq[1] : leg == 2 ? zq[2] : zq[3];
     }
 }
 
@@ -841,6 +845,16 @@ int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t cou
     const int blocks = (int)(nb < 2048 ? nb : 2048);
     fishing::noise_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(n, (uint64_t)env_offset, seed, counter,
                                                                  (uint32_t)stream_tag, words, z0, z1);
+    return (int)hipGetLastError();
+}
+
+int fishing_step_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, float* z,
+                             fishing_stream_t stream) {
+    if (n < 0 || env_offset < 0) return FISHING_ERR_SIZE;
+    if (!z) return FISHING_ERR_NULL;
+    if (n == 0) return FISHING_OK;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, fishing::kMaxBlocks);
+    fishing::step_normals_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(n, (uint64_t)env_offset, seed, counter, z);
     return (int)hipGetLastError();
 }
 

@@ -95,7 +95,7 @@ class BaseFishingEnv(_gym_env_base()):
         if self.num_envs < 1:
             raise ValueError("num_envs must be >= 1")
         if env_offset % 4 or env_offset < 0:
-            raise ValueError("env_offset must be a non-negative multiple of 4 (noise pairs / 16-byte rows)")
+            raise ValueError("env_offset must be a non-negative multiple of 4 (noise quads / 16-byte rows)")
         self.env_offset = int(env_offset)
         # compact layout: years_passed as one byte per env instead of four (19 instead of 25 bytes per
         # env-step in the fp32 layout); needs Tmax <= 254

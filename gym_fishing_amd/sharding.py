@@ -12,7 +12,7 @@ import math
 
 def shard_range(total_envs, rank, world_size, multiple=4):
     """Contiguous [offset, offset + count) block of `rank`.  Offsets are multiples of
-    `multiple` (4: noise pairs and 16-byte rows must not straddle shards); the blocks
+    `multiple` (4: noise quads and 16-byte rows must not straddle shards); the blocks
     tile [0, total_envs) exactly."""
     if world_size < 1 or not 0 <= rank < world_size:
         raise ValueError("bad rank %r / world_size %r" % (rank, world_size))

@@ -197,13 +197,20 @@ int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x
                                 fishing_stream_t stream);
 
 /* Test/diagnostic: the generator itself.  For Philox index (env_offset + i): words[4*i..4*i+3] =
- * the Philox4x32-10 block, z0 / z1 = the cos / sin legs of its Box-Muller pair.  On the step-noise
- * stream (stream_tag 0) the index is the env PAIR (global env >> 1): z0 is the noise of env 2*index,
- * z1 of env 2*index + 1, words 2 / 3 their random-policy actions.  On the reset streams (tags 1, 2)
- * fishing-v11 indexes by global env (word 0 = the model draw) and fishing-v4 by env PAIR, see
- * fishing_reset_normals_f32.  Any output pointer may be NULL. */
+ * the Philox4x32-10 block on stream `stream_tag`, z0 / z1 = the cos / sin legs of the Box-Muller
+ * pair of words (0, 1).  What the index means per stream: tags 0 (step noise) and 3 (random-policy
+ * actions of the fused rollout) index by env QUAD (global env >> 2), see fishing_step_normals_f32;
+ * tags 1 / 2 (reset streams) by env PAIR for fishing-v4, see fishing_reset_normals_f32, and by env
+ * for fishing-v11 (word 0 = the model draw).  Any output pointer may be NULL. */
 int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
                       uint32_t* words, float* z0, float* z1, fishing_stream_t stream);
+
+/* Test/diagnostic: the process noise z the step and rollout kernels draw for envs env_offset ..
+ * env_offset + n - 1 at step `counter` (np.random.normal(0, 1) of base_fishing_env.py:130).  One
+ * Philox block per env quad on stream 0: Box-Muller of words (0, 1) -> z of envs 4q, 4q + 1, of
+ * words (2, 3) -> z of envs 4q + 2, 4q + 3. */
+int fishing_step_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, float* z,
+                             fishing_stream_t stream);
 
 /* Test/diagnostic: the standard normals behind fishing-v4's (K, r) redraw (fishing_model_error.py:42-43)
  * for envs env_offset .. env_offset + n - 1 on reset stream `stream_tag` (1 = auto-reset inside step,

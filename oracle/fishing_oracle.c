@@ -108,16 +108,23 @@ DEFINE_QUOTA(quota_f32, float)
 DEFINE_VSTEP(oracle_step_f64, double, step_one_f64, quota_f64)
 DEFINE_VSTEP(oracle_step_f32, float, step_one_f32, quota_f32)
 
-/* Noise / random-policy action of global env `env` at step `counter` (pair scheme of the kernels). */
+/* Noise / random-policy action of global env `env` at step `counter` (quad scheme of the kernels:
+ * one block per 4 envs on stream 0 for the normals, one on stream 3 for the actions). */
 void oracle_noise_f32(int64_t n, uint64_t env_offset, uint64_t seed, uint64_t counter, float* z, float* action_cts) {
     for (int64_t i = 0; i < n; ++i) {
         const uint64_t env = env_offset + (uint64_t)i;
+        const int leg = (int)(env & 3u);
         uint32_t w[4];
-        oracle_philox_block(seed, env >> 1, counter, 0u, w);
-        float zc, zs;
-        box_muller(w[0], w[1], &zc, &zs);
-        if (z) z[i] = (env & 1) ? zs : zc;
-        if (action_cts) action_cts[i] = (float)((env & 1) ? w[3] : w[2]) * 0x1p-31f - 1.0f;
+        if (z) {
+            oracle_philox_block(seed, env >> 2, counter, 0u, w);
+            float zc, zs;
+            box_muller(w[leg & 2], w[(leg & 2) + 1], &zc, &zs);
+            z[i] = (leg & 1) ? zs : zc;
+        }
+        if (action_cts) {
+            oracle_philox_block(seed, env >> 2, counter, 3u, w);
+            action_cts[i] = (float)w[leg] * 0x1p-31f - 1.0f;
+        }
     }
 }
 
@@ -132,21 +139,23 @@ double oracle_rollout_random_f32(int model, int64_t n, uint64_t env_offset, int3
     if (threads > 0) omp_set_num_threads(threads);
 #endif
 #pragma omp parallel for schedule(static) reduction(+ : total)
-    for (int64_t pair = 0; pair < (n + 1) / 2; ++pair) {
+    for (int64_t quad = 0; quad < (n + 3) / 4; ++quad) {
         for (int32_t s = 0; s < T; ++s) {
-            uint32_t w[4];
-            oracle_philox_block(seed, (env_offset >> 1) + (uint64_t)pair, step_counter0 + (uint64_t)s, 0u, w);
-            float zz[2];
-            box_muller(w[0], w[1], &zz[0], &zz[1]);
-            for (int leg = 0; leg < 2; ++leg) {
-                const int64_t i = 2 * pair + leg;
+            uint32_t w[4], wn[4];
+            oracle_philox_block(seed, (env_offset >> 2) + (uint64_t)quad, step_counter0 + (uint64_t)s, 0u, wn);
+            oracle_philox_block(seed, (env_offset >> 2) + (uint64_t)quad, step_counter0 + (uint64_t)s, 3u, w);
+            float zz[4];
+            box_muller(wn[0], wn[1], &zz[0], &zz[1]);
+            box_muller(wn[2], wn[3], &zz[2], &zz[3]);
+            for (int leg = 0; leg < 4; ++leg) {
+                const int64_t i = 4 * quad + leg;
                 if (i >= n) break;
                 float quota;
                 if (model == MODEL_V0) {
-                    const int32_t a = (int32_t)(((uint64_t)w[2 + leg] * (uint64_t)(uint32_t)n_actions) >> 32);
+                    const int32_t a = (int32_t)(((uint64_t)w[leg] * (uint64_t)(uint32_t)n_actions) >> 32);
                     quota = ((float)a / (float)n_actions) * K;
                 } else {
-                    float a = (float)w[2 + leg] * 0x1p-31f - 1.0f;
+                    float a = (float)w[leg] * 0x1p-31f - 1.0f;
                     a = (a < -1.0f) ? -1.0f : a;
                     a = (a > 1.0f) ? 1.0f : a;
                     quota = (a + 1.0f) * K;

@@ -67,9 +67,10 @@ V11_TABLE = [
 ]
 
 # RNG stream tags (top byte of Philox counter word 1)
-STREAM_NOISE = 0      # per-step process noise z  (+ in-kernel policy action)
+STREAM_NOISE = 0      # per-step process noise z
 STREAM_AUTORESET = 1  # v4 (K, r) redraw when step() auto-resets a finished env
 STREAM_RESET = 2      # v4 (K, r) redraw in an explicit reset()
+STREAM_POLICY = 3     # random-policy actions of the fused rollout
 
 
 def quota_from_action(model, action, K, n_actions, dtype=np.float64):
@@ -256,8 +257,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def philox_words(seed, env_index, step_counter, stream):
     """Counter layout shared with csrc/fishing_common.h (`env_index` = the Philox index:
-    the env PAIR index on the noise stream and for fishing-v4's redraw on the reset streams
-    (reset_normals), the env index for fishing-v11's model draw):
+    the env QUAD index on the noise and policy streams (noise_normal, policy_random_action), the
+    env PAIR index for fishing-v4's redraw on the reset streams (reset_normals), the env index for
+    fishing-v11's model draw):
     c0 = index[31:0], c1 = stream<<24 | index[55:32], c2 = step[31:0], c3 = step[63:32];
     key = (seed[31:0], seed[63:32])."""
     env = np.asarray(env_index, dtype=np.uint64)
@@ -292,23 +294,30 @@ def box_muller(w0, w1):
             (rad * np.sin(2.0 * np.pi * u2)).astype(np.float32))
 
 
+def _quad_words(seed, env_index, step_counter, stream):
+    """(even-leg word, odd-leg word, leg) of env_index within its quad's block."""
+    env = np.asarray(env_index, dtype=np.uint64)
+    w = philox_words(seed, env >> np.uint64(2), step_counter, stream)
+    return env, w
+
+
 def noise_normal(seed, env_index, step_counter):
     """Process-noise z (float32) of global env `env_index` at global step `step_counter`.
-    One Philox block serves an env PAIR (index env >> 1): the even env takes the cos leg
-    of the Box-Muller pair, the odd env the sin leg."""
-    env = np.asarray(env_index, dtype=np.uint64)
-    w0, w1, _, _ = philox_words(seed, env >> np.uint64(1), step_counter, STREAM_NOISE)
-    zc, zs = box_muller(w0, w1)
+    One Philox block serves an env QUAD (index env >> 2): Box-Muller of words (0, 1) gives the
+    cos / sin legs = z of envs 4q, 4q + 1, of words (2, 3) z of envs 4q + 2, 4q + 3
+    (fishing_common.h: noise_quad)."""
+    env, (w0, w1, w2, w3) = _quad_words(seed, env_index, step_counter, STREAM_NOISE)
+    hi = (env & np.uint64(2)).astype(bool)
+    zc, zs = box_muller(np.where(hi, w2, w0), np.where(hi, w3, w1))
     return np.where((env & np.uint64(1)).astype(bool), zs, zc).astype(np.float32)
 
 
 def policy_random_action(model, seed, env_index, step_counter, n_actions=100):
-    """Random policy sampled in-kernel from word 2 (even env) / word 3 (odd env) of the
-    pair's noise block: continuous a = float32(w) * 2**-31 - 1 in [-1, 1]; discrete
-    a = (w * n_actions) >> 32."""
-    env = np.asarray(env_index, dtype=np.uint64)
-    _, _, w2, w3 = philox_words(seed, env >> np.uint64(1), step_counter, STREAM_NOISE)
-    w = np.where((env & np.uint64(1)).astype(bool), w3, w2).astype(np.uint32)
+    """Random policy sampled in-kernel: word (env & 3) of the quad's block on the policy
+    stream: continuous a = float32(w) * 2**-31 - 1 in [-1, 1]; discrete a = (w * n_actions) >> 32."""
+    env, ws = _quad_words(seed, env_index, step_counter, STREAM_POLICY)
+    leg = (env & np.uint64(3)).astype(np.int64)
+    w = np.choose(leg, [np.broadcast_to(x, leg.shape) for x in ws]).astype(np.uint32)
     if model == MODEL_V0:
         return ((w.astype(np.uint64) * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int32)
     return w.astype(np.float32) * np.float32(2.0 ** -31) - np.float32(1.0)

@@ -132,11 +132,12 @@ def device_noise(n, seed, counter, stream_tag=0, env_offset=0):
 
 
 def device_step_noise(n, seed, step_counter, env_offset=0):
-    """The float32 z the step kernel uses for envs env_offset .. env_offset+n-1 (pair legs)."""
-    assert env_offset % 2 == 0
-    npairs = (n + 1) // 2
-    _, zc, zs = device_noise(npairs, seed, step_counter, _capi.STREAM_NOISE, env_offset // 2)
-    return np.stack([zc, zs], axis=1).reshape(-1)[:n]
+    """The float32 z the step kernel uses for envs env_offset .. env_offset+n-1 (quad scheme)."""
+    z = torch.zeros(max(n, 1), dtype=torch.float32, device="cuda")
+    rc = _capi.lib().fishing_step_normals_f32(n, env_offset, seed, step_counter, z.data_ptr(), None)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return z.cpu().numpy()[:n]
 
 
 def ulp_diff(a, b):

@@ -268,6 +268,12 @@ def test_device_philox_words_bit_exact_and_normals_close(hh):
     assert stats.kstest(z, "norm").pvalue > 1e-4
     assert abs(np.corrcoef(zs[0], zs[1])[0, 1]) < 0.02            # consecutive steps
     assert abs(np.corrcoef(zs[0][0::2], zs[0][1::2])[0, 1]) < 0.02  # cos / sin legs of a pair
+    assert abs(np.corrcoef(zs[0][0::4], zs[0][2::4])[0, 1]) < 0.02  # the two pairs of a quad's block
+    # the quad scheme against the oracle's restatement (libm in float64 vs hardware transcendentals)
+    assert np.abs(zs[5] - fo.noise_normal(seed, np.arange(n), 5)).max() < 2e-5
+    off = (1 << 34) + 8
+    assert np.abs(hh.device_step_noise(999, seed, 77, off + 1)
+                  - fo.noise_normal(seed, np.arange(off + 1, off + 1000, dtype=np.uint64), 77)).max() < 2e-5
     assert (hh.device_step_noise(64, seed, 3, env_offset=1000) == zs[3][1000:1064]).all()
 
 
@@ -705,7 +711,7 @@ def test_huge_batch_64bit_indexing(hh):
     t.zero_()
     assert lib.fishing_step_f32(p2, n, 0, b, 77, 5, None) == 0
     torch.cuda.synchronize()
-    w = 2053                      # n is odd: an even window start keeps the noise pairs aligned
+    w = 2053                      # n is odd; the per-env noise hook takes any window start
     lo = n - w
     z = hh.device_step_noise(w, 77, 5, lo)
     eo2, _, _, _, _ = fo.step(fo.MODEL_V1, np.full(w, -0.25, np.float32), np.zeros(w, np.int32),
