@@ -658,11 +658,12 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
     launch_shape(p, n, blocks, threads);
     hipStream_t s = (hipStream_t)stream;
 
-    // lean fast path (fp32, v0/v1/v2/v4, no optional stream but the return accumulator)
-    if constexpr (sizeof(T) == 4) {
+    // lean fast path (v0/v1/v2/v4, no optional stream but the return accumulator)
+    {
         const bool core = is_core_model(p->model);
         const int64_t tile = 256 * kEnvsPerThread;
-        if (core && noise != kNoiseExt && !(p->flags & FISHING_FLAG_GENERAL_KERNEL) && b->reward && b->done &&
+        // (fp64 fishing-v4 stays on the general kernel: measured 50.1 vs 51.6 us at N = 2^22)
+        if (core && (sizeof(T) == 4 || p->model != FISHING_MODEL_V4) && noise != kNoiseExt && !(p->flags & FISHING_FLAG_GENERAL_KERNEL) && b->reward && b->done &&
             !b->done_bits && !b->terminal_obs &&
             (!b->sigma || (p->model == FISHING_MODEL_V4 && noise == kNoisePhilox && !(p->flags & FISHING_FLAG_T_U8))) &&
             (p->launch_threads == 0 || p->launch_threads == 256) && n >= tile) {

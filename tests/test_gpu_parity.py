@@ -642,17 +642,19 @@ def test_random_parameter_sets_match_oracle(hh, model, dtype):
 @pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 @pytest.mark.parametrize("n", [1024, 1024 * 7 + 5, (1 << 18) + 1027])
-def test_lean_and_general_kernels_agree(hh, model, ret, n):
-    """step() takes a lean fp32 kernel for whole 1024-env tiles (+ a general launch for the
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_lean_and_general_kernels_agree(hh, model, ret, n, dtype):
+    """step() takes a lean kernel for whole 1024-env tiles (+ a general launch for the
     ragged tail); FISHING_FLAG_GENERAL_KERNEL forces the general kernel everywhere.  Both must
     give the same bits for every stream over 12 auto-resetting steps (sigma > 0 and sigma = 0)."""
     import torch
+    step_fn = "fishing_step_f32" if dtype == np.float32 else "fishing_step_f64"
     per_env = model == fo.MODEL_V4
     for sigma in (0.1, 0.0):
         kw = dict(sigma=sigma, C=0.5, Tmax=4, sigma_p=0.2, auto_reset=True)
         pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
         sig_arr = np.random.default_rng(n).uniform(0.0, 0.3, n) if (per_env and sigma > 0) else None   # config 5
-        mk = lambda: hh.State(n, np.float32, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
+        mk = lambda: hh.State(n, dtype, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
                               K=np.full(n, 1.0) if per_env else None, sigma=sig_arr, ep_return=ret)
         A, B = mk(), mk()
         A.reset(pa, seed=5, env_offset=12)
@@ -663,7 +665,7 @@ def test_lean_and_general_kernels_agree(hh, model, ret, n):
             a = (torch.randint(0, 100, (n,), device="cuda", generator=g, dtype=torch.int32) if model == fo.MODEL_V0
                  else (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float())
             for st, p in ((A, pa), (B, pb)):
-                assert lib.fishing_step_f32(p, n, 12, st.buffers(a), 5, s, None) == 0
+                assert getattr(lib, step_fn)(p, n, 12, st.buffers(a), 5, s, None) == 0
             torch.cuda.synchronize()
             for name in ("obs", "reward", "done", "t") + (("K", "r") if per_env else ()) + (("ep_return",) if ret else ()):
                 assert torch.equal(getattr(A, name), getattr(B, name)), (name, s, sigma)
