@@ -249,6 +249,8 @@ struct LeanArgs {
     T pr, pK, sigma, C, x0, r_mean, K_mean, sigma_p;
     int32_t Tmax, n_actions;
     uint32_t auto_reset;
+    GrowthT<T> growth;       // fishing-v5..v9: the growth function's parameter set (unused, hence never
+                             // loaded, by the v0/v1/v2/v4 instantiations)
 };
 
 #ifndef FISHING_LEAN_ATTRS
@@ -259,6 +261,9 @@ __global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
 step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_offset, const uint64_t seed,
                  const uint64_t step_counter_arg) {
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
+    constexpr bool kZoo = is_zoo_tag(MODEL);              // one growth function of the zoo (never the mixed tag)
+    constexpr int kZooKind = kZoo ? (MODEL - kModelZoo) : -1;
+    static_assert(MODEL != kModelZooMixed, "fishing-v11 runs on the general kernel");
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
     // trips in front of the first global load of every wave.  Measured (scripts/exp/ab_lean_variants.py,
@@ -270,6 +275,10 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                      "s"(ntiles), "s"(env_offset), "s"(seed), "s"(step_counter_arg));
         if constexpr (kPerEnv) asm volatile("" ::"s"(a.r), "s"(a.K), "s"(a.r_mean), "s"(a.K_mean), "s"(a.sigma_p));
         if constexpr (SIGARR) asm volatile("" ::"s"(a.sigma_arr));
+        if constexpr (kZoo)
+            asm volatile("" ::"s"(a.growth.r), "s"(a.growth.K), "s"(a.growth.sigma), "s"(a.growth.C), "s"(a.growth.M),
+                         "s"(a.growth.theta), "s"(a.growth.q), "s"(a.growth.b), "s"(a.growth.a), "s"(a.growth.bq),
+                         "s"(a.growth.logA), "s"(a.growth.B));
     }
     const uint64_t step_counter = a.counter ? (*a.counter + step_counter_arg) : step_counter_arg;
     const bool auto_reset = a.auto_reset != 0;
@@ -351,8 +360,12 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         for (int j = 0; j < 4; ++j) {
             const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
                                                         : quota_cts<T>((T)a_f[j], KK[j]);
-            env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
-                               dn[j], t_next[j]);
+            if constexpr (kZoo)
+                env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota, z[j], kZooKind, a.growth, KK[j], a.Tmax, obs_next[j],
+                                                 rew[j], dn[j], t_next[j]);
+            else
+                env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
+                                   dn[j], t_next[j]);
         }
         {
             Vec4<T> qr;
@@ -609,7 +622,7 @@ BuffersT<T> offset_buffers(const BuffersT<T>& b, int64_t off, bool t_u8) {
 template <typename T, int MODEL>
 int launch_lean(const LeanArgs<T>& a, int noise, bool ret, bool t8, int64_t ntiles, uint64_t env_offset, uint64_t seed,
                 uint64_t step_counter, int blocks, hipStream_t s) {
-    if (t8) {       // compact layout: one-byte year counters
+    if constexpr (!is_zoo_tag(MODEL)) if (t8) {       // compact layout: one-byte year counters
 #define FISHING_LEAN8(NZ, RT) \
     step_kernel_lean<T, MODEL, NZ, RT, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter)
         if (noise == kNoiseNone) {
@@ -660,7 +673,11 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
 
     // lean fast path (v0/v1/v2/v4, no optional stream but the return accumulator)
     {
-        const bool core = is_core_model(p->model);
+        // fishing-v5..v9 (one growth function, scalar parameters) share the lean kernel; v10 (drifting
+        // per-env r) and v11 (growth function per env) need the general kernel's extra streams
+        const bool zoo_lean = sizeof(T) == 4 && is_zoo_model(p->model) && p->model != FISHING_MODEL_V10 &&
+                              p->model != FISHING_MODEL_V11 && !(p->flags & FISHING_FLAG_T_U8) && !b->sigma;
+        const bool core = is_core_model(p->model) || zoo_lean;
         const int64_t tile = 256 * kEnvsPerThread;
         // (fp64 fishing-v4 stays on the general kernel: measured 50.1 vs 51.6 us at N = 2^22)
         if (core && (sizeof(T) == 4 || p->model != FISHING_MODEL_V4) && noise != kNoiseExt && !(p->flags & FISHING_FLAG_GENERAL_KERNEL) && b->reward && b->done &&
@@ -672,7 +689,7 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
             LeanArgs<T> a{bt.obs,      bt.action,  bt.reward,  bt.done,     bt.t,        bt.r,
                           bt.K,        bt.ep_return, bt.partials, bt.counter, bt.sigma,  pt.r,      pt.K,
                           pt.sigma,    pt.C,       pt.x0,      pt.r_mean,   pt.K_mean,   pt.sigma_p,
-                          pt.Tmax,     pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET)};
+                          pt.Tmax,     pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET), pt.growth};
             int cap = p->launch_blocks ? p->launch_blocks : 2048;
             if (cap > kMaxBlocks) cap = kMaxBlocks;
             const int lb = (int)(ntiles < cap ? ntiles : cap);
@@ -681,7 +698,7 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
             const int rc2 = with_model_tag(p->model, [&](auto tag) {
                 constexpr int kTag = decltype(tag)::value;
                 if constexpr (kTag == FISHING_MODEL_V0 || kTag == FISHING_MODEL_V1 || kTag == FISHING_MODEL_V2 ||
-                              kTag == FISHING_MODEL_V4)
+                              kTag == FISHING_MODEL_V4 || (sizeof(T) == 4 && is_zoo_tag(kTag) && kTag != kModelZooMixed))
                     return launch_lean<T, kTag>(a, noise, ret, t8, ntiles, env_offset, seed, step_counter, lb, s);
                 else
                     return (int)FISHING_ERR_MODEL;

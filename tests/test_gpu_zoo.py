@@ -270,3 +270,36 @@ def test_zoo_simulate_uses_the_fused_rollout(hh):
             return esc.predict(obs, **kw)
     stepwise = venv.simulate(Plain()).to_numpy(dtype=np.float64)
     assert fused.shape == stepwise.shape == (800, 5) and np.array_equal(fused, stepwise)
+
+
+@pytest.mark.parametrize("model", [fo.MODEL_V5, fo.MODEL_V6, fo.MODEL_V7, fo.MODEL_V8, fo.MODEL_V9])
+@pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
+def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
+    """fishing-v5..v9 in float32 take the lean step kernel for whole 1024-env tiles (one growth
+    function, scalar parameters); FISHING_FLAG_GENERAL_KERNEL forces the general kernel.  Same bits
+    on every stream over 12 auto-resetting steps, sigma > 0 and sigma = 0, ragged tail included."""
+    import torch
+    env_id = {v: k for k, v in fo.MODEL_OF_ID.items()}[model]
+    P = dict(ZOO_DEFAULTS[env_id])
+    n = 1024 * 5 + 7
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    for sigma in (0.1, 0.0):
+        kw = dict(r=float(P.get("r", 0.3)), K=float(P["K"]), sigma=sigma, C=float(P.get("C", 0.5)),
+                  x0=float(P["init_state"]), Tmax=4, M=float(P.get("M", 0.0)), theta=float(P.get("theta", 0.0)),
+                  q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)), auto_reset=True)
+        pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
+        A, B = (hh.State(n, np.float32, model, np.zeros(n), ep_return=ret) for _ in range(2))
+        A.reset(pa, seed=5, env_offset=12)
+        B.reset(pb, seed=5, env_offset=12)
+        g = torch.Generator(device="cuda").manual_seed(n)
+        for s in range(12):
+            a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
+            for st, p in ((A, pa), (B, pb)):
+                assert lib.fishing_step_f32(p, n, 12, st.buffers(a), 5, s, None) == 0
+            torch.cuda.synchronize()
+            for name in ("obs", "reward", "done", "t") + (("ep_return",) if ret else ()):
+                assert torch.equal(getattr(A, name), getattr(B, name)), (name, s, sigma)
+        assert int(A.done.sum()) >= 0 and bool(torch.isfinite(A.obs).all())
+        if ret:
+            ra, rb = A.record(), B.record()
+            assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12) and ra[2] > 0
