@@ -249,14 +249,15 @@ struct LeanArgs {
     T pr, pK, sigma, C, x0, r_mean, K_mean, sigma_p;
     int32_t Tmax, n_actions;
     uint32_t auto_reset;
-    GrowthT<T> growth;       // fishing-v5..v9: the growth function's parameter set (unused, hence never
+    GrowthT<T> growth;       // fishing-v5..v10: the growth function's parameter set (unused, hence never
                              // loaded, by the v0/v1/v2/v4 instantiations)
+    T alpha;                 // fishing-v10: per-draw drift of the per-env r (DRIFT)
 };
 
 #ifndef FISHING_LEAN_ATTRS
 #define FISHING_LEAN_ATTRS
 #endif
-template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false, bool T8 = false>
+template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false, bool T8 = false, bool DRIFT = false>
 __global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
 step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_offset, const uint64_t seed,
                  const uint64_t step_counter_arg) {
@@ -264,6 +265,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
     constexpr bool kZoo = is_zoo_tag(MODEL);              // one growth function of the zoo (never the mixed tag)
     constexpr int kZooKind = kZoo ? (MODEL - kModelZoo) : -1;
     static_assert(MODEL != kModelZooMixed, "fishing-v11 runs on the general kernel");
+    static_assert(!DRIFT || kZoo, "DRIFT is fishing-v10 (NonStationary Beverton-Holt)");
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
     // trips in front of the first global load of every wave.  Measured (scripts/exp/ab_lean_variants.py,
@@ -279,6 +281,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
             asm volatile("" ::"s"(a.growth.r), "s"(a.growth.K), "s"(a.growth.sigma), "s"(a.growth.C), "s"(a.growth.M),
                          "s"(a.growth.theta), "s"(a.growth.q), "s"(a.growth.b), "s"(a.growth.a), "s"(a.growth.bq),
                          "s"(a.growth.logA), "s"(a.growth.B));
+        if constexpr (DRIFT) asm volatile("" ::"s"(a.r), "s"(a.alpha));
     }
     const uint64_t step_counter = a.counter ? (*a.counter + step_counter_arg) : step_counter_arg;
     const bool auto_reset = a.auto_reset != 0;
@@ -335,6 +338,11 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                     KK[j] = qk.v[j];
                 }
             }
+            if (DRIFT) {
+                const Vec4<T> qr = *reinterpret_cast<const Vec4<T>*>(a.r + base);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rr[j] = qr.v[j];
+            }
             if (RET) {
                 const Vec4<T> qe = *reinterpret_cast<const Vec4<T>*>(a.ep_return + base);
 #pragma unroll
@@ -360,7 +368,13 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         for (int j = 0; j < 4; ++j) {
             const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
                                                         : quota_cts<T>((T)a_f[j], KK[j]);
-            if constexpr (kZoo)
+            if constexpr (DRIFT) {                   // growth_models.py:151: drift first, then draw
+                GrowthT<T> P = a.growth;
+                rr[j] = rr[j] + a.alpha;
+                P.r = rr[j];
+                env_step_zoo<T, kZooKind, true>(obs[j], t[j], quota, z[j], kZooKind, P, KK[j], a.Tmax, obs_next[j], rew[j],
+                                                dn[j], t_next[j]);
+            } else if constexpr (kZoo)
                 env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota, z[j], kZooKind, a.growth, KK[j], a.Tmax, obs_next[j],
                                                  rew[j], dn[j], t_next[j]);
             else
@@ -422,6 +436,12 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                 qt.v[j] = t_next[j];
             }
             *reinterpret_cast<Vec4<T>*>(a.obs + base) = qo;
+            if (DRIFT) {
+                Vec4<T> qr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qr.v[j] = rr[j];
+                *reinterpret_cast<Vec4<T>*>(a.r + base) = qr;
+            }
             if (T8) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.t) + base) = pack_t4(t_next);
             else *reinterpret_cast<Vec4<int32_t>*>(a.t + base) = qt;
         }
@@ -620,8 +640,21 @@ BuffersT<T> offset_buffers(const BuffersT<T>& b, int64_t off, bool t_u8) {
 }
 
 template <typename T, int MODEL>
-int launch_lean(const LeanArgs<T>& a, int noise, bool ret, bool t8, int64_t ntiles, uint64_t env_offset, uint64_t seed,
-                uint64_t step_counter, int blocks, hipStream_t s) {
+int launch_lean(const LeanArgs<T>& a, int noise, bool ret, bool t8, bool drift, int64_t ntiles, uint64_t env_offset,
+                uint64_t seed, uint64_t step_counter, int blocks, hipStream_t s) {
+    if constexpr (MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT) {
+        if (drift) {        // fishing-v10: per-env r, read and written every step
+#define FISHING_LEAND(NZ, RT) \
+    step_kernel_lean<T, MODEL, NZ, RT, false, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter)
+            if (noise == kNoiseNone) {
+                if (ret) FISHING_LEAND(kNoiseNone, true); else FISHING_LEAND(kNoiseNone, false);
+            } else {
+                if (ret) FISHING_LEAND(kNoisePhilox, true); else FISHING_LEAND(kNoisePhilox, false);
+            }
+#undef FISHING_LEAND
+            return (int)hipGetLastError();
+        }
+    }
     if constexpr (!is_zoo_tag(MODEL)) if (t8) {       // compact layout: one-byte year counters
 #define FISHING_LEAN8(NZ, RT) \
     step_kernel_lean<T, MODEL, NZ, RT, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter)
@@ -673,10 +706,10 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
 
     // lean fast path (v0/v1/v2/v4, no optional stream but the return accumulator)
     {
-        // fishing-v5..v9 (one growth function, scalar parameters) share the lean kernel; v10 (drifting
-        // per-env r) and v11 (growth function per env) need the general kernel's extra streams
-        const bool zoo_lean = sizeof(T) == 4 && is_zoo_model(p->model) && p->model != FISHING_MODEL_V10 &&
-                              p->model != FISHING_MODEL_V11 && !(p->flags & FISHING_FLAG_T_U8) && !b->sigma;
+        // fishing-v5..v10 (one growth function; v10 adds the drifting per-env r stream) share the lean
+        // kernel; v11 (growth function per env) needs the general kernel
+        const bool zoo_lean = sizeof(T) == 4 && is_zoo_model(p->model) && p->model != FISHING_MODEL_V11 &&
+                              !(p->flags & FISHING_FLAG_T_U8) && !b->sigma;
         const bool core = is_core_model(p->model) || zoo_lean;
         const int64_t tile = 256 * kEnvsPerThread;
         // (fp64 fishing-v4 stays on the general kernel: measured 50.1 vs 51.6 us at N = 2^22)
@@ -689,7 +722,7 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
             LeanArgs<T> a{bt.obs,      bt.action,  bt.reward,  bt.done,     bt.t,        bt.r,
                           bt.K,        bt.ep_return, bt.partials, bt.counter, bt.sigma,  pt.r,      pt.K,
                           pt.sigma,    pt.C,       pt.x0,      pt.r_mean,   pt.K_mean,   pt.sigma_p,
-                          pt.Tmax,     pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET), pt.growth};
+                          pt.Tmax,     pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET), pt.growth, pt.alpha};
             int cap = p->launch_blocks ? p->launch_blocks : 2048;
             if (cap > kMaxBlocks) cap = kMaxBlocks;
             const int lb = (int)(ntiles < cap ? ntiles : cap);
@@ -699,7 +732,8 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
                 constexpr int kTag = decltype(tag)::value;
                 if constexpr (kTag == FISHING_MODEL_V0 || kTag == FISHING_MODEL_V1 || kTag == FISHING_MODEL_V2 ||
                               kTag == FISHING_MODEL_V4 || (sizeof(T) == 4 && is_zoo_tag(kTag) && kTag != kModelZooMixed))
-                    return launch_lean<T, kTag>(a, noise, ret, t8, ntiles, env_offset, seed, step_counter, lb, s);
+                    return launch_lean<T, kTag>(a, noise, ret, t8, p->model == FISHING_MODEL_V10, ntiles, env_offset, seed,
+                                                step_counter, lb, s);
                 else
                     return (int)FISHING_ERR_MODEL;
             });

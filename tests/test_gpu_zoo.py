@@ -272,12 +272,13 @@ def test_zoo_simulate_uses_the_fused_rollout(hh):
     assert fused.shape == stepwise.shape == (800, 5) and np.array_equal(fused, stepwise)
 
 
-@pytest.mark.parametrize("model", [fo.MODEL_V5, fo.MODEL_V6, fo.MODEL_V7, fo.MODEL_V8, fo.MODEL_V9])
+@pytest.mark.parametrize("model", [fo.MODEL_V5, fo.MODEL_V6, fo.MODEL_V7, fo.MODEL_V8, fo.MODEL_V9, fo.MODEL_V10])
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
-    """fishing-v5..v9 in float32 take the lean step kernel for whole 1024-env tiles (one growth
-    function, scalar parameters); FISHING_FLAG_GENERAL_KERNEL forces the general kernel.  Same bits
-    on every stream over 12 auto-resetting steps, sigma > 0 and sigma = 0, ragged tail included."""
+    """fishing-v5..v10 in float32 take the lean step kernel for whole 1024-env tiles (one growth
+    function; v10 adds its drifting per-env r stream); FISHING_FLAG_GENERAL_KERNEL forces the general
+    kernel.  Same bits on every stream over 12 auto-resetting steps, sigma > 0 and sigma = 0, ragged
+    tail included."""
     import torch
     env_id = {v: k for k, v in fo.MODEL_OF_ID.items()}[model]
     P = dict(ZOO_DEFAULTS[env_id])
@@ -286,9 +287,12 @@ def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
     for sigma in (0.1, 0.0):
         kw = dict(r=float(P.get("r", 0.3)), K=float(P["K"]), sigma=sigma, C=float(P.get("C", 0.5)),
                   x0=float(P["init_state"]), Tmax=4, M=float(P.get("M", 0.0)), theta=float(P.get("theta", 0.0)),
-                  q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)), auto_reset=True)
+                  q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)),
+                  alpha=float(P.get("alpha", 0.0)), auto_reset=True)
         pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
-        A, B = (hh.State(n, np.float32, model, np.zeros(n), ep_return=ret) for _ in range(2))
+        drift = model == fo.MODEL_V10
+        A, B = (hh.State(n, np.float32, model, np.zeros(n), ep_return=ret,
+                         r=np.full(n, kw["r"]) if drift else None) for _ in range(2))
         A.reset(pa, seed=5, env_offset=12)
         B.reset(pb, seed=5, env_offset=12)
         g = torch.Generator(device="cuda").manual_seed(n)
@@ -297,8 +301,10 @@ def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
             for st, p in ((A, pa), (B, pb)):
                 assert lib.fishing_step_f32(p, n, 12, st.buffers(a), 5, s, None) == 0
             torch.cuda.synchronize()
-            for name in ("obs", "reward", "done", "t") + (("ep_return",) if ret else ()):
+            for name in ("obs", "reward", "done", "t") + (("ep_return",) if ret else ()) + (("r",) if drift else ()):
                 assert torch.equal(getattr(A, name), getattr(B, name)), (name, s, sigma)
+        if drift:
+            assert np.allclose(A.r.cpu().numpy(), kw["r"] + 12 * kw["alpha"], rtol=1e-5)
         assert int(A.done.sum()) >= 0 and bool(torch.isfinite(A.obs).all())
         if ret:
             ra, rb = A.record(), B.record()
