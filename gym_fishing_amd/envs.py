@@ -598,7 +598,10 @@ class BaseFishingEnv(_gym_env_base()):
         if isinstance(state, torch.Tensor):
             pop = (state.to(torch.float64).reshape(-1) + 1.0) * K
             return pop
-        pop = (np.asarray(state, dtype=np.float64).reshape(-1)[0] + 1) * K
+        # (state[0] + 1) * K: a (1,) observation gives a scalar, the reference's VecEnv idiom
+        # get_fish_population((obs_i,)) (shared_env.py:17-19) an array of shape (1,)
+        s0 = state if np.ndim(state) == 0 else state[0]
+        pop = (np.asarray(s0, dtype=np.float64) + 1) * K
         if self._scalar:
             self.fish_population = pop
         return pop

@@ -1,0 +1,127 @@
+"""NumPy-facing VecEnv adapter: the stable-baselines3 `VecEnv` protocol around an N-env fishing env.
+
+The reference trains and evaluates its agents through SB3 (tests/test-PPO.py:10-21,
+examples/PPO.py:7-16) and codes its own helpers against the VecEnv shape
+(gym_fishing/envs/shared_env.py:15-26,57-79).  The tensor protocol of `BaseFishingEnv` keeps
+everything on the device; this wrapper is the boundary for callers that want what SB3's
+`DummyVecEnv` hands them:
+
+    obs      float32 ndarray [N, 1]   (the post-reset observation where an env just finished)
+    rewards  float32 ndarray [N]
+    dones    bool    ndarray [N]
+    infos    list of N dicts; infos[i]["terminal_observation"] (ndarray [1]) where dones[i]
+
+The hot path is unchanged -- one kernel launch per step with the fused auto-reset -- followed by one
+device-to-host copy per output.  When stable_baselines3 is importable the class derives from its
+`VecEnv`, so `PPO("MlpPolicy", FishingVecEnv(env))` accepts it as is; without SB3 it is a plain
+class with the same methods.
+"""
+import numpy as np
+import torch
+
+
+def _vec_env_base():
+    try:
+        from stable_baselines3.common.vec_env import VecEnv
+        return VecEnv
+    except Exception:  # noqa: BLE001 -- SB3 is optional
+        return object
+
+
+_BASE = _vec_env_base()
+
+
+class FishingVecEnv(_BASE):
+    """`env` must be an N-env (tensor protocol) env built with auto_reset=True and
+    record_terminal_obs=True; `make_vec_env(id, n_envs, **kwargs)` builds one."""
+
+    def __init__(self, env):
+        if getattr(env, "_scalar", True):
+            raise ValueError("FishingVecEnv wraps the N-env protocol: construct the env with num_envs=N")
+        if not env.auto_reset or env._terminal_obs is None:
+            raise ValueError("FishingVecEnv needs auto_reset=True and record_terminal_obs=True "
+                             "(SB3 semantics: the returned obs is the post-reset one, the terminal obs goes to info)")
+        self.env = env
+        if _BASE is not object:
+            _BASE.__init__(self, env.num_envs, env.observation_space, env.action_space)
+        else:
+            self.num_envs = env.num_envs
+            self.observation_space = env.observation_space
+            self.action_space = env.action_space
+        self._obs_dtype = np.dtype(getattr(env.observation_space, "dtype", np.float32))
+        self._pending = None
+        self.render_mode = None
+        self.metadata = dict(getattr(env, "metadata", {}))
+
+    # ------------------------------------------------------------------ VecEnv protocol
+    def reset(self):
+        obs = self.env.reset()
+        return obs.detach().to("cpu", torch.float32).numpy().astype(self._obs_dtype, copy=False)
+
+    def step_async(self, actions):
+        self._pending = actions
+
+    def step_wait(self):
+        a = np.asarray(self._pending)
+        self._pending = None
+        obs, rew, done, info = self.env.step(a.reshape(self.num_envs))
+        # one stream sync for the four copies
+        obs_h = obs.detach().to("cpu", torch.float32, non_blocking=False).numpy().astype(self._obs_dtype, copy=False)
+        rew_h = rew.detach().to("cpu", torch.float32).numpy()
+        done_h = done.detach().cpu().numpy().astype(bool, copy=False)
+        infos = [{} for _ in range(self.num_envs)]
+        idx = np.flatnonzero(done_h)
+        if idx.size:
+            term = info["terminal_observation"].detach().to("cpu", torch.float32).numpy().astype(self._obs_dtype, copy=False)
+            for i in idx:
+                infos[i]["terminal_observation"] = term[i].copy()
+        return obs_h, rew_h, done_h, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.env.close()
+
+    def seed(self, seed=None):
+        self.env.seed(seed)
+        return [None if seed is None else int(seed) + i for i in range(self.num_envs)]
+
+    def get_attr(self, attr_name, indices=None):
+        return list(self.env.get_attr(attr_name, self._indices(indices)))
+
+    def set_attr(self, attr_name, value, indices=None):
+        self.env.set_attr(attr_name, value, self._indices(indices))
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        return list(self.env.env_method(method_name, *method_args, indices=self._indices(indices), **method_kwargs))
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * len(self._indices(indices))
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode="human"):
+        return self.env.render(mode)
+
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        if isinstance(indices, (int, np.integer)):
+            return [int(indices)]
+        return [int(i) for i in indices]
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+def make_vec_env(env_id, n_envs, **kwargs):
+    """`stable_baselines3.common.env_util.make_vec_env(env_id, n_envs)` for the fishing ids: N envs on the
+    device behind the NumPy VecEnv protocol."""
+    from . import make
+    kwargs.setdefault("auto_reset", True)
+    kwargs["record_terminal_obs"] = True
+    return FishingVecEnv(make(env_id, num_envs=int(n_envs), **kwargs))

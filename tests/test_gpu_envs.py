@@ -501,3 +501,54 @@ def test_examples_run(gf, script):
         assert "scalar protocol: 100 steps, return 7.675000" in out.stdout and "mean_return" in out.stdout
     else:
         assert "env-steps/s" in out.stdout
+
+
+def test_numpy_vec_env_adapter_follows_the_sb3_protocol(gf):
+    """gym_fishing_amd.vec_env.FishingVecEnv: what SB3's DummyVecEnv hands its callers --
+    float32 obs [N, 1], float32 rewards [N], bool dones [N], a list of N info dicts with the terminal
+    observation of every env that just finished, the returned obs already reset -- and the calls the
+    reference's own VecEnv helpers make (shared_env.py:15-26,57-79)."""
+    import torch
+    from gym_fishing_amd.vec_env import FishingVecEnv, make_vec_env
+    n, Tmax = 64, 5
+    venv = make_vec_env("fishing-v1", n, sigma=0.1, seed=3, Tmax=Tmax)
+    twin = gf.make("fishing-v1", num_envs=n, sigma=0.1, seed=3, Tmax=Tmax, record_terminal_obs=True)
+    obs = venv.reset()
+    twin.reset()
+    assert isinstance(obs, np.ndarray) and obs.shape == (n, 1) and obs.dtype == np.float32 and (obs == -0.25).all()
+    assert venv.num_envs == n and venv.get_attr("Tmax") == [Tmax] * n and venv.get_attr("Tmax", indices=3) == [Tmax]
+    assert venv.env_is_wrapped(object) == [False] * n and venv.action_space.low[0] == -1
+    rng = np.random.default_rng(0)
+    finished = 0
+    for s in range(14):
+        a = rng.uniform(-1, -0.5, (n, 1)).astype(np.float32)
+        venv.step_async(a)
+        obs, rew, done, infos = venv.step_wait()
+        o2, r2, d2, i2 = twin.step(torch.as_tensor(a))
+        assert obs.shape == (n, 1) and obs.dtype == np.float32 and rew.shape == (n,) and rew.dtype == np.float32
+        assert done.shape == (n,) and done.dtype == np.bool_ and isinstance(infos, list) and len(infos) == n
+        assert np.array_equal(obs, o2.cpu().numpy()) and np.array_equal(rew, r2.cpu().numpy())
+        assert np.array_equal(done, d2.cpu().numpy())
+        term = i2["terminal_observation"].cpu().numpy()
+        for i in range(n):
+            if done[i]:
+                finished += 1
+                assert infos[i]["terminal_observation"].shape == (1,) and infos[i]["terminal_observation"][0] == term[i, 0]
+                assert obs[i, 0] == np.float32(-0.25)                 # already reset
+            else:
+                assert infos[i] == {}
+        # the reference's df_entry_vec idiom (shared_env.py:15-26)
+        pop = venv.env_method("get_fish_population", (obs[7],), indices=7)[0][0]
+        assert np.isclose(pop, (obs[7, 0] + 1.0) * 1.0)
+    assert finished >= n                                              # Tmax = 5: every env finished at least once
+    # discrete actions arrive as an int array of shape [N]
+    v0 = make_vec_env("fishing-v0", 8, sigma=0.0, seed=1)
+    v0.reset()
+    obs, rew, done, infos = v0.step(np.full(8, 10))
+    assert np.allclose(rew, 0.1) and not done.any() and obs.dtype == np.float32
+    with pytest.raises(ValueError):
+        FishingVecEnv(gf.make("fishing-v1", num_envs=4))              # no terminal-obs record
+    with pytest.raises(ValueError):
+        FishingVecEnv(gf.make("fishing-v1"))                          # scalar protocol
+    assert venv.seed(5) == [5 + i for i in range(n)]
+    venv.close()
