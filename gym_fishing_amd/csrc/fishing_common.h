@@ -61,7 +61,7 @@ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32
 // feeds the four envs of a thread tile: noise (w0, w1) -> Box-Muller cos / sin legs = z of envs
 // 4q, 4q+1, (w2, w3) -> z of envs 4q+2, 4q+3; policy word j -> the random action of env 4q+j --,
 // the env PAIR index for fishing-v4's redraw on the reset streams (draw_model_error_pair) and the
-// env index for fishing-v11's model draw.
+// env QUAD index for fishing-v11's model draw (redraw_kinds: word j -> env 4q + j).
 __device__ __forceinline__ Words4 philox_block(uint64_t seed, uint64_t index, uint64_t counter,
                                                uint32_t stream) {
     return philox4x32_10((uint32_t)index, (stream << 24) | ((uint32_t)(index >> 32) & 0xFFFFFFu),
@@ -372,6 +372,65 @@ __device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const Gr
     return (g > (T)0) ? g : ((g != g) ? g : (T)0);    // np.maximum(0, g)
 }
 
+// fishing-v11: the growth function differs per env, so a straight per-lane switch runs all five
+// functions for every one of a thread's four envs (20 masked passes per wave, most lanes idle in
+// each).  Instead each wave regroups its 256 envs BY KIND through a wave-private LDS window: for kind
+// k the envs of that kind are compacted (ballot + mbcnt ranks) into consecutive slots, the wave
+// evaluates growth function k on full 64-lane chunks with wave-uniform parameters, and every env
+// reads its result back from its slot -- about ceil(n_k / 64) passes per kind, 5-7 in total.  Same
+// function on the same inputs as zoo_population_draw<T, k>: identical bits.
+// Must be called by all 64 lanes of the wave (envs that do not take part pass kind < 0).
+// `win` is this wave's window: 2 * 256 elements of T.
+template <typename T, int K>
+__device__ __forceinline__ void zoo_draw_kind_pass(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
+                                                   const GrowthT<T>& P, T (&out)[4], T* __restrict__ win, int lane) {
+    bool mine[4];
+    int pos[4];
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mine[j] = kind[j] == K;
+        const uint64_t bal = __ballot(mine[j]);
+        pos[j] = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        total += __popcll(bal);
+    }
+    if (total == 0) return;                       // wave-uniform
+    T* wx = win;
+    T* wz = win + 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (mine[j]) {
+            wx[pos[j]] = x[j];
+            wz[pos[j]] = z[j];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int c = 0; c < total; c += kWave) {      // wave-uniform trip count
+        const int p = c + lane;
+        if (p < total) wx[p] = zoo_population_draw<T, K, false>(K, wx[p], wz[p], P);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = mine[j] ? wx[pos[j]] : out[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();              // the next kind reuses the window
+}
+
+template <typename T>
+__device__ __forceinline__ void zoo_draw_regrouped(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
+                                                   const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[4],
+                                                   T* __restrict__ win, int lane) {
+    zoo_draw_kind_pass<T, FISHING_KIND_ALLEN>(kind, x, z, zoo[FISHING_KIND_ALLEN], out, win, lane);
+    zoo_draw_kind_pass<T, FISHING_KIND_BEVERTON_HOLT>(kind, x, z, zoo[FISHING_KIND_BEVERTON_HOLT], out, win, lane);
+    zoo_draw_kind_pass<T, FISHING_KIND_MYERS>(kind, x, z, zoo[FISHING_KIND_MYERS], out, win, lane);
+    zoo_draw_kind_pass<T, FISHING_KIND_MAY>(kind, x, z, zoo[FISHING_KIND_MAY], out, win, lane);
+    zoo_draw_kind_pass<T, FISHING_KIND_RICKER>(kind, x, z, zoo[FISHING_KIND_RICKER], out, win, lane);
+}
+
 // step() with a zoo growth function: quota / obs maps use the env's K (K_obs), the growth its
 // own parameter set (self.params in the reference).
 template <typename T, int KIND = -1, bool RECOMPUTE = false>
@@ -452,6 +511,20 @@ __device__ __forceinline__ T clip_param(T v) {
     v = (v > (T)1e6) ? (T)1e6 : v;
     return v;
 }
+// fishing-v11 (growth_models.py:187,200): a new growth function for the finished envs of one thread's
+// 4-env tile.  One Philox block per env quad on the reset streams, word j -> env 4q + j.  Returns
+// whether any kind was redrawn.
+__device__ __forceinline__ bool redraw_kinds(uint64_t seed, uint64_t base, uint64_t counter, uint32_t stream,
+                                             const int32_t (&kinds)[FISHING_N_KINDS], int32_t n_models,
+                                             const bool (&fin)[4], int32_t (&kind)[4]) {
+    if (!(fin[0] | fin[1] | fin[2] | fin[3])) return false;
+    const Words4 w = philox_block(seed, base >> 2, counter, stream);
+    const uint32_t ww[4] = {w.w0, w.w1, w.w2, w.w3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kind[j] = fin[j] ? kinds[action_int_from_word(ww[j], n_models)] : kind[j];
+    return true;
+}
+
 // reset observation: x0 / K - 1 (base_fishing_env.py:84); v4 returns x0 un-normalised
 // (fishing_model_error.py:44, quirk B8).
 template <typename T, int MODEL>

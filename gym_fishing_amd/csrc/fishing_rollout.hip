@@ -174,6 +174,11 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             // ---- wave-ballot: only waves holding a finished env do the record / reset work
             if (__any(fin[0] | fin[1] | fin[2] | fin[3])) {
                 record_tile<T>(fin, er, t, acc);
+                if (AUTO && zoo_mixed) {      // growth_models.py:200: a new model for the next episode
+                    if (redraw_kinds(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, p.kinds, p.n_models,
+                                     fin, kind))
+                        kind_dirty = true;
+                }
                 if (AUTO && kPerEnv) {
                     if (redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
                                               p.K_mean, p.r_mean, p.sigma_p, p.x0, fin, KK, rr, obs, t))
@@ -183,14 +188,6 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                 for (int j = 0; j < 4; ++j) {
                     const bool f = fin[j];
                     if (AUTO) {
-                        if (zoo_mixed) {
-                            if (f) {      // growth_models.py:200: a new model for the next episode
-                                const Words4 w = philox_block(seed, env_offset + (uint64_t)(base + j), step_counter,
-                                                              kStreamAutoReset);
-                                kind[j] = p.kinds[action_int_from_word(w.w0, p.n_models)];
-                                kind_dirty = true;
-                            }
-                        }
                         const T ro = kPerEnv ? reset_obs<T, MODEL>(p.x0, KK[j]) : robs_scalar;
                         er[j] = f ? (T)0 : er[j];
                         obs[j] = f ? ro : obs[j];

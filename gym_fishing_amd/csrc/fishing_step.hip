@@ -112,6 +112,34 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         T obs_next[4], rew[4];
         int32_t t_next[4];
         bool dn[4];
+        bool stepped = false;
+        if constexpr (zoo_mixed) {
+            if (!b.sigma) {     // wave-uniform.  fishing-v11: regroup the wave's envs by growth function
+                __shared__ T win[(FISHING_STEP_MAXTHREADS / kWave) * 512];
+                T xh[4], hv[4], xn[4];
+                int kk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const T quota = quota_cts<T>((T)a_f[j], KK[j]);
+                    const T x = (obs[j] + (T)1) * KK[j];
+                    hv[j] = (quota < x) ? quota : x;
+                    const T d = x - hv[j];
+                    xh[j] = ((T)0 > d) ? (T)0 : d;
+                    xn[j] = (T)0;
+                    kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+                }
+                zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * 512, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    obs_next[j] = xn[j] / KK[j] - (T)1;
+                    rew[j] = ((T)0 > hv[j]) ? (T)0 : hv[j];
+                    t_next[j] = t[j] + 1;
+                    dn[j] = ((t_next[j] > p.Tmax) || (xn[j] <= (T)0)) && (base + j < n);
+                }
+                stepped = true;
+            }
+        }
+        if (!stepped) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], p.n_actions, KK[j])
@@ -138,6 +166,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                                    obs_next[j], rew[j], dn[j], t_next[j]);
             }
             dn[j] = dn[j] && (base + j < n);
+        }
         }
         const bool lane_done = dn[0] | dn[1] | dn[2] | dn[3];
         // wave-ballot termination mask: a wave with no finished env skips everything below
@@ -185,18 +214,10 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         if (zoo_drift && active) store4<T>(b.r, base, n, full, rr);
         if (auto_reset && wave_done) {
             bool redrawn = false;
-            if (zoo_mixed) {
-                bool any = false;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (dn[j]) {      // growth_models.py:200: a new model for the next episode
-                        const Words4 w = philox_block(seed, env_offset + (uint64_t)(base + j), step_counter,
-                                                      kStreamAutoReset);
-                        kind[j] = p.kinds[action_int_from_word(w.w0, p.n_models)];
-                        any = true;
-                    }
-                }
-                if (any) store4<int32_t>(b.model_idx, base, n, full, kind);
+            if (zoo_mixed) {      // growth_models.py:200: a new model for the next episode
+                if (redraw_kinds(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, p.kinds, p.n_models, dn,
+                                 kind))
+                    store4<int32_t>(b.model_idx, base, n, full, kind);
             }
             if (kPerEnv) {
                 redrawn = redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
@@ -462,8 +483,11 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
         if (mask && !mask[i]) continue;
         T K = p.K;
         if (is_zoo_tag(MODEL) && p.model == FISHING_MODEL_V11) {
-            const Words4 w = philox_block(seed, env_offset + (uint64_t)i, reset_counter, kStreamReset);
-            b.model_idx[i] = p.kinds[action_int_from_word(w.w0, p.n_models)];
+            const uint64_t env = env_offset + (uint64_t)i;      // quad scheme of redraw_kinds
+            const Words4 w = philox_block(seed, env >> 2, reset_counter, kStreamReset);
+            const uint32_t leg = (uint32_t)(env & 3);
+            const uint32_t word = leg == 0 ? w.w0 : leg == 1 ? w.w1 : leg == 2 ? w.w2 : w.w3;
+            b.model_idx[i] = p.kinds[action_int_from_word(word, p.n_models)];
         }
         if (MODEL == FISHING_MODEL_V4) {
             T r;

@@ -258,8 +258,8 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def philox_words(seed, env_index, step_counter, stream):
     """Counter layout shared with csrc/fishing_common.h (`env_index` = the Philox index:
     the env QUAD index on the noise and policy streams (noise_normal, policy_random_action), the
-    env PAIR index for fishing-v4's redraw on the reset streams (reset_normals), the env index for
-    fishing-v11's model draw):
+    env PAIR index for fishing-v4's redraw on the reset streams (reset_normals), the env QUAD index
+    for fishing-v11's model draw (model_draw)):
     c0 = index[31:0], c1 = stream<<24 | index[55:32], c2 = step[31:0], c3 = step[63:32];
     key = (seed[31:0], seed[63:32])."""
     env = np.asarray(env_index, dtype=np.uint64)
@@ -312,12 +312,26 @@ def noise_normal(seed, env_index, step_counter):
     return np.where((env & np.uint64(1)).astype(bool), zs, zc).astype(np.float32)
 
 
+def quad_word(seed, env_index, counter, stream):
+    """Word (env & 3) of the Philox block of env quad (env >> 2) on `stream`: the per-env word of
+    the policy stream (random actions) and of the reset streams' fishing-v11 model draw."""
+    env, ws = _quad_words(seed, env_index, counter, stream)
+    leg = (env & np.uint64(3)).astype(np.int64)
+    return np.choose(leg, [np.broadcast_to(x, leg.shape) for x in ws]).astype(np.uint32)
+
+
+def model_draw(seed, env_index, counter, stream, kinds):
+    """fishing-v11 (growth_models.py:187,200): index into the model list, (w * n_models) >> 32,
+    mapped to its FISHING_KIND_*."""
+    w = quad_word(seed, env_index, counter, stream).astype(np.uint64)
+    idx = ((w * np.uint64(len(kinds))) >> np.uint64(32)).astype(np.int64)
+    return np.asarray(kinds, dtype=np.int32)[idx]
+
+
 def policy_random_action(model, seed, env_index, step_counter, n_actions=100):
     """Random policy sampled in-kernel: word (env & 3) of the quad's block on the policy
     stream: continuous a = float32(w) * 2**-31 - 1 in [-1, 1]; discrete a = (w * n_actions) >> 32."""
-    env, ws = _quad_words(seed, env_index, step_counter, STREAM_POLICY)
-    leg = (env & np.uint64(3)).astype(np.int64)
-    w = np.choose(leg, [np.broadcast_to(x, leg.shape) for x in ws]).astype(np.uint32)
+    w = quad_word(seed, env_index, step_counter, STREAM_POLICY)
     if model == MODEL_V0:
         return ((w.astype(np.uint64) * np.uint64(n_actions)) >> np.uint64(32)).astype(np.int32)
     return w.astype(np.float32) * np.float32(2.0 ** -31) - np.float32(1.0)

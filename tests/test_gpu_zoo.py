@@ -150,9 +150,11 @@ def test_zoo_philox_auto_reset_vs_oracle(hh, model, dtype):
     r_arr = np.full(n, P.get("r", 0.3), dtype)
     kind = st.model_idx.cpu().numpy() if model == fo.MODEL_V11 else None
     if model == fo.MODEL_V11:
-        w = hh.device_noise(n, seed, 0, fo.STREAM_RESET, off)[0]
-        want = np.array([4, 0, 3])[((w[:, 0].astype(np.uint64) * np.uint64(3)) >> np.uint64(32)).astype(int)]
+        want = fo.model_draw(seed, np.arange(off, off + n, dtype=np.uint64), 0, fo.STREAM_RESET, [4, 0, 3])
         assert np.array_equal(kind, want) and set(np.unique(kind)) == {0, 3, 4}
+        w = hh.device_noise(n // 4, seed, 0, fo.STREAM_RESET, off // 4)[0]          # the device's own words, by quad
+        assert np.array_equal(np.array([4, 0, 3])[((w.reshape(-1)[:n].astype(np.uint64) * np.uint64(3))
+                                                    >> np.uint64(32)).astype(int)], want[:4 * (n // 4)])
     rtol = F64_RTOL if dtype == np.float64 else F32_RTOL
     for s in range(T):
         a = rng.uniform(-1, -0.6, n).astype(np.float32)
@@ -181,8 +183,7 @@ def test_zoo_philox_auto_reset_vs_oracle(hh, model, dtype):
         assert np.array_equal(o, obs)
         t = np.where(m, 0, et).astype(np.int32)
         if model == fo.MODEL_V11 and m.any():
-            w = hh.device_noise(n, seed, s, fo.STREAM_AUTORESET, off)[0]
-            draw = np.array([4, 0, 3])[((w[:, 0].astype(np.uint64) * np.uint64(3)) >> np.uint64(32)).astype(int)]
+            draw = fo.model_draw(seed, np.arange(off, off + n, dtype=np.uint64), s, fo.STREAM_AUTORESET, [4, 0, 3])
             kind = np.where(m, draw, kind).astype(np.int32)
             assert np.array_equal(st.model_idx.cpu().numpy(), kind)
 
