@@ -95,7 +95,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             }
             // ---- all four envs advance branch-free (independent chains, full ILP); a finished
             // env of a no-auto-reset rollout is frozen by selects, not by control flow
-            T obs_in[4], act_rec[4];
+            T obs_in[4], act_rec[4], quota[4];
             bool fin[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -120,45 +120,81 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_quota<T>(q, p.n_actions, KK[j]);
                     else a_c = (T)action_cts_from_quota<T>(q, KK[j], dk);
                 }
-                const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j])
-                                                            : quota_cts<T>(a_c, KK[j]);
+                quota[j] = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j]) : quota_cts<T>(a_c, KK[j]);
                 act_rec[j] = (MODEL == FISHING_MODEL_V0) ? (T)a_d : a_c;
-                T o2, r2;
-                bool d2;
-                int32_t t2;
-                if constexpr (kZoo) {
-                    GrowthT<T> P = p.growth;
-                    if (zoo_mixed) {
-                        const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
-                        P = p.zoo[kk];
+            }
+            T o2[4], r2[4];
+            bool d2[4];
+            int32_t t2[4];
+            bool stepped = false;
+            if constexpr (zoo_mixed) {
+                if (!b.sigma) {     // wave-uniform.  fishing-v11: regroup the wave's envs by growth function
+                    __shared__ T win[4 * 512];
+                    T xh[4], hv[4], xn[4];
+                    int kk[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const T x = (obs[j] + (T)1) * KK[j];
+                        hv[j] = (quota[j] < x) ? quota[j] : x;
+                        const T d = x - hv[j];
+                        xh[j] = ((T)0 > d) ? (T)0 : d;
+                        xn[j] = (T)0;
+                        kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                     }
-                    if (b.sigma) P.sigma = sg[j];
-                    if (zoo_drift) {                 // growth_models.py:151: r += alpha before every draw;
-                        const T r_new = rr[j] + p.alpha;   // a frozen env makes no draw, so its r stays
-                        P.r = r_new;
-                        rr[j] = (AUTO || live[j]) ? r_new : rr[j];
-                        env_step_zoo<T, kZooKind, true>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, o2, r2, d2, t2);
-                    } else {
-                        env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], p.Tmax, o2, r2, d2, t2);
+                    zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * 512, lane);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o2[j] = xn[j] / KK[j] - (T)1;
+                        r2[j] = ((T)0 > hv[j]) ? (T)0 : hv[j];
+                        t2[j] = t[j] + 1;
+                        d2[j] = (t2[j] > p.Tmax) || (xn[j] <= (T)0);
                     }
-                } else {
-                    env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], p.C, p.Tmax, o2, r2, d2, t2, dk);
+                    stepped = true;
                 }
+            }
+            if (!stepped) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (kZoo) {
+                        GrowthT<T> P = p.growth;
+                        if (zoo_mixed) {
+                            const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+                            P = p.zoo[kk];
+                        }
+                        if (b.sigma) P.sigma = sg[j];
+                        if (zoo_drift) {                 // growth_models.py:151: r += alpha before every draw;
+                            const T r_new = rr[j] + p.alpha;   // a frozen env makes no draw, so its r stays
+                            P.r = r_new;
+                            rr[j] = (AUTO || live[j]) ? r_new : rr[j];
+                            env_step_zoo<T, kZooKind, true>(obs[j], t[j], quota[j], z[j], kind[j], P, KK[j], p.Tmax, o2[j], r2[j],
+                                                            d2[j], t2[j]);
+                        } else {
+                            env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota[j], z[j], kind[j], P, KK[j], p.Tmax, o2[j],
+                                                             r2[j], d2[j], t2[j]);
+                        }
+                    } else {
+                        env_step<T, MODEL>(obs[j], t[j], quota[j], z[j], rr[j], KK[j], sg[j], p.C, p.Tmax, o2[j], r2[j], d2[j],
+                                           t2[j], dk);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
                 if (AUTO) {
-                    obs[j] = o2;
-                    rew[j] = r2;
-                    dn[j] = d2;
-                    t[j] = t2;
-                    er[j] = er[j] + r2;
-                    fin[j] = d2 && live[j];
+                    obs[j] = o2[j];
+                    rew[j] = r2[j];
+                    dn[j] = d2[j];
+                    t[j] = t2[j];
+                    er[j] = er[j] + r2[j];
+                    fin[j] = d2[j] && live[j];
                 } else {
                     const bool lv = live[j];
-                    obs[j] = lv ? o2 : obs[j];
-                    rew[j] = lv ? r2 : (T)0;
-                    dn[j] = lv ? d2 : dn[j];
-                    t[j] = lv ? t2 : t[j];
-                    er[j] = lv ? er[j] + r2 : er[j];
-                    fin[j] = d2 && lv;
+                    obs[j] = lv ? o2[j] : obs[j];
+                    rew[j] = lv ? r2[j] : (T)0;
+                    dn[j] = lv ? d2[j] : dn[j];
+                    t[j] = lv ? t2[j] : t[j];
+                    er[j] = lv ? er[j] + r2[j] : er[j];
+                    fin[j] = d2[j] && lv;
                 }
             }
             if (traj && active) {

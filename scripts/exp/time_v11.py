@@ -20,3 +20,15 @@ for dtype, auto in ((torch.float32, True), (torch.float32, False), (torch.float6
     print(json.dumps({"id": "fishing-v11", "dtype": str(dtype)[6:], "auto_reset": auto, "us": round(us, 2), "bytes_per_env_step": per,
                       "TBps": round(n * per / us / 1e6, 2)}), flush=True)
     del env
+for policy, param in (("random", 0.0), ("escapement", 0.5)):
+    env = gf.make("fishing-v11", num_envs=n, seed=1)
+    for d in env.model_params.values():
+        d["sigma"] = 0.1
+    env.reset(); env.rollout(101, policy=policy, param=param); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); env.rollout(505, policy=policy, param=param); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = statistics.median(ts)
+    print(json.dumps({"id": "fishing-v11", "rollout": policy, "env_steps_per_s": "%.3e" % (n * 505 / ms * 1e3)}), flush=True)
