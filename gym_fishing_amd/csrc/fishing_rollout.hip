@@ -3,8 +3,8 @@
 // The callers of step() in the reference are Python loops (shared_env.py:29-54 simulate_mdp,
 // examples/const_escapement.py:19-26, SB3's DummyVecEnv).  Here the loop over time runs inside
 // the kernel: a thread keeps its 4 envs' (obs, t, r, K, sigma, ep_return) in registers for
-// T steps, draws noise and the policy's action from the same Philox block a step-by-step
-// run would use, and touches HBM once at entry and once at exit (plus the optional
+// T steps, draws the noise from the same Philox blocks a step-by-step run would use (and the
+// random policy's actions from the policy stream), and touches HBM once at entry and once at exit (plus the optional
 // trajectory record).  Results equal T fishing_step_* calls fed the policy's actions.
 //
 // Bound: VALU (Philox + transcendental issue), not HBM -- reported as env-steps/s only.

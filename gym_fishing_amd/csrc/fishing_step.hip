@@ -6,7 +6,7 @@
 // f32 / i32 stream is read or written with one 16-byte access per lane (1 KiB per wave
 // instruction) and the done bytes with one dword per lane.  No env ever reads another env's
 // state: there is no LDS staging of the streams (nothing is reused) -- LDS only carries the
-// per-workgroup reduction of the episodic-return record.
+// per-workgroup reduction of the episodic-return record and fishing-v11's regroup-by-kind windows.
 //
 // Roofline: HBM.  Algorithmic bytes per env-step: f32 layout 25 B
 // (R obs 4 + action 4 + t 4; W obs 4 + reward 4 + done 1 + t 4), v4 +12 B (r, K, sigma
