@@ -509,8 +509,15 @@ reduce_returns_kernel(const double* __restrict__ partials, double* __restrict__ 
     // order, then a fixed shuffle tree combines the 64 lanes: same bits on every run.
     const int field = threadIdx.x >> 6;
     const int lane = threadIdx.x & (kWave - 1);
+    // all 64 loads of a lane are issued before the first add (one latency instead of 64 in a row:
+    // 20 us -> a few us), the adds stay in slot order
+    constexpr int kPerLane = kMaxBlocks / kWave;
+    double v[kPerLane];
+#pragma unroll
+    for (int k = 0; k < kPerLane; ++k) v[k] = partials[(lane + k * kWave) * kPartialFields + field];
     double s = 0.0;
-    for (int slot = lane; slot < kMaxBlocks; slot += kWave) s += partials[slot * kPartialFields + field];
+#pragma unroll
+    for (int k = 0; k < kPerLane; ++k) s += v[k];
     s = wave_sum(s);
     if (lane == 0) out4[field] = s;
 }
