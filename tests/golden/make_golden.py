@@ -215,6 +215,12 @@ def main():
     edge_actions = [-5.0, -1.0, -0.9375, 0.0, 5.0, 1.0, -0.5, -1.0, 0.25, -0.75]
     run_case("v1_edge_noreset", "fishing-v1", {"sigma": 0.1, "Tmax": 6}, [31, 32], 10,
              lambda g, s, e: f32(edge_actions[s]), auto_reset=False)
+    # non-finite and huge actions: np.clip passes NaN through, Python's min(x, nan) keeps x (everything is
+    # harvested), +-inf / +-1e30 clip to the Box bounds
+    special = [float("nan"), -0.9, float("inf"), -0.95, float("-inf"), -0.9, float("nan"), float("nan"), 0.0, -1.0,
+               1e30, -1e30]
+    run_case("v1_special_actions", "fishing-v1", {"sigma": 0.1, "Tmax": 9}, [33, 34], 12,
+             lambda g, s, e: f32(special[s]))
     # --- fishing-v0 (BASELINE config 3 at toy N)
     run_case("v0_sigma01_random", "fishing-v0", {"sigma": 0.1}, list(range(41, 49)), 130,
              lambda g, s, e: g.randint(0, 100))
