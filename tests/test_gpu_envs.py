@@ -552,3 +552,35 @@ def test_numpy_vec_env_adapter_follows_the_sb3_protocol(gf):
         FishingVecEnv(gf.make("fishing-v1"))                          # scalar protocol
     assert venv.seed(5) == [5 + i for i in range(n)]
     venv.close()
+
+
+def test_two_envs_on_concurrent_streams_match_sequential_runs(gf):
+    """The library holds no state and only enqueues on the caller's stream (re-entrant per
+    stream): two envs stepped concurrently on two streams give exactly what each gives alone."""
+    import torch
+    n, K = 1 << 16, 40
+
+    def build(seed):
+        env = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=seed, track_returns=True)
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        acts = (torch.rand((4, n), device="cuda", generator=g) * 2 - 1).float()
+        env.reset()
+        return env, acts
+    alone = []
+    for seed in (1, 2):
+        env, acts = build(seed)
+        env.step_many(acts, K)
+        torch.cuda.synchronize()
+        alone.append((env._obs.clone(), env._t.clone(), env.episode_stats()))
+    pairs = [build(1), build(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for k in range(K):                       # interleave the enqueues, one step at a time
+        for (env, acts), s in zip(pairs, streams):
+            with torch.cuda.stream(s):
+                env.step(acts[k % 4])
+    torch.cuda.synchronize()
+    for (env, _), (obs, t, stats), s in zip(pairs, alone, streams):
+        with torch.cuda.stream(s):
+            got = env.episode_stats()
+        assert torch.equal(env._obs, obs) and torch.equal(env._t, t) and got == stats
