@@ -31,6 +31,17 @@ POLICIES = {"random": POLICY_RANDOM, "constant": POLICY_CONSTANT, "escapement": 
             "msy": POLICY_MSY}
 
 
+# raw hipStream_t of torch's current stream: the private fast path Inductor / Triton use (0.2 us) instead
+# of building a torch.cuda.Stream object per call (2.6 us of a 10 us step() on the host)
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _current_stream_ptr(device_index):
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def _require_device(device):
     if not torch.cuda.is_available():
         raise FishingLibraryError(
@@ -309,7 +320,7 @@ class BaseFishingEnv(_gym_env_base()):
         return b
 
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return _current_stream_ptr(self.device.index)
 
     # ------------------------------------------------------------------ state
     def _set_initial_state(self):
@@ -451,7 +462,7 @@ class BaseFishingEnv(_gym_env_base()):
         on_device = self._counter is not None
         host_count = 0 if on_device else self._step_count
         if torch.cuda.current_device() == self.device.index:
-            stream = torch.cuda.current_stream().cuda_stream
+            stream = _current_stream_ptr(self.device.index)
             rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed, host_count, stream)
             if on_device and not rc:
                 rc = self._lib.fishing_counter_add(self._counter.data_ptr(), 1, stream)
