@@ -914,6 +914,8 @@ int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stre
     return (int)hipGetLastError();
 }
 
+int fishing_stream_synchronize(fishing_stream_t stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }
+
 int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream) {
     if (!return_partials || !out4) return FISHING_ERR_NULL;
     fishing::reduce_returns_kernel<<<1, 256, 0, (hipStream_t)stream>>>(return_partials, out4);

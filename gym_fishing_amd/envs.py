@@ -187,6 +187,7 @@ class BaseFishingEnv(_gym_env_base()):
             self._partials = torch.zeros(int(self._lib.fishing_partials_len()), dtype=torch.float64, device=dev)
             self._record = torch.zeros(4, dtype=torch.float64, device=dev)
         self._action_buf = None
+        self._scalar_views = None
         self._last_action = None
         self._cparams = self._pkey = self._cbuf = None
         self._counter = None          # device-resident step counter (graph-replay mode), else host int
@@ -331,14 +332,18 @@ class BaseFishingEnv(_gym_env_base()):
 
     def _read_scalar(self):
         """obs, t, reward, done of the single env, read straight from the pinned arena."""
-        torch.cuda.current_stream(self.device).synchronize()      # the kernels wrote pinned host memory
-        host = self._arena_np
-        o_obs, o_t, o_rew, o_done = self._arena_offs[:4]
-        ftype = np.float64 if self.dtype == torch.float64 else np.float32
-        obs = host[o_obs:o_obs + np.dtype(ftype).itemsize].view(ftype).astype(np.float64)
-        t = int(host[o_t:o_t + 4].view(np.int32)[0])
-        rew = float(host[o_rew:o_rew + np.dtype(ftype).itemsize].view(ftype)[0])
-        return obs, t, rew, bool(host[o_done])
+        rc = self._lib.fishing_stream_synchronize(self._stream())   # the kernels wrote pinned host memory
+        if rc:
+            _capi.check(rc, "fishing_stream_synchronize")
+        v = self._scalar_views
+        if v is None:       # NumPy views of the env's four cells in the pinned arena, made once
+            host = self._arena_np
+            o_obs, o_t, o_rew, o_done = self._arena_offs[:4]
+            ftype = np.float64 if self.dtype == torch.float64 else np.float32
+            w = np.dtype(ftype).itemsize
+            v = self._scalar_views = (host[o_obs:o_obs + w].view(ftype), host[o_t:o_t + 4].view(np.int32),
+                                      host[o_rew:o_rew + w].view(ftype), host[o_done:o_done + 1])
+        return v[0].astype(np.float64), int(v[1][0]), float(v[2][0]), bool(v[3][0])
 
     def _publish_scalar_state(self):
         if self._scalar:

@@ -196,6 +196,11 @@ int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x
 int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
                                 fishing_stream_t stream);
 
+/* hipStreamSynchronize(stream): lets a host binding without a HIP runtime binding of its own (ctypes)
+ * wait for the launches it enqueued -- the scalar gym.Env protocol reads its one env's results from
+ * pinned, device-mapped memory right after.  Returns 0 or the hipError_t. */
+int fishing_stream_synchronize(fishing_stream_t stream);
+
 /* Test/diagnostic: the generator itself.  For Philox index (env_offset + i): words[4*i..4*i+3] =
  * the Philox4x32-10 block on stream `stream_tag`, z0 / z1 = the cos / sin legs of the Box-Muller
  * pair of words (0, 1).  What the index means per stream: tags 0 (step noise) and 3 (random-policy
