@@ -12,7 +12,7 @@ everything on the device; this wrapper is the boundary for callers that want wha
     infos    list of N dicts; infos[i]["terminal_observation"] (ndarray [1]) where dones[i]
 
 The hot path is unchanged -- one kernel launch per step with the fused auto-reset -- followed by one
-device-to-host copy per output.  When stable_baselines3 is importable the class derives from its
+asynchronous device-to-host copy per output into pinned staging buffers and a single stream sync.  When stable_baselines3 is importable the class derives from its
 `VecEnv`, so `PPO("MlpPolicy", FishingVecEnv(env))` accepts it as is; without SB3 it is a plain
 class with the same methods.
 """
@@ -49,32 +49,59 @@ class FishingVecEnv(_BASE):
             self.observation_space = env.observation_space
             self.action_space = env.action_space
         self._obs_dtype = np.dtype(getattr(env.observation_space, "dtype", np.float32))
+        # Pinned staging: the actions go up and the env's state arena (obs | t | reward | done, one
+        # allocation) plus the terminal observations come down as three asynchronous copies around the
+        # step kernel, followed by ONE stream sync -- a .cpu() per output would sync four times and an
+        # upload from pageable memory once more.
+        n = env.num_envs
+        esz = torch.empty(0, dtype=env.dtype).element_size()
+        offs = env._arena_offs
+        self._arena_end = offs[3] + n
+        self._h_arena = torch.empty(self._arena_end, dtype=torch.uint8).pin_memory()
+        self._hv_obs = self._h_arena[offs[0]:offs[0] + n * esz].view(env.dtype).numpy()
+        self._hv_rew = self._h_arena[offs[2]:offs[2] + n * esz].view(env.dtype).numpy()
+        self._hv_done = self._h_arena[offs[3]:offs[3] + n].numpy()
+        self._h_term = torch.empty(n, dtype=env.dtype).pin_memory()
+        self._hv_term = self._h_term.numpy()
+        self._h_act = torch.empty(n, dtype=env._want).pin_memory()
+        self._hv_act = self._h_act.numpy()
+        self._d_act = torch.empty(n, dtype=env._want, device=env.device)
         self._pending = None
         self.render_mode = None
         self.metadata = dict(getattr(env, "metadata", {}))
 
     # ------------------------------------------------------------------ VecEnv protocol
+    def _download(self, with_terminal):
+        env = self.env
+        self._h_arena.copy_(env._arena[:self._arena_end], non_blocking=True)
+        if with_terminal:
+            self._h_term.copy_(env._terminal_obs, non_blocking=True)
+        torch.cuda.current_stream(env.device).synchronize()
+
     def reset(self):
-        obs = self.env.reset()
-        return obs.detach().to("cpu", torch.float32).numpy().astype(self._obs_dtype, copy=False)
+        self.env.reset()
+        self._download(False)
+        return self._hv_obs.astype(self._obs_dtype).reshape(self.num_envs, 1)
 
     def step_async(self, actions):
         self._pending = actions
 
     def step_wait(self):
-        a = np.asarray(self._pending)
+        self._hv_act[:] = np.asarray(self._pending).reshape(self.num_envs)
         self._pending = None
-        obs, rew, done, info = self.env.step(a.reshape(self.num_envs))
-        # one stream sync for the four copies
-        obs_h = obs.detach().to("cpu", torch.float32, non_blocking=False).numpy().astype(self._obs_dtype, copy=False)
-        rew_h = rew.detach().to("cpu", torch.float32).numpy()
-        done_h = done.detach().cpu().numpy().astype(bool, copy=False)
-        infos = [{} for _ in range(self.num_envs)]
+        self._d_act.copy_(self._h_act, non_blocking=True)
+        self.env.step(self._d_act)
+        self._download(True)
+        n = self.num_envs
+        obs_h = self._hv_obs.astype(self._obs_dtype).reshape(n, 1)      # copies: callers may keep them across steps
+        rew_h = self._hv_rew.astype(np.float32)
+        done_h = self._hv_done.astype(bool)
+        infos = [{} for _ in range(n)]
         idx = np.flatnonzero(done_h)
         if idx.size:
-            term = info["terminal_observation"].detach().to("cpu", torch.float32).numpy().astype(self._obs_dtype, copy=False)
+            term = self._hv_term.astype(self._obs_dtype)
             for i in idx:
-                infos[i]["terminal_observation"] = term[i].copy()
+                infos[i]["terminal_observation"] = term[i:i + 1]
         return obs_h, rew_h, done_h, infos
 
     def step(self, actions):
