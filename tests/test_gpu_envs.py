@@ -546,6 +546,18 @@ def test_numpy_vec_env_adapter_follows_the_sb3_protocol(gf):
     v0.reset()
     obs, rew, done, infos = v0.step(np.full(8, 10))
     assert np.allclose(rew, 0.1) and not done.any() and obs.dtype == np.float32
+    # the fp64 parity layout and per-env parameters behind the same float32 NumPy boundary
+    v4 = make_vec_env("fishing-v4", 16, sigma=0.05, seed=2, dtype=torch.float64)
+    t4 = gf.make("fishing-v4", num_envs=16, sigma=0.05, seed=2, dtype=torch.float64, record_terminal_obs=True)
+    o = v4.reset()
+    t4.reset()
+    assert o.shape == (16, 1) and o.dtype == np.float32 and (o == np.float32(0.75)).all()      # quirk a9: x0 un-normalised
+    a4 = np.full((16, 1), -0.8, np.float32)
+    for _ in range(3):
+        o, r, d, inf = v4.step(a4)
+        o2, r2, d2, _ = t4.step(torch.as_tensor(a4))
+        assert np.array_equal(o, o2.cpu().numpy().astype(np.float32)) and np.array_equal(r, r2.cpu().numpy().astype(np.float32))
+        assert np.array_equal(d, d2.cpu().numpy())
     with pytest.raises(ValueError):
         FishingVecEnv(gf.make("fishing-v1", num_envs=4))              # no terminal-obs record
     with pytest.raises(ValueError):
