@@ -1,4 +1,5 @@
-"""A/B build variants on the general-kernel workloads (fp64 v1, fp32 zoo v9, fp32 v1 with done_bits)."""
+"""A/B build variants on the general-kernel workloads (fp64 v4, fp32 v11, fp32 v1 with done_bits, fp32 v1 with
+the terminal-observation record)."""
 import glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
@@ -8,8 +9,11 @@ import gym_fishing_amd as gf
 n = 1 << 22
 acts = torch.rand((4, n), device="cuda") * 0.5 - 1
 res = {}
-for key, env_id, kw in (("v1_f64", "fishing-v1", dict(dtype=torch.float64)), ("v9_f32", "fishing-v9", {}), ("v1_f32_bits", "fishing-v1", dict(done_bits=True))):
-    env = gf.make(env_id, sigma=0.1, num_envs=n, seed=1, **kw); env.reset(); env.step_many(acts, 100)
+for key, env_id, kw in (("v4_f64", "fishing-v4", dict(dtype=torch.float64)), ("v11_f32", "fishing-v11", {}), ("v1_f32_bits", "fishing-v1", dict(done_bits=True)),
+                        ("v1_f32_term", "fishing-v1", dict(record_terminal_obs=True))):
+    if env_id != "fishing-v11":
+        kw = dict(kw, sigma=0.1)
+    env = gf.make(env_id, num_envs=n, seed=1, **kw); env.reset(); env.step_many(acts, 100)
     ts = []
     for _ in range(7):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
