@@ -596,3 +596,40 @@ def test_two_envs_on_concurrent_streams_match_sequential_runs(gf):
         with torch.cuda.stream(s):
             got = env.episode_stats()
         assert torch.equal(env._obs, obs) and torch.equal(env._t, t) and got == stats
+
+
+@pytest.mark.parametrize("env_id", ["fishing-v0", "fishing-v1", "fishing-v2", "fishing-v4", "fishing-v5", "fishing-v6",
+                                    "fishing-v7", "fishing-v8", "fishing-v9", "fishing-v10", "fishing-v11"])
+def test_long_run_invariants_every_id(gf, env_id):
+    """Size-independent invariants over a long auto-resetting run of every id (N = 4096 + 3, ragged; 600 steps
+    of in-kernel noise and random actions): the observation never drops below -1 (population >= 0), stays
+    finite, the year counter stays in [0, Tmax], rewards are >= 0 and never exceed the stock, and the
+    episodic-return record counts exactly the dones it was shown."""
+    import torch
+    n, T, Tmax = 4096 + 3, 600, 25
+    kw = dict(num_envs=n, seed=11, Tmax=Tmax, track_returns=True)
+    if env_id != "fishing-v11":
+        kw["sigma"] = 0.1
+    env = gf.make(env_id, **kw)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dones = 0
+    K = float(env.params["K"]) if env_id not in ("fishing-v4",) else None
+    for s in range(T):
+        if env_id == "fishing-v0":
+            a = torch.randint(0, 100, (n,), device="cuda", generator=g, dtype=torch.int32)
+        else:
+            a = torch.rand(n, device="cuda", generator=g) * 1.2 - 1.0          # quota in [0, 1.2 K)
+        prev = env._obs.clone()
+        obs, rew, done, _ = env.step(a)
+        dones += int(done.sum())
+        if s % 50 == 0 or s == T - 1:
+            assert bool(torch.isfinite(obs).all()) and bool((obs >= -1.0).all()), (env_id, s)
+            assert bool((env._t >= 0).all()) and bool((env._t <= Tmax).all())
+            assert bool((rew >= 0).all())
+            if K is not None and env_id != "fishing-v11":
+                # harvest <= stock before the step: reward <= (obs_prev + 1) * K (+ rounding)
+                assert bool((rew <= (prev + 1.0) * K + 1e-5).all()), (env_id, s)
+    st = env.episode_stats()
+    assert st["n_episodes"] == dones and dones >= n * (T // (Tmax + 1))
+    assert st["sum_length"] <= dones * (Tmax + 1) and st["mean_return"] >= 0
