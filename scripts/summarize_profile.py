@@ -91,6 +91,10 @@ def main():
         per = 25 + (8 if a.with_returns else 0)
         summ["algorithmic_bytes_per_launch"] = per * a.n_envs
         summ["traffic_over_algorithmic"] = (rd + wr) / (per * a.n_envs)
+        if "avg_ns" in summ:        # achieved HBM rate from rocprofv3 alone: bytes per launch / average duration
+            summ["achieved_GBps_algorithmic"] = per * a.n_envs / summ["avg_ns"]
+            summ["achieved_GBps_pmc_traffic"] = (rd + wr) / summ["avg_ns"]
+            summ["frac_of_8TBps_peak"] = summ["achieved_GBps_algorithmic"] / 8000.0
     bj = os.path.join(a.raw, "bench_trace.json")
     if os.path.exists(bj):
         try:
