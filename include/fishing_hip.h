@@ -10,12 +10,14 @@
  * the reference would add.
  *
  * Conventions
- *   - extern "C", plain pointers and sizes only.  Every pointer is a DEVICE pointer
- *     owned by the caller (e.g. torch tensors), 16-byte aligned, contiguous.
+ *   - extern "C", plain pointers and sizes only.  Every pointer is a DEVICE-accessible pointer
+ *     owned by the caller (device memory such as torch tensors, or pinned device-mapped host
+ *     memory), 16-byte aligned, contiguous.
  *   - every function returns 0 on success or a negative FISHING_ERR_* code (argument
  *     errors, nothing launched) or a positive hipError_t (launch failure).
  *   - the library keeps no global state: re-entrant, one call = kernel launches
- *     enqueued on `stream` (a hipStream_t), no host synchronisation, graph-capturable.
+ *     enqueued on `stream` (a hipStream_t), no host synchronisation (fishing_stream_synchronize
+ *     is the one call that waits), graph-capturable.
  *   - `_f32` = fp32 fast layout (obs/reward/params float, 25 B per env-step);
  *     `_f64` = fp64 parity layout (obs/reward/params double; bit-exact to the
  *     reference's NumPy arithmetic for v0/v1/v4 given the same noise).
