@@ -488,7 +488,7 @@ def test_bench_contract_json_line(gf):
     assert abs(d["value"] - (1 << 18) * 40 / (d["ms_per_step"] * 40 / 1e3)) / d["value"] < 1e-9
 
 
-@pytest.mark.parametrize("script", ["const_escapement.py", "random_rollout.py"])
+@pytest.mark.parametrize("script", ["const_escapement.py", "random_rollout.py", "vec_env_numpy.py"])
 def test_examples_run(gf, script):
     import subprocess
     import sys
@@ -499,6 +499,8 @@ def test_examples_run(gf, script):
     assert out.returncode == 0, out.stderr[-1500:]
     if script == "const_escapement.py":
         assert "scalar protocol: 100 steps, return 7.675000" in out.stdout and "mean_return" in out.stdout
+    elif script == "vec_env_numpy.py":
+        assert "episodes 768, mean reward" in out.stdout          # 256 envs x three 101-step episodes
     else:
         assert "env-steps/s" in out.stdout
 
