@@ -95,7 +95,7 @@ class BaseFishingEnv(_gym_env_base()):
 
     def __init__(self, params=None, Tmax=100, file=None, *, num_envs=None, device=None, seed=0,
                  dtype=None, auto_reset=None, env_offset=0, record_terminal_obs=False,
-                 track_returns=False, done_bits=False, launch_blocks=0, launch_threads=0, compact=False):
+                 track_returns=False, done_bits=False, launch_blocks=0, launch_threads=0, compact=False, rng=None):
         params = dict({"r": 0.3, "K": 1, "sigma": 0.0, "x0": 0.75} if params is None else params)
         self.params = params
         self.Tmax = int(Tmax)
@@ -119,6 +119,16 @@ class BaseFishingEnv(_gym_env_base()):
             raise ValueError("dtype must be torch.float32 (fast layout) or torch.float64 (parity layout)")
         self.dtype = dtype
         self.auto_reset = (not self._scalar) if auto_reset is None else bool(auto_reset)
+        # Where the random numbers come from.  "philox": the counter-based in-kernel streams keyed by `seed`.
+        # "numpy" (scalar protocol only, its default): exactly the reference's draws from NumPy's global legacy
+        # stream -- np.random.normal(0, 1) once per step() also at sigma = 0 (base_fishing_env.py:130),
+        # np.random.normal(mean, sigma_p) for fishing-v4's K then r (fishing_model_error.py:37-43),
+        # np.random.choice(models) for fishing-v11 (growth_models.py:187,200) -- handed to the kernel as external
+        # noise, so `np.random.seed(s)` reproduces the reference's trajectory.
+        rng = ("numpy" if self._scalar else "philox") if rng is None else rng
+        if rng not in ("numpy", "philox") or (rng == "numpy" and not self._scalar):
+            raise ValueError("rng must be 'philox', or 'numpy' for the scalar protocol")
+        self._np_rng = rng == "numpy"
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._step_count = 0
         self._reset_count = 0
@@ -195,6 +205,8 @@ class BaseFishingEnv(_gym_env_base()):
         if self._scalar:
             self._host_action = self._arena[self._action_off:self._action_off + 4].view(self._want)
             self._host_action_np = self._host_action.numpy()
+            self._host_z = self._arena[self._action_off + 16:self._action_off + 16 + esz].view(dtype)
+            self._host_z_np = self._host_z.numpy()
         self._obs_view = self._obs.view(N, 1)
         self._done_view = self._done.view(torch.bool)
         self._info = {}
@@ -330,6 +342,19 @@ class BaseFishingEnv(_gym_env_base()):
         self._t.zero_()
         self._publish_scalar_state()
 
+    def _numpy_redraw(self):
+        """rng="numpy": the per-episode draws of fishing-v4 / fishing-v11 from NumPy's global stream, in the
+        reference's order, replacing what the reset kernel drew from Philox."""
+        if not self._np_rng:
+            return
+        if self.MODEL == MODEL_V4:
+            K = float(np.clip(np.random.normal(self.K_mean, self.sigma_p), 0, 1e6))
+            r = float(np.clip(np.random.normal(self.r_mean, self.sigma_p), 0, 1e6))
+            self._K_arr.fill_(K)
+            self._r_arr.fill_(r)
+        elif self.MODEL == MODEL_V11:
+            self._model_idx.fill_(KIND_OF_NAME[str(np.random.choice(self.models))])
+
     def _read_scalar(self):
         """obs, t, reward, done of the single env, read straight from the pinned arena."""
         rc = self._lib.fishing_stream_synchronize(self._stream())   # the kernels wrote pinned host memory
@@ -355,8 +380,11 @@ class BaseFishingEnv(_gym_env_base()):
             self.years_passed = self._t
 
     def seed(self, seed=None):
-        """The reference has no seed() (base_fishing_env.py:13); this keys the Philox streams."""
+        """The reference has no seed() (base_fishing_env.py:13); this keys the Philox streams and, for
+        rng="numpy", seeds NumPy's global stream the way a user of the reference would (np.random.seed)."""
         self._seed = int(0 if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        if self._np_rng and seed is not None:
+            np.random.seed(int(seed) & 0xFFFFFFFF)
         self._step_count = 0
         self._reset_count = 0
         if self._counter is not None:
@@ -416,6 +444,7 @@ class BaseFishingEnv(_gym_env_base()):
                                 self._seed, self._reset_count, self._stream())
         _capi.check(rc, "fishing_reset")
         self._reset_count += 1
+        self._numpy_redraw()
         if self._scalar:
             self.reward = 0 if self.MODEL != MODEL_V4 else self.reward   # v4 leaves it (quirk B8)
             self.harvest = 0
@@ -463,6 +492,9 @@ class BaseFishingEnv(_gym_env_base()):
         z = None
         if noise is not None:
             z = torch.as_tensor(noise).to(device=self.device, dtype=self.dtype).reshape(self.num_envs).contiguous()
+        elif self._np_rng:
+            self._host_z_np[0] = np.random.normal(0, 1)       # the reference's draw, from the global stream
+            z = self._host_z
         bufs = self._step_buffers(a.data_ptr(), z.data_ptr() if z is not None else None)
         on_device = self._counter is not None
         host_count = 0 if on_device else self._step_count
@@ -741,6 +773,7 @@ class FishingModelError(BaseFishingEnv):
                                 self._stream())
         _capi.check(rc, "fishing_reset")
         self._reset_count += 1
+        self._numpy_redraw()
         if self._scalar:       # the arena is host memory here: let the reset kernel land before overwriting
             torch.cuda.current_stream(self.device).synchronize()
         self._obs.fill_(float(self.init_state) / float(self.K_mean) - 1.0)
@@ -852,6 +885,7 @@ class ModelUncertainty(BaseFishingEnv):
                                 self._stream())
         _capi.check(rc, "fishing_reset")
         self._reset_count += 1
+        self._numpy_redraw()
         self._publish_scalar_state()
 
     @property

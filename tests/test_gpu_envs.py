@@ -24,6 +24,40 @@ def bits(x):
     return np.asarray(x, dtype=np.float64).view(np.int64)
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_scalar_protocol_seeded_like_the_reference_reproduces_it(gf, name):
+    """The north star's "seeded identically": np.random.seed(s), then the drop-in env driven exactly like the
+    reference was when the fixtures were captured (tests/golden/make_golden.py: construct, reset, step, reset on
+    done) -- no recorded noise handed in.  The scalar protocol draws from NumPy's global legacy stream in the
+    reference's order (one normal per step also at sigma = 0, K then r for fishing-v4) and the kernels do the
+    arithmetic: every obs / reward / done / K / r equals the reference bit-for-bit (fishing-v2: exp tolerance)."""
+    c = CASES[name]
+    is_v2, is_v4 = c.id == "fishing-v2", c.id == "fishing-v4"
+    for e, seed in enumerate(c.meta["seeds"]):
+        np.random.seed(seed)
+        env = gf.make(c.id, **c.kwargs)
+        if c.init_reset:
+            obs = env.reset()
+            assert bits(obs[0]) == bits(c.reset_obs[e, 0])
+        for s in range(c.nsteps):
+            if is_v4:
+                assert bits(float(env.K)) == bits(c.K[e, s]) and bits(float(env.r)) == bits(c.r[e, s]), (name, e, s)
+            a = int(c.action[e, s]) if c.id == "fishing-v0" else np.array([c.action[e, s]], dtype=np.float32)
+            obs, rew, done, info = env.step(a)
+            if is_v2:
+                assert abs(obs[0] - c.obs[e, s]) < 1e-12, (name, e, s)   # free-running: exp ulps accumulate
+            else:
+                assert bits(obs[0]) == bits(c.obs[e, s]) or (np.isnan(obs[0]) and np.isnan(c.obs[e, s])), (name, e, s)
+                assert bits(rew) == bits(c.reward[e, s]) and done == bool(c.done[e, s])
+            assert env.years_passed == c.t[e, s]
+            if done and c.auto_reset:
+                obs = env.reset()
+                assert bits(obs[0]) == bits(c.reset_obs[e, s + 1])
+        env.close()
+    with pytest.raises(ValueError):
+        gf.make("fishing-v1", num_envs=8, rng="numpy")
+
+
 @pytest.mark.parametrize("name", ["v1_sigma0_const", "v1_sigma01_random", "v1_params", "v1_edge_noreset",
                                   "v0_sigma01_random", "v0_edge", "v2_sigma0_zeroquota", "v4_sigma005",
                                   "v4_noinitreset"])

@@ -310,3 +310,37 @@ def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
         if ret:
             ra, rb = A.record(), B.record()
             assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12) and ra[2] > 0
+
+
+ZOO_BY_NAME = {c.name: c for c in load_zoo_cases()}
+
+
+@pytest.mark.parametrize("name", sorted(ZOO_BY_NAME))
+def test_zoo_scalar_protocol_seeded_like_the_reference(name):
+    """np.random.seed(s) + the drop-in scalar env, driven as the fixtures were captured: the env consumes NumPy's
+    global stream like the reference (one lognormal's normal per step, np.random.choice(models) per fishing-v11
+    episode), so the whole free-running trajectory follows the reference -- exactly for rewards taken from an
+    unchanged stock, the growth-function picks of fishing-v11 and fishing-v10's drifting r, within the
+    accumulated log / exp rounding for the populations."""
+    import gym_fishing_amd as gf
+    c = ZOO_BY_NAME[name]
+    names = ["allen", "beverton_holt", "myers", "may", "ricker"]
+    for e, seed in enumerate(c.meta["seeds"][:3]):
+        np.random.seed(seed)
+        env = gf.make(c.id, **c.kwargs)
+        K = float(env.params["K"])
+        obs = env.reset()
+        assert obs[0] == c.reset_obs[e, 0]
+        for s in range(c.nsteps):
+            if c.id == "fishing-v11":
+                assert env.model == names[c.model_idx[e, s]], (name, e, s)
+            a = np.array([c.action[e, s]], dtype=np.float32)
+            obs, rew, done, _ = env.step(a)
+            if c.id == "fishing-v10":
+                assert float(env.r) == c.params_r[e, s] + c.kwargs["alpha"]      # drifted once more by this step
+            assert np.isclose((obs[0] + 1.0) * K, (c.obs[e, s] + 1.0) * K, rtol=1e-9, atol=1e-12), (name, e, s)
+            assert np.isclose(rew, c.reward[e, s], rtol=1e-9, atol=1e-12) and done == bool(c.done[e, s])
+            if done:
+                obs = env.reset()
+                assert obs[0] == c.reset_obs[e, s + 1]
+        env.close()
