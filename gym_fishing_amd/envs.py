@@ -125,9 +125,13 @@ class BaseFishingEnv(_gym_env_base()):
         # np.random.normal(mean, sigma_p) for fishing-v4's K then r (fishing_model_error.py:37-43),
         # np.random.choice(models) for fishing-v11 (growth_models.py:187,200) -- handed to the kernel as external
         # noise, so `np.random.seed(s)` reproduces the reference's trajectory.
+        # With N envs "numpy" draws np.random.normal(0, 1, N) per step -- the order in which SB3's DummyVecEnv
+        # steps N reference envs one after the other -- for the ids whose reset() draws nothing (not v4 / v11,
+        # whose per-episode draws interleave with the step draws env by env).
         rng = ("numpy" if self._scalar else "philox") if rng is None else rng
-        if rng not in ("numpy", "philox") or (rng == "numpy" and not self._scalar):
-            raise ValueError("rng must be 'philox', or 'numpy' for the scalar protocol")
+        if rng not in ("numpy", "philox") or (rng == "numpy" and not self._scalar and self.MODEL in (MODEL_V4, MODEL_V11)):
+            raise ValueError("rng must be 'philox' or 'numpy' ('numpy' with num_envs is not available for "
+                             "fishing-v4 / fishing-v11)")
         self._np_rng = rng == "numpy"
         self._seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._step_count = 0
@@ -493,8 +497,11 @@ class BaseFishingEnv(_gym_env_base()):
         if noise is not None:
             z = torch.as_tensor(noise).to(device=self.device, dtype=self.dtype).reshape(self.num_envs).contiguous()
         elif self._np_rng:
-            self._host_z_np[0] = np.random.normal(0, 1)       # the reference's draw, from the global stream
-            z = self._host_z
+            if self._scalar:
+                self._host_z_np[0] = np.random.normal(0, 1)   # the reference's draw, from the global stream
+                z = self._host_z
+            else:                                             # N reference envs stepped in order (DummyVecEnv)
+                z = torch.as_tensor(np.random.normal(0, 1, self.num_envs)).to(device=self.device, dtype=self.dtype)
         bufs = self._step_buffers(a.data_ptr(), z.data_ptr() if z is not None else None)
         on_device = self._counter is not None
         host_count = 0 if on_device else self._step_count

@@ -55,7 +55,50 @@ def test_scalar_protocol_seeded_like_the_reference_reproduces_it(gf, name):
                 assert bits(obs[0]) == bits(c.reset_obs[e, s + 1])
         env.close()
     with pytest.raises(ValueError):
-        gf.make("fishing-v1", num_envs=8, rng="numpy")
+        gf.make("fishing-v4", num_envs=8, rng="numpy")
+
+
+@pytest.mark.parametrize("env_id", ["fishing-v0", "fishing-v1", "fishing-v2"])
+def test_n_env_numpy_rng_equals_a_dummy_vec_env_of_reference_envs(gf, env_id):
+    """rng="numpy" with N envs: one np.random.normal(0, 1, N) per step = the draws SB3's DummyVecEnv makes when it
+    steps N reference envs one after the other.  Against N reference-equivalent scalar envs (oracle/scalar_env.py,
+    pinned to the reference bit-for-bit) sharing the global stream: same obs / reward / done, bit-for-bit in
+    float64 (fishing-v2: exp tolerance), over 130 steps with resets on done."""
+    import torch
+    from oracle.scalar_env import ScalarFishingEnv
+    n, T, seed = 8, 130, 77
+    kw = dict(sigma=0.1, Tmax=40)
+    rng = np.random.RandomState(5)
+    acts = (rng.randint(0, 60, (T, n)) if env_id == "fishing-v0" else rng.uniform(-1, -0.3, (T, n)).astype(np.float32))
+    np.random.seed(seed)
+    refs = [ScalarFishingEnv(env_id, **kw) for _ in range(n)]
+    for r in refs:
+        r.reset()
+    want = []
+    for t in range(T):
+        row = []
+        for i, r in enumerate(refs):
+            # float32 action value, float64 arithmetic: the reference-era promotion (SURVEY A.3), as in the fixtures
+            a = int(acts[t, i]) if env_id == "fishing-v0" else np.array([acts[t, i]], dtype=np.float32).astype(np.float64)
+            o, rew, d, _ = r.step(a)
+            row.append((float(o[0]), float(rew), bool(d)))
+            if d:
+                r.reset()
+        want.append(row)
+    np.random.seed(seed)
+    env = gf.make(env_id, num_envs=n, dtype=torch.float64, rng="numpy", record_terminal_obs=True, **kw)
+    env.reset()
+    for t in range(T):
+        a = torch.as_tensor(acts[t])
+        _, rew, done, info = env.step(a)
+        term = info["terminal_observation"].cpu().numpy().reshape(-1)
+        for i in range(n):
+            o, r, d = want[t][i]
+            if env_id == "fishing-v2":
+                assert abs(term[i] - o) < 1e-11 and abs(float(rew[i]) - r) < 1e-11
+            else:
+                assert bits(term[i]) == bits(o) and bits(float(rew[i])) == bits(r), (t, i)
+            assert bool(done[i]) == d
 
 
 @pytest.mark.parametrize("name", ["v1_sigma0_const", "v1_sigma01_random", "v1_params", "v1_edge_noreset",
