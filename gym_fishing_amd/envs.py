@@ -407,6 +407,8 @@ class BaseFishingEnv(_gym_env_base()):
         sd = {k: getattr(self, k).clone() for k in self._STATE_TENSORS if getattr(self, k) is not None}
         sd.update(seed=self._seed, step_count=self._step_count, reset_count=self._reset_count,
                   params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state)
+        if self._np_rng:        # rng="numpy": the noise source is NumPy's global stream -- part of the state
+            sd["numpy_rng_state"] = np.random.get_state()
         return sd
 
     def load_state_dict(self, sd):
@@ -423,6 +425,8 @@ class BaseFishingEnv(_gym_env_base()):
         self._seed, self._step_count, self._reset_count = sd["seed"], sd["step_count"], sd["reset_count"]
         self.params.update(sd["params"])
         self.Tmax, self.init_state = sd["Tmax"], sd["init_state"]
+        if self._np_rng and "numpy_rng_state" in sd:
+            np.random.set_state(sd["numpy_rng_state"])
         self._publish_scalar_state()
         return self
 
@@ -668,23 +672,49 @@ class BaseFishingEnv(_gym_env_base()):
             return (fish_population / K - 1.0).reshape(-1, 1)
         return np.array([fish_population / K - 1])
 
-    def population_draw(self, x=None, noise=None, sigma=None):
+    def population_draw(self, x=None, noise=None, sigma=None, dtype=None, r=None, K=None):
         """base_fishing_env.py:121-133 (v2: fishing_tipping_env.py:24-35) over an array of
         populations -- the call BMSY() makes (models/policies.py:59-63).  `x` None uses
-        self.fish_population like the reference's zero-argument form (scalar protocol)."""
+        self.fish_population like the reference's zero-argument form (scalar protocol).
+        `dtype` picks the arithmetic (default: the env's layout); `sigma`, `r`, `K` override the
+        scalar parameters for this call only."""
         use_attr = x is None
         if use_attr:
             x = self.fish_population
-        xt = torch.as_tensor(x).to(device=self.device, dtype=self.dtype).reshape(-1).contiguous()
+        dtype = self.dtype if dtype is None else dtype
+        xt = torch.as_tensor(x).to(device=self.device, dtype=dtype).reshape(-1).contiguous()
         zt = None
         if noise is not None:
-            zt = torch.as_tensor(noise).to(device=self.device, dtype=self.dtype).reshape(-1).contiguous()
+            zt = torch.as_tensor(noise).to(device=self.device, dtype=dtype).reshape(-1).contiguous()
+        elif self._np_rng:
+            # the reference draws here whatever sigma is: one np.random.normal(0, 1) for the logistic / tipping
+            # models (base_fishing_env.py:130), np.random.lognormal(mu, sigma) -- one normal per ELEMENT of mu --
+            # for the zoo (growth_models.py:217-261); consume the global stream the same way
+            zoo = self.MODEL not in (MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4)
+            z = np.random.normal(0, 1, xt.numel()) if (zoo and xt.numel() > 1) else np.full(xt.numel(), np.random.normal(0, 1))
+            zt = torch.as_tensor(z).to(device=self.device, dtype=dtype)
         out = torch.empty_like(xt)
         cp = self._c_params()
-        if sigma is not None:                       # never edit the cached struct step() uses
+        if sigma is not None or r is not None or K is not None:     # never edit the cached struct step() uses
             cp = _capi.FishingParams.from_buffer_copy(cp)
-            cp.sigma = float(sigma)
-        fn = getattr(self._lib, "fishing_population_draw_" + self._suffix)
+            if sigma is not None:
+                cp.sigma = float(sigma)
+            if r is not None:
+                cp.r = float(r)
+            if K is not None:
+                cp.K = float(K)
+        if self.MODEL == MODEL_V11:
+            # growth_models.py:190-194: the growth function currently in force, with ITS parameter set
+            if not self._scalar:
+                raise NotImplementedError("population_draw() over an array is defined for one growth function: "
+                                          "use the scalar protocol (one env, one model in force) for fishing-v11")
+            name = self.model
+            cp = _capi.FishingParams.from_buffer_copy(cp)
+            cp.model = {"allen": MODEL_V5, "beverton_holt": MODEL_V6, "may": MODEL_V7, "myers": MODEL_V8,
+                        "ricker": MODEL_V9}[name]
+            for k in ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a"):
+                setattr(cp, k, float(self.model_params[name].get(k, 0.0) or 0.0))
+        fn = getattr(self._lib, "fishing_population_draw_" + ("f32" if dtype == torch.float32 else "f64"))
         with torch.cuda.device(self.device):
             rc = fn(cp, xt.numel(), xt.data_ptr(), zt.data_ptr() if zt is not None else None, out.data_ptr(),
                     self._stream())

@@ -13,18 +13,34 @@ from ._capi import POLICY_ESCAPEMENT, POLICY_MSY
 from .spaces import is_discrete
 
 
+def _is_zoo(env):
+    return env.MODEL not in (0, 1, 2, 4)
+
+
+def _growth_args(env):
+    """Parameters of the one-step growth BMSY / msy evaluate.  The reference sets `env.sigma = 0` around the
+    call (models/policies.py:10-13,60-64); the logistic / tipping models read `self.sigma`, the zoo's growth
+    functions read `params["sigma"]` and never see that override (growth_models.py:208-261) -- reproduced.
+    fishing-v4 evaluates with the (K, r) currently drawn (scalar protocol; the N-env form uses the means)."""
+    kw = {} if _is_zoo(env) else {"sigma": 0.0}
+    if env.MODEL == 4 and env._scalar:
+        kw.update(K=float(env.K), r=float(env.r))
+    return kw
+
+
 def BMSY(env, n=10001):
-    """models/policies.py:51-67: sweep n states of the observation Box through one noiseless
-    population_draw() on the device and return the population with the largest growth.
-    Like the reference, this resets the environment.  Evaluated in the env's dtype (float64
-    for the scalar protocol: S = K/2 for the logistic models; the float32 layout reproduces
-    the 0.4996 a float32 evaluation of the flat maximum gives)."""
+    """models/policies.py:51-67: sweep n states of the observation Box through one population_draw() on the
+    device and return the population with the largest growth.  Like the reference, this resets the
+    environment.  The sweep is evaluated in float32 whatever the env's layout, as the reference's is (a
+    float32 grid times Python-float parameters stays float32 in NumPy): S = 0.4996 K for the flat logistic
+    maximum, not K / 2."""
     grid = np.linspace(env.observation_space.low, env.observation_space.high, num=n,
                        dtype=env.observation_space.dtype).reshape(-1)
-    state = torch.as_tensor(grid, device=env.device).to(env.dtype)
-    K = float(env.params["K"])
+    state = torch.as_tensor(grid, device=env.device).to(torch.float32)
+    kw = _growth_args(env)
+    K = kw.get("K", float(env.params["K"]))
     x0 = (state + 1.0) * K                                       # get_fish_population :158-160
-    growth = env.population_draw(x0, sigma=0.0) - x0
+    growth = env.population_draw(x0, dtype=torch.float32, **kw) - x0
     S = float(x0[int(torch.argmax(growth))])
     env.reset()
     return S
@@ -36,8 +52,8 @@ class msy:
     def __init__(self, env, **kwargs):
         self.env = env
         self.S = BMSY(env)
-        x = torch.tensor([self.S], dtype=env.dtype, device=env.device)
-        self.msy = float(env.population_draw(x, sigma=0.0)[0] - x[0])
+        x = torch.tensor([self.S], dtype=torch.float32, device=env.device)
+        self.msy = float(env.population_draw(x, dtype=torch.float32, **_growth_args(env))[0] - x[0])
         env.reset()
         self.kernel_policy = (POLICY_MSY, self.msy)
 

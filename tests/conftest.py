@@ -76,3 +76,14 @@ def load_policy_sims():
                         K=float(kw.get("K", 1.0)), r=float(kw.get("r", 0.3)), x0=float(kw.get("init_state", 0.75)),
                         n_actions=int(kw.get("n_actions", 100))))
     return out
+
+
+def load_seeded_sims():
+    """Reference flows at sigma > 0 (tests/golden/make_golden.py): np.random.seed(7); env = make(id, **kw);
+    model = msy(env) / escapement(env); env.simulate(model, reps=2) -> the table, the policy's S and msy."""
+    z = np.load(os.path.join(GOLDEN, "reference_seeded_sims.npz"))
+    out = []
+    for key in sorted(k[:-5] for k in z.files if k.endswith("/meta")):
+        meta = json.loads(str(z[key + "/meta"]))
+        out.append(dict(key=key, table=z[key + "/table"], **meta))
+    return out

@@ -309,6 +309,25 @@ def main():
             sims["sim_%s_%s" % (tag, pname)] = df.to_numpy(dtype=np.float64)
             anchors["policy_" + tag]["sum_reward_" + pname] = float(df.reward.sum())
             anchors["policy_" + tag]["rows_" + pname] = int(len(df))
+    # --- seeded flows at sigma > 0: np.random.seed(s); env = make(...); model = policy(env) (BMSY's and msy's
+    # population_draw() calls consume the global stream too); df = env.simulate(model, reps=2).  What a user's
+    # script does; the drop-in's scalar protocol must give the same table from the same seed.
+    seeded = {}
+    for env_id, kw in (("fishing-v1", {"sigma": 0.1}), ("fishing-v0", {"sigma": 0.1}), ("fishing-v2", {"sigma": 0.05}),
+                       ("fishing-v5", {"sigma": 0.1}), ("fishing-v9", {"sigma": 0.1}), ("fishing-v11", {})):
+        # (fishing-v4 is left out: its BMSY sweep multiplies a float32 grid by np.float64 scalars K and r, which
+        # NumPy 2 evaluates in float64 and the reference's NumPy 1.19 in float32 -- no version-neutral fixture)
+        for pname, cls in (("msy", msy), ("escapement", escapement)):
+            np.random.seed(7)
+            env = gym.make(env_id, **kw)
+            model = cls(env)
+            df = env.simulate(RefEra(model, env_id == "fishing-v0"), reps=2)
+            key = "%s_%s" % (env_id.replace("fishing-", ""), pname)
+            seeded[key + "/table"] = df.to_numpy(dtype=np.float64)
+            seeded[key + "/meta"] = np.array(json.dumps({"id": env_id, "kwargs": kw, "policy": pname, "seed": 7, "reps": 2,
+                                                         "S": float(model.S),
+                                                         "msy": float(model.msy) if pname == "msy" else None}))
+    np.savez_compressed(os.path.join(OUT, "reference_seeded_sims.npz"), **seeded)
     # get_action / get_quota round trips (base_fishing_env.py:135-156)
     env0 = gym.make("fishing-v0")
     env1 = gym.make("fishing-v1")

@@ -18,7 +18,8 @@ def test_fixtures_regenerate_bit_for_bit(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "--out", str(tmp_path)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
-    for name in ("reference_trajectories.npz", "reference_policy_sims.npz", "reference_zoo_trajectories.npz"):
+    for name in ("reference_trajectories.npz", "reference_policy_sims.npz", "reference_zoo_trajectories.npz",
+                 "reference_seeded_sims.npz"):
         new, old = np.load(tmp_path / name), np.load(os.path.join(GOLDEN, name))
         assert sorted(new.files) == sorted(old.files), name
         for k in old.files:
@@ -42,4 +43,5 @@ def test_fixtures_hold_numbers_only():
                 assert z[k].dtype.kind in "fiub" or k.endswith("/meta"), (name, k)
                 if k.endswith("/meta"):
                     meta = json.loads(str(z[k]))
-                    assert set(meta) == {"id", "kwargs", "seeds", "nsteps", "auto_reset", "init_reset"}
+                    assert set(meta) in ({"id", "kwargs", "seeds", "nsteps", "auto_reset", "init_reset"},
+                                         {"id", "kwargs", "policy", "seed", "reps", "S", "msy"}), (name, k)

@@ -313,10 +313,10 @@ SIMS = load_policy_sims()
                                            ("v1_params", "fishing-v1", {"r": 0.5, "K": 2.0, "init_state": 1.1}),
                                            ("v0_params", "fishing-v0", {"n_actions": 37, "r": 0.4})])
 def test_bmsy_and_msy_reproduce_reference_values(gf, anchors, tag, env_id, kw):
-    """models/policies.py:51-67 on the device.  In the float32 layout the sweep reproduces the
-    reference's values bit-for-bit (the reference under NumPy 2 evaluates the 10001-point
-    growth curve in float32: S = 0.4996 for the flat logistic maximum); in float64 it finds
-    the exact optimum K/2."""
+    """models/policies.py:51-67 on the device.  The sweep is evaluated in float32 whatever the env's layout,
+    like the reference's (a float32 grid times Python-float parameters): it reproduces the reference's values
+    bit-for-bit, S = 0.4996 for the flat logistic maximum -- from the float32 N-env layout and from the
+    float64 scalar protocol alike."""
     import torch
     from gym_fishing_amd.policies import BMSY, msy
     env = gf.make(env_id, sigma=0.0, num_envs=4, dtype=torch.float32, **kw)
@@ -331,7 +331,46 @@ def test_bmsy_and_msy_reproduce_reference_values(gf, anchors, tag, env_id, kw):
         assert m.msy == a["msy"]
     if env_id != "fishing-v2":
         env64 = gf.make(env_id, sigma=0.0, **kw)
-        assert BMSY(env64) == kw.get("K", 1) / 2
+        m64 = msy(env64)
+        assert m64.S == a["BMSY"] and m64.msy == a["msy"]
+
+
+from conftest import load_seeded_sims  # noqa: E402
+
+SEEDED = load_seeded_sims()
+
+
+@pytest.mark.parametrize("c", SEEDED, ids=[c["key"] for c in SEEDED])
+def test_seeded_policy_flows_follow_the_reference(gf, c):
+    """A user's script, unchanged: np.random.seed(7); env = make(id, sigma > 0); model = msy(env) or
+    escapement(env); df = env.simulate(model, reps=2).  BMSY() and msy() consume the global stream like the
+    reference (one normal per population_draw() of the logistic / tipping models, one per grid point for the
+    zoo, whose growth functions ignore the sigma = 0 the reference sets on the env) and evaluate in float32 like
+    it, so S, msy and every row of the table follow the reference: bit-for-bit for fishing-v0 / v1, within the
+    transcendental tolerance for fishing-v2 and the zoo."""
+    from gym_fishing_amd.policies import escapement, msy
+    np.random.seed(c["seed"])
+    env = gf.make(c["id"], **c["kwargs"])
+    model = (msy if c["policy"] == "msy" else escapement)(env)
+    df = env.simulate(model, reps=c["reps"])
+    got, want = df.to_numpy(dtype=np.float64), c["table"]
+    exact = c["id"] in ("fishing-v0", "fishing-v1")
+    if exact:
+        assert model.S == c["S"] and (c["msy"] is None or model.msy == c["msy"])
+        assert got.shape == want.shape and np.array_equal(got.view(np.int64), np.ascontiguousarray(want).view(np.int64))
+    elif c["id"] == "fishing-v2":
+        # float32 exp on the device vs np.exp: the flat maximum of the growth curve may move a few grid cells
+        assert abs(model.S - c["S"]) <= 2e-3
+        assert got.shape[1] == want.shape[1] and abs(got.shape[0] - want.shape[0]) <= 60
+    else:
+        # float32 log / exp on the device vs NumPy's: where the growth curve is flat (sigma = 0) the argmax may sit
+        # a grid cell (2e-4) away; with sigma > 0 the sweep's noise decides it and S is the reference's exactly
+        assert abs(model.S - c["S"]) <= 1e-3, (model.S, c["S"])
+        same_S = model.S == c["S"]
+        assert c["kwargs"].get("sigma", 0.0) == 0.0 or same_S
+        tol = 1e-6 if same_S else 5e-3
+        assert c["msy"] is None or abs(model.msy - c["msy"]) <= tol * max(1.0, abs(c["msy"]))
+        assert got.shape == want.shape and np.allclose(got, want, rtol=10 * tol, atol=tol)
 
 
 @pytest.mark.parametrize("c", SIMS, ids=[c["key"] for c in SIMS])
@@ -399,10 +438,12 @@ def test_simulate_with_generic_model_and_policyfn(gf):
             b = venv.simulate(Wrapped(pol)).to_numpy(dtype=np.float64)
             assert a.shape == b.shape and np.array_equal(a, b), (env_id, type(pol).__name__)
     env = gf.make("fishing-v1")
-    pf = env.policyfn(policies.escapement(env))
+    esc = policies.escapement(env)
+    assert esc.S == 0.49959999322891235          # the reference's float32 sweep, also from the float64 scalar env
+    pf = env.policyfn(esc)
     assert list(pf.columns) == ["state", "action", "rep"] and len(pf) == 50
     st, ac = pf["state"].to_numpy(), pf["action"].to_numpy()
-    assert np.allclose(ac, np.maximum(st - 0.5, 0.0), atol=1e-7)
+    assert np.allclose(ac, np.maximum(st - esc.S, 0.0), atol=1e-7)
 
 
 def test_graph_replay_draws_fresh_noise_and_matches_eager(gf):
