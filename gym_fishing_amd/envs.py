@@ -586,7 +586,9 @@ class BaseFishingEnv(_gym_env_base()):
     # ------------------------------------------------------------------ fused rollout
     def rollout(self, n_steps, policy="random", param=0.0, record=False):
         """n_steps of step() inside one kernel with an in-kernel policy (csrc/fishing_rollout.hip).
-        record=True returns the [n_steps, 4, N] table {obs_in, action, reward, done}."""
+        record=True returns the [n_steps, 4, N] table {obs_in, action, reward, done}.  The fused kernel always
+        draws from the Philox streams keyed by `seed` (also for an env built with rng="numpy": a kernel cannot
+        consume NumPy's host-side stream)."""
         if isinstance(policy, tuple):                 # ("constant", a) or a policies.* kernel_policy pair
             policy, param = policy
         pol = POLICIES[policy] if isinstance(policy, str) else int(policy)
