@@ -549,6 +549,10 @@ class BaseFishingEnv(_gym_env_base()):
         R = actions.shape[0]
         row_stride = actions.stride(0) if R > 1 else self.num_envs
         n_steps = R if n_steps is None else int(n_steps)
+        if self._np_rng:                    # the draws come from NumPy's host-side stream: one step() per step
+            for k in range(n_steps):
+                self.step(actions[k % R])
+            return self._step_result()
         with torch.cuda.device(self.device):
             rc = self._fn_step_many(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(actions),
                                     row_stride, R, n_steps, self._seed,
