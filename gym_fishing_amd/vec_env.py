@@ -67,6 +67,7 @@ class FishingVecEnv(_BASE):
         self._hv_act = self._h_act.numpy()
         self._d_act = torch.empty(n, dtype=env._want, device=env.device)
         self._pending = None
+        self.reset_infos = [{} for _ in range(env.num_envs)]      # SB3 >= 2.0 reads this after reset()
         self.render_mode = None
         self.metadata = dict(getattr(env, "metadata", {}))
 
