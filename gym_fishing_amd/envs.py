@@ -12,6 +12,11 @@ fishing_model_error}.py, so it is a drop-in for the rollout path:
   ``step(actions[N,1]) -> (obs[N,1], rewards[N], dones[N], info)``; tensors stay on the
   GPU (torch, zero-copy views of the env's buffers, valid until the next step/reset).
 
+Random numbers: ``rng="philox"`` (default with num_envs) = the in-kernel counter-based streams keyed
+by ``seed`` and the global env index; ``rng="numpy"`` (default for the scalar protocol) = the reference's
+own draws from NumPy's global legacy stream, in its order, handed to the kernel as external noise -- so
+``np.random.seed(s)`` reproduces the reference's trajectories.
+
 All arithmetic happens in the HIP kernels (csrc/); this file only owns buffers, counters
 and argument plumbing.  No CPU fallback: without the library or a HIP device the
 constructor raises FishingLibraryError.
