@@ -445,9 +445,13 @@ class BaseFishingEnv(_gym_env_base()):
             self._cbuf = None
         return self
 
-    def reset(self, mask=None):
+    def reset(self, mask=None, *, seed=None, options=None):
         """base_fishing_env.py:83-91 (v4: fishing_model_error.py:41-48).  `mask` (bool[N]) resets
-        a subset -- what a VecEnv wrapper without in-kernel auto-reset would call."""
+        a subset -- what a VecEnv wrapper without in-kernel auto-reset would call.  `seed` / `options`
+        are accepted for callers written against the newer gym signature (seed -> self.seed(seed));
+        the return value stays the reference's: the observation alone."""
+        if seed is not None:
+            self.seed(seed)
         m = None
         if mask is not None:
             m = torch.as_tensor(mask).to(device=self.device).reshape(self.num_envs).to(torch.uint8).contiguous()
