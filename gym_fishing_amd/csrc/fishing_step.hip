@@ -267,6 +267,7 @@ struct LeanArgs {
     double* partials;
     const uint64_t* counter;
     const T* sigma_arr;      // per-env noise scale (fishing-v4 with parameter arrays, SIGARR)
+    T* terminal_obs;         // TERM: the observation before the fused auto-reset (SB3's terminal_observation)
     T pr, pK, sigma, C, x0, r_mean, K_mean, sigma_p;
     int32_t Tmax, n_actions;
     uint32_t auto_reset;
@@ -278,7 +279,8 @@ struct LeanArgs {
 #ifndef FISHING_LEAN_ATTRS
 #define FISHING_LEAN_ATTRS
 #endif
-template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false, bool T8 = false, bool DRIFT = false>
+template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false, bool T8 = false, bool DRIFT = false,
+          bool TERM = false>
 __global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
 step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_offset, const uint64_t seed,
                  const uint64_t step_counter_arg) {
@@ -298,6 +300,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                      "s"(ntiles), "s"(env_offset), "s"(seed), "s"(step_counter_arg));
         if constexpr (kPerEnv) asm volatile("" ::"s"(a.r), "s"(a.K), "s"(a.r_mean), "s"(a.K_mean), "s"(a.sigma_p));
         if constexpr (SIGARR) asm volatile("" ::"s"(a.sigma_arr));
+        if constexpr (TERM) asm volatile("" ::"s"(a.terminal_obs));
         if constexpr (kZoo)
             asm volatile("" ::"s"(a.growth.r), "s"(a.growth.K), "s"(a.growth.sigma), "s"(a.growth.C), "s"(a.growth.M),
                          "s"(a.growth.theta), "s"(a.growth.q), "s"(a.growth.b), "s"(a.growth.a), "s"(a.growth.bq),
@@ -410,6 +413,10 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
             __builtin_nontemporal_store(qv, reinterpret_cast<nt4*>(a.reward + base));
             __builtin_nontemporal_store((uint32_t)dn[0] | ((uint32_t)dn[1] << 8) | ((uint32_t)dn[2] << 16) | ((uint32_t)dn[3] << 24),
                                         reinterpret_cast<uint32_t*>(a.done + base));
+            if constexpr (TERM) {       // obs_next is still the pre-reset observation here
+                const nt4 qt = {obs_next[0], obs_next[1], obs_next[2], obs_next[3]};
+                __builtin_nontemporal_store(qt, reinterpret_cast<nt4*>(a.terminal_obs + base));
+            }
         }
         const bool lane_done = dn[0] | dn[1] | dn[2] | dn[3];
         if (RET) {
@@ -705,6 +712,14 @@ int launch_lean(const LeanArgs<T>& a, int noise, bool ret, bool t8, bool drift, 
             return (int)hipGetLastError();
         }
     }
+    if constexpr (sizeof(T) == 4 && (MODEL == FISHING_MODEL_V0 || MODEL == FISHING_MODEL_V1 || MODEL == FISHING_MODEL_V2 ||
+                                     MODEL == FISHING_MODEL_V4)) {
+        if (a.terminal_obs) {       // SB3 semantics: record the pre-reset observation (float32, in-kernel noise)
+            if (ret) step_kernel_lean<T, MODEL, kNoisePhilox, true, false, false, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
+            else step_kernel_lean<T, MODEL, kNoisePhilox, false, false, false, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
+            return (int)hipGetLastError();
+        }
+    }
 #define FISHING_LEAN(NZ, RT) step_kernel_lean<T, MODEL, NZ, RT><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter)
     if (noise == kNoiseNone) {
         if (ret) FISHING_LEAN(kNoiseNone, true); else FISHING_LEAN(kNoiseNone, false);
@@ -746,13 +761,15 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
         const int64_t tile = 256 * kEnvsPerThread;
         // (fp64 fishing-v4 stays on the general kernel: measured 50.1 vs 51.6 us at N = 2^22)
         if (core && (sizeof(T) == 4 || p->model != FISHING_MODEL_V4) && noise != kNoiseExt && !(p->flags & FISHING_FLAG_GENERAL_KERNEL) && b->reward && b->done &&
-            !b->done_bits && !b->terminal_obs &&
+            !b->done_bits &&
+            (!b->terminal_obs || (sizeof(T) == 4 && is_core_model(p->model) && noise == kNoisePhilox && !b->sigma &&
+                                  !(p->flags & FISHING_FLAG_T_U8))) &&
             (!b->sigma || (p->model == FISHING_MODEL_V4 && noise == kNoisePhilox && !(p->flags & FISHING_FLAG_T_U8))) &&
             (p->launch_threads == 0 || p->launch_threads == 256) && n >= tile) {
             const int64_t ntiles = n / tile;
             const int64_t n_full = ntiles * tile;
             LeanArgs<T> a{bt.obs,      bt.action,  bt.reward,  bt.done,     bt.t,        bt.r,
-                          bt.K,        bt.ep_return, bt.partials, bt.counter, bt.sigma,  pt.r,      pt.K,
+                          bt.K,        bt.ep_return, bt.partials, bt.counter, bt.sigma,  bt.terminal_obs, pt.r, pt.K,
                           pt.sigma,    pt.C,       pt.x0,      pt.r_mean,   pt.K_mean,   pt.sigma_p,
                           pt.Tmax,     pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET), pt.growth, pt.alpha};
             int cap = p->launch_blocks ? p->launch_blocks : 2048;

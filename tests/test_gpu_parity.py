@@ -863,3 +863,32 @@ def test_philox_ensemble_matches_numpy_ensemble(hh, model, policy, param):
     assert abs(ret_dev.std() / ret_ref.std() - 1.0) < 0.05
     assert stats.ks_2samp(final_dev[::4], final_ref).pvalue > 1e-4
     assert abs((traj[:, 3].sum(axis=0) > 0).mean() - (~alive).mean()) < 0.02     # same fraction of finished episodes
+
+
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
+@pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
+def test_lean_terminal_obs_variant_agrees_with_general_kernel(hh, model, ret):
+    """With the terminal-observation record (SB3's info["terminal_observation"]) the float32 step of
+    fishing-v0/v1/v2/v4 takes the TERM instantiation of the lean kernel; the general kernel must give the same
+    bits on every stream, the recorded pre-reset observation included."""
+    import torch
+    per_env = model == fo.MODEL_V4
+    n = 1024 * 3 + 5
+    kw = dict(sigma=0.1, C=0.5, Tmax=4, sigma_p=0.2, auto_reset=True)
+    pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
+    mk = lambda: hh.State(n, np.float32, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
+                          K=np.full(n, 1.0) if per_env else None, ep_return=ret, terminal=True)
+    A, B = mk(), mk()
+    A.reset(pa, seed=9, env_offset=8)
+    B.reset(pb, seed=9, env_offset=8)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    for s in range(12):
+        a = (torch.randint(0, 100, (n,), device="cuda", generator=g, dtype=torch.int32) if model == fo.MODEL_V0
+             else (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float())
+        for st, p in ((A, pa), (B, pb)):
+            assert lib.fishing_step_f32(p, n, 8, st.buffers(a), 9, s, None) == 0
+        torch.cuda.synchronize()
+        for name in ("obs", "reward", "done", "t", "terminal") + (("K", "r") if per_env else ()) + (("ep_return",) if ret else ()):
+            assert torch.equal(getattr(A, name), getattr(B, name)), (name, s)
+    assert not torch.equal(A.terminal, A.obs)        # some env was reset: the two really differ
