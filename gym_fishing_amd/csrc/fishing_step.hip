@@ -268,6 +268,7 @@ struct LeanArgs {
     const uint64_t* counter;
     const T* sigma_arr;      // per-env noise scale (fishing-v4 with parameter arrays, SIGARR)
     T* terminal_obs;         // TERM: the observation before the fused auto-reset (SB3's terminal_observation)
+    uint64_t* done_bits;     // BITS: wave-ballot termination mask, bit i % 64 of word i / 64 = done[i]
     T pr, pK, sigma, C, x0, r_mean, K_mean, sigma_p;
     int32_t Tmax, n_actions;
     uint32_t auto_reset;
@@ -280,7 +281,7 @@ struct LeanArgs {
 #define FISHING_LEAN_ATTRS
 #endif
 template <typename T, int MODEL, int NOISE, bool RET, bool SIGARR = false, bool T8 = false, bool DRIFT = false,
-          bool TERM = false>
+          bool TERM = false, bool BITS = false>
 __global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
 step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_offset, const uint64_t seed,
                  const uint64_t step_counter_arg) {
@@ -301,6 +302,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         if constexpr (kPerEnv) asm volatile("" ::"s"(a.r), "s"(a.K), "s"(a.r_mean), "s"(a.K_mean), "s"(a.sigma_p));
         if constexpr (SIGARR) asm volatile("" ::"s"(a.sigma_arr));
         if constexpr (TERM) asm volatile("" ::"s"(a.terminal_obs));
+        if constexpr (BITS) asm volatile("" ::"s"(a.done_bits));
         if constexpr (kZoo)
             asm volatile("" ::"s"(a.growth.r), "s"(a.growth.K), "s"(a.growth.sigma), "s"(a.growth.C), "s"(a.growth.M),
                          "s"(a.growth.theta), "s"(a.growth.q), "s"(a.growth.b), "s"(a.growth.a), "s"(a.growth.bq),
@@ -416,6 +418,13 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
             if constexpr (TERM) {       // obs_next is still the pre-reset observation here
                 const nt4 qt = {obs_next[0], obs_next[1], obs_next[2], obs_next[3]};
                 __builtin_nontemporal_store(qt, reinterpret_cast<nt4*>(a.terminal_obs + base));
+            }
+            if constexpr (BITS) {       // the wave's 256 flags as four 64-bit words (ballots, no LDS)
+                const int lane = threadIdx.x & (kWave - 1);
+                const uint32_t nibble = (uint32_t)dn[0] | ((uint32_t)dn[1] << 1) | ((uint32_t)dn[2] << 2) | ((uint32_t)dn[3] << 3);
+                const uint64_t word = ballot_tile_words(nibble, lane);
+                const int64_t wave_env0 = (tile * 256 + (threadIdx.x & ~(kWave - 1))) * kEnvsPerThread;
+                if (lane < 4) a.done_bits[(wave_env0 >> 6) + lane] = word;
             }
         }
         const bool lane_done = dn[0] | dn[1] | dn[2] | dn[3];
@@ -667,6 +676,7 @@ BuffersT<T> offset_buffers(const BuffersT<T>& b, int64_t off, bool t_u8) {
     q.action = b.action ? (const void*)((const char*)b.action + 4 * off) : nullptr;
     q.reward = b.reward ? b.reward + off : nullptr;
     q.done = b.done ? b.done + off : nullptr;
+    q.done_bits = b.done_bits ? b.done_bits + (off >> 6) : nullptr;      // off is a multiple of 1024
     q.t = t_u8 ? reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(b.t) + off) : b.t + off;
     q.r = b.r ? b.r + off : nullptr;
     q.K = b.K ? b.K + off : nullptr;
@@ -714,6 +724,11 @@ int launch_lean(const LeanArgs<T>& a, int noise, bool ret, bool t8, bool drift, 
     }
     if constexpr (sizeof(T) == 4 && (MODEL == FISHING_MODEL_V0 || MODEL == FISHING_MODEL_V1 || MODEL == FISHING_MODEL_V2 ||
                                      MODEL == FISHING_MODEL_V4)) {
+        if (a.done_bits) {          // ballot bitmask of the finished envs next to the byte flags
+            if (ret) step_kernel_lean<T, MODEL, kNoisePhilox, true, false, false, false, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
+            else step_kernel_lean<T, MODEL, kNoisePhilox, false, false, false, false, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
+            return (int)hipGetLastError();
+        }
         if (a.terminal_obs) {       // SB3 semantics: record the pre-reset observation (float32, in-kernel noise)
             if (ret) step_kernel_lean<T, MODEL, kNoisePhilox, true, false, false, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
             else step_kernel_lean<T, MODEL, kNoisePhilox, false, false, false, false, true><<<blocks, 256, 0, s>>>(a, ntiles, env_offset, seed, step_counter);
@@ -761,15 +776,15 @@ int step_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fishi
         const int64_t tile = 256 * kEnvsPerThread;
         // (fp64 fishing-v4 stays on the general kernel: measured 50.1 vs 51.6 us at N = 2^22)
         if (core && (sizeof(T) == 4 || p->model != FISHING_MODEL_V4) && noise != kNoiseExt && !(p->flags & FISHING_FLAG_GENERAL_KERNEL) && b->reward && b->done &&
-            !b->done_bits &&
-            (!b->terminal_obs || (sizeof(T) == 4 && is_core_model(p->model) && noise == kNoisePhilox && !b->sigma &&
-                                  !(p->flags & FISHING_FLAG_T_U8))) &&
+            (!(b->done_bits || b->terminal_obs) ||
+             (!(b->done_bits && b->terminal_obs) && sizeof(T) == 4 && is_core_model(p->model) && noise == kNoisePhilox &&
+              !b->sigma && !(p->flags & FISHING_FLAG_T_U8))) &&
             (!b->sigma || (p->model == FISHING_MODEL_V4 && noise == kNoisePhilox && !(p->flags & FISHING_FLAG_T_U8))) &&
             (p->launch_threads == 0 || p->launch_threads == 256) && n >= tile) {
             const int64_t ntiles = n / tile;
             const int64_t n_full = ntiles * tile;
             LeanArgs<T> a{bt.obs,      bt.action,  bt.reward,  bt.done,     bt.t,        bt.r,
-                          bt.K,        bt.ep_return, bt.partials, bt.counter, bt.sigma,  bt.terminal_obs, pt.r, pt.K,
+                          bt.K,        bt.ep_return, bt.partials, bt.counter, bt.sigma,  bt.terminal_obs, bt.done_bits, pt.r, pt.K,
                           pt.sigma,    pt.C,       pt.x0,      pt.r_mean,   pt.K_mean,   pt.sigma_p,
                           pt.Tmax,     pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET), pt.growth, pt.alpha};
             int cap = p->launch_blocks ? p->launch_blocks : 2048;

@@ -892,3 +892,36 @@ def test_lean_terminal_obs_variant_agrees_with_general_kernel(hh, model, ret):
         for name in ("obs", "reward", "done", "t", "terminal") + (("K", "r") if per_env else ()) + (("ep_return",) if ret else ()):
             assert torch.equal(getattr(A, name), getattr(B, name)), (name, s)
     assert not torch.equal(A.terminal, A.obs)        # some env was reset: the two really differ
+
+
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V4])
+@pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
+def test_lean_done_bits_variant_agrees_with_general_kernel_and_the_byte_mask(hh, model, ret):
+    """With the ballot bitmask requested the float32 step takes the BITS instantiation of the lean kernel (whole
+    tiles) plus the general kernel for the ragged tail: the words must equal the general kernel's and, bit for
+    bit, the byte flags -- including the tail's words, which start at word n_full / 64."""
+    import torch
+    per_env = model == fo.MODEL_V4
+    n = 1024 * 3 + 77
+    kw = dict(sigma=0.1, Tmax=3, sigma_p=0.2, auto_reset=True)
+    pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
+    mk = lambda: hh.State(n, np.float32, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
+                          K=np.full(n, 1.0) if per_env else None, ep_return=ret, done_bits=True)
+    A, B = mk(), mk()
+    A.reset(pa, seed=9, env_offset=8)
+    B.reset(pb, seed=9, env_offset=8)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    seen = 0
+    for s in range(10):
+        a = (torch.randint(0, 100, (n,), device="cuda", generator=g, dtype=torch.int32) if model == fo.MODEL_V0
+             else (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float())
+        for st, p in ((A, pa), (B, pb)):
+            assert lib.fishing_step_f32(p, n, 8, st.buffers(a), 9, s, None) == 0
+        torch.cuda.synchronize()
+        for name in ("obs", "reward", "done", "t", "done_bits") + (("ep_return",) if ret else ()):
+            assert torch.equal(getattr(A, name), getattr(B, name)), (name, s)
+        bits = np.unpackbits(A.done_bits.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+        assert np.array_equal(bits, A.done.cpu().numpy())
+        seen += int(bits.sum())
+    assert seen > n
