@@ -63,17 +63,35 @@ def _compile(out_path, verbose, extra_flags):
         raise RuntimeError("hipcc not found: cannot build libfishing_hip.so")
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     tmp = out_path + ".tmp.%d" % os.getpid()
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + sources() + ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if proc.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError("hipcc failed (%d):\n%s" % (proc.returncode, proc.stdout))
-    if verbose and proc.stdout.strip():
-        print(proc.stdout)
-    os.replace(tmp, out_path)
+    srcs = sources()
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    objs = ["%s.%d.o" % (tmp, i) for i in range(len(srcs))]
+    # one hipcc per translation unit, side by side (the two kernel files take about as long as each other),
+    # then one link step
+    cmds = [[hipcc] + flags + ["-c", src, "-o", obj] for src, obj in zip(srcs, objs)]
+    procs = []
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate()[0] for p in procs]
+    try:
+        for p, o in zip(procs, outs):
+            if p.returncode != 0:
+                raise RuntimeError("hipcc failed (%d):\n%s" % (p.returncode, o))
+            if verbose and o.strip():
+                print(o)
+        link = [hipcc] + HIPCC_FLAGS + list(extra_flags) + objs + ["-o", tmp]
+        if verbose:
+            print(" ".join(link), flush=True)
+        proc = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError("hipcc link failed (%d):\n%s" % (proc.returncode, proc.stdout))
+        os.replace(tmp, out_path)
+    finally:
+        for f in objs + [tmp]:
+            if os.path.exists(f):
+                os.remove(f)
     return out_path
 
 
