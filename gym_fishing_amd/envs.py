@@ -100,13 +100,18 @@ class BaseFishingEnv(_gym_env_base()):
 
     def __init__(self, params=None, Tmax=100, file=None, *, num_envs=None, device=None, seed=0,
                  dtype=None, auto_reset=None, env_offset=0, record_terminal_obs=False,
-                 track_returns=False, done_bits=False, launch_blocks=0, launch_threads=0, compact=False, rng=None):
+                 track_returns=False, done_bits=False, launch_blocks=0, launch_threads=0, compact=False, rng=None,
+                 host_mapped=False):
         params = dict({"r": 0.3, "K": 1, "sigma": 0.0, "x0": 0.75} if params is None else params)
         self.params = params
         self.Tmax = int(Tmax)
         self.file = file
         self.init_state = params["x0"]
         self._scalar = num_envs is None
+        # host_mapped (N-env protocol, meant for small N behind the NumPy VecEnv adapter): the env's streams live
+        # in pinned, device-mapped host memory like the scalar protocol's, the kernels read and write them over
+        # PCIe, step() / reset() wait for the stream and hand back CPU tensors -- no staging copies
+        self._host_mapped = self._scalar or bool(host_mapped)
         self.num_envs = 1 if self._scalar else int(num_envs)
         if self.num_envs < 1:
             raise ValueError("num_envs must be >= 1")
@@ -168,13 +173,13 @@ class BaseFishingEnv(_gym_env_base()):
                  (torch.uint8, N)]
         if track_returns:
             sizes.append((dtype, N * esz))
-        stagger = 0 if self._scalar else 12288       # one env: keep the arena one small D2H copy
+        stagger = 0 if self._host_mapped else 12288  # host-mapped: nothing to de-alias, keep the arena small
         offs, off = [], 0
         for k, (_, nbytes) in enumerate(sizes):
             offs.append(off)
             off = (off + nbytes + stagger * (k + 1) + 255) & ~255
         self._arena_offs = offs
-        if self._scalar:
+        if self._host_mapped:
             # scalar protocol: the single env's streams (+ its action) live in pinned, device-mapped
             # host memory.  The kernels read and write it directly over PCIe (a few bytes), so a step
             # is launch + stream sync with no staging copies: 17 us instead of ~80 us per step.
@@ -198,7 +203,10 @@ class BaseFishingEnv(_gym_env_base()):
         if self.MODEL == MODEL_V10:      # the drifting growth rate is per-env state (growth_models.py:151)
             self._r_arr = torch.full((N,), float(params["r"]), dtype=dtype, device=dev)
         self._model_idx = torch.zeros(N, dtype=torch.int32, device=dev) if self.MODEL == MODEL_V11 else None
-        self._terminal_obs = torch.empty(N, dtype=dtype, device=dev) if record_terminal_obs else None
+        self._terminal_obs = None
+        if record_terminal_obs:
+            self._terminal_obs = (torch.empty(N, dtype=dtype).pin_memory() if self._host_mapped
+                                  else torch.empty(N, dtype=dtype, device=dev))
         self._done_bits = (torch.zeros((N + 63) // 64, dtype=torch.int64, device=dev) if done_bits else None)
         self._ep_return = self._partials = self._record = None
         if track_returns:
@@ -216,6 +224,9 @@ class BaseFishingEnv(_gym_env_base()):
             self._host_action_np = self._host_action.numpy()
             self._host_z = self._arena[self._action_off + 16:self._action_off + 16 + esz].view(dtype)
             self._host_z_np = self._host_z.numpy()
+        elif self._host_mapped:
+            self._host_action = torch.zeros(N, dtype=self._want).pin_memory()
+            self._host_action_np = self._host_action.numpy()
         self._obs_view = self._obs.view(N, 1)
         self._done_view = self._done.view(torch.bool)
         self._info = {}
@@ -351,6 +362,11 @@ class BaseFishingEnv(_gym_env_base()):
         self._t.zero_()
         self._publish_scalar_state()
 
+    def _host_sync(self):
+        rc = self._lib.fishing_stream_synchronize(self._stream())
+        if rc:
+            _capi.check(rc, "fishing_stream_synchronize")
+
     def _numpy_redraw(self):
         """rng="numpy": the per-episode draws of fishing-v4 / fishing-v11 from NumPy's global stream, in the
         reference's order, replacing what the reset kernel drew from Philox."""
@@ -417,7 +433,7 @@ class BaseFishingEnv(_gym_env_base()):
         return sd
 
     def load_state_dict(self, sd):
-        if self._scalar:
+        if self._host_mapped:
             torch.cuda.current_stream(self.device).synchronize()
         for k in self._STATE_TENSORS:
             if k in sd:
@@ -462,6 +478,8 @@ class BaseFishingEnv(_gym_env_base()):
         _capi.check(rc, "fishing_reset")
         self._reset_count += 1
         self._numpy_redraw()
+        if self._host_mapped and not self._scalar:
+            self._host_sync()
         if self._scalar:
             self.reward = 0 if self.MODEL != MODEL_V4 else self.reward   # v4 leaves it (quirk B8)
             self.harvest = 0
@@ -479,6 +497,14 @@ class BaseFishingEnv(_gym_env_base()):
             if a.size != 1:
                 raise ValueError("expected 1 action, got shape %s" % (np.shape(action),))
             self._host_action_np[0] = a[0]
+            return self._host_action
+        if self._host_mapped:                 # N actions into the pinned buffer the kernel reads over PCIe
+            if isinstance(action, torch.Tensor):
+                action = action.detach().cpu().numpy()
+            a = np.asarray(action)
+            if a.size != N:
+                raise ValueError("expected %d actions, got shape %s" % (N, np.shape(action)))
+            self._host_action_np[:] = a.reshape(N)
             return self._host_action
         if isinstance(action, torch.Tensor):
             a = action
@@ -536,6 +562,8 @@ class BaseFishingEnv(_gym_env_base()):
         self._last_action = a
         if self._scalar:
             return self._step_result()
+        if self._host_mapped:                 # the results are in host memory: valid once the stream has drained
+            self._host_sync()
         return self._obs_view, self._reward, self._done_view, self._info
 
     def _step_result(self):
@@ -826,7 +854,7 @@ class FishingModelError(BaseFishingEnv):
         _capi.check(rc, "fishing_reset")
         self._reset_count += 1
         self._numpy_redraw()
-        if self._scalar:       # the arena is host memory here: let the reset kernel land before overwriting
+        if self._host_mapped:  # the arena is host memory here: let the reset kernel land before overwriting
             torch.cuda.current_stream(self.device).synchronize()
         self._obs.fill_(float(self.init_state) / float(self.K_mean) - 1.0)
         self._publish_scalar_state()

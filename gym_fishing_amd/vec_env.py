@@ -11,8 +11,10 @@ everything on the device; this wrapper is the boundary for callers that want wha
     dones    bool    ndarray [N]
     infos    list of N dicts; infos[i]["terminal_observation"] (ndarray [1]) where dones[i]
 
-The hot path is unchanged -- one kernel launch per step with the fused auto-reset -- followed by one
-asynchronous device-to-host copy per output into pinned staging buffers and a single stream sync.  When stable_baselines3 is importable the class derives from its
+The hot path is unchanged -- one kernel launch per step with the fused auto-reset.  Up to 8192 envs
+(`make_vec_env`'s default, `host_mapped=True`) the env's streams live in pinned, device-mapped host memory: the kernel
+reads the actions and writes the results over PCIe and a step is launch + stream sync with no copies; larger batches
+keep their state in HBM and come down as two asynchronous copies into pinned staging buffers and one stream sync.  When stable_baselines3 is importable the class derives from its
 `VecEnv`, so `PPO("MlpPolicy", FishingVecEnv(env))` accepts it as is; without SB3 it is a plain
 class with the same methods.
 """
@@ -54,6 +56,7 @@ class FishingVecEnv(_BASE):
         # step kernel, followed by ONE stream sync -- a .cpu() per output would sync four times and an
         # upload from pageable memory once more.
         n = env.num_envs
+        self._host_mapped = bool(getattr(env, "_host_mapped", False))
         esz = torch.empty(0, dtype=env.dtype).element_size()
         offs = env._arena_offs
         self._arena_end = offs[3] + n
@@ -63,6 +66,9 @@ class FishingVecEnv(_BASE):
         self._hv_done = self._h_arena[offs[3]:offs[3] + n].numpy()
         self._h_term = torch.empty(n, dtype=env.dtype).pin_memory()
         self._hv_term = self._h_term.numpy()
+        if self._host_mapped:       # zero-copy: NumPy views of the env's own pinned streams
+            self._hv_obs, self._hv_rew = env._obs.numpy(), env._reward.numpy()
+            self._hv_done, self._hv_term = env._done.numpy(), env._terminal_obs.numpy()
         self._h_act = torch.empty(n, dtype=env._want).pin_memory()
         self._hv_act = self._h_act.numpy()
         self._d_act = torch.empty(n, dtype=env._want, device=env.device)
@@ -74,6 +80,8 @@ class FishingVecEnv(_BASE):
     # ------------------------------------------------------------------ VecEnv protocol
     def _download(self, with_terminal):
         env = self.env
+        if self._host_mapped:       # the env's streams ARE host memory and step() / reset() already waited
+            return
         self._h_arena.copy_(env._arena[:self._arena_end], non_blocking=True)
         if with_terminal:
             self._h_term.copy_(env._terminal_obs, non_blocking=True)
@@ -88,11 +96,15 @@ class FishingVecEnv(_BASE):
         self._pending = actions
 
     def step_wait(self):
-        self._hv_act[:] = np.asarray(self._pending).reshape(self.num_envs)
-        self._pending = None
-        self._d_act.copy_(self._h_act, non_blocking=True)
-        self.env.step(self._d_act)
-        self._download(True)
+        if self._host_mapped:
+            self.env.step(np.asarray(self._pending))
+            self._pending = None
+        else:
+            self._hv_act[:] = np.asarray(self._pending).reshape(self.num_envs)
+            self._pending = None
+            self._d_act.copy_(self._h_act, non_blocking=True)
+            self.env.step(self._d_act)
+            self._download(True)
         n = self.num_envs
         obs_h = self._hv_obs.astype(self._obs_dtype).reshape(n, 1)      # copies: callers may keep them across steps
         rew_h = self._hv_rew.astype(np.float32)
@@ -151,5 +163,6 @@ def make_vec_env(env_id, n_envs, **kwargs):
     device behind the NumPy VecEnv protocol."""
     from . import make
     kwargs.setdefault("auto_reset", True)
+    kwargs.setdefault("host_mapped", int(n_envs) <= 8192)      # small batches: state in pinned host memory, no copies
     kwargs["record_terminal_obs"] = True
     return FishingVecEnv(make(env_id, num_envs=int(n_envs), **kwargs))

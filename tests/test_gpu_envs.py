@@ -666,6 +666,19 @@ def test_numpy_vec_env_adapter_follows_the_sb3_protocol(gf):
     v0.reset()
     obs, rew, done, infos = v0.step(np.full(8, 10))
     assert np.allclose(rew, 0.1) and not done.any() and obs.dtype == np.float32
+    # above 8192 envs the adapter keeps the state in HBM and downloads it (two async copies + one sync)
+    assert venv.env._host_mapped and venv.env._obs.device.type == "cpu" and venv.env._obs.is_pinned()
+    big = make_vec_env("fishing-v1", 9216, sigma=0.1, seed=3, Tmax=Tmax)
+    tbig = gf.make("fishing-v1", num_envs=9216, sigma=0.1, seed=3, Tmax=Tmax, record_terminal_obs=True)
+    assert not big.env._host_mapped and big.env._obs.device.type == "cuda"
+    ob, tb = big.reset(), tbig.reset()
+    ab = rng.uniform(-1, -0.5, (9216, 1)).astype(np.float32)
+    for _ in range(7):
+        ob, rb, db, ib = big.step(ab)
+        o2, r2, d2, i2 = tbig.step(torch.as_tensor(ab))
+        assert np.array_equal(ob, o2.cpu().numpy()) and np.array_equal(rb, r2.cpu().numpy()) and np.array_equal(db, d2.cpu().numpy())
+        for j in np.flatnonzero(db)[:3]:
+            assert ib[j]["terminal_observation"][0] == i2["terminal_observation"].cpu().numpy()[j, 0]
     # the fp64 parity layout and per-env parameters behind the same float32 NumPy boundary
     v4 = make_vec_env("fishing-v4", 16, sigma=0.05, seed=2, dtype=torch.float64)
     t4 = gf.make("fishing-v4", num_envs=16, sigma=0.05, seed=2, dtype=torch.float64, record_terminal_obs=True)
