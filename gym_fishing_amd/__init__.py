@@ -79,4 +79,7 @@ def __getattr__(name):
                 "BevertonHolt", "May", "Myers", "Ricker", "NonStationary", "ModelUncertainty"):
         from . import envs
         return getattr(envs, name)
+    if name in ("make_vec_env", "FishingVecEnv"):       # NumPy / SB3 VecEnv adapter
+        from . import vec_env
+        return getattr(vec_env, name)
     raise AttributeError(name)
