@@ -217,7 +217,8 @@ def main():
                    "collective": "1 all-reduce of 4 doubles per rollout" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "fishing::step_kernel_lean<float, 1, 2, %s, false, %s>" % (
+                     # <T, MODEL, NOISE, RET, SIGARR, T8, DRIFT, TERM, BITS> as rocprofv3 prints it
+                     "kernel": "fishing::step_kernel_lean<float, 1, 2, %s, false, %s, false, false, false>" % (
                          "true" if with_returns else "false", "true" if args.compact else "false"),
                      "bytes_per_env_step": bytes_per,
                      "avg_launch_us": kernel_ms * 1e3, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
