@@ -293,9 +293,11 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
     // trips in front of the first global load of every wave.  Measured (scripts/exp/ab_lean_variants.py,
-    // N = 2^22): bare step 16.9 -> 16.5 us; with the return accumulator the three extra SGPRs cost
-    // more than the batch saves (23.0 -> 23.15 us), so only the RET = false variants do it.
-    if constexpr (FISHING_LEAN_BATCH_ARGS && !RET) {
+    // N = 2^22): bare step 16.9 -> 16.5 us.  With the return accumulator the batch used to cost more than
+    // it saved (23.0 -> 23.15 us) while the record ran sixteen double operations per tile; with the cheaper
+    // record it pays there too, 21.67 -> 21.45 us, as long as the ep_return / partials pointers stay out of
+    // the batch (21.50 with them): profiles/r01f_lean_fence_ab.txt.
+    if constexpr (FISHING_LEAN_BATCH_ARGS != 0) {
         asm volatile("" ::"s"(a.obs), "s"(a.action), "s"(a.reward), "s"(a.done), "s"(a.t), "s"(a.counter), "s"(a.pr),
                      "s"(a.pK), "s"(a.sigma), "s"(a.C), "s"(a.x0), "s"(a.Tmax), "s"(a.n_actions), "s"(a.auto_reset),
                      "s"(ntiles), "s"(env_offset), "s"(seed), "s"(step_counter_arg));
