@@ -925,3 +925,32 @@ def test_lean_done_bits_variant_agrees_with_general_kernel_and_the_byte_mask(hh,
         assert np.array_equal(bits, A.done.cpu().numpy())
         seen += int(bits.sum())
     assert seen > n
+
+
+@pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
+def test_zigzag_walk_at_large_n_agrees_with_general_kernel(hh, ret):
+    """From N = 2^25 the float32 lean kernel walks the tiles backwards on odd steps (what the previous step touched
+    last is still in the Infinity Cache).  The order of the walk must not show: three steps (even, odd, even
+    counters) at N = 2^25 + 3077 against the general kernel, every stream bit-for-bit."""
+    import torch
+    n = (1 << 25) + 3077
+    kw = dict(sigma=0.1, Tmax=2, auto_reset=True)
+    pa, pb = hh.params(fo.MODEL_V1, **kw), hh.params(fo.MODEL_V1, general=True, **kw)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    outs = []
+    for p in (pa, pb):
+        st = hh.State(n, np.float32, fo.MODEL_V1, np.float32(-0.25), ep_return=ret)
+        for s in range(3):
+            assert lib.fishing_step_f32(p, n, 0, st.buffers(a), 11, s, None) == 0
+        torch.cuda.synchronize()
+        outs.append(st)
+    A, B = outs
+    for name in ("obs", "reward", "done", "t") + (("ep_return",) if ret else ()):
+        assert torch.equal(getattr(A, name), getattr(B, name)), name
+    if ret:
+        ra, rb = A.record(), B.record()
+        assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12) and ra[2] > n
+    del A, B, outs
+    torch.cuda.empty_cache()
