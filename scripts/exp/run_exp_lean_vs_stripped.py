@@ -32,13 +32,13 @@ def run(kind, k):
         lib.exp_step(4, 0, 2048, n, obs, a, rew, done, t, 1, k, st)
     elif kind.startswith("pipelined"):
         lib.exp_step(43, 0, int(kind.split("_")[1]), n, obs, a, rew, done, t, 1, k, st)
-    elif kind == "copy":
-        lib.exp_step(4, 1, 2048, n, obs, a, rew, done, t, 1, k, st)
+    elif kind.startswith("copy"):
+        lib.exp_step(4, 1, int(kind.split("_")[1]) if "_" in kind else 2048, n, obs, a, rew, done, t, 1, k, st)
     else:
         b = _capi.make_buffers(obs=obs, action=a, reward=rew, done=done, t=t)
         rc = prod.fishing_step_f32(p if kind == "lean" else pg, n, 0, b, 1, k, st)
         assert rc == 0
-kinds = ["stripped", "pipelined_2048", "pipelined_1024", "pipelined_1365", "lean", "copy"]
+kinds = ["stripped", "pipelined_2048", "lean", "general", "copy", "copy_4096"]
 res = {k: [] for k in kinds}
 for rnd in range(6):
     for kind in kinds:
