@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the vectorised step() at N = 2^22 envs, fishing-v1.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config v1|v0|v2|v4]
 
 A "step" is one pass of the hot path over one batch: one fishing_step_f32 launch that
 advances every env of this rank's shard by one timestep (actions are read from HBM:
 a ring of pre-generated random-policy action batches, resident before the clock starts).
-Workload (BASELINE.json metric / config 2 at the metric's N): fishing-v1, sigma = 0.1,
-r = 0.3, K = 1, x0 = 0.75, Tmax = 100, N = 2^22 envs per GPU, U[-1,1) float32 actions,
-in-kernel Philox noise, fused auto-reset, per-env episodic-return accumulation.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): every rank
-owns its own 2^22 envs (weak scaling; global env index = rank * 2^22 + i keys the noise),
-no data-path collective; one RCCL all-reduce of the 4-double episodic-return record at the
-end of the rollout, inside the timed region.
+Workloads (--config; SURVEY.md section 8d's concrete inputs for BASELINE.json's configs):
+  v1 (default, the metric's config)  fishing-v1 sigma=0.1, N = 2^22 per GPU, U[-1,1) float32 actions
+  v0 (config 3)  fishing-v0 n_actions=100 sigma=0.1, N = 2^22, uniform int32 actions in [0, 100)
+  v2 (config 4)  fishing-v2 C=0.5 sigma=0.1, U[-1,-0.8) actions; N = 2^22 on one GPU, 2^19 per GPU otherwise
+  v4 (config 5)  fishing-v4 K_mean=1 r_mean=0.3 sigma_p=0.1, sigma ARRAY filled with 0.05, U[-1,1) actions,
+                 N = 2^21 per GPU (2^24 over 8); (K, r) derived in-kernel (--v4-stored: r / K arrays in HBM)
+all with in-kernel Philox noise, fused auto-reset, per-env episodic-return accumulation.
+
+Multi-GPU (--gpus N): one rank per GPU over RCCL.  Started bare (no WORLD_SIZE in the environment) this script
+launches its N ranks itself as CHILD processes -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ... bench.py <same flags>` -- before anything touches the GPU, relays rank 0's JSON line
+and exits with the children's status; started by torch.distributed.run it is one of those ranks.  Every rank owns
+its own envs (weak scaling; global env index = rank * n + i keys the noise), no data-path collective; one
+all-reduce of the 4-double episodic-return record per rollout, inside the timed region.
+
+Timed region: a device spin-up (the same launches, >= --spinup-ms, reported) and W warm-up steps come first;
+then EXACTLY K steps between barrier + synchronize on both sides: K launches + the record's reduce kernel
+(+ the all-reduce) enqueued, one synchronize.  The record is read back to the host after the clock stops.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,15 +40,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-N_ENVS = 1 << 22
 RING = 8
 # algorithmic bytes per env-step: fp32 layout 25 B (R obs 4 + action 4 + t 4,
 # W obs 4 + reward 4 + done 1 + t 4) + 8 B for the per-env episodic-return accumulator (R+W 4)
 BYTES_STEP = 25
 BYTES_STEP_COMPACT = 19     # --compact: years_passed as uint8 (R 1 + W 1 instead of R 4 + W 4)
 BYTES_RETURN_ACC = 8
+BYTES_SIGMA_ARRAY = 4       # fishing-v4: per-env sigma (R 4)
+BYTES_RK_ARRAYS = 8         # fishing-v4 --v4-stored: per-env r, K (R 4 + 4); their redraw writes are NOT counted
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 HBM_COPY_GBS = 6290.0       # measured float4 copy on the same table
+
+CONFIGS = {
+    "v1": dict(env_id="fishing-v1", kwargs=dict(sigma=0.1), actions=("uniform", -1.0, 1.0), log2_n=22, log2_n_multi=22,
+               baseline_config=2, what="fishing-v1 sigma=0.1 r=0.3 K=1 x0=0.75 Tmax=100"),
+    "v0": dict(env_id="fishing-v0", kwargs=dict(sigma=0.1, n_actions=100), actions=("int", 0, 100), log2_n=22, log2_n_multi=22,
+               baseline_config=3, what="fishing-v0 n_actions=100 sigma=0.1 (index->quota map in-kernel)"),
+    "v2": dict(env_id="fishing-v2", kwargs=dict(sigma=0.1, C=0.5), actions=("uniform", -1.0, -0.8), log2_n=22, log2_n_multi=19,
+               baseline_config=4, what="fishing-v2 tipping point C=0.5 sigma=0.1"),
+    "v4": dict(env_id="fishing-v4", kwargs=dict(K_mean=1.0, r_mean=0.3, sigma_p=0.1), actions=("uniform", -1.0, 1.0),
+               log2_n=21, log2_n_multi=21, baseline_config=5,
+               what="fishing-v4 K_mean=1 r_mean=0.3 sigma_p=0.1, per-env sigma array (0.05), (K, r) redrawn per episode"),
+}
 
 
 def parse():
@@ -43,32 +69,71 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5050)
     ap.add_argument("--warmup", type=int, default=505)
-    ap.add_argument("--n-envs", type=int, default=N_ENVS, help="envs per GPU (default 2^22, the metric's N)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="v1", help="workload (default v1 = the metric's)")
+    ap.add_argument("--n-envs", type=int, default=0, help="envs per GPU (default: the config's N)")
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
+                    help="device spin-up ahead of --warmup: the same launches for at least this long (clocks, caches, "
+                         "code objects); reported, never part of the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-returns", action="store_true", help="pure 25 B step (no episodic-return accumulator)")
+    ap.add_argument("--no-subrecords", action="store_true", help="skip the bare-step / HBM-resident / fused sub-records")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--compact", action="store_true",
                     help="opt-in compact layout (uint8 year counter, 19 B/env-step); NOT the BASELINE layout")
-    ap.add_argument("--extra", action="store_true", help="also time the fused rollout and an L3-spilling N")
+    ap.add_argument("--v4-stored", action="store_true", help="config v4 with r / K arrays in HBM instead of derived (K, r)")
+    ap.add_argument("--extra", action="store_true", help="also time the fused rollout and an N sweep")
     return ap.parse_args()
 
 
-def cpu_baseline(seconds):
-    """Reference-equivalent scalar Python port (oracle/scalar_env.py), one core, bounded sample."""
+# --------------------------------------------------------------------------------------- multi-GPU self-launch
+def self_launch(args):
+    """--gpus N > 1 without a torch.distributed.run parent: start the N ranks as children (nothing in THIS process
+    has touched the GPU), relay rank 0's JSON line, return the children's exit status."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)       # stderr passes through
+    line = None
+    for out in proc.stdout:
+        out = out.strip()
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+# --------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline(seconds, cfg_name):
+    """Reference-equivalent scalar Python port (oracle/scalar_env.py), one core, bounded sample; beside it the same
+    port on every core, the NumPy-vectorised (N,) restatement and the plain-C port."""
+    cfg = CONFIGS[cfg_name]
+    env_id = cfg["env_id"]
+    scalar_id = env_id if env_id != "fishing-v4" else "fishing-v1"   # the scalar port has no v4 (same arithmetic as v1)
+    skw = dict(sigma=0.1 if cfg_name != "v4" else 0.05)
     from oracle.scalar_env import time_random_rollout
-    rate, _ = time_random_rollout("fishing-v1", 20_000, seed=0, sigma=0.1)      # calibrate
+    rate, _ = time_random_rollout(scalar_id, 20_000, seed=0, **skw)      # calibrate
     n = int(max(50_000, min(rate * seconds, 5_000_000)))
-    rate, _ = time_random_rollout("fishing-v1", n, seed=1, sigma=0.1)
+    rate, _ = time_random_rollout(scalar_id, n, seed=1, **skw)
     out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": "oracle/scalar_env.py (per-env NumPy step(), same op sequence as the reference): "
-                     "%d env-steps of fishing-v1 sigma=0.1, random policy, reset on done, 1 core" % n}
+                     "%d env-steps of %s sigma=%g, random policy, reset on done, 1 core" % (n, scalar_id, skw["sigma"])}
     try:    # the same Python port on every core of the box's CPU share (BASELINE.md section 4a);
         # independent `python -c` workers: nothing here depends on how this file was started
-        import subprocess
         procs = max(1, min(os.cpu_count() or 1, 16))
         per = max(20_000, n // 8)
         code = ("import sys; sys.path.insert(0, %r); from oracle.scalar_env import time_random_rollout; "
-                "print(time_random_rollout('fishing-v1', %d, seed=int(sys.argv[1]), sigma=0.1)[0])" % (ROOT, per))
+                "print(time_random_rollout(%r, %d, seed=int(sys.argv[1]), sigma=%r)[0])" % (ROOT, scalar_id, per, skw["sigma"]))
         kids = [subprocess.Popen([sys.executable, "-c", code, str(100 + i)], stdout=subprocess.PIPE,
                                  stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
         rates = [float(k.communicate(timeout=180)[0].strip().splitlines()[-1]) for k in kids]
@@ -78,18 +143,34 @@ def cpu_baseline(seconds):
                                                       "per-process rates" % (procs, per)}
     except Exception as e:  # noqa: BLE001
         out["python_port_all_cores_error"] = repr(e)[:200]
+    try:    # the NumPy-vectorised (N,) restatement, one process
+        from oracle.vector_env import time_vectorised_rollout
+        kind, lo, hi = cfg["actions"]
+        vkw = dict(cfg["kwargs"])
+        vkw.setdefault("sigma", 0.05)
+        if kind == "uniform":
+            vkw.update(action_low=lo, action_high=hi)
+        nv, tv = 1 << 16, 40
+        time_vectorised_rollout(env_id, nv, 3, seed=0, **vkw)
+        vrate, _ = time_vectorised_rollout(env_id, nv, tv, seed=1, **vkw)
+        out["numpy_vectorised"] = {"value": vrate, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                                   "sample": "oracle/vector_env.py: the oracle's float64 step() over (N,) arrays, N = %d envs x "
+                                             "%d steps of %s, np.random.normal(0, 1, N) per step, 1 process" % (nv, tv, env_id)}
+    except Exception as e:  # noqa: BLE001
+        out["numpy_vectorised_error"] = repr(e)[:200]
     try:    # stronger CPU figure for context: the plain-C oracle over all host cores
         from oracle import c_oracle
+        model = {"v0": 0, "v1": 1, "v2": 2, "v4": 1}[cfg_name]
         threads = min(os.cpu_count() or 1, 64)
-        c_oracle.rollout_random_f32(1, 1 << 16, 8, threads=threads)             # warm the thread pool
+        c_oracle.rollout_random_f32(model, 1 << 16, 8, threads=threads)             # warm the thread pool
         nn, T = 1 << 20, 32
         t0 = time.perf_counter()
-        c_oracle.rollout_random_f32(1, nn, T, threads=threads)
+        c_oracle.rollout_random_f32(model, nn, T, threads=threads)
         dt = time.perf_counter() - t0
         out["c_port_all_cores"] = {"value": nn * T / dt, "unit": "env-steps/s", "cores": threads,
                                    "sample": "oracle/fishing_oracle.c float32 + OpenMP, %d envs x %d steps" % (nn, T)}
         t0 = time.perf_counter()
-        c_oracle.rollout_random_f32(1, nn // 8, T, threads=1)
+        c_oracle.rollout_random_f32(model, nn // 8, T, threads=1)
         dt = time.perf_counter() - t0
         out["c_port_1_core"] = {"value": nn // 8 * T / dt, "unit": "env-steps/s", "cores": 1}
     except Exception as e:  # noqa: BLE001 - the C port is optional context
@@ -97,22 +178,95 @@ def cpu_baseline(seconds):
     return out
 
 
-def pmc_traffic(n_envs, with_returns):
+def pmc_traffic(kernel, n_envs):
     """HBM bytes per launch from a committed rocprofv3 --pmc summary of this same command
     (profiles/pmc_latest.json), or None.  bench.py cannot profile itself."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(path) as f:
             rec = json.load(f)
-        if rec.get("n_envs") == n_envs and bool(rec.get("with_returns")) == bool(with_returns):
-            return rec.get("hbm_bytes_per_launch"), rec.get("source")
+        for r in rec if isinstance(rec, list) else [rec]:
+            if r.get("n_envs") == n_envs and r.get("kernel") == kernel:
+                return r.get("hbm_bytes_per_launch"), r.get("source")
     except Exception:  # noqa: BLE001
         pass
     return None, None
 
 
+# --------------------------------------------------------------------------------------- one rank
+def make_actions(torch, cfg, n, rows, generator, pad=3072):
+    """[rows, n] action ring; rows are `pad` elements longer than n so consecutive batches do not start at
+    power-of-two-spaced addresses (same reason the env staggers its own streams)."""
+    kind, lo, hi = cfg["actions"]
+    dtype = torch.int32 if kind == "int" else torch.float32
+    ring = torch.empty((rows, n + pad), device="cuda", dtype=dtype)
+    view = ring[:, :n]
+    if kind == "int":
+        view.copy_(torch.randint(lo, hi, (rows, n), device="cuda", generator=generator, dtype=torch.int32))
+    else:
+        view.copy_(torch.rand((rows, n), device="cuda", generator=generator, dtype=torch.float32) * (hi - lo) + lo)
+    return view
+
+
+def make_env(gf, torch, cfg_name, n, env_offset, with_returns, compact=False, v4_stored=False):
+    cfg = CONFIGS[cfg_name]
+    kw = dict(cfg["kwargs"])
+    if cfg_name == "v4":
+        kw["sigma"] = torch.full((n,), 0.05, dtype=torch.float32, device="cuda")
+        kw["derived_params"] = not v4_stored
+    return gf.make(cfg["env_id"], num_envs=n, env_offset=env_offset, seed=1234, track_returns=with_returns,
+                   auto_reset=True, compact=compact, **kw)
+
+
+def bytes_per_env_step(cfg_name, with_returns, compact=False, v4_stored=False):
+    b = BYTES_STEP_COMPACT if compact else BYTES_STEP
+    if cfg_name == "v4":
+        b += BYTES_SIGMA_ARRAY + (BYTES_RK_ARRAYS if v4_stored else 0)
+    return b + (BYTES_RETURN_ACC if with_returns else 0)
+
+
+def spin_up(torch, env, actions, min_ms):
+    """Run the benchmark's own launches until `min_ms` of wall time has passed (device clocks ramp under load;
+    the first launches of a cold device run 10-40 % slow).  Returns (ms, launches)."""
+    t0 = time.perf_counter()
+    launches = 0
+    while (time.perf_counter() - t0) * 1e3 < min_ms:
+        env.step_many(actions, 256)
+        torch.cuda.synchronize()
+        launches += 256
+    return (time.perf_counter() - t0) * 1e3, launches
+
+
+def per_launch_us(torch, env, actions, launches):
+    """Event-to-event duration of `launches` single steps (one event pair per launch, same stream): median / mean.
+    Includes the event packets' own gaps, so it sits a little above the kernel time rocprofv3 reports."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+    R = actions.shape[0]
+    evs[0].record()
+    for i in range(launches):
+        env.step_many(actions[i % R:i % R + 1], 1)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    d = [evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(launches)]
+    return statistics.median(d), statistics.fmean(d)
+
+
+def timed_steps(torch, env, actions, steps, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    env.step_many(actions, steps, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / steps, time.perf_counter() - t0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     import torch
     import torch.distributed as dist
 
@@ -120,7 +274,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d under torch.distributed.run needs %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     # rehearsal knobs (not used by the driver): several ranks on ONE device over gloo, to run the
@@ -153,17 +307,13 @@ def main():
             os.close(saved_fd)
 
     import gym_fishing_amd as gf
-    n = args.n_envs
+    cfg = CONFIGS[args.config]
+    n = args.n_envs or (1 << (cfg["log2_n"] if world == 1 else cfg["log2_n_multi"]))
     with_returns = not args.no_returns
-    env = gf.make("fishing-v1", sigma=0.1, num_envs=n, env_offset=rank * n, seed=1234,
-                  track_returns=with_returns, auto_reset=True, compact=args.compact)
+    env = make_env(gf, torch, args.config, n, rank * n, with_returns, args.compact, args.v4_stored)
     env.reset()
     g = torch.Generator(device="cuda").manual_seed(4321 + rank)
-    # ring rows are 12 KiB longer than N so consecutive batches do not start at power-of-two-spaced
-    # addresses (same reason the env staggers its own streams)
-    ring = torch.empty((RING, n + 3072), device="cuda", dtype=torch.float32)
-    actions = ring[:, :n]
-    actions.copy_(torch.rand((RING, n), device="cuda", generator=g, dtype=torch.float32) * 2 - 1)
+    actions = make_actions(torch, cfg, n, RING, g)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -171,6 +321,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    spin_ms, spin_launches = spin_up(torch, env, actions, args.spinup_ms)
     env.step_many(actions, args.warmup)
     if with_returns:
         env.episode_stats()           # warm the reduce kernel and the RCCL communicator
@@ -180,7 +331,7 @@ def main():
     ev0.record()
     env.step_many(actions, args.steps)            # K launches on torch's current stream
     ev1.record()
-    stats = env.episode_stats() if with_returns else {}
+    record = env.episode_record() if with_returns else None     # reduce kernel (+ all-reduce), enqueued only
     sync_all()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)     # HIP events around the K launches
@@ -188,14 +339,25 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    stats = {}
+    if record is not None:
+        from gym_fishing_amd.sharding import summarize_record
+        stats = summarize_record(record)
+    med_us, mean_us = per_launch_us(torch, env, actions, max(1, min(args.steps, 200)))
 
     total_env_steps = float(n) * world * args.steps
-    bytes_per = (BYTES_STEP_COMPACT if args.compact else BYTES_STEP) + (BYTES_RETURN_ACC if with_returns else 0)
+    bytes_per = bytes_per_env_step(args.config, with_returns, args.compact, args.v4_stored)
     achieved = n * bytes_per / (kernel_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(n, with_returns)
-    resident = n * (4 + (1 if args.compact else 4) + 4 + 1 + (4 if with_returns else 0)) + RING * (n + 3072) * 4
+    kernel = env.step_kernel_name(actions[0])
+    traffic, traffic_src = pmc_traffic(kernel, n)
+    esz = 1 if args.compact else 4
+    resident = n * (4 + esz + 4 + 1 + (4 if with_returns else 0) + (4 if args.config == "v4" else 0)
+                    + (8 if args.v4_stored and args.config == "v4" else 0)) + RING * (n + 3072) * 4
+    fits = resident < 256 * 2 ** 20
+    log2n = n.bit_length() - 1 if n & (n - 1) == 0 else None
     out = {
-        "metric": "env-steps/sec at N=2^22, fishing-v1",
+        "metric": "env-steps/sec at N=2^22, fishing-v1" if args.config == "v1" else
+                  "env-steps/sec, BASELINE config %d (%s)" % (cfg["baseline_config"], cfg["env_id"]),
         "value": total_env_steps / elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,
@@ -207,57 +369,110 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "fishing-v1 sigma=0.1 r=0.3 K=1 x0=0.75 Tmax=100, N=2^%d envs per GPU, random-policy "
-                               "float32 actions read from HBM (ring of %d batches), in-kernel Philox4x32-10 noise, "
-                               "fused auto-reset%s%s; one fishing_step_f32 launch per step" % (
-                                   n.bit_length() - 1, RING,
-                                   ", per-env episodic-return accumulator + return record" if with_returns else "",
-                                   "; COMPACT layout (uint8 year counter)" if args.compact else ""),
+        "config": {"workload": "%s, N=%s envs per GPU, random-policy %s actions read from HBM (ring of %d batches), "
+                               "in-kernel Philox4x32-10 noise, fused auto-reset%s%s%s; one fishing_step_f32 launch per step" % (
+                                   cfg["what"], ("2^%d" % log2n) if log2n is not None else str(n),
+                                   "int32 [0,100)" if cfg["actions"][0] == "int" else "float32 U[%g,%g)" % cfg["actions"][1:],
+                                   RING, ", per-env episodic-return accumulator + return record" if with_returns else "",
+                                   "; COMPACT layout (uint8 year counter)" if args.compact else "",
+                                   ("; r / K arrays in HBM" if args.v4_stored else "; (K, r) re-derived in-kernel, no r / K arrays")
+                                   if args.config == "v4" else ""),
+                   "name": args.config, "baseline_config": cfg["baseline_config"],
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-shard x%d" % world,
-                   "collective": "1 all-reduce of 4 doubles per rollout" if world > 1 else "none"},
+                   "collective": "1 all-reduce of 4 doubles per rollout (%s)" % ("RCCL" if backend == "nccl" else backend)
+                                 if world > 1 else "none"},
+        "spinup": {"ms": spin_ms, "launches": spin_launches,
+                   "note": "same launches as the timed region, ahead of --warmup; not timed"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     # <T, MODEL, NOISE, RET, SIGARR, T8, DRIFT, TERM, BITS> as rocprofv3 prints it
-                     "kernel": "fishing::step_kernel_lean<float, 1, 2, %s, false, %s, false, false, false>" % (
-                         "true" if with_returns else "false", "true" if args.compact else "false"),
-                     "bytes_per_env_step": bytes_per,
-                     "avg_launch_us": kernel_ms * 1e3, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                     "note": "resident arrays %.0f MB (obs, t, reward, done%s + %d action batches): %s the 256 MiB "
-                             "Infinity Cache" % (resident / 1e6, ", ep_return" if with_returns else "", RING,
-                                                 "fits" if resident < 256 * 2 ** 20 else "exceeds")},
+                     "kernel": kernel, "bytes_per_env_step": bytes_per,
+                     "avg_launch_us": kernel_ms * 1e3, "launch_us_median": med_us, "launch_us_mean_event_pairs": mean_us,
+                     "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                     "cache_resident": fits,
+                     "note": "avg_launch_us = HIP events around the K timed launches / K; launch_us_median = median of "
+                             "event-to-event durations of single launches, measured right after.  Resident arrays %.0f MB "
+                             "(state streams + %d action batches): %s the 256 MiB Infinity Cache%s" % (
+                                 resident / 1e6, RING, "fits" if fits else "exceeds",
+                                 " -- the HBM-resident figure is the hbm_resident sub-record" if fits else "")},
     }
     if stats:
         out["episode_stats"] = {k: stats[k] for k in ("n_episodes", "mean_return", "std_return", "mean_length") if k in stats}
 
-    if with_returns and rank == 0 and world == 1 and not args.compact:
-        # for reference on the same line: the bare 25-byte step (no return accumulator), i.e. exactly
+    subrecords = rank == 0 and world == 1 and not args.no_subrecords and not args.compact
+    if subrecords and with_returns:
+        # for reference on the same line: the bare step (no return accumulator), i.e. exactly
         # SURVEY 8(d)'s per-unit figure, measured right after the headline region on the same device
-        bare = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=1234, auto_reset=True)
+        bare = make_env(gf, torch, args.config, n, 0, False, False, args.v4_stored)
         bare.reset()
-        bare.step_many(actions, min(args.warmup, 200))
-        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        kb = max(1, min(args.steps, 2020))
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        b0.record()
-        bare.step_many(actions, kb)
-        b1.record()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - tb
-        us = b0.elapsed_time(b1) * 1e3 / kb
-        out["bare_step"] = {"value": n * kb / wall, "unit": "env-steps/s", "steps": kb, "bytes_per_env_step": BYTES_STEP,
-                            "avg_launch_us": us, "achieved_GBps": n * BYTES_STEP / us / 1e3,
-                            "frac": n * BYTES_STEP / us / 1e3 / HBM_PEAK_GBS,
+        bare.step_many(actions, min(max(args.warmup, 50), 200))
+        kb = max(20, min(args.steps, 2020))
+        us, wall = timed_steps(torch, bare, actions, kb)
+        bb = bytes_per_env_step(args.config, False, False, args.v4_stored)
+        out["bare_step"] = {"value": n * kb / wall, "unit": "env-steps/s", "steps": kb, "bytes_per_env_step": bb,
+                            "avg_launch_us": us, "achieved_GBps": n * bb / us / 1e3, "frac": n * bb / us / 1e3 / HBM_PEAK_GBS,
+                            "kernel": bare.step_kernel_name(actions[0]),
                             "note": "same env family without the per-env episodic-return accumulator"}
         del bare
+    if subrecords:
+        # HBM-resident figure: the same workload at a size whose state streams alone are several times the
+        # 256 MiB Infinity Cache
+        del env
+        torch.cuda.empty_cache()
+        big = 1 << (26 if args.config != "v4" else 25)
+        rows = 4
+        eb = make_env(gf, torch, args.config, big, 0, with_returns, False, args.v4_stored)
+        eb.reset()
+        ab = make_actions(torch, cfg, big, rows, g)
+        eb.step_many(ab, 12)
+        us, _ = timed_steps(torch, eb, ab, 40)
+        out["hbm_resident"] = {"n_envs": big, "steps": 40, "bytes_per_env_step": bytes_per, "avg_launch_us": us,
+                               "achieved_GBps": big * bytes_per / us / 1e3, "frac": big * bytes_per / us / 1e3 / HBM_PEAK_GBS,
+                               "env_steps_per_s": big / us * 1e6, "kernel": eb.step_kernel_name(ab[0]),
+                               "resident_MB": (big * (bytes_per - 1 - 4) / 2 + big * 5 + rows * big * 4) / 1e6,
+                               "note": "same workload, N = 2^%d: far outside the Infinity Cache" % (big.bit_length() - 1)}
+        del eb, ab
+        torch.cuda.empty_cache()
+        # launch-bound sizes: the fused multi-step kernel (K steps per launch, state in registers) next to
+        # the launch-per-step path; env-steps/s only -- its HBM traffic is 9 B/env-step, not the headline's
+        fused = {}
+        for ln in (19, 20):
+            nn = 1 << ln
+            ef = make_env(gf, torch, args.config, nn, 0, with_returns, False, args.v4_stored)
+            ef.reset()
+            af = make_actions(torch, cfg, nn, RING, g)
+            rows_r = torch.empty((101, nn), dtype=torch.float32, device="cuda")
+            rows_d = torch.empty((101, nn), dtype=torch.uint8, device="cuda")
+            ef.step_many(af, 101, fused=True, rewards_out=rows_r, dones_out=rows_d)
+            ef.step_many(af, 202)
+            us_l, _ = timed_steps(torch, ef, af, 1010)
+            us_f, _ = timed_steps(torch, ef, af, 101, fused=True, rewards_out=rows_r, dones_out=rows_d)
+            us_f2, _ = timed_steps(torch, ef, af, 101, fused=True)
+            fb = 9 + (BYTES_SIGMA_ARRAY if args.config == "v4" else 0) * 0
+            fused["2^%d" % ln] = {
+                "per_step_launches": {"us_per_step": us_l, "env_steps_per_s": nn / us_l * 1e6,
+                                      "frac_of_25B_roofline_rate": nn / us_l * 1e6 * BYTES_STEP / (HBM_PEAK_GBS * 1e9)},
+                "fused_with_reward_done_rows": {"us_per_step": us_f, "env_steps_per_s": nn / us_f * 1e6,
+                                                "bytes_per_env_step": fb, "achieved_GBps": nn * fb / us_f / 1e3,
+                                                "frac_of_25B_roofline_rate": nn / us_f * 1e6 * BYTES_STEP / (HBM_PEAK_GBS * 1e9)},
+                "fused_last_step_outputs_only": {"us_per_step": us_f2, "env_steps_per_s": nn / us_f2 * 1e6,
+                                                 "bytes_per_env_step": 4},
+            }
+            del ef, af, rows_r, rows_d
+            torch.cuda.empty_cache()
+        out["fused_step_many"] = dict(fused, note="fishing_step_fused_f32: 101 steps per launch, bit-identical to 101 "
+                                                  "fishing_step_f32 launches; VALU-bound (Philox + Box-Muller), not HBM-bound: "
+                                                  "reported as env-steps/s, never the headline")
+        env = None
 
     if args.extra and rank == 0:
         extra = {}
-        del env, actions
+        if env is not None:
+            del env
+        del actions
         torch.cuda.empty_cache()
         # fused T-step rollout, in-kernel policy (VALU-bound, not HBM-bound): env-steps/s only
         for pol, param in (("random", 0.0), ("escapement", 0.5)):
-            env2 = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=1234, track_returns=True)
+            env2 = make_env(gf, torch, args.config, n, 0, True, False, args.v4_stored)
             env2.reset()
             env2.rollout(101, policy=pol, param=param)
             torch.cuda.synchronize()
@@ -266,28 +481,23 @@ def main():
             torch.cuda.synchronize()
             extra["fused_rollout_%s_env_steps_per_s" % pol] = n * 2020 / (time.perf_counter() - t1)
             del env2
-        # pure 25 B step at sizes that do / do not fit the Infinity Cache (kernel-only, HIP events)
-        for ln in (20, 22, 24, 26):
+        # pure step at sizes that do / do not fit the Infinity Cache (kernel-only, HIP events)
+        bb = bytes_per_env_step(args.config, False, False, args.v4_stored)
+        for ln in (19, 20, 22, 24, 26):
             nn = 1 << ln
-            e3 = gf.make("fishing-v1", sigma=0.1, num_envs=nn, seed=1234)
+            e3 = make_env(gf, torch, args.config, nn, 0, False, False, args.v4_stored)
             e3.reset()
-            acts = torch.rand((4, nn), device="cuda") * 2 - 1
+            acts = make_actions(torch, cfg, nn, 4, g)
             k = max(20, min(400, (1 << 31) // nn))
             e3.step_many(acts, k)
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record()
-            e3.step_many(acts, k)
-            a1.record()
-            torch.cuda.synchronize()
-            us = a0.elapsed_time(a1) * 1e3 / k
-            extra["step_only_2^%d" % ln] = {"us_per_launch": us, "GBps": nn * BYTES_STEP / us / 1e3,
-                                            "env_steps_per_s": nn / us * 1e6}
+            us, _ = timed_steps(torch, e3, acts, k)
+            extra["step_only_2^%d" % ln] = {"us_per_launch": us, "GBps": nn * bb / us / 1e3, "env_steps_per_s": nn / us * 1e6}
             del e3, acts
             torch.cuda.empty_cache()
         out["extra"] = extra
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.config)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

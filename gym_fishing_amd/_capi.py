@@ -10,7 +10,7 @@ import os
 c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 c_dbl, c_vp = ctypes.c_double, ctypes.c_void_p
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4 = 0, 1, 2, 4
 MODEL_V5, MODEL_V6, MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11 = 5, 6, 7, 8, 9, 10, 11
@@ -19,8 +19,9 @@ KIND_OF_NAME = {"allen": KIND_ALLEN, "beverton_holt": KIND_BEVERTON_HOLT, "myers
                 "ricker": KIND_RICKER}
 N_KINDS = 5
 FLAG_AUTO_RESET = 1
-FLAG_GENERAL_KERNEL = 2
 FLAG_T_U8 = 4
+FLAG_V4_DERIVED = 8                  # fishing-v4: (K, r) re-derived in-kernel, no r / K arrays
+FLAG_GENERAL_KERNEL = 0x80000000     # FISHING_FLAG_DIAG_GENERAL_KERNEL (tests, A/B timing)
 POLICY_RANDOM, POLICY_CONSTANT, POLICY_ESCAPEMENT, POLICY_MSY = 0, 1, 2, 3
 STREAM_NOISE, STREAM_AUTORESET, STREAM_RESET, STREAM_POLICY = 0, 1, 2, 3
 
@@ -39,7 +40,8 @@ class FishingParams(ctypes.Structure):
                 ("r_mean", c_dbl), ("K_mean", c_dbl), ("sigma_p", c_dbl),
                 ("launch_blocks", c_i32), ("launch_threads", c_i32),
                 ("M", c_dbl), ("theta", c_dbl), ("q", c_dbl), ("b", c_dbl), ("a", c_dbl), ("alpha", c_dbl),
-                ("n_models", c_i32), ("kinds", c_i32 * 5), ("zoo", FishingGrowthParams * 5)]
+                ("n_models", c_i32), ("kinds", c_i32 * 5), ("zoo", FishingGrowthParams * 5),
+                ("v4_origin_step", c_u64), ("v4_origin_counter", c_u64)]
 
 
 BUFFER_FIELDS = ("obs", "action", "reward", "done", "done_bits", "t", "r", "K", "sigma", "z_ext",
@@ -63,6 +65,12 @@ SIGNATURES = {
     "fishing_step_many_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_i64, c_i32, c_i32, c_u64, c_u64, c_vp]),
     "fishing_reset_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_vp, c_u64, c_u64, c_vp]),
     "fishing_reset_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_step_fused_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_u64, c_u64, c_vp]),
+    "fishing_step_fused_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_u64, c_u64, c_vp]),
+    "fishing_v4_params_f32": (c_i32, [_PP, c_i64, c_i64, c_vp, c_vp, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_v4_params_f64": (c_i32, [_PP, c_i64, c_i64, c_vp, c_vp, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_step_kernel_name_f32": (c_i32, [_PP, c_i64, _BP, ctypes.c_char_p, c_i64]),
+    "fishing_step_kernel_name_f64": (c_i32, [_PP, c_i64, _BP, ctypes.c_char_p, c_i64]),
     "fishing_rollout_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),
     "fishing_rollout_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),
     "fishing_reduce_returns": (c_i32, [c_vp, c_vp, c_vp]),

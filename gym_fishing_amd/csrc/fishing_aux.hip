@@ -1,0 +1,289 @@
+// fishing_aux.hip -- everything of libfishing_hip.so that is not on the per-step hot path (gfx950):
+// reset(), the return-record reduction, population_draw() sweeps, fishing-v4's parameter materialisation,
+// the graph-replay counter and the generator's test hooks.
+#include "fishing_common.h"
+#include "fishing_host.h"
+
+#include <algorithm>
+
+namespace fishing {
+
+// reset(): one env per thread (not on the hot path; runs once per rollout).
+template <typename T, int MODEL>
+__global__ void __launch_bounds__(256)
+reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
+             const uint8_t* __restrict__ mask, const uint64_t seed, const uint64_t reset_counter) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (mask && !mask[i]) continue;
+        T K = p.K;
+        if (is_zoo_tag(MODEL) && p.model == FISHING_MODEL_V11) {
+            const uint64_t env = env_offset + (uint64_t)i;      // quad scheme of redraw_kinds
+            const Words4 w = philox_block(seed, env >> 2, reset_counter, kStreamReset);
+            const uint32_t leg = (uint32_t)(env & 3);
+            const uint32_t word = leg == 0 ? w.w0 : leg == 1 ? w.w1 : leg == 2 ? w.w2 : w.w3;
+            b.model_idx[i] = p.kinds[action_int_from_word(word, p.n_models)];
+        }
+        if (MODEL == FISHING_MODEL_V4 && b.K && b.r) {      // derived mode keeps no arrays: nothing to draw here
+            T r;
+            draw_model_error<T>(seed, env_offset + (uint64_t)i, reset_counter, kStreamReset, p.K_mean,
+                                p.r_mean, p.sigma_p, K, r);
+            b.K[i] = K;
+            b.r[i] = r;
+        }
+        b.obs[i] = reset_obs<T, MODEL>(p.x0, K);
+        if (p.flags & FISHING_FLAG_T_U8) reinterpret_cast<uint8_t*>(b.t)[i] = 0;
+        else b.t[i] = 0;
+        if (b.ep_return) b.ep_return[i] = (T)0;
+    }
+}
+
+// fishing-v4, derived parameters: the (K, r) in force for each env, from its year counter
+template <typename T>
+__global__ void __launch_bounds__(256)
+v4_params_kernel(const ParamsT<T> p, const int64_t n, const uint64_t env_offset, const int32_t* __restrict__ t,
+                 T* __restrict__ K_out, T* __restrict__ r_out, const uint64_t seed, const uint64_t step_counter) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        T K, r;
+        derive_model_error<T>(seed, env_offset + (uint64_t)i, step_counter, t[i], p.origin_step, p.origin_counter,
+                              p.K_mean, p.r_mean, p.sigma_p, K, r);
+        if (K_out) K_out[i] = K;
+        if (r_out) r_out[i] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+reduce_returns_kernel(const double* __restrict__ partials, double* __restrict__ out4) {
+    // one workgroup of 4 waves: wave f sums field f.  Lane l adds slots l, l+64, ... in slot
+    // order, then a fixed shuffle tree combines the 64 lanes: same bits on every run.
+    const int field = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    // all 64 loads of a lane are issued before the first add (one latency instead of 64 in a row:
+    // 20 us -> a few us), the adds stay in slot order
+    constexpr int kPerLane = kMaxBlocks / kWave;
+    double v[kPerLane];
+#pragma unroll
+    for (int k = 0; k < kPerLane; ++k) v[k] = partials[(lane + k * kWave) * kPartialFields + field];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPerLane; ++k) s += v[k];
+    s = wave_sum(s);
+    if (lane == 0) out4[field] = s;
+}
+
+// population_draw() over an array of populations, as BMSY() drives it (models/policies.py:59-63)
+template <typename T, int MODEL>
+__global__ void __launch_bounds__(256)
+population_draw_kernel(const ParamsT<T> p, const int kind, const int64_t n, const T* __restrict__ x_in,
+                       const T* __restrict__ z, T* __restrict__ x_out) {
+    const GrowthT<T> P = p.growth;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if constexpr (is_zoo_tag(MODEL))
+            x_out[i] = zoo_population_draw<T>(kind, x_in[i], z ? z[i] : (T)0, P);
+        else
+            x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, p.r, p.K, p.sigma, p.C);
+    }
+}
+
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t delta) { *counter += delta; }
+
+__global__ void __launch_bounds__(256)
+noise_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, const uint64_t counter,
+             const uint32_t stream_tag, uint32_t* __restrict__ words, float* __restrict__ z0,
+             float* __restrict__ z1) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const Words4 w = philox_block(seed, env_offset + (uint64_t)i, counter, stream_tag);
+        float zc, zs;
+        box_muller(w.w0, w.w1, zc, zs);
+        if (words) {
+            words[4 * i + 0] = w.w0;
+            words[4 * i + 1] = w.w1;
+            words[4 * i + 2] = w.w2;
+            words[4 * i + 3] = w.w3;
+        }
+        if (z0) z0[i] = zc;
+        if (z1) z1[i] = zs;
+    }
+}
+
+// test hook: the per-env process noise the step / rollout kernels draw (quad scheme of noise_quad)
+__global__ void __launch_bounds__(256)
+step_normals_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, const uint64_t counter,
+                    float* __restrict__ z) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t env = env_offset + (uint64_t)i;
+        float zq[4];
+        noise_quad(seed, env >> 2, counter, zq);
+        const int leg = (int)(env & 3);
+        z[i] = leg == 0 ? zq[0] : leg == 1 ? zq[1] : leg == 2 ? zq[2] : zq[3];
+    }
+}
+
+// test hook: the (zK, zr) normals of the fishing-v4 draw (draw_model_error: one Philox2x32-10 block per env)
+__global__ void __launch_bounds__(256)
+reset_normals_kernel(const int64_t n, const uint64_t env_offset, const uint64_t seed, const uint64_t counter,
+                     const uint32_t stream_tag, float* __restrict__ zK, float* __restrict__ zr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t env = env_offset + (uint64_t)i;
+        uint32_t w0, w1;
+        philox2x32_10((uint32_t)env, (uint32_t)counter, param_key(seed, env, counter, stream_tag), w0, w1);
+        float a, c;
+        box_muller(w0, w1, a, c);
+        if (zK) zK[i] = a;
+        if (zr) zr[i] = c;
+    }
+}
+
+static inline int grid_for(int64_t n, int cap) {
+    const int64_t nb = (n + 255) / 256;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(nb, cap));
+}
+
+template <typename T>
+int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+               const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream) {
+    const int rc = check_common(p, n, env_offset, b);
+    if (rc != FISHING_OK) return rc;
+    if (n == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    BuffersT<T> bt = typed_buffers<T>(*b);
+    if (p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED)) bt.K = bt.r = nullptr;
+    const int blocks = grid_for(n, 2048);
+    hipStream_t s = (hipStream_t)stream;
+    return with_model_tag(p->model, [&](auto tag) {
+        // reset only distinguishes v4 (parameter redraw, un-normalised obs) and v11 (model draw)
+        constexpr int kTag = decltype(tag)::value;
+        constexpr int kResetTag = (kTag == FISHING_MODEL_V4) ? FISHING_MODEL_V4
+                                  : is_zoo_tag(kTag)         ? kModelZooMixed
+                                                             : FISHING_MODEL_V1;
+        return launch_kernel(reset_kernel<T, kResetTag>, blocks, 256, s, pt, bt, n, (uint64_t)env_offset, mask, seed,
+                             reset_counter);
+    });
+}
+
+template <typename T>
+int v4_params_impl(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out, void* r_out,
+                   uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+    if (!p || !t) return FISHING_ERR_NULL;
+    if (p->model != FISHING_MODEL_V4) return FISHING_ERR_MODEL;
+    if (n < 0 || env_offset < 0) return FISHING_ERR_SIZE;
+    if (n == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    return launch_kernel(v4_params_kernel<T>, grid_for(n, 2048), 256, (hipStream_t)stream, pt, n, (uint64_t)env_offset, t,
+                         (T*)K_out, (T*)r_out, seed, step_counter);
+}
+
+template <typename T>
+int population_draw_impl(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
+                         fishing_stream_t stream) {
+    if (!p || !x_in || !x_out) return FISHING_ERR_NULL;
+    if (n < 0) return FISHING_ERR_SIZE;
+    if (n == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    const int blocks = grid_for(n, 2048);
+    hipStream_t s = (hipStream_t)stream;
+    if (is_zoo_model(p->model) && p->model != FISHING_MODEL_V11)
+        return launch_kernel(population_draw_kernel<T, kModelZoo>, blocks, 256, s, pt, kind_of_model(p->model), n,
+                             (const T*)x_in, (const T*)z, (T*)x_out);
+    if (p->model == FISHING_MODEL_V2)
+        return launch_kernel(population_draw_kernel<T, FISHING_MODEL_V2>, blocks, 256, s, pt, 0, n, (const T*)x_in,
+                             (const T*)z, (T*)x_out);
+    if (p->model == FISHING_MODEL_V0 || p->model == FISHING_MODEL_V1 || p->model == FISHING_MODEL_V4)
+        return launch_kernel(population_draw_kernel<T, FISHING_MODEL_V1>, blocks, 256, s, pt, 0, n, (const T*)x_in,
+                             (const T*)z, (T*)x_out);
+    return FISHING_ERR_MODEL;
+}
+
+}  // namespace fishing
+
+extern "C" {
+
+int fishing_abi_version(void) { return FISHING_ABI_VERSION; }
+
+const char* fishing_error_string(int code) {
+    switch (code) {
+        case FISHING_OK: return "ok";
+        case FISHING_ERR_NULL: return "a required pointer is NULL";
+        case FISHING_ERR_MODEL: return "unknown model id";
+        case FISHING_ERR_ALIGN: return "buffer not 16-byte aligned";
+        case FISHING_ERR_SIZE: return "bad size / count / offset argument";
+        case FISHING_ERR_POLICY: return "unknown in-kernel policy";
+        case FISHING_ERR_NO_DEVICE: return "no usable HIP device";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int64_t fishing_partials_len(void) { return (int64_t)fishing::kMaxBlocks * fishing::kPartialFields; }
+
+int fishing_reset_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                      const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream) {
+    return fishing::reset_impl<float>(p, n, env_offset, b, mask, seed, reset_counter, stream);
+}
+int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                      const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream) {
+    return fishing::reset_impl<double>(p, n, env_offset, b, mask, seed, reset_counter, stream);
+}
+
+int fishing_v4_params_f32(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out,
+                          void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::v4_params_impl<float>(p, n, env_offset, t, K_out, r_out, seed, step_counter, stream);
+}
+int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out,
+                          void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::v4_params_impl<double>(p, n, env_offset, t, K_out, r_out, seed, step_counter, stream);
+}
+
+int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
+                                fishing_stream_t stream) {
+    return fishing::population_draw_impl<float>(p, n, x_in, z, x_out, stream);
+}
+int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
+                                fishing_stream_t stream) {
+    return fishing::population_draw_impl<double>(p, n, x_in, z, x_out, stream);
+}
+
+int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stream) {
+    if (!counter) return FISHING_ERR_NULL;
+    if (((uintptr_t)counter) & 7u) return FISHING_ERR_ALIGN;
+    return fishing::launch_kernel(fishing::counter_add_kernel, 1, 1, (hipStream_t)stream, counter, delta);
+}
+
+int fishing_stream_synchronize(fishing_stream_t stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }
+
+int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream) {
+    if (!return_partials || !out4) return FISHING_ERR_NULL;
+    return fishing::launch_kernel(fishing::reduce_returns_kernel, 1, 256, (hipStream_t)stream, return_partials, out4);
+}
+
+int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
+                      uint32_t* words, float* z0, float* z1, fishing_stream_t stream) {
+    if (n < 0 || env_offset < 0 || stream_tag < 0 || stream_tag > 255) return FISHING_ERR_SIZE;
+    if (n == 0) return FISHING_OK;
+    return fishing::launch_kernel(fishing::noise_kernel, fishing::grid_for(n, 2048), 256, (hipStream_t)stream, n,
+                                  (uint64_t)env_offset, seed, counter, (uint32_t)stream_tag, words, z0, z1);
+}
+
+int fishing_step_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, float* z,
+                             fishing_stream_t stream) {
+    if (n < 0 || env_offset < 0) return FISHING_ERR_SIZE;
+    if (!z) return FISHING_ERR_NULL;
+    if (n == 0) return FISHING_OK;
+    return fishing::launch_kernel(fishing::step_normals_kernel, fishing::grid_for(n, fishing::kMaxBlocks), 256,
+                                  (hipStream_t)stream, n, (uint64_t)env_offset, seed, counter, z);
+}
+
+int fishing_reset_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
+                              float* zK, float* zr, fishing_stream_t stream) {
+    if (n < 0 || env_offset < 0 || stream_tag < 0 || stream_tag > 255) return FISHING_ERR_SIZE;
+    if (n == 0) return FISHING_OK;
+    return fishing::launch_kernel(fishing::reset_normals_kernel, fishing::grid_for(n, fishing::kMaxBlocks), 256,
+                                  (hipStream_t)stream, n, (uint64_t)env_offset, seed, counter, (uint32_t)stream_tag, zK,
+                                  zr);
+}
+
+}  // extern "C"

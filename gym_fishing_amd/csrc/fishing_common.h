@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <tuple>
 #include <type_traits>
 
 #include "../../include/fishing_hip.h"
@@ -23,8 +24,8 @@ constexpr int kMaxBlocks = 4096;    // slots of the return_partials buffer
 constexpr int kPartialFields = 4;   // {sum R, sum R^2, n_episodes, sum length}
 
 constexpr uint32_t kStreamNoise = 0;      // step noise
-constexpr uint32_t kStreamAutoReset = 1;  // v4 (K, r) redraw inside step()
-constexpr uint32_t kStreamReset = 2;      // v4 (K, r) redraw in reset()
+constexpr uint32_t kStreamAutoReset = 1;  // v4 (K, r) / v11 model redraw inside step()
+constexpr uint32_t kStreamReset = 2;      // v4 (K, r) / v11 model redraw in reset()
 constexpr uint32_t kStreamPolicy = 3;     // random-policy actions of the fused rollout
 
 enum NoiseMode { kNoiseNone = 0, kNoiseExt = 1, kNoisePhilox = 2 };
@@ -60,13 +61,38 @@ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32
 // `index` is the global env QUAD index (env >> 2) on the noise and policy streams -- one block
 // feeds the four envs of a thread tile: noise (w0, w1) -> Box-Muller cos / sin legs = z of envs
 // 4q, 4q+1, (w2, w3) -> z of envs 4q+2, 4q+3; policy word j -> the random action of env 4q+j --,
-// the env PAIR index for fishing-v4's redraw on the reset streams (draw_model_error_pair) and the
-// env QUAD index for fishing-v11's model draw (redraw_kinds: word j -> env 4q + j).
+// and for fishing-v11's model draw on the reset streams (redraw_kinds: word j -> env 4q + j).
+// fishing-v4's (K, r) draws use a Philox2x32-10 block per ENV instead (draw_model_error).
 __device__ __forceinline__ Words4 philox_block(uint64_t seed, uint64_t index, uint64_t counter,
                                                uint32_t stream) {
     return philox4x32_10((uint32_t)index, (stream << 24) | ((uint32_t)(index >> 32) & 0xFFFFFFu),
                          (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)seed,
                          (uint32_t)(seed >> 32));
+}
+
+// Philox2x32-10 (same paper; Random123 known answers in tests/test_oracle_golden.py): one 32x32->64
+// multiply per round, two words out -- exactly the (zK, zr) Box-Muller pair of ONE env.  fishing-v4's
+// parameter draws use it per env, so that the draw can be re-derived inside step() every step for
+// half the multiplies a 4x32 block would cost (derive_model_error below).
+__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t& o0, uint32_t& o1) {
+#pragma unroll
+    for (int rnd = 0; rnd < 10; ++rnd) {
+        const uint64_t p = (uint64_t)0xD256D193u * c0;
+        c0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        k += 0x9E3779B9u;
+    }
+    o0 = c0;
+    o1 = c1;
+}
+
+// Key of the per-env parameter draw: counter = {env[31:0], counter[31:0]}; the 32-bit key folds in the
+// seed, the stream tag and the high halves of env index and counter (odd multipliers: each term is a
+// bijection of its input, so streams differ whenever exactly one ingredient differs; mirrored in
+// oracle/fishing_oracle.py: param_words).
+__device__ __forceinline__ uint32_t param_key(uint64_t seed, uint64_t env, uint64_t counter, uint32_t stream) {
+    return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ (stream * 0xC2B2AE35u) ^
+           ((uint32_t)(env >> 32) * 0x27D4EB2Fu) ^ ((uint32_t)(counter >> 32) * 0x165667B1u);
 }
 
 // Two standard normals from two words.  u1 in (0, 1], u2 = fraction of a turn in [0, 1].
@@ -101,7 +127,8 @@ __device__ __forceinline__ int32_t action_int_from_word(uint32_t w, int32_t n_ac
 // its own log/exp/pow chain); kModelZooMixed = fishing-v11, kind per env (per-lane switch)
 constexpr int kModelZoo = 100;
 constexpr int kModelZooMixed = kModelZoo + FISHING_N_KINDS;
-constexpr bool is_zoo_tag(int model_tag) { return model_tag >= kModelZoo && model_tag <= kModelZooMixed; }
+constexpr int kModelZooRT = kModelZooMixed + 1;    // general kernel: one growth function, kind decided at run time
+constexpr bool is_zoo_tag(int model_tag) { return model_tag >= kModelZoo && model_tag <= kModelZooRT; }
 
 template <typename T>
 struct GrowthT {                 // FishingGrowthParams narrowed to T
@@ -128,6 +155,22 @@ inline GrowthT<T> make_growth(double r, double K, double sigma, double C, double
     return g;
 }
 
+inline bool is_zoo_model(int model) { return model >= FISHING_MODEL_V5 && model <= FISHING_MODEL_V11; }
+inline bool is_core_model(int model) {
+    return model == FISHING_MODEL_V0 || model == FISHING_MODEL_V1 || model == FISHING_MODEL_V2 || model == FISHING_MODEL_V4;
+}
+
+// growth-function kind of a single-kind zoo model (v11 carries it per env)
+inline int kind_of_model(int model) {
+    switch (model) {
+        case FISHING_MODEL_V5: return FISHING_KIND_ALLEN;
+        case FISHING_MODEL_V7: return FISHING_KIND_MAY;
+        case FISHING_MODEL_V8: return FISHING_KIND_MYERS;
+        case FISHING_MODEL_V9: return FISHING_KIND_RICKER;
+        default: return FISHING_KIND_BEVERTON_HOLT;   // v6, v10
+    }
+}
+
 template <typename T>
 struct ParamsT {
     int32_t model, n_actions, Tmax;
@@ -135,6 +178,8 @@ struct ParamsT {
     T r, K, sigma, C, x0, r_mean, K_mean, sigma_p;
     T M, theta, q, b, a, alpha;
     GrowthT<T> growth;           // the single growth function of fishing-v5..v10 (+ host constants)
+    int32_t kind;                // FISHING_KIND_* of that function (run-time kind of the general kernel)
+    uint64_t origin_step, origin_counter;   // fishing-v4 derived parameters: see derive_model_error
     int32_t n_models;
     int32_t kinds[FISHING_N_KINDS];
     GrowthT<T> zoo[FISHING_N_KINDS];
@@ -162,30 +207,23 @@ inline ParamsT<T> narrow_params(const FishingParams& p) {
     q.a = (T)p.a;
     q.alpha = (T)p.alpha;
     q.n_models = p.n_models;
-    q.growth = make_growth<T>(p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a,
-                              p.model == FISHING_MODEL_V6 || p.model == FISHING_MODEL_V10);
+    q.kind = kind_of_model(p.model);
+    q.origin_step = p.v4_origin_step;
+    q.origin_counter = p.v4_origin_counter;
+    // the host-side constants (pow / log) only where a growth function of the zoo will read them
+    q.growth = GrowthT<T>{};
+    if (is_zoo_model(p.model) && p.model != FISHING_MODEL_V11)
+        q.growth = make_growth<T>(p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a,
+                                  p.model == FISHING_MODEL_V6 || p.model == FISHING_MODEL_V10);
     for (int k = 0; k < FISHING_N_KINDS; ++k) {
         q.kinds[k] = p.kinds[k];
-        const FishingGrowthParams& g = p.zoo[k];
-        q.zoo[k] = make_growth<T>(g.r, g.K, g.sigma, g.C, g.M, g.theta, g.q, g.b, g.a, k == FISHING_KIND_BEVERTON_HOLT);
+        q.zoo[k] = GrowthT<T>{};
+        if (p.model == FISHING_MODEL_V11) {
+            const FishingGrowthParams& g = p.zoo[k];
+            q.zoo[k] = make_growth<T>(g.r, g.K, g.sigma, g.C, g.M, g.theta, g.q, g.b, g.a, k == FISHING_KIND_BEVERTON_HOLT);
+        }
     }
     return q;
-}
-
-inline bool is_zoo_model(int model) { return model >= FISHING_MODEL_V5 && model <= FISHING_MODEL_V11; }
-inline bool is_core_model(int model) {
-    return model == FISHING_MODEL_V0 || model == FISHING_MODEL_V1 || model == FISHING_MODEL_V2 || model == FISHING_MODEL_V4;
-}
-
-// growth-function kind of a single-kind zoo model (v11 carries it per env)
-inline int kind_of_model(int model) {
-    switch (model) {
-        case FISHING_MODEL_V5: return FISHING_KIND_ALLEN;
-        case FISHING_MODEL_V7: return FISHING_KIND_MAY;
-        case FISHING_MODEL_V8: return FISHING_KIND_MYERS;
-        case FISHING_MODEL_V9: return FISHING_KIND_RICKER;
-        default: return FISHING_KIND_BEVERTON_HOLT;   // v6, v10
-    }
 }
 
 template <typename T>
@@ -252,6 +290,35 @@ inline int with_model_tag(int model, F&& f) {
         case FISHING_KIND_RICKER: return f(ModelTag<kModelZoo + FISHING_KIND_RICKER>{});
         default: return f(ModelTag<kModelZoo + FISHING_KIND_BEVERTON_HOLT>{});
     }
+}
+
+// the same for the general step kernel, which keeps the zoo's growth-function kind a run-time value
+template <typename F>
+inline int with_general_tag(int model, F&& f) {
+    switch (model) {
+        case FISHING_MODEL_V0: return f(ModelTag<FISHING_MODEL_V0>{});
+        case FISHING_MODEL_V1: return f(ModelTag<FISHING_MODEL_V1>{});
+        case FISHING_MODEL_V2: return f(ModelTag<FISHING_MODEL_V2>{});
+        case FISHING_MODEL_V4: return f(ModelTag<FISHING_MODEL_V4>{});
+        case FISHING_MODEL_V11: return f(ModelTag<kModelZooMixed>{});
+        default: break;
+    }
+    if (!is_zoo_model(model)) return FISHING_ERR_MODEL;
+    return f(ModelTag<kModelZooRT>{});
+}
+
+// Launch status of THIS launch (hipLaunchKernel's own return value), not whatever sticky error an
+// unrelated earlier call left on the thread -- and without consuming that state either.
+template <typename... P, typename... A>
+inline int launch_kernel(void (*kernel)(P...), int blocks, int threads, hipStream_t stream, A&&... args) {
+    std::tuple<P...> packed{static_cast<P>(args)...};
+    return std::apply(
+        [&](auto&... a) {
+            void* argv[] = {(void*)&a...};
+            return (int)hipLaunchKernel((const void*)kernel, dim3((unsigned)blocks), dim3((unsigned)threads), argv, 0,
+                                        stream);
+        },
+        packed);
 }
 
 // ---------------------------------------------------------------- the env arithmetic
@@ -532,64 +599,64 @@ __device__ __forceinline__ T reset_obs(T x0, T K) {
     return (MODEL == FISHING_MODEL_V4) ? x0 : (x0 / K - (T)1);
 }
 
-// fishing-v4 (K, r) redraw for the env pair {2 * pair, 2 * pair + 1}: ONE Philox block per pair on the
-// reset streams -- (w0, w1) -> Box-Muller (zK, zr) of the even env, (w2, w3) -> of the odd env; K is
-// drawn before r (fishing_model_error.py:42-43).  Halves the generator work of the auto-reset path,
-// which runs in practically every wave (256 envs: some env finishes almost every step).
-template <typename T>
-__device__ __forceinline__ void draw_model_error_pair(uint64_t seed, uint64_t pair, uint64_t counter,
-                                                      uint32_t stream, T K_mean, T r_mean, T sigma_p,
-                                                      T (&K)[2], T (&r)[2]) {
-    const Words4 w = philox_block(seed, pair, counter, stream);
-    float zK, zr;
-    box_muller(w.w0, w.w1, zK, zr);
-    K[0] = clip_param<T>(K_mean + sigma_p * (T)zK);
-    r[0] = clip_param<T>(r_mean + sigma_p * (T)zr);
-    box_muller(w.w2, w.w3, zK, zr);
-    K[1] = clip_param<T>(K_mean + sigma_p * (T)zK);
-    r[1] = clip_param<T>(r_mean + sigma_p * (T)zr);
-}
-
-// the same draw for one env (reset kernel, ragged tails)
+// fishing-v4 (K, r) draw of ONE env (fishing_model_error.py:37-38 / :42-43: K first, then r): one
+// Philox2x32-10 block keyed by (seed, env, counter, stream) -> Box-Muller (zK, zr).
+//   stream kStreamReset,     counter = reset counter          : reset()
+//   stream kStreamAutoReset, counter = step counter of the step that finished the episode : auto-reset
 template <typename T>
 __device__ __forceinline__ void draw_model_error(uint64_t seed, uint64_t env, uint64_t counter,
                                                  uint32_t stream, T K_mean, T r_mean, T sigma_p,
                                                  T& K, T& r) {
-    T K2[2], r2[2];
-    draw_model_error_pair<T>(seed, env >> 1, counter, stream, K_mean, r_mean, sigma_p, K2, r2);
-    K = (env & 1) ? K2[1] : K2[0];
-    r = (env & 1) ? r2[1] : r2[0];
+    uint32_t w0, w1;
+    philox2x32_10((uint32_t)env, (uint32_t)counter, param_key(seed, env, counter, stream), w0, w1);
+    float zK, zr;
+    box_muller(w0, w1, zK, zr);
+    K = clip_param<T>(K_mean + sigma_p * (T)zK);
+    r = clip_param<T>(r_mean + sigma_p * (T)zr);
+}
+
+// The (K, r) in force for an env are a pure function of where its episode began, and that is readable
+// from the env's own year counter: at global step c an env with years_passed t either has run since
+// the last full reset() (made at step count `origin_step` with reset counter `origin_counter`), in
+// which case c - t == origin_step, or was auto-reset by the step with counter c - t - 1.  So a
+// fishing-v4 batch on the Philox streams needs NO r / K arrays in HBM: step() re-derives them
+// (FISHING_FLAG_V4_DERIVED; 8 B/env-step of reads and, on the random-policy workload where nearly every
+// 128-byte line holds a finished env, 8 B/env-step of redraw writes saved).  Same values bit for bit
+// as the stored-array path, which draws from the same blocks at the moment of the reset.
+template <typename T>
+__device__ __forceinline__ void derive_model_error(uint64_t seed, uint64_t env, uint64_t step_counter, int32_t t,
+                                                   uint64_t origin_step, uint64_t origin_counter, T K_mean,
+                                                   T r_mean, T sigma_p, T& K, T& r) {
+    const uint64_t since = step_counter - (uint64_t)(int64_t)t;
+    const bool from_reset = since == origin_step;
+    draw_model_error<T>(seed, env, from_reset ? origin_counter : since - 1,
+                        from_reset ? kStreamReset : kStreamAutoReset, K_mean, r_mean, sigma_p, K, r);
 }
 
 // Redraw (K, r) and restart the finished envs of one thread's 4-env tile (`base` = global index of
-// its first env, a multiple of 4): two pair blocks at most.  Returns whether anything was redrawn.
+// its first env).  Returns whether anything was redrawn.
 template <typename T, int MODEL>
 __device__ __forceinline__ bool redraw_tile(uint64_t seed, uint64_t base, uint64_t counter, uint32_t stream,
                                             T K_mean, T r_mean, T sigma_p, T x0, const bool (&fin)[4],
                                             T (&KK)[4], T (&rr)[4], T (&obs)[4], int32_t (&t)[4]) {
-    bool redrawn = false;
+    if (!(fin[0] | fin[1] | fin[2] | fin[3])) return false;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (fin[2 * q] | fin[2 * q + 1]) {
-            T K2[2], r2[2];
-            draw_model_error_pair<T>(seed, (base >> 1) + q, counter, stream, K_mean, r_mean, sigma_p, K2, r2);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = 2 * q + h;
-                KK[j] = fin[j] ? K2[h] : KK[j];
-                rr[j] = fin[j] ? r2[h] : rr[j];
-                obs[j] = fin[j] ? reset_obs<T, MODEL>(x0, KK[j]) : obs[j];
-                t[j] = fin[j] ? 0 : t[j];
-            }
-            redrawn = true;
-        }
+    for (int j = 0; j < 4; ++j) {
+        T K2, r2;
+        draw_model_error<T>(seed, base + (uint64_t)j, counter, stream, K_mean, r_mean, sigma_p, K2, r2);
+        KK[j] = fin[j] ? K2 : KK[j];
+        rr[j] = fin[j] ? r2 : rr[j];
+        obs[j] = fin[j] ? reset_obs<T, MODEL>(x0, KK[j]) : obs[j];
+        t[j] = fin[j] ? 0 : t[j];
     }
-    return redrawn;
+    return true;
 }
 
 // ---------------------------------------------------------------- 4-wide access helpers
+// 16-byte aligned at most: that is what the ABI guarantees for every buffer (a Vec4<double> is moved as two
+// 16-byte accesses either way)
 template <typename T>
-struct alignas(4 * sizeof(T)) Vec4 {
+struct alignas(16) Vec4 {
     T v[4];
 };
 

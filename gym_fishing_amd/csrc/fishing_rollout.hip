@@ -13,6 +13,7 @@
 // reference's simulate loop breaks on done, shared_env.py:51-52) and a wave whose 256 envs
 // have all finished leaves the time loop (__all over the per-lane masks).
 #include "fishing_common.h"
+#include "fishing_host.h"
 
 namespace fishing {
 
@@ -23,6 +24,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                const uint64_t step_counter_arg, const int noise_on, const int policy_rt, const DivK dk_arg) {
     const uint64_t step_counter0 = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
+    const bool derived = kPerEnv && (p.flags & FISHING_FLAG_V4_DERIVED) != 0;   // no r / K arrays (derive_model_error)
     const DivK dk = kPerEnv ? DivK{false, 0.0f, 0.0} : dk_arg;      // per-env K keeps the true division
     // POLICY >= 0: compile-time policy (v0/v1/v2/v4); POLICY < 0: wave-uniform run-time policy (zoo,
     // to keep the number of instantiations of the transcendental-heavy bodies small)
@@ -62,7 +64,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         if (active) {
             load4<T>(b.obs, base, n, full, obs, (T)0);
             load_t4(b.t, (p.flags & FISHING_FLAG_T_U8) != 0, base, n, full, t);
-            if (kPerEnv) {
+            if (kPerEnv && !derived) {
                 load4<T>(b.r, base, n, full, rr, p.r);
                 load4<T>(b.K, base, n, full, KK, p.K);
             }
@@ -70,6 +72,12 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             if (zoo_mixed) load4<int32_t>(b.model_idx, base, n, full, kind, FISHING_KIND_BEVERTON_HOLT);
             if (b.sigma) load4<T>(b.sigma, base, n, full, sg, p.sigma);
             if (b.ep_return) load4<T>(b.ep_return, base, n, full, er, (T)0);
+        }
+        if (derived) {      // once per launch; the redraws below keep (K, r) current from then on
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter0, t[j], p.origin_step,
+                                      p.origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
         }
         bool kind_dirty = false;
         const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
@@ -242,7 +250,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             store_t4(b.t, (p.flags & FISHING_FLAG_T_U8) != 0, base, n, full, t);
             if (b.ep_return) store4<T>(b.ep_return, base, n, full, er);
             if (b.reward) store4<T>(b.reward, base, n, full, rew);
-            if (kPerEnv && kr_dirty) {
+            if (kPerEnv && kr_dirty && !derived) {
                 store4<T>(b.K, base, n, full, KK);
                 store4<T>(b.r, base, n, full, rr);
             }
@@ -268,37 +276,28 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     if (b.partials) add_block_partials<4>(acc, b.partials);
 }
 
-int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b);
-void launch_shape(const FishingParams* p, int64_t n, int& blocks, int& threads);
-
 template <typename T, int MODEL>
 int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& bt, int64_t n, uint64_t env_offset,
                           T policy_param, int32_t Tsteps, T* traj, uint64_t seed, uint64_t step_counter,
                           int noise_on, int blocks, int threads, hipStream_t s) {
     const DivK dk = make_divk((double)pt.K);
-#define FISHING_LAUNCH_ROLLOUT(POL)                                                                                \
-    do {                                                                                                           \
-        if (pt.flags & FISHING_FLAG_AUTO_RESET)                                                                    \
-            rollout_kernel<T, MODEL, POL, true><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param,  \
-                                                                           Tsteps, traj, seed, step_counter,      \
-                                                                           noise_on, policy, dk);                 \
-        else                                                                                                       \
-            rollout_kernel<T, MODEL, POL, false><<<blocks, threads, 0, s>>>(pt, bt, n, env_offset, policy_param, \
-                                                                            Tsteps, traj, seed, step_counter,     \
-                                                                            noise_on, policy, dk);                \
-    } while (0)
+#define FISHING_LAUNCH_ROLLOUT(POL)                                                                              \
+    ((pt.flags & FISHING_FLAG_AUTO_RESET)                                                                        \
+         ? launch_kernel(rollout_kernel<T, MODEL, POL, true>, blocks, threads, s, pt, bt, n, env_offset,         \
+                         policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk)                   \
+         : launch_kernel(rollout_kernel<T, MODEL, POL, false>, blocks, threads, s, pt, bt, n, env_offset,        \
+                         policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk))
     if constexpr (is_zoo_tag(MODEL)) {
-        FISHING_LAUNCH_ROLLOUT(-1);          // run-time policy switch
+        return FISHING_LAUNCH_ROLLOUT(-1);          // run-time policy switch
     } else {
         switch (policy) {
-            case FISHING_POLICY_RANDOM: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_RANDOM); break;
-            case FISHING_POLICY_CONSTANT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_CONSTANT); break;
-            case FISHING_POLICY_ESCAPEMENT: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_ESCAPEMENT); break;
-            default: FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_MSY); break;
+            case FISHING_POLICY_RANDOM: return FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_RANDOM);
+            case FISHING_POLICY_CONSTANT: return FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_CONSTANT);
+            case FISHING_POLICY_ESCAPEMENT: return FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_ESCAPEMENT);
+            default: return FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_MSY);
         }
     }
 #undef FISHING_LAUNCH_ROLLOUT
-    return (int)hipGetLastError();
 }
 
 template <typename T>
@@ -330,6 +329,268 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     });
 }
 
+
+// ---------------------------------------------------------------- fused step_many: K caller-driven steps per launch
+// fishing_step_fused_*: what n_steps fishing_step_* launches do, in one launch -- a thread keeps its four envs'
+// (obs, t, r, K, ep_return) in registers, step s reads the caller's action row (s % ring_len) of the [R, n] ring
+// and, optionally, writes that step's reward / done row.  HBM traffic per env-step drops from 25 B to 9 B
+// (action 4 R, reward 4 + done 1 W) or 4 B (no per-step outputs); what it removes above all is the ~2.7 us a
+// dependent launch costs whatever it moves, which bounds the per-step path below N ~ 2^20.
+// The action rows do not depend on the state, so they are prefetched kPrefetch steps ahead: at N = 2^19 only two
+// waves share a SIMD and nothing else would hide the load latency.
+// step() semantics, not the rollout's: without FISHING_FLAG_AUTO_RESET a finished env keeps being stepped.
+// Same Philox counters, same arithmetic, same record as the per-step kernels: identical bits.
+template <typename T>
+struct FusedArgs {
+    T* obs;
+    const void* action;      // row 0 of the ring
+    T* reward;               // last step's values (FishingBuffers.reward / .done), nullable
+    uint8_t* done;
+    int32_t* t;
+    T* r;
+    T* K;
+    T* ep_return;
+    double* partials;
+    const uint64_t* counter;
+    const T* sigma_arr;
+    T* reward_steps;         // [n_steps][out_stride], nullable
+    uint8_t* done_steps;     // [n_steps][out_stride], nullable
+    int64_t action_stride, out_stride;
+    int32_t ring_len, n_steps;
+    T pr, pK, sigma, C, x0, r_mean, K_mean, sigma_p;
+    int32_t Tmax, n_actions;
+    uint32_t auto_reset, t8, derived, drift;
+    int32_t noise;           // kNoiseNone / kNoisePhilox
+    uint64_t origin_step, origin_counter;
+    GrowthT<T> growth;
+    T alpha;
+    DivK dk;                 // exact x / K as a multiply when the scalar K is a power of two (never for per-env K)
+};
+
+constexpr int kPrefetch = 4;
+
+template <typename T, int MODEL>
+__global__ void __launch_bounds__(256)
+step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offset, const uint64_t seed,
+                  const uint64_t step_counter_arg) {
+    constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
+    constexpr bool kZoo = is_zoo_tag(MODEL);
+    constexpr int kZooKind = kZoo ? (MODEL - kModelZoo) : -1;
+    static_assert(MODEL != kModelZooMixed && MODEL != kModelZooRT, "fishing-v11 steps through the per-step kernels");
+    const uint64_t step_counter0 = a.counter ? (*a.counter + step_counter_arg) : step_counter_arg;
+    const bool auto_reset = a.auto_reset != 0;
+    const bool derived = kPerEnv && a.derived != 0;
+    const bool drift = kZoo && a.drift != 0;
+    const bool t8 = a.t8 != 0;
+    const DivK dk = a.dk;
+    const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
+    const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
+    double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
+    const T robs_scalar = reset_obs<T, MODEL>(a.x0, a.pK);
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
+        const bool active = base < n;
+        const bool full = base + kEnvsPerThread <= n;
+        T obs[4], rr[4], KK[4], sg[4], er[4], rew[4];
+        int32_t t[4];
+        bool dn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            obs[j] = (T)0;
+            t[j] = 0;
+            rr[j] = a.pr;
+            KK[j] = a.pK;
+            sg[j] = a.sigma;
+            er[j] = (T)0;
+            rew[j] = (T)0;
+            dn[j] = false;
+        }
+        if (active) {
+            load4<T>(a.obs, base, n, full, obs, (T)0);
+            load_t4(a.t, t8, base, n, full, t);
+            if (kPerEnv && !derived) {
+                load4<T>(a.r, base, n, full, rr, a.pr);
+                load4<T>(a.K, base, n, full, KK, a.pK);
+            }
+            if (drift) load4<T>(a.r, base, n, full, rr, a.pr);
+            if (a.sigma_arr) load4<T>(a.sigma_arr, base, n, full, sg, a.sigma);
+            if (a.ep_return) load4<T>(a.ep_return, base, n, full, er, (T)0);
+        }
+        // the action rows: kPrefetch steps in flight
+        float pf_f[kPrefetch][4];
+        int32_t pf_i[kPrefetch][4];
+        auto load_action = [&](int32_t s, float (&af)[4], int32_t (&ai)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                af[j] = -1.0f;
+                ai[j] = 0;
+            }
+            if (!active) return;
+            const int64_t row = (int64_t)(s % a.ring_len) * a.action_stride;
+            if (MODEL == FISHING_MODEL_V0) load4<int32_t>((const int32_t*)a.action + row, base, n, full, ai, 0);
+            else load4<float>((const float*)a.action + row, base, n, full, af, -1.0f);
+        };
+#pragma unroll
+        for (int u = 0; u < kPrefetch; ++u)
+            if (u < a.n_steps) load_action(u, pf_f[u], pf_i[u]);
+        if (derived) {      // once per launch; the redraws below keep (K, r) current from then on
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter0, t[j], a.origin_step,
+                                      a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+        }
+        const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
+        bool kr_dirty = false;
+
+        for (int32_t s0 = 0; s0 < a.n_steps; s0 += kPrefetch) {
+#pragma unroll
+            for (int u = 0; u < kPrefetch; ++u) {
+                const int32_t s = s0 + u;
+                if (s >= a.n_steps) break;          // wave-uniform
+                float a_f[4];
+                int32_t a_i[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a_f[j] = pf_f[u][j];
+                    a_i[j] = pf_i[u][j];
+                }
+                if (s + kPrefetch < a.n_steps) load_action(s + kPrefetch, pf_f[u], pf_i[u]);
+                const uint64_t step_counter = step_counter0 + (uint64_t)s;
+                T z[4] = {(T)0, (T)0, (T)0, (T)0};
+                if (a.noise == kNoisePhilox) {
+                    float zq[4];
+                    noise_quad(seed, quad, step_counter, zq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[j] = (T)zq[j];
+                }
+                T o2[4];
+                int32_t t2[4];
+                bool fresh[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
+                                                                : quota_cts<T>((T)a_f[j], KK[j]);
+                    fresh[j] = auto_reset || !((t[j] > a.Tmax) || ((obs[j] + (T)1) * KK[j] <= (T)0));
+                    if constexpr (kZoo) {
+                        GrowthT<T> P = a.growth;
+                        if (a.sigma_arr) P.sigma = sg[j];
+                        if (drift) {                     // growth_models.py:151: drift first, then draw
+                            rr[j] = rr[j] + a.alpha;
+                            P.r = rr[j];
+                            env_step_zoo<T, kZooKind, true>(obs[j], t[j], quota, z[j], kZooKind, P, KK[j], a.Tmax, o2[j],
+                                                            rew[j], dn[j], t2[j]);
+                        } else {
+                            env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota, z[j], kZooKind, P, KK[j], a.Tmax, o2[j],
+                                                             rew[j], dn[j], t2[j]);
+                        }
+                    } else {
+                        env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, o2[j], rew[j], dn[j],
+                                           t2[j], dk);
+                    }
+                    dn[j] = dn[j] && (base + j < n);
+                    fresh[j] = fresh[j] && dn[j];
+                    er[j] = er[j] + rew[j];
+                    obs[j] = o2[j];
+                    t[j] = t2[j];
+                }
+                if (active) {
+                    if (a.reward_steps) store4<T, 1>(a.reward_steps + (int64_t)s * a.out_stride, base, n, full, rew);
+                    if (a.done_steps) {
+                        uint8_t* row = a.done_steps + (int64_t)s * a.out_stride;
+                        if (full) {
+                            __builtin_nontemporal_store((uint32_t)dn[0] | ((uint32_t)dn[1] << 8) | ((uint32_t)dn[2] << 16) |
+                                                            ((uint32_t)dn[3] << 24),
+                                                        reinterpret_cast<uint32_t*>(row + base));
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (base + j < n) row[base + j] = (uint8_t)dn[j];
+                        }
+                    }
+                }
+                if (__any(dn[0] | dn[1] | dn[2] | dn[3])) {
+                    if (a.ep_return) {
+                        record_tile<T>(fresh, er, t, acc);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
+                    }
+                    if (auto_reset) {
+                        if (kPerEnv) {      // the next episode's (K, r): the draw a later derivation would re-make
+                            if (redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
+                                                      a.K_mean, a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs, t))
+                                kr_dirty = true;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                obs[j] = dn[j] ? robs_scalar : obs[j];
+                                t[j] = dn[j] ? 0 : t[j];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        if (active) {
+            store4<T>(a.obs, base, n, full, obs);
+            store_t4(a.t, t8, base, n, full, t);
+            if (a.ep_return) store4<T>(a.ep_return, base, n, full, er);
+            if (a.reward) store4<T>(a.reward, base, n, full, rew);
+            if (kPerEnv && kr_dirty && !derived) {
+                store4<T>(a.K, base, n, full, KK);
+                store4<T>(a.r, base, n, full, rr);
+            }
+            if (drift) store4<T>(a.r, base, n, full, rr);
+            if (a.done) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (base + j < n) a.done[base + j] = (uint8_t)dn[j];
+            }
+        }
+    }
+    if (a.partials) add_block_partials<4>(acc, a.partials);
+}
+
+template <typename T>
+int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b, int64_t action_stride,
+                    int32_t ring_len, int32_t n_steps, void* reward_steps, uint8_t* done_steps, int64_t out_stride,
+                    uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+    const int rc = check_common(p, n, env_offset, b);
+    if (rc != FISHING_OK) return rc;
+    if (!b->action) return FISHING_ERR_NULL;
+    if (ring_len <= 0 || n_steps < 0 || action_stride < 0 || out_stride < 0) return FISHING_ERR_SIZE;
+    if (ring_len > 1 && (action_stride & 3)) return FISHING_ERR_ALIGN;
+    if ((reward_steps || done_steps) && (out_stride < n || (out_stride & 15))) return FISHING_ERR_ALIGN;
+    if (misaligned(reward_steps) || misaligned(done_steps)) return FISHING_ERR_ALIGN;
+    // the streams only the per-step kernels produce
+    if (b->z_ext || b->terminal_obs || b->done_bits || p->model == FISHING_MODEL_V11) return FISHING_ERR_MODEL;
+    if (p->launch_threads != 0 && p->launch_threads != 256) return FISHING_ERR_SIZE;
+    if (n == 0 || n_steps == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    const BuffersT<T> bt = typed_buffers<T>(*b);
+    const int noise = noise_mode(p, b);
+    const bool per_env = p->model == FISHING_MODEL_V4;
+    const FusedArgs<T> a{bt.obs, bt.action, bt.reward, bt.done, bt.t, bt.r, bt.K, bt.ep_return, bt.partials, bt.counter,
+                         bt.sigma, (T*)reward_steps, done_steps, action_stride, out_stride, ring_len, n_steps, pt.r, pt.K,
+                         pt.sigma, pt.C, pt.x0, pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions,
+                         (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET), (uint32_t)((p->flags & FISHING_FLAG_T_U8) != 0),
+                         (uint32_t)(per_env && (p->flags & FISHING_FLAG_V4_DERIVED)), (uint32_t)(p->model == FISHING_MODEL_V10),
+                         noise, pt.origin_step, pt.origin_counter, pt.growth, pt.alpha,
+                         // x / K as an exact multiply changes no bit, so the per-step kernels' true division agrees
+                         per_env ? DivK{false, 0.0f, 0.0} : make_divk((double)pt.K)};
+    int blocks, threads;
+    launch_shape(p, n, blocks, threads);
+    return with_model_tag(p->model, [&](auto tag) {
+        constexpr int kTag = decltype(tag)::value;
+        if constexpr (kTag != kModelZooMixed)
+            return launch_kernel(step_fused_kernel<T, kTag>, blocks, 256, (hipStream_t)stream, a, n, (uint64_t)env_offset,
+                                 seed, step_counter);
+        else
+            return (int)FISHING_ERR_MODEL;
+    });
+}
+
 }  // namespace fishing
 
 extern "C" {
@@ -343,6 +604,21 @@ int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, c
                         int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
                         uint64_t step_counter, fishing_stream_t stream) {
     return fishing::rollout_impl<double>(p, n, env_offset, b, policy, policy_param, T, traj, seed, step_counter, stream);
+}
+
+int fishing_step_fused_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                           int64_t action_stride, int32_t ring_len, int32_t n_steps, void* reward_steps,
+                           uint8_t* done_steps, int64_t out_stride, uint64_t seed, uint64_t step_counter,
+                           fishing_stream_t stream) {
+    return fishing::step_fused_impl<float>(p, n, env_offset, b, action_stride, ring_len, n_steps, reward_steps, done_steps,
+                                           out_stride, seed, step_counter, stream);
+}
+int fishing_step_fused_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                           int64_t action_stride, int32_t ring_len, int32_t n_steps, void* reward_steps,
+                           uint8_t* done_steps, int64_t out_stride, uint64_t seed, uint64_t step_counter,
+                           fishing_stream_t stream) {
+    return fishing::step_fused_impl<double>(p, n, env_offset, b, action_stride, ring_len, n_steps, reward_steps, done_steps,
+                                            out_stride, seed, step_counter, stream);
 }
 
 }  // extern "C"

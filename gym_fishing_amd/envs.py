@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import (FLAG_AUTO_RESET, FLAG_T_U8, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
+from ._capi import (FLAG_AUTO_RESET, FLAG_T_U8, FLAG_V4_DERIVED, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
                     MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11, POLICY_CONSTANT, POLICY_ESCAPEMENT,
                     POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
 from .spaces import is_discrete, space_classes
@@ -101,7 +101,7 @@ class BaseFishingEnv(_gym_env_base()):
     def __init__(self, params=None, Tmax=100, file=None, *, num_envs=None, device=None, seed=0,
                  dtype=None, auto_reset=None, env_offset=0, record_terminal_obs=False,
                  track_returns=False, done_bits=False, launch_blocks=0, launch_threads=0, compact=False, rng=None,
-                 host_mapped=False):
+                 host_mapped=False, derived_params=None):
         params = dict({"r": 0.3, "K": 1, "sigma": 0.0, "x0": 0.75} if params is None else params)
         self.params = params
         self.Tmax = int(Tmax)
@@ -161,6 +161,7 @@ class BaseFishingEnv(_gym_env_base()):
         self._fn_reset = getattr(self._lib, "fishing_reset_" + self._suffix)
         self._fn_rollout = getattr(self._lib, "fishing_rollout_" + self._suffix)
         self._fn_step_many = getattr(self._lib, "fishing_step_many_" + self._suffix)
+        self._fn_step_fused = getattr(self._lib, "fishing_step_fused_" + self._suffix)
 
         N, dev = self.num_envs, self.device
         self._per_env = self.MODEL == MODEL_V4
@@ -197,7 +198,18 @@ class BaseFishingEnv(_gym_env_base()):
             self._sigma_scalar = float(self._sigma_arr[0])
         else:
             self._sigma_scalar = float(sigma)
-        if self._per_env:
+        # fishing-v4 on the Philox streams keeps NO r / K arrays: every kernel re-derives an env's (K, r) from the
+        # block that drew them, which the env's year counter identifies (fishing_common.h: derive_model_error) --
+        # 8 B/env-step of reads and about as much of redraw writes less.  Arrays come back (once, through
+        # fishing_v4_params_*) when something makes the parameters underivable: a masked reset(), env.K = ... /
+        # env.r = ..., seed(); the next full reset() returns to the derived mode.
+        self._derived_capable = (self._per_env and not self._np_rng and not self._scalar and not self.compact
+                                 and (derived_params is None or bool(derived_params)))
+        if derived_params and not self._derived_capable:
+            raise ValueError("derived_params=True needs fishing-v4 with num_envs, rng='philox' and the int32 year counter")
+        self._derived = self._derived_capable
+        self._origin = (0, 0)            # (step count, reset counter) of the last reset() of all envs
+        if self._per_env and not self._derived:
             self._r_arr = torch.full((N,), float(params["r"]), dtype=dtype, device=dev)
             self._K_arr = torch.full((N,), float(params["K"]), dtype=dtype, device=dev)
         if self.MODEL == MODEL_V10:      # the drifting growth rate is per-env state (growth_models.py:151)
@@ -271,16 +283,45 @@ class BaseFishingEnv(_gym_env_base()):
         else:
             self._sigma_arr = None
             self._sigma_scalar = float(v)
-            self.params["sigma"] = v
+            if self.MODEL in (MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4):
+                # (the zoo's growth functions read their own params dict, which env.sigma never reaches in the
+                # reference: growth_models.py:208-261)
+                self.params["sigma"] = v
+
+    def _derive_params(self):
+        """(K, r) tensors of a fishing-v4 env in the derived mode, materialised by fishing_v4_params_*."""
+        K = torch.empty(self.num_envs, dtype=self.dtype, device=self.device)
+        r = torch.empty_like(K)
+        with torch.cuda.device(self.device):
+            rc = getattr(self._lib, "fishing_v4_params_" + self._suffix)(
+                self._c_params(), self.num_envs, self.env_offset, self._t.data_ptr(), K.data_ptr(), r.data_ptr(),
+                self._seed, self._current_step_count(), self._stream())
+        _capi.check(rc, "fishing_v4_params")
+        return K, r
+
+    def _current_step_count(self):
+        return self._step_count             # (kept in step with the device-resident counter of the graph-replay mode)
+
+    def _leave_derived_mode(self):
+        """Store the parameters in force and continue with r / K arrays (until the next full reset())."""
+        if self._derived:
+            self._K_arr, self._r_arr = self._derive_params()
+            self._derived = False
+            self._cbuf = None
 
     def _K_view(self):
+        if self._derived:
+            return self._derive_params()[0]
         return float(self._K_arr[0]) if self._scalar else self._K_arr
 
     def _r_view(self):
+        if self._derived:
+            return self._derive_params()[1]
         return float(self._r_arr[0]) if self._scalar else self._r_arr
 
     def _set_param(self, name, v):
         if self._per_env:
+            self._leave_derived_mode()
             arr = self._K_arr if name == "K" else self._r_arr
             if isinstance(v, (torch.Tensor, np.ndarray, list, tuple)):
                 arr.copy_(torch.as_tensor(v).to(device=self.device, dtype=self.dtype).reshape(self.num_envs))
@@ -293,7 +334,8 @@ class BaseFishingEnv(_gym_env_base()):
         p = self.params
         if self.compact and self.Tmax > 254:
             raise ValueError("compact layout needs Tmax <= 254")
-        return (self.Tmax, self.init_state, self.auto_reset, self._sigma_scalar, p["r"], p["K"], self._launch,
+        return (self.Tmax, self.init_state, self.auto_reset, self._derived, self._origin, self._sigma_scalar, p["r"],
+                p["K"], self._launch,
                 getattr(self, "n_actions", 0), getattr(self, "C", None), getattr(self, "r_mean", None),
                 getattr(self, "K_mean", None), getattr(self, "sigma_p", None),
                 tuple(p.get(k) for k in ("C", "M", "theta", "q", "b", "a", "alpha")))
@@ -309,7 +351,9 @@ class BaseFishingEnv(_gym_env_base()):
         cp.model = self.MODEL
         cp.n_actions = int(getattr(self, "n_actions", 0) or 0)
         cp.Tmax = int(self.Tmax)
-        cp.flags = (FLAG_AUTO_RESET if self.auto_reset else 0) | (FLAG_T_U8 if self.compact else 0)
+        cp.flags = ((FLAG_AUTO_RESET if self.auto_reset else 0) | (FLAG_T_U8 if self.compact else 0)
+                    | (FLAG_V4_DERIVED if self._derived else 0))
+        cp.v4_origin_step, cp.v4_origin_counter = self._origin
         cp.r = float(p["r"])
         cp.K = float(p["K"])
         cp.sigma = self._sigma_scalar
@@ -407,6 +451,7 @@ class BaseFishingEnv(_gym_env_base()):
     def seed(self, seed=None):
         """The reference has no seed() (base_fishing_env.py:13); this keys the Philox streams and, for
         rng="numpy", seeds NumPy's global stream the way a user of the reference would (np.random.seed)."""
+        self._leave_derived_mode()          # the parameters in force were drawn under the old seed / counters
         self._seed = int(0 if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         if self._np_rng and seed is not None:
             np.random.seed(int(seed) & 0xFFFFFFFF)
@@ -419,6 +464,7 @@ class BaseFishingEnv(_gym_env_base()):
     # ------------------------------------------------------------------ checkpoint / resume
     _STATE_TENSORS = ("_obs", "_t", "_reward", "_done", "_r_arr", "_K_arr", "_sigma_arr", "_ep_return", "_partials",
                       "_model_idx", "_counter")
+    _STATE_ATTRS = ("_sigma_scalar", "n_actions", "C", "K_mean", "r_mean", "sigma_p")
 
     def state_dict(self):
         """Everything a rollout needs to resume bit-for-bit: the per-env streams, the counters that
@@ -427,7 +473,11 @@ class BaseFishingEnv(_gym_env_base()):
             torch.cuda.current_stream(self.device).synchronize()
         sd = {k: getattr(self, k).clone() for k in self._STATE_TENSORS if getattr(self, k) is not None}
         sd.update(seed=self._seed, step_count=self._step_count, reset_count=self._reset_count,
-                  params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state)
+                  params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state,
+                  v4_derived=self._derived, v4_origin=tuple(self._origin), auto_reset=self.auto_reset,
+                  attrs={k: getattr(self, k) for k in self._STATE_ATTRS if hasattr(self, k)})
+        if self.MODEL == MODEL_V11:
+            sd["attrs"].update(models=list(self.models), model_params={k: dict(v) for k, v in self.model_params.items()})
         if self._np_rng:        # rng="numpy": the noise source is NumPy's global stream -- part of the state
             sd["numpy_rng_state"] = np.random.get_state()
         return sd
@@ -435,6 +485,17 @@ class BaseFishingEnv(_gym_env_base()):
     def load_state_dict(self, sd):
         if self._host_mapped:
             torch.cuda.current_stream(self.device).synchronize()
+        if self._per_env:                       # fishing-v4: same parameter mode as the saved env
+            if sd.get("v4_derived", False):
+                if not self._derived_capable:
+                    raise ValueError("state was saved in the derived-parameter mode, which this env cannot run")
+                self._derived, self._K_arr, self._r_arr = True, None, None
+            elif self._derived:
+                self._derived = False
+                self._K_arr = torch.empty(self.num_envs, dtype=self.dtype, device=self.device)
+                self._r_arr = torch.empty_like(self._K_arr)
+            self._origin = tuple(sd.get("v4_origin", (0, 0)))
+            self._cbuf = None
         for k in self._STATE_TENSORS:
             if k in sd:
                 if getattr(self, k) is None:
@@ -446,6 +507,11 @@ class BaseFishingEnv(_gym_env_base()):
         self._seed, self._step_count, self._reset_count = sd["seed"], sd["step_count"], sd["reset_count"]
         self.params.update(sd["params"])
         self.Tmax, self.init_state = sd["Tmax"], sd["init_state"]
+        self.auto_reset = sd.get("auto_reset", self.auto_reset)
+        for k, v in sd.get("attrs", {}).items():          # the scalar attributes FishingParams is built from
+            setattr(self, k, [*v] if k == "models" else ({m: dict(d) for m, d in v.items()} if k == "model_params" else v))
+        if self._sigma_arr is None and "_sigma_scalar" not in sd.get("attrs", {}):
+            self._sigma_scalar = float(self.params["sigma"])
         if self._np_rng and "numpy_rng_state" in sd:
             np.random.set_state(sd["numpy_rng_state"])
         self._publish_scalar_state()
@@ -470,7 +536,11 @@ class BaseFishingEnv(_gym_env_base()):
             self.seed(seed)
         m = None
         if mask is not None:
+            self._leave_derived_mode()      # envs reset at different times: their parameters go to arrays
             m = torch.as_tensor(mask).to(device=self.device).reshape(self.num_envs).to(torch.uint8).contiguous()
+        elif self._derived_capable:         # a reset of ALL envs: its counters date every episode from here on
+            self._derived, self._K_arr, self._r_arr, self._cbuf = True, None, None, None
+            self._origin = (self._current_step_count(), self._reset_count)
         with torch.cuda.device(self.device):
             rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
                                 self._c_buffers(with_outputs=False), m.data_ptr() if m is not None else None,
@@ -574,9 +644,14 @@ class BaseFishingEnv(_gym_env_base()):
             return self.state, self.reward, self._last_done, {}
         return self._obs_view, self._reward, self._done_view, self._info
 
-    def step_many(self, actions, n_steps=None):
+    def step_many(self, actions, n_steps=None, fused=False, rewards_out=None, dones_out=None):
         """n_steps consecutive step() calls enqueued by one C call; `actions` is [R, N]
-        (a ring of R action batches, cycled).  Returns the last step's result."""
+        (a ring of R action batches, cycled).  Returns the last step's result.
+        fused=True runs them in ONE kernel launch (fishing_step_fused_*: state in registers, action rows
+        prefetched) -- bit-identical results, and the fast path while a launch per step is latency-bound
+        (N <= 2^20); `rewards_out` [n_steps, N] (env dtype) / `dones_out` [n_steps, N] (uint8 or bool) then receive every
+        step's reward / done rows.  Not available with terminal-observation / done_bits records, fishing-v11 or
+        rng="numpy"."""
         want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
         if not (isinstance(actions, torch.Tensor) and actions.device == self.device and actions.dtype == want
                 and actions.dim() == 2 and actions.shape[1] == self.num_envs and actions.stride(1) == 1
@@ -590,13 +665,33 @@ class BaseFishingEnv(_gym_env_base()):
             for k in range(n_steps):
                 self.step(actions[k % R])
             return self._step_result()
+        if (rewards_out is not None or dones_out is not None) and not fused:
+            raise ValueError("rewards_out / dones_out need fused=True")
         with torch.cuda.device(self.device):
-            rc = self._fn_step_many(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(actions),
-                                    row_stride, R, n_steps, self._seed,
-                                    0 if self._counter is not None else self._step_count, self._stream())
+            count = 0 if self._counter is not None else self._step_count
+            if fused:
+                out_stride = 0
+                for name, o, ok in (("rewards_out", rewards_out, (self.dtype,)), ("dones_out", dones_out, (torch.uint8, torch.bool))):
+                    if o is None:
+                        continue
+                    if not (isinstance(o, torch.Tensor) and o.device == self.device and o.dtype in ok and o.dim() == 2
+                            and o.shape[0] >= n_steps and o.shape[1] == self.num_envs and o.stride(1) == 1
+                            and o.stride(0) % 16 == 0 and o.data_ptr() % 16 == 0
+                            and (out_stride in (0, o.stride(0)))):
+                        raise ValueError("%s must be a [>= %d, %d] device tensor with unit inner stride and a row stride "
+                                         "that is a multiple of 16 elements (the same for both outputs)"
+                                         % (name, n_steps, self.num_envs))
+                    out_stride = o.stride(0)
+                rc = self._fn_step_fused(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(actions),
+                                         row_stride, R, n_steps, rewards_out.data_ptr() if rewards_out is not None else None,
+                                         dones_out.data_ptr() if dones_out is not None else None, out_stride,
+                                         self._seed, count, self._stream())
+            else:
+                rc = self._fn_step_many(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(actions),
+                                        row_stride, R, n_steps, self._seed, count, self._stream())
             if self._counter is not None and not rc:
                 rc = self._lib.fishing_counter_add(self._counter.data_ptr(), n_steps, self._stream())
-        _capi.check(rc, "fishing_step_many")
+        _capi.check(rc, "fishing_step_fused" if fused else "fishing_step_many")
         self._step_count += n_steps
         self._last_action = actions[(n_steps - 1) % R] if n_steps else self._last_action
         return self._step_result()
@@ -650,20 +745,35 @@ class BaseFishingEnv(_gym_env_base()):
             self._publish_scalar_state()
         return traj
 
-    def episode_stats(self, all_reduce=True):
-        """Episodic-return record over every episode finished since construction:
-        {sum R, sum R^2, n, sum length}, reduced on the device in slot order and -- when
-        torch.distributed is initialised -- summed across ranks (one RCCL all-reduce)."""
+    def episode_record(self, all_reduce=True):
+        """The episodic-return record {sum R, sum R^2, n, sum length} as a 4-double DEVICE tensor: reduced on the
+        device in slot order and -- when torch.distributed is initialised -- summed across ranks (one RCCL
+        all-reduce).  Everything is enqueued on the current stream; nothing here waits for the GPU (with a
+        non-RCCL backend the all-reduce goes through a 32-byte host copy)."""
         if self._partials is None:
             raise RuntimeError("construct the env with track_returns=True")
         with torch.cuda.device(self.device):
             rc = self._lib.fishing_reduce_returns(self._partials.data_ptr(), self._record.data_ptr(), self._stream())
         _capi.check(rc, "fishing_reduce_returns")
-        from .sharding import all_reduce_record, summarize_record
+        from .sharding import all_reduce_record
         rec = self._record
         if all_reduce:
             rec = all_reduce_record(rec.clone())
-        return summarize_record(rec)
+        return rec
+
+    def episode_stats(self, all_reduce=True):
+        """episode_record() read back to the host, with mean / std of the return and mean episode length."""
+        from .sharding import summarize_record
+        return summarize_record(self.episode_record(all_reduce))
+
+    def step_kernel_name(self, actions=None):
+        """Diagnostic: the kernel (as rocprofv3 names it) that step() launches for this env's whole tiles."""
+        import ctypes
+        out = ctypes.create_string_buffer(160)
+        a = self._obs if actions is None else actions         # any aligned device pointer: nothing is launched
+        fn = getattr(self._lib, "fishing_step_kernel_name_" + self._suffix)
+        _capi.check(fn(self._c_params(), self.num_envs, self._c_buffers(a), out, 160), "fishing_step_kernel_name")
+        return out.value.decode()
 
     # ------------------------------------------------------------------ helpers (base_fishing_env.py:135-164)
     def _K_for_math(self):
@@ -738,6 +848,11 @@ class BaseFishingEnv(_gym_env_base()):
             zt = torch.as_tensor(z).to(device=self.device, dtype=dtype)
         out = torch.empty_like(xt)
         cp = self._c_params()
+        if self.MODEL == MODEL_V10 and self._scalar and r is None:
+            # growth_models.py:151: every population_draw() call -- BMSY()'s and msy()'s sweeps included -- first
+            # moves r by alpha, and keeps the moved value
+            r = float(self._r_arr[0]) + float(self.params.get("alpha", 0.0))
+            self._r_arr.fill_(r)
         if sigma is not None or r is not None or K is not None:     # never edit the cached struct step() uses
             cp = _capi.FishingParams.from_buffer_copy(cp)
             if sigma is not None:
@@ -847,6 +962,7 @@ class FishingModelError(BaseFishingEnv):
     def _set_initial_state(self):
         # constructor: draw (K, r) once (fishing_model_error.py:37-38) but keep the base
         # class's obs = x0 / K_mean - 1 (base_fishing_env.py:46) until the first reset()
+        self._origin = (self._step_count, self._reset_count)
         with torch.cuda.device(self.device):
             rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
                                 self._c_buffers(with_outputs=False), None, self._seed, self._reset_count,

@@ -60,7 +60,7 @@ def _cut_tables(env, traj, rep0):
     """[T][4][N] record {obs_in, action, reward, done} -> rows of the simulate table."""
     T, _, N = traj.shape
     obs_in, act, rew, done = (traj[:, k].to(torch.float64) for k in range(4))
-    K = env._K_arr.to(torch.float64).reshape(1, N) if env._per_env else float(env.params["K"])
+    K = env._K_view().to(torch.float64).reshape(1, N) if env._per_env else float(env.params["K"])
     state = (obs_in + 1.0) * K                                   # get_fish_population :158-160
     if env.MODEL == 0:
         quota = (act / env.n_actions) * K                        # get_quota :140

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FISHING_ABI_VERSION 2
+#define FISHING_ABI_VERSION 3
 
 typedef void* fishing_stream_t; /* hipStream_t */
 
@@ -60,10 +60,18 @@ typedef void* fishing_stream_t; /* hipStream_t */
 
 /* FishingParams.flags */
 #define FISHING_FLAG_AUTO_RESET 1u /* SB3-VecEnv semantics: a finished env is reset inside step() */
-#define FISHING_FLAG_GENERAL_KERNEL 2u /* test knob: never take the lean fp32 fast path of step()  */
 #define FISHING_FLAG_T_U8 4u /* compact layout: FishingBuffers.t is uint8_t[n] instead of int32_t[n]
                                 (needs Tmax <= 254; a counter that would pass 255 stays at 255).
                                 Saves 6 of the 25 bytes per env-step of the fp32 layout.          */
+#define FISHING_FLAG_V4_DERIVED 8u /* fishing-v4 on the in-kernel streams: FishingBuffers.r / .K are not
+                                read or written (may be NULL); every kernel re-derives an env's (K, r)
+                                from (seed, env index, the step or reset() that began its episode), which
+                                it reads off years_passed -- see v4_origin_step below.  Same values as the
+                                stored-array mode bit for bit.  Not with FISHING_FLAG_T_U8, z-less
+                                user-supplied parameters, or after a masked reset (the host then calls
+                                fishing_v4_params_* once and continues with arrays).                 */
+/* diagnostic (tests, A/B timing): route step() to the general kernel even where a lean instantiation applies */
+#define FISHING_FLAG_DIAG_GENERAL_KERNEL 0x80000000u
 
 /* error codes */
 #define FISHING_OK 0
@@ -99,6 +107,11 @@ typedef struct FishingParams {
     int32_t n_models;         /* fishing-v11: length of the model list (1..5)           */
     int32_t kinds[FISHING_N_KINDS]; /* fishing-v11: FISHING_KIND_* of each list entry   */
     FishingGrowthParams zoo[FISHING_N_KINDS]; /* fishing-v11: parameters per KIND       */
+    /* FISHING_FLAG_V4_DERIVED: the last reset() of ALL envs happened when `v4_origin_step` step() calls had
+     * been made and drew with reset counter `v4_origin_counter`; an env whose years_passed t satisfies
+     * step_counter - t == v4_origin_step still runs on those parameters, any other env was auto-reset by
+     * step (step_counter - t - 1) and runs on that step's redraw (fishing_model_error.py:42-43). */
+    uint64_t v4_origin_step, v4_origin_counter;
 } FishingParams;
 
 /* Device buffers, all of length n unless noted.  "real" = float (_f32) or double (_f64). */
@@ -110,8 +123,9 @@ typedef struct FishingBuffers {
     uint64_t* done_bits; /* u64[ceil(n/64)] out, bit (i%64) of word i/64 = done[i]; nullable      */
     int32_t* t;          /* i32   in/out  years_passed (base_fishing_env.py:75); uint8_t[n] under
                                           FISHING_FLAG_T_U8                                        */
-    void* r;             /* real  in/out  per-env growth rate; required for v4 and v10 (drift)    */
-    void* K;             /* real  in/out  per-env carrying capacity; required for v4              */
+    void* r;             /* real  in/out  per-env growth rate; required for v4 (unless FISHING_FLAG_V4_DERIVED)
+                                          and v10 (drift)                                          */
+    void* K;             /* real  in/out  per-env carrying capacity; required for v4 (unless ..._V4_DERIVED) */
     const void* sigma;   /* real  in      per-env noise scale; nullable => FishingParams.sigma    */
     const void* z_ext;   /* real  in      externally supplied standard normals; nullable =>
                                           in-kernel Philox4x32-10 + Box-Muller                    */
@@ -180,6 +194,36 @@ int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, c
                         int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
                         uint64_t step_counter, fishing_stream_t stream);
 
+/* n_steps consecutive step() calls in ONE launch: obs, t, (r, K,) ep_return stay in registers, step k
+ * reads its actions at action + (k % ring_len) * action_stride elements (the caller's [R, n] ring) and
+ * -- optionally -- writes its reward / done rows at reward_steps + k * out_stride (real[n_steps][out_stride])
+ * and done_steps + k * out_stride (u8).  The launch-bound regime's fast path (n <= 2^20: a dependent
+ * launch costs ~2.7 us whatever it moves).  Bit-identical to n_steps fishing_step_* calls with the same
+ * step_counter: same Philox counters, same arithmetic; FishingBuffers.reward / .done receive the last
+ * step's values, return_partials the same record.  Not for z_ext / terminal_obs / done_bits (use step()). */
+int fishing_step_fused_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                           int64_t action_stride, int32_t ring_len, int32_t n_steps, void* reward_steps,
+                           uint8_t* done_steps, int64_t out_stride, uint64_t seed, uint64_t step_counter,
+                           fishing_stream_t stream);
+int fishing_step_fused_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                           int64_t action_stride, int32_t ring_len, int32_t n_steps, void* reward_steps,
+                           uint8_t* done_steps, int64_t out_stride, uint64_t seed, uint64_t step_counter,
+                           fishing_stream_t stream);
+
+/* fishing-v4 under FISHING_FLAG_V4_DERIVED: materialise the (K, r) in force for envs [0, n) given their
+ * years_passed `t` at step count `step_counter` (what env.K / env.r show, and what the host stores when it
+ * leaves the derived mode).  K_out / r_out: real[n], either may be NULL. */
+int fishing_v4_params_f32(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out,
+                          void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream);
+int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out,
+                          void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream);
+
+/* Diagnostic: the demangled name (as rocprofv3 prints it, without the argument list) of the kernel that
+ * fishing_step_f32/_f64 would launch for the whole tiles of this request -- the same dispatch code decides,
+ * nothing is launched.  Writes at most len - 1 characters + NUL; returns 0 or a FISHING_ERR_*. */
+int fishing_step_kernel_name_f32(const FishingParams* p, int64_t n, const FishingBuffers* b, char* out, int64_t len);
+int fishing_step_kernel_name_f64(const FishingParams* p, int64_t n, const FishingBuffers* b, char* out, int64_t len);
+
 /* *counter += delta on `stream` (one thread).  Pair with FishingBuffers.counter to make a
  * captured step() / rollout() replayable: capture {step, counter_add(1)} once, replay K times. */
 int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stream);
@@ -207,8 +251,9 @@ int fishing_stream_synchronize(fishing_stream_t stream);
  * the Philox4x32-10 block on stream `stream_tag`, z0 / z1 = the cos / sin legs of the Box-Muller
  * pair of words (0, 1).  What the index means per stream: tags 0 (step noise) and 3 (random-policy
  * actions of the fused rollout) index by env QUAD (global env >> 2), see fishing_step_normals_f32;
- * tags 1 / 2 (reset streams) by env PAIR for fishing-v4, see fishing_reset_normals_f32, and by env
- * for fishing-v11 (word 0 = the model draw).  Any output pointer may be NULL. */
+ * tags 1 / 2 (reset streams) by env QUAD for fishing-v11 (word j = the model draw of env 4q + j);
+ * fishing-v4's parameter draws on those tags are Philox2x32 blocks, see fishing_reset_normals_f32.
+ * Any output pointer may be NULL. */
 int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
                       uint32_t* words, float* z0, float* z1, fishing_stream_t stream);
 
@@ -221,8 +266,9 @@ int fishing_step_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint6
 
 /* Test/diagnostic: the standard normals behind fishing-v4's (K, r) redraw (fishing_model_error.py:42-43)
  * for envs env_offset .. env_offset + n - 1 on reset stream `stream_tag` (1 = auto-reset inside step,
- * counter = that step's counter; 2 = reset(), counter = the reset counter).  One Philox block per env
- * pair: Box-Muller of (w0, w1) -> (zK, zr) of the even env, of (w2, w3) -> the odd env. */
+ * counter = that step's counter; 2 = reset(), counter = the reset counter).  One Philox2x32-10 block per
+ * env, counter words {env[31:0], counter[31:0]}, key folded from seed / stream / the high halves:
+ * Box-Muller of (w0, w1) -> (zK, zr). */
 int fishing_reset_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
                               float* zK, float* zr, fishing_stream_t stream);
 

@@ -257,9 +257,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def philox_words(seed, env_index, step_counter, stream):
     """Counter layout shared with csrc/fishing_common.h (`env_index` = the Philox index:
-    the env QUAD index on the noise and policy streams (noise_normal, policy_random_action), the
-    env PAIR index for fishing-v4's redraw on the reset streams (reset_normals), the env QUAD index
-    for fishing-v11's model draw (model_draw)):
+    the env QUAD index on the noise and policy streams (noise_normal, policy_random_action) and for
+    fishing-v11's model draw on the reset streams (model_draw); fishing-v4's parameter draws use
+    param_words instead):
     c0 = index[31:0], c1 = stream<<24 | index[55:32], c2 = step[31:0], c3 = step[63:32];
     key = (seed[31:0], seed[63:32])."""
     env = np.asarray(env_index, dtype=np.uint64)
@@ -357,15 +357,54 @@ def policy_action(policy, param, model, obs, K, n_actions=100, dtype=np.float64)
     return (q / K - dt(1.0)).astype(np.float32)
 
 
+_M2 = np.uint64(0xD256D193)
+
+
+def philox2x32_10(c0, c1, k):
+    """Vectorised Philox2x32 with 10 rounds (Salmon et al. 2011): one multiply per round, two words out.
+    Inputs uint32 arrays / scalars (the key may be an array: one key per lane)."""
+    c0, c1, k = (np.asarray(x, dtype=np.uint32) for x in (c0, c1, k))
+    c0, c1, k = np.broadcast_arrays(c0, c1, k)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p = _M2 * c0.astype(np.uint64)
+            hi = (p >> np.uint64(32)).astype(np.uint32)
+            lo = (p & _MASK).astype(np.uint32)
+            c0, c1 = hi ^ k ^ c1, lo
+            k = (k.astype(np.uint64) + np.uint64(0x9E3779B9)).astype(np.uint32)
+    return c0, c1
+
+
+def param_words(seed, env_index, counter, stream):
+    """The two words behind fishing-v4's (K, r) draw of env `env_index` (fishing_common.h: draw_model_error,
+    param_key): Philox2x32-10 with counter {env[31:0], counter[31:0]} and a 32-bit key folded from the seed,
+    the stream tag and the high halves of env index and counter."""
+    env = np.asarray(env_index, dtype=np.uint64)
+    counter, seed, stream = int(counter), int(seed), int(stream)
+    m32 = 0xFFFFFFFF
+    key0 = ((seed & m32) ^ (((seed >> 32) * 0x85EBCA6B) & m32) ^ ((stream * 0xC2B2AE35) & m32)
+            ^ ((((counter >> 32) & m32) * 0x165667B1) & m32))
+    with np.errstate(over="ignore"):
+        key = np.uint32(key0) ^ (((env >> np.uint64(32)) * np.uint64(0x27D4EB2F)) & _MASK).astype(np.uint32)
+    return philox2x32_10((env & _MASK).astype(np.uint32), np.uint32(counter & m32), key)
+
+
 def reset_normals(seed, env_index, counter, stream):
-    """(zK, zr) float32 for a fishing-v4 parameter redraw: the cos and sin legs of
-    ONE Box-Muller pair, K first then r (fishing_model_error.py:42-43 order).  The reset streams
-    are indexed by env PAIR: words (0, 1) of block env_index >> 1 serve the even env, words (2, 3)
-    the odd env (fishing_common.h: draw_model_error_pair)."""
-    env_index = np.asarray(env_index, dtype=np.uint64)
-    w0, w1, w2, w3 = philox_words(seed, env_index >> np.uint64(1), counter, stream)
-    odd = (env_index & np.uint64(1)).astype(bool)
-    return box_muller(np.where(odd, w2, w0), np.where(odd, w3, w1))
+    """(zK, zr) float32 for a fishing-v4 parameter draw: the cos and sin legs of ONE Box-Muller pair, K first
+    then r (fishing_model_error.py:42-43 order), from the env's own Philox2x32-10 block (param_words)."""
+    w0, w1 = param_words(seed, env_index, counter, stream)
+    return box_muller(w0, w1)
+
+
+def v4_origin(step_counter, t, origin_step, origin_counter):
+    """Which (stream, counter) drew the parameters in force for an env with years_passed `t` at global step
+    `step_counter` (fishing_common.h: derive_model_error): the last full reset if the env has run since it
+    (step_counter - t == origin_step), else the auto-reset of step (step_counter - t - 1)."""
+    since = np.asarray(step_counter, dtype=np.int64) - np.asarray(t, dtype=np.int64)
+    from_reset = since == int(origin_step)
+    counter = np.where(from_reset, int(origin_counter), since - 1)
+    stream = np.where(from_reset, STREAM_RESET, STREAM_AUTORESET)
+    return stream, counter
 
 
 def auto_reset(model, obs_next, done, t_next, K, r, x0, zK=None, zr=None, K_mean=1.0,

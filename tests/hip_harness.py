@@ -20,7 +20,7 @@ def dev(a, dtype=None):
 
 def params(model, r=0.3, K=1.0, sigma=0.0, C=0.5, x0=0.75, Tmax=100, n_actions=100, K_mean=1.0, r_mean=0.3,
            sigma_p=0.1, auto_reset=False, launch_blocks=0, launch_threads=0, M=0.0, theta=0.0, q=0.0, b=0.0, a=0.0,
-           alpha=0.0, models=None, zoo_table=None, general=False, t_u8=False):
+           alpha=0.0, models=None, zoo_table=None, general=False, t_u8=False, derived=False, origin=(0, 0)):
     p = _capi.FishingParams()
     p.M, p.theta, p.q, p.b, p.a, p.alpha = M, theta, q, b, a, alpha
     if models is not None:                      # fishing-v11: list of kind indices + per-kind dicts
@@ -32,7 +32,8 @@ def params(model, r=0.3, K=1.0, sigma=0.0, C=0.5, x0=0.75, Tmax=100, n_actions=1
                 setattr(p.zoo[k], name, float(d.get(name, 0.0)))
     p.model, p.n_actions, p.Tmax = model, n_actions, Tmax
     p.flags = ((_capi.FLAG_AUTO_RESET if auto_reset else 0) | (_capi.FLAG_GENERAL_KERNEL if general else 0)
-               | (_capi.FLAG_T_U8 if t_u8 else 0))
+               | (_capi.FLAG_T_U8 if t_u8 else 0) | (_capi.FLAG_V4_DERIVED if derived else 0))
+    p.v4_origin_step, p.v4_origin_counter = origin
     p.r, p.K, p.sigma, p.C, p.x0 = r, K, sigma, C, x0
     p.r_mean, p.K_mean, p.sigma_p = r_mean, K_mean, sigma_p
     p.launch_blocks, p.launch_threads = launch_blocks, launch_threads
@@ -101,6 +102,47 @@ class State:
         torch.cuda.synchronize()
         return traj.cpu().numpy() if record else None
 
+    def ring_tensor(self, actions):
+        """[R, n] host actions -> device ring whose rows start 16-byte aligned (row stride padded to 4 elements);
+        returns the [R, n] view."""
+        a = np.asarray(actions)
+        R = a.shape[0]
+        stride = (self.n + 3) // 4 * 4
+        buf = torch.zeros((R, stride), dtype=torch.int32 if self.model == _capi.MODEL_V0 else torch.float32, device="cuda")
+        view = buf[:, :self.n]
+        view.copy_(torch.as_tensor(a).to(buf.dtype))
+        return view
+
+    def step_fused(self, p, actions, n_steps, seed=0, step_counter=0, env_offset=0, per_step=True, expect=0):
+        """fishing_step_fused_*: `actions` a [R, n] host array (the ring); returns (reward_steps, done_steps) host
+        arrays [n_steps, n] when per_step."""
+        a = self.ring_tensor(actions)
+        R = a.shape[0]
+        td = TORCH_OF[self.np_dtype]
+        stride = (self.n + 15) // 16 * 16
+        rs = torch.zeros((n_steps, stride), dtype=td, device="cuda") if per_step else None
+        ds = torch.zeros((n_steps, stride), dtype=torch.uint8, device="cuda") if per_step else None
+        fn = getattr(_capi.lib(), "fishing_step_fused_" + self.suffix)
+        rc = fn(p, self.n, env_offset, self.buffers(a), a.stride(0), R, n_steps,
+                rs.data_ptr() if per_step else None, ds.data_ptr() if per_step else None, stride if per_step else 0,
+                seed, step_counter, None)
+        assert rc == expect, "fishing_step_fused rc=%d (%s)" % (rc, _capi.lib().fishing_error_string(rc))
+        torch.cuda.synchronize()
+        if per_step:
+            return rs[:, :self.n].cpu().numpy(), ds[:, :self.n].cpu().numpy()
+        return None, None
+
+    def v4_params(self, p, seed=0, step_counter=0, env_offset=0):
+        """(K, r) in force under FISHING_FLAG_V4_DERIVED, materialised by fishing_v4_params_*."""
+        td = TORCH_OF[self.np_dtype]
+        K = torch.zeros(self.n, dtype=td, device="cuda")
+        r = torch.zeros(self.n, dtype=td, device="cuda")
+        fn = getattr(_capi.lib(), "fishing_v4_params_" + self.suffix)
+        rc = fn(p, self.n, env_offset, self.t.data_ptr(), K.data_ptr(), r.data_ptr(), seed, step_counter, None)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return K.cpu().numpy(), r.cpu().numpy()
+
     def host(self):
         return (self.obs.cpu().numpy(), self.reward.cpu().numpy(), self.done.cpu().numpy(), self.t.cpu().numpy())
 
@@ -112,9 +154,20 @@ class State:
         return out.cpu().numpy()
 
 
+def kernel_name(p, n, buffers, dtype=np.float32):
+    """Name of the kernel step() would launch for the whole tiles of this request (fishing_step_kernel_name_*)."""
+    import ctypes
+    out = ctypes.create_string_buffer(160)
+    fn = getattr(_capi.lib(), "fishing_step_kernel_name_" + ("f32" if np.dtype(dtype) == np.float32 else "f64"))
+    rc = fn(p, n, buffers, out, 160)
+    assert rc == 0, rc
+    return out.value.decode()
+
+
 def device_noise(n, seed, counter, stream_tag=0, env_offset=0):
     """(words[n,4], z0[n], z1[n]) of Philox index env_offset + i from the device generator; on the reset
-    streams z0 / z1 are the (zK, zr) normals of ENV env_offset + i (pair scheme), words stay per index."""
+    streams z0 / z1 are the (zK, zr) normals of ENV env_offset + i (its own Philox2x32 block), words stay the
+    Philox4x32 block of that index."""
     words = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
     z0 = torch.zeros(n, dtype=torch.float32, device="cuda")
     z1 = torch.zeros(n, dtype=torch.float32, device="cuda")

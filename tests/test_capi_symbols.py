@@ -37,8 +37,8 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_abi_version_and_struct_layout(lib):
     assert lib.fishing_abi_version() == _capi.ABI_VERSION
-    # FishingParams: 4 x i32, 8 x f64, 2 x i32 (88) + 6 x f64 + 6 x i32 (160) + 5 x 9 x f64 -> 520 bytes
-    assert ctypes.sizeof(_capi.FishingParams) == 520
+    # FishingParams: 4 x i32, 8 x f64, 2 x i32 (88) + 6 x f64 + 6 x i32 (160) + 5 x 9 x f64 (520) + 2 x u64 -> 536 bytes
+    assert ctypes.sizeof(_capi.FishingParams) == 536
     assert ctypes.sizeof(_capi.FishingBuffers) == 15 * ctypes.sizeof(ctypes.c_void_p)
     hdr = open(HEADER).read()
     body = hdr[hdr.index("typedef struct FishingBuffers {"):hdr.index("} FishingBuffers;")]
@@ -72,7 +72,27 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.fishing_step_f32(p, 4, 0, b, 0, 0, None) == -2             # unknown model
     p.model = _capi.MODEL_V4
     assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -1      # v4 needs r, K arrays
+    p.flags = _capi.FLAG_V4_DERIVED | _capi.FLAG_T_U8
+    assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -4      # derived parameters need the int32 year counter
+    p.flags = 0
+    assert lib.fishing_v4_params_f32(p, 4, 0, None, None, None, 0, 0, None) == -1
     p.model = _capi.MODEL_V1
+    assert lib.fishing_v4_params_f32(p, 4, 0, 4096, None, None, 0, 0, None) == -2     # fishing-v4 only
+    assert lib.fishing_step_fused_f32(p, 4, 0, b, 4, 0, 3, None, None, 0, 0, 0, None) == -4   # ring_len <= 0
+    assert lib.fishing_step_fused_f32(p, 4, 0, b, 4, 2, 3, 4096, None, 2, 0, 0, None) == -3   # out_stride < n
+    bz = _capi.make_buffers(obs=4096, t=8192, action=12288, z_ext=16384)
+    assert lib.fishing_step_fused_f32(p, 4, 0, bz, 4, 2, 3, None, None, 0, 0, 0, None) == -2  # external noise: step() only
+    name = ctypes.create_string_buffer(128)
+    bo = _capi.make_buffers(obs=4096, t=8192, action=12288, reward=16384, done=20480)
+    assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
+    assert name.value == b"fishing::step_kernel_lean<float, 1, 1151>"        # sigma = 0 (no generator): the catch-all
+    p.sigma = 0.1
+    bo.ep_return = 24576
+    assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
+    assert name.value == b"fishing::step_kernel_lean<float, 1, 6>"           # Philox (2) | RET (4)
+    assert lib.fishing_step_kernel_name_f32(p, 1000, bo, name, 128) == 0
+    assert name.value == b"fishing::step_kernel<float, 1>"                   # below one tile: the general kernel
+    p.sigma = 0.0
     assert lib.fishing_rollout_f32(p, 4, 0, b, 17, 0.0, 3, None, 0, 0, None) == -5
     assert lib.fishing_rollout_f32(p, 4, 0, b, 0, 0.0, -1, None, 0, 0, None) == -4
     assert lib.fishing_reduce_returns(None, None, None) == -1
@@ -95,7 +115,7 @@ def test_header_is_valid_c_and_cxx(tmp_path):
     inc = os.path.join(ROOT, "include")
     src_c = tmp_path / "t.c"
     src_c.write_text('#include "fishing_hip.h"\nint main(void){FishingParams p; FishingBuffers b; (void)p; (void)b; '
-                     'return sizeof(FishingParams) == 520 ? 0 : 1;}\n')
+                     'return sizeof(FishingParams) == 536 ? 0 : 1;}\n')
     exe = tmp_path / "t"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, str(src_c), "-o", str(exe)], check=True)
     assert subprocess.run([str(exe)]).returncode == 0

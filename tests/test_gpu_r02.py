@@ -1,0 +1,420 @@
+"""GPU parity tests of the round-2 kernels, all through the C ABI (tests/hip_harness.py):
+
+* fishing-v4 with derived parameters (FISHING_FLAG_V4_DERIVED: no r / K arrays, every kernel re-derives an
+  env's (K, r) from the Philox2x32 block its year counter points at) == the stored-array mode, bit for bit;
+* fishing_step_fused_* (K steps per launch, state in registers) == K fishing_step_* calls, bit for bit;
+* the episodic-return record counts an episode once, however long a finished env is stepped on;
+* fishing_step_kernel_name_* names the instantiation the dispatch picks.
+"""
+import numpy as np
+import pytest
+
+from oracle import fishing_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hh():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import hip_harness
+    return hip_harness
+
+
+def same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    it = {4: np.uint32, 8: np.uint64, 1: np.uint8}[a.dtype.itemsize]
+    assert a.dtype == b.dtype and a.shape == b.shape, what
+    bad = np.flatnonzero(a.view(it) != b.view(it))
+    assert bad.size == 0, "%s: %d differing, first at %d: %r vs %r" % (what, bad.size, bad[0], a.flat[bad[0]], b.flat[bad[0]])
+
+
+# ------------------------------------------------------------------ fishing-v4: derived == stored parameters
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("kernel", ["lean", "general"])
+@pytest.mark.parametrize("sigarr", [False, True], ids=["sigma_scalar", "sigma_array"])
+def test_v4_derived_parameters_equal_stored_arrays(hh, dtype, kernel, sigarr):
+    """Two fishing-v4 batches (N = 3 * 1024 + 77, env_offset 8), same seed and actions: one keeps r / K arrays
+    (the redraw stores into them), the other runs under FISHING_FLAG_V4_DERIVED with NO arrays.  Over 220
+    auto-resetting steps -- with a second full reset() at step 120, so both origin rules are exercised away from
+    zero -- obs / reward / done / t / ep_return are bit-identical every step, and the (K, r) fishing_v4_params_*
+    materialises from the year counters equal the stored arrays."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n, off, seed = 3 * 1024 + 77, 8, 0xFEEDF00D12
+    general = kernel == "general"
+    kw = dict(sigma=0.1, Tmax=7, K_mean=1.0, r_mean=0.3, sigma_p=0.2, auto_reset=True, general=general)
+    sig = np.random.default_rng(3).uniform(0.02, 0.2, n) if sigarr else None
+    fn = lib.fishing_step_f32 if dtype == np.float32 else lib.fishing_step_f64
+    S = hh.State(n, dtype, fo.MODEL_V4, np.zeros(n), r=np.full(n, 0.3), K=np.full(n, 1.0), sigma=sig, ep_return=True)
+    D = hh.State(n, dtype, fo.MODEL_V4, np.zeros(n), sigma=sig, ep_return=True)
+    assert D.r is None and D.K is None
+    g = torch.Generator(device="cuda").manual_seed(11)
+    origin, resets = (0, 0), 0
+    ps = hh.params(fo.MODEL_V4, **kw)
+    pd = hh.params(fo.MODEL_V4, derived=True, origin=origin, **kw)
+    S.reset(ps, seed=seed, counter=resets, env_offset=off)
+    D.reset(pd, seed=seed, counter=resets, env_offset=off)
+    finished = 0
+    for s in range(220):
+        if s == 120:        # a reset of all envs in mid-run: new origin (step count 120, reset counter 1)
+            resets = 1
+            origin = (s, resets)
+            pd = hh.params(fo.MODEL_V4, derived=True, origin=origin, **kw)
+            S.reset(ps, seed=seed, counter=resets, env_offset=off)
+            D.reset(pd, seed=seed, counter=resets, env_offset=off)
+        # a wide action range: many envs fish themselves out early, others run to Tmax + 1
+        a = (torch.rand(n, device="cuda", generator=g) * 1.3 - 1.15).float()
+        Kd, rd = D.v4_params(pd, seed=seed, step_counter=s, env_offset=off)      # in force BEFORE the step
+        same(Kd, S.K.cpu().numpy(), "K before step %d" % s)
+        same(rd, S.r.cpu().numpy(), "r before step %d" % s)
+        assert fn(ps, n, off, S.buffers(a), seed, s, None) == 0
+        assert fn(pd, n, off, D.buffers(a), seed, s, None) == 0
+        torch.cuda.synchronize()
+        for name in ("obs", "reward", "done", "t", "ep_return"):
+            assert torch.equal(getattr(S, name), getattr(D, name)), (name, s)
+        finished += int(S.done.sum())
+    assert finished > 20 * n                 # plenty of redraws happened
+    assert len(np.unique(S.K.cpu().numpy())) > n // 2
+    rs, rd_ = S.record(), D.record()
+    assert rs[2] == rd_[2] == finished and np.array_equal(rs, rd_)
+    if not general:
+        want = fo_mask(derived=True, sigarr=sigarr, ret=True) if dtype == np.float32 else None
+        name = hh.kernel_name(pd, n, D.buffers(a), dtype)
+        assert name.startswith("fishing::step_kernel_lean<%s, 4, " % ("float" if dtype == np.float32 else "double")), name
+        if want is not None:
+            assert name.endswith(", %d>" % want), (name, want)
+
+
+def fo_mask(noise=2, ret=False, sigarr=False, t8=False, term=False, bits=False, zz=False, derived=False, drift=False):
+    """Feature mask of step_kernel_lean (csrc/fishing_step.hip: namespace feat)."""
+    return (noise | (4 if ret else 0) | (8 if sigarr else 0) | (16 if t8 else 0) | (32 if term else 0) | (64 if bits else 0)
+            | (128 if zz else 0) | (256 if derived else 0) | (512 if drift else 0))
+
+
+def test_v4_derived_parameters_against_the_oracle(hh):
+    """The derived mode end to end against the oracle: the oracle dates every env's episode with v4_origin() and
+    draws (K, r) from reset_normals() (its own Philox2x32), the device's Box-Muller being within 2e-5 of libm's;
+    so K / r agree to 1e-5 and the float64 trajectories stay within 1e-4 over 40 steps."""
+    n, off, seed = 2048 + 12, 4, 77
+    kw = dict(sigma=0.05, Tmax=5, K_mean=1.0, r_mean=0.3, sigma_p=0.1, auto_reset=True)
+    p = hh.params(fo.MODEL_V4, derived=True, origin=(0, 0), **kw)
+    D = hh.State(n, np.float64, fo.MODEL_V4, np.zeros(n))
+    D.reset(p, seed=seed, counter=0, env_offset=off)
+    env = np.arange(off, off + n, dtype=np.uint64)
+    rng = np.random.default_rng(1)
+    t = np.zeros(n, np.int64)
+    for s in range(40):
+        stream, counter = fo.v4_origin(s, t, 0, 0)
+        zK = np.empty(n, np.float32)
+        zr = np.empty(n, np.float32)
+        for st_, c in set(zip(stream.tolist(), counter.tolist())):
+            m = (stream == st_) & (counter == c)
+            zK[m], zr[m] = fo.reset_normals(seed, env[m], c, st_)
+        K, r = fo.draw_model_error_params(zK, zr, 1.0, 0.3, 0.1, np.float64)
+        Kd, rd = D.v4_params(p, seed=seed, step_counter=s, env_offset=off)
+        assert np.abs(Kd - K).max() < 1e-5 and np.abs(rd - r).max() < 1e-5, s
+        a = rng.uniform(-1.1, 0.1, n).astype(np.float32)
+        obs_in = D.obs.cpu().numpy()
+        o, rew, done, t2 = D.step(p, a, seed=seed, step_counter=s, env_offset=off)
+        z = hh.device_step_noise(n, seed, s, off).astype(np.float64)
+        eo, er, ed, et, _ = fo.step(fo.MODEL_V4, obs_in, t.astype(np.int32), a, z, rd, Kd, 0.05, Tmax=5)
+        same(rew, er, "reward step %d" % s)
+        assert np.array_equal(done, ed)
+        exp_obs = np.where(ed.astype(bool), 0.75, eo)        # fishing-v4 restarts at x0 un-normalised (quirk B8)
+        same(o, exp_obs, "obs step %d" % s)
+        t = np.where(ed.astype(bool), 0, et).astype(np.int64)
+        assert np.array_equal(t2, t)
+
+
+# ------------------------------------------------------------------ fused step_many == per-step launches
+FUSED_CASES = [
+    ("v0", fo.MODEL_V0, dict(sigma=0.1, n_actions=100), False),
+    ("v1", fo.MODEL_V1, dict(sigma=0.1), False),
+    ("v1_K2", fo.MODEL_V1, dict(sigma=0.1, K=2.0, r=0.5, x0=1.1), False),      # power-of-two K: the exact x * (1/K)
+    ("v1_K3", fo.MODEL_V1, dict(sigma=0.1, K=3.0), False),                     # ... and a K that keeps the division
+    ("v1_quiet", fo.MODEL_V1, dict(sigma=0.0), False),
+    ("v2", fo.MODEL_V2, dict(sigma=0.1, C=0.5), False),
+    ("v4_stored", fo.MODEL_V4, dict(sigma=0.05, sigma_p=0.2), False),
+    ("v4_derived", fo.MODEL_V4, dict(sigma=0.05, sigma_p=0.2), True),
+    ("v6", fo.MODEL_V6, dict(sigma=0.1), False),
+    ("v7", fo.MODEL_V7, dict(sigma=0.1, r=0.7, K=1.5, M=1.5, q=3.0, b=0.15, a=0.2), False),
+    ("v10", fo.MODEL_V10, dict(sigma=0.1, r=0.8, alpha=-0.007), False),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("auto", [True, False], ids=["auto_reset", "no_reset"])
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_fused_step_many_equals_per_step_launches(hh, case, auto, dtype):
+    """fishing_step_fused_*: 23 steps in ONE launch (action ring of 5 rows, so it wraps; N = 2 * 1024 + 37, ragged;
+    env_offset 12; start counter 100) against 23 fishing_step_* launches with the same counters.  Every per-step
+    reward / done row, the final obs / t / ep_return / (K, r) and the return record are bit-identical -- for
+    every model family, with and without auto-reset (step() semantics: a finished env is stepped on)."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    _, model, kw, derived = case
+    n, off, seed, T, R, c0 = 2 * 1024 + 37, 12, 4242, 23, 5, 100
+    per_env = model == fo.MODEL_V4
+    drift = model == fo.MODEL_V10
+    kw = dict(kw, Tmax=6, auto_reset=auto)
+    pk = dict(derived=True, origin=(c0, 0)) if derived else {}
+    p = hh.params(model, **kw, **pk)
+    rng = np.random.default_rng(5)
+    if model == fo.MODEL_V0:
+        ring = rng.integers(0, 100, (R, n)).astype(np.int32)
+    else:
+        ring = rng.uniform(-1.1, 0.2, (R, n)).astype(np.float32)
+
+    def mk():
+        st = hh.State(n, dtype, model, np.zeros(n), r=(np.full(n, kw.get("r", 0.3)) if (per_env and not derived) or drift else None),
+                      K=np.full(n, 1.0) if per_env and not derived else None, ep_return=True)
+        st.reset(p, seed=seed, counter=0, env_offset=off)
+        return st
+    A, B = mk(), mk()
+    fn = lib.fishing_step_f32 if dtype == np.float32 else lib.fishing_step_f64
+    rows_r, rows_d = [], []
+    ring_dev = A.ring_tensor(ring)
+    for s in range(T):
+        assert fn(p, n, off, A.buffers(ring_dev[s % R]), seed, c0 + s, None) == 0
+        torch.cuda.synchronize()
+        rows_r.append(A.reward.cpu().numpy())
+        rows_d.append(A.done.cpu().numpy())
+    rs, ds = B.step_fused(p, ring, T, seed=seed, step_counter=c0, env_offset=off)
+    for s in range(T):
+        same(rs[s], rows_r[s], "reward row %d" % s)
+        assert np.array_equal(ds[s], rows_d[s]), "done row %d" % s
+    names = ["obs", "t", "reward", "done", "ep_return"] + (["K", "r"] if per_env and not derived else []) + (["r"] if drift else [])
+    for name in names:
+        assert torch.equal(getattr(A, name), getattr(B, name)), name
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12)
+    assert ra[2] > 0
+    if derived:
+        Ka, ra_ = A.v4_params(p, seed=seed, step_counter=c0 + T, env_offset=off)
+        Kb, rb_ = B.v4_params(p, seed=seed, step_counter=c0 + T, env_offset=off)
+        same(Ka, Kb, "derived K after the run")
+        same(ra_, rb_, "derived r after the run")
+    # ... and without the per-step rows (only the last step's reward / done are written)
+    C = mk()
+    C.step_fused(p, ring, T, seed=seed, step_counter=c0, env_offset=off, per_step=False)
+    for name in ("obs", "t", "reward", "done", "ep_return"):
+        assert torch.equal(getattr(A, name), getattr(C, name)), name
+
+
+def test_fused_step_many_at_the_launch_bound_sizes(hh):
+    """BASELINE configs 2 and 4's per-GPU shard (N = 2^20 fishing-v1, 2^19 fishing-v2): 101 fused steps == 101
+    launches on all envs, plus the compact (uint8 year counter) layout."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    for model, n, t8 in ((fo.MODEL_V1, 1 << 20, False), (fo.MODEL_V2, 1 << 19, False), (fo.MODEL_V1, 1 << 18, True)):
+        p = hh.params(model, sigma=0.1, C=0.5, auto_reset=True, t_u8=t8)
+        g = torch.Generator(device="cuda").manual_seed(n)
+        ring = (torch.rand((8, n), device="cuda", generator=g) * 2 - 1).float()
+        A = hh.State(n, np.float32, model, np.full(n, -0.25), ep_return=True, t_u8=t8)
+        B = hh.State(n, np.float32, model, np.full(n, -0.25), ep_return=True, t_u8=t8)
+        assert lib.fishing_step_many_f32(p, n, 0, A.buffers(ring), n, 8, 101, 7, 0, None) == 0
+        assert lib.fishing_step_fused_f32(p, n, 0, B.buffers(ring), n, 8, 101, None, None, 0, 7, 0, None) == 0
+        torch.cuda.synchronize()
+        for name in ("obs", "t", "reward", "done", "ep_return"):
+            assert torch.equal(getattr(A, name), getattr(B, name)), (model, name)
+        ra, rb = A.record(), B.record()
+        assert ra[2] == rb[2] > n // 2 and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ the return record counts an episode once
+@pytest.mark.parametrize("kernel", ["lean", "general", "fused"])
+def test_finished_envs_stepped_on_are_recorded_once(hh, kernel):
+    """Without auto-reset a finished env keeps being stepped (the reference allows it: quirk B7) and stays done;
+    the episodic-return record must hold each env's episode once -- at the step its done flag first rose."""
+    import torch
+    n, Tmax, T = 2048, 5, 14
+    p = hh.params(fo.MODEL_V1, sigma=0.1, Tmax=Tmax, auto_reset=False, general=(kernel == "general"))
+    st = hh.State(n, np.float32, fo.MODEL_V1, np.full(n, -0.25), ep_return=True)
+    rng = np.random.default_rng(0)
+    ring = rng.uniform(-1.0, -0.2, (T, n)).astype(np.float32)
+    ring[:, ::3] = 1.0                       # every third env takes the whole stock at once: done at step 0
+    first_done = np.full(n, -1)
+    ret_at_done = np.zeros(n, np.float32)
+    running = np.zeros(n, np.float32)
+    if kernel == "fused":
+        rs, ds = st.step_fused(p, ring, T, seed=3)
+        for s in range(T):
+            running = (running + rs[s]).astype(np.float32)
+            new = (ds[s] == 1) & (first_done < 0)
+            first_done[new] = s
+            ret_at_done[new] = running[new]
+    else:
+        for s in range(T):
+            _, rew, done, _ = st.step(p, ring[s], seed=3, step_counter=s)
+            running = (running + rew).astype(np.float32)
+            new = (done == 1) & (first_done < 0)
+            first_done[new] = s
+            ret_at_done[new] = running[new]
+    assert (first_done >= 0).all() and (first_done[::3] == 0).all() and first_done.max() == Tmax
+    rec = st.record()
+    assert rec[2] == n, rec                                   # one episode per env, not one per step after the end
+    assert rec[3] == (first_done + 1).sum()
+    assert np.isclose(rec[0], ret_at_done.astype(np.float64).sum(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ which kernel runs what
+def test_kernel_names_follow_the_dispatch(hh):
+    """fishing_step_kernel_name_* reports the instantiation the launch code picks: exact masks for the hot
+    requests, the catch-all of the (T, MODEL) for everything else, the general kernel for fishing-v11, batches
+    below one tile and the diagnostic flag."""
+    n = 1 << 22
+    st = hh.State(4096, np.float32, fo.MODEL_V1, np.zeros(4096), ep_return=True, terminal=True, done_bits=True)
+    full = st.buffers(st.action_tensor(np.zeros(4096, np.float32)))
+
+    def name(p, n=n, dtype=np.float32, **drop):
+        from gym_fishing_amd import _capi
+        b = _capi.FishingBuffers.from_buffer_copy(full)
+        for k in ("terminal_obs", "done_bits", "ep_return", "return_partials"):
+            if not drop.get(k, False):
+                setattr(b, k, None)
+        return hh.kernel_name(p, n, b, dtype)
+    p1 = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True)
+    assert name(p1) == "fishing::step_kernel_lean<float, 1, 2>"
+    assert name(p1, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 6>"
+    assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 130>"
+    assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 1151>"
+    assert name(p1, terminal_obs=True, done_bits=True) == "fishing::step_kernel_lean<float, 1, 1151>"
+    assert name(p1, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 1151>"
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 18>"
+    assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 2>"
+    assert name(hh.params(fo.MODEL_V9, sigma=0.1)) == "fishing::step_kernel_lean<float, 104, 2>"
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, general=True)) == "fishing::step_kernel<float, 1>"
+    assert name(p1, n=1000) == "fishing::step_kernel<float, 1>"
+    assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True)) == "fishing::step_kernel_lean<float, 4, 258>"
+
+
+# ------------------------------------------------------------------ the host mirror in the derived mode
+def test_env_v4_derived_mode_equals_the_stored_mode_and_survives_its_exits(hh):
+    """make("fishing-v4", num_envs=N) keeps no r / K arrays (derived_params defaults to on for the Philox streams);
+    derived_params=False keeps them.  Same seed => same trajectories and the same env.K / env.r, through step(),
+    step_many(), the fused rollout, a mid-run full reset(), and the three exits from the derived mode: a masked
+    reset(), env.K = ..., seed()."""
+    import torch
+    import gym_fishing_amd as gf
+    n = 4096 + 8
+    mk = lambda derived: gf.make("fishing-v4", num_envs=n, sigma=0.05, sigma_p=0.2, Tmax=6, seed=5, env_offset=16,   # noqa: E731
+                                 track_returns=True, derived_params=derived)
+    D, S = mk(None), mk(False)
+    assert D._derived and D._K_arr is None and not S._derived and S._K_arr is not None
+    g = torch.Generator(device="cuda").manual_seed(0)
+
+    def check(tag):
+        torch.cuda.synchronize()
+        for name in ("_obs", "_t", "_reward", "_done", "_ep_return"):
+            assert torch.equal(getattr(D, name), getattr(S, name)), (tag, name)
+        assert torch.equal(D.K, S.K) and torch.equal(D.r, S.r), tag
+    check("constructor")                                         # the constructor's draw (reset counter 0)
+    for e in (D, S):
+        e.reset()
+    check("reset")
+    for s in range(30):
+        a = torch.rand(n, device="cuda", generator=g) * 1.3 - 1.15
+        for e in (D, S):
+            e.step(a)
+        check("step %d" % s)
+    ring = torch.rand((4, n), device="cuda", generator=g) * 1.3 - 1.15
+    for e in (D, S):
+        e.step_many(ring, 11)
+    check("step_many")
+    for e in (D, S):
+        e.step_many(ring, 9, fused=True)
+    check("fused step_many")
+    for e in (D, S):
+        e.rollout(13, policy="random")
+    check("fused rollout")
+    for e in (D, S):
+        e.reset()                                                # a full reset in mid-run: new origin
+    assert D._derived and D._origin == (63, 2)
+    for e in (D, S):
+        e.step_many(ring, 7)
+    check("after the second reset")
+    sd = D.state_dict()                                          # checkpoint in the derived mode
+    mask = torch.zeros(n, dtype=torch.bool, device="cuda")
+    mask[::5] = True
+    for e in (D, S):
+        e.reset(mask)                                            # envs restart at different times -> arrays
+    assert not D._derived and D._K_arr is not None
+    for e in (D, S):
+        e.step_many(ring, 8)
+    check("after a masked reset")
+    for e in (D, S):
+        e.reset()
+    assert D._derived and D._K_arr is None                       # a full reset returns to the derived mode
+    for e in (D, S):
+        e.step_many(ring, 5)
+        e.K = 1.25                                               # user-supplied parameters -> arrays
+        e.step_many(ring, 5)
+    assert not D._derived
+    check("after env.K = 1.25")
+    for e in (D, S):
+        e.seed(77)                                               # new stream, parameters in force stay
+        e.step_many(ring, 4)
+        e.reset()
+        e.step_many(ring, 6)
+    assert D._derived
+    check("after seed()")
+    sa, sb = D.episode_stats(), S.episode_stats()
+    assert sa["n_episodes"] == sb["n_episodes"] > n and sa["sum_return"] == sb["sum_return"]
+    # resume from the checkpoint taken in the derived mode
+    R = mk(None)
+    R.load_state_dict(sd)
+    assert R._derived and R._origin == (63, 2)
+    D2 = mk(None)
+    D2.load_state_dict(sd)
+    for e in (R, D2):
+        e.step_many(ring, 12)
+    torch.cuda.synchronize()
+    assert torch.equal(R._obs, D2._obs) and torch.equal(R.K, D2.K)
+
+
+def test_state_dict_round_trip_carries_sigma_and_scalar_attributes(hh):
+    """load_state_dict() restores what FishingParams is built from: sigma changed after construction (env.sigma
+    = ...), n_actions, C, the fishing-v4 means -- a freshly built env resumes bit for bit."""
+    import torch
+    import gym_fishing_amd as gf
+    n = 2048
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for env_id, kw, attr in (("fishing-v1", {}, None), ("fishing-v2", dict(C=0.4), "C"), ("fishing-v0", dict(n_actions=50), "n_actions")):
+        A = gf.make(env_id, num_envs=n, sigma=0.0, seed=3, **kw)
+        A.reset()
+        A.sigma = 0.2                                            # after construction
+        if attr == "C":
+            A.C = 0.45
+        acts = (torch.randint(0, 50, (3, n), device="cuda", generator=g, dtype=torch.int32) if env_id == "fishing-v0"
+                else torch.rand((3, n), device="cuda", generator=g) - 1.0)
+        A.step_many(acts, 5)
+        sd = A.state_dict()
+        B = gf.make(env_id, num_envs=n, sigma=0.0, seed=3)       # built with the defaults
+        B.load_state_dict(sd)
+        assert B.sigma == 0.2 and (attr is None or getattr(B, attr) == getattr(A, attr))
+        A.step_many(acts, 6)
+        B.step_many(acts, 6)
+        torch.cuda.synchronize()
+        assert torch.equal(A._obs, B._obs) and torch.equal(A._reward, B._reward), env_id
+
+
+def test_v10_population_draw_drifts_r_like_the_reference(hh):
+    """NonStationary.population_draw (growth_models.py:148-154) moves params['r'] by alpha on EVERY call -- the
+    calls BMSY() / msy() make included -- and evaluates Beverton-Holt with the moved value."""
+    import gym_fishing_amd as gf
+    env = gf.make("fishing-v10", sigma=0.0, rng="philox")
+    env.reset()
+    r0, alpha = 0.8, -0.007
+    x = np.array([0.3, 0.6, 0.9])
+    for k in range(1, 4):
+        got = env.population_draw(x, noise=np.zeros(3))
+        r = r0 + k * alpha
+        want = fo.zoo_population_draw(fo.KIND_OF_MODEL[fo.MODEL_V10], x, np.zeros(3), dict(r=r, K=1.0, sigma=0.0))
+        assert np.allclose(got, want, rtol=1e-12, atol=0), (k, got, want)
+        assert np.isclose(env.r, r)

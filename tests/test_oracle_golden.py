@@ -148,6 +148,40 @@ def test_philox_known_answers(ctr, key, want):
     assert tuple(int(x) for x in got) == want
 
 
+PHILOX2_KAT = [  # Random123 kat_vectors: philox2x32-10  (ctr0, ctr1), key -> (out0, out1)
+    ((0, 0), 0, (0xFF1DAE59, 0x6CD10DF2)),
+    ((0xFFFFFFFF, 0xFFFFFFFF), 0xFFFFFFFF, (0x2C3F628B, 0xAB4FD7AD)),
+    ((0x243F6A88, 0x85A308D3), 0x13198A2E, (0xDD7CE038, 0xF62A4C12)),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX2_KAT)
+def test_philox2x32_known_answers(ctr, key, want):
+    """fishing-v4's per-env parameter draws (fishing_common.h: draw_model_error) use Philox2x32-10."""
+    got = fo.philox2x32_10(*ctr, key)
+    assert tuple(int(x) for x in got) == want
+
+
+def test_v4_parameter_draw_statistics_and_origin_rule():
+    """(zK, zr) of the Philox2x32 parameter stream: standard normal, uncorrelated, distinct per env / counter /
+    stream / seed half; and the rule that dates an episode from the env's year counter (v4_origin)."""
+    n = 1 << 16
+    env = np.arange(n, dtype=np.uint64)
+    zK, zr = (x.astype(np.float64) for x in fo.reset_normals(99, env, 5, fo.STREAM_RESET))
+    for z in (zK, zr):
+        assert abs(z.mean()) < 4.0 / np.sqrt(n) and abs(z.var() - 1.0) < 0.03
+    assert abs(np.corrcoef(zK, zr)[0, 1]) < 0.02
+    base = fo.param_words(99, env[:64], 5, fo.STREAM_RESET)[0]
+    for other in (fo.param_words(99, env[:64], 5, fo.STREAM_AUTORESET), fo.param_words(99, env[:64], 6, fo.STREAM_RESET),
+                  fo.param_words(99 + (1 << 32), env[:64], 5, fo.STREAM_RESET),
+                  fo.param_words(99, env[:64] + np.uint64(1 << 32), 5, fo.STREAM_RESET),
+                  fo.param_words(99, env[:64], 5 + (1 << 32), fo.STREAM_RESET)):
+        assert not np.array_equal(base, other[0])
+    # an env that has run since the reset made at step count 40 (reset counter 3); one auto-reset by step 57
+    stream, counter = fo.v4_origin(step_counter=60, t=np.array([20, 2]), origin_step=40, origin_counter=3)
+    assert stream.tolist() == [fo.STREAM_RESET, fo.STREAM_AUTORESET] and counter.tolist() == [3, 57]
+
+
 def test_noise_statistics():
     """The Philox + Box-Muller stream is standard normal and independent of sharding."""
     n = 1 << 16
