@@ -119,7 +119,7 @@ def cpu_baseline(seconds, cfg_name):
     port on every core, the NumPy-vectorised (N,) restatement and the plain-C port."""
     cfg = CONFIGS[cfg_name]
     env_id = cfg["env_id"]
-    scalar_id = env_id if env_id != "fishing-v4" else "fishing-v1"   # the scalar port has no v4 (same arithmetic as v1)
+    scalar_id = env_id
     skw = dict(sigma=0.1 if cfg_name != "v4" else 0.05)
     from oracle.scalar_env import time_random_rollout
     rate, _ = time_random_rollout(scalar_id, 20_000, seed=0, **skw)      # calibrate
@@ -194,17 +194,31 @@ def pmc_traffic(kernel, n_envs):
 
 
 # --------------------------------------------------------------------------------------- one rank
-def make_actions(torch, cfg, n, rows, generator, pad=3072):
-    """[rows, n] action ring; rows are `pad` elements longer than n so consecutive batches do not start at
-    power-of-two-spaced addresses (same reason the env staggers its own streams)."""
+ACTION_CHUNK = 1 << 16
+
+
+def make_actions(torch, cfg, n, rows, env_offset=0, pad=3072, seed=4321):
+    """[rows, n] action ring of the envs [env_offset, env_offset + n).  The random policy's actions are a function
+    of the GLOBAL env index -- chunk c = envs [c * 2^16, (c + 1) * 2^16) is drawn from torch's generator seeded
+    seed + c -- so a sharded run steps exactly the workload of the single-process run over all envs.  Rows are
+    `pad` elements longer than n so consecutive batches do not start at power-of-two-spaced addresses (same
+    reason the env staggers its own streams)."""
     kind, lo, hi = cfg["actions"]
     dtype = torch.int32 if kind == "int" else torch.float32
     ring = torch.empty((rows, n + pad), device="cuda", dtype=dtype)
     view = ring[:, :n]
-    if kind == "int":
-        view.copy_(torch.randint(lo, hi, (rows, n), device="cuda", generator=generator, dtype=torch.int32))
-    else:
-        view.copy_(torch.rand((rows, n), device="cuda", generator=generator, dtype=torch.float32) * (hi - lo) + lo)
+    g = torch.Generator(device="cuda")
+    first = env_offset // ACTION_CHUNK
+    last = (env_offset + n - 1) // ACTION_CHUNK
+    for c in range(first, last + 1):
+        g.manual_seed(seed + c)
+        if kind == "int":
+            blk = torch.randint(lo, hi, (rows, ACTION_CHUNK), device="cuda", generator=g, dtype=torch.int32)
+        else:
+            blk = torch.rand((rows, ACTION_CHUNK), device="cuda", generator=g, dtype=torch.float32) * (hi - lo) + lo
+        a = max(c * ACTION_CHUNK, env_offset)
+        b = min((c + 1) * ACTION_CHUNK, env_offset + n)
+        view[:, a - env_offset:b - env_offset] = blk[:, a - c * ACTION_CHUNK:b - c * ACTION_CHUNK]
     return view
 
 
@@ -312,8 +326,7 @@ def main():
     with_returns = not args.no_returns
     env = make_env(gf, torch, args.config, n, rank * n, with_returns, args.compact, args.v4_stored)
     env.reset()
-    g = torch.Generator(device="cuda").manual_seed(4321 + rank)
-    actions = make_actions(torch, cfg, n, RING, g)
+    actions = make_actions(torch, cfg, n, RING, rank * n)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -343,11 +356,25 @@ def main():
     if record is not None:
         from gym_fishing_amd.sharding import summarize_record
         stats = summarize_record(record)
+    # The kernel's own duration, for the roofline: the same K launches once more, this time enqueued BEHIND a short
+    # lead-in so that the device is already busy when the first event fires -- HIP events around the K launches then
+    # hold K kernel durations and nothing else.  (The bracket over the timed region above also contains the idle
+    # device's pick-up of the first launch, ~10-25 us once: 0.5 us per step at K = 20, invisible at K = 5050.)
+    lead = 16
+    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    k_steady = max(args.steps, 256)          # (at the driver's K = 20 the events' own few us would be 1-2 % of the bracket)
+    env.step_many(actions, lead)
+    s0.record()
+    env.step_many(actions, k_steady)
+    s1.record()
+    torch.cuda.synchronize()
+    steady_ms = s0.elapsed_time(s1) / k_steady
     med_us, mean_us = per_launch_us(torch, env, actions, max(1, min(args.steps, 200)))
 
     total_env_steps = float(n) * world * args.steps
     bytes_per = bytes_per_env_step(args.config, with_returns, args.compact, args.v4_stored)
-    achieved = n * bytes_per / (kernel_ms * 1e-3) / 1e9
+    achieved = n * bytes_per / (steady_ms * 1e-3) / 1e9
     kernel = env.step_kernel_name(actions[0])
     traffic, traffic_src = pmc_traffic(kernel, n)
     esz = 1 if args.compact else 4
@@ -386,11 +413,16 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": kernel, "bytes_per_env_step": bytes_per,
-                     "avg_launch_us": kernel_ms * 1e3, "launch_us_median": med_us, "launch_us_mean_event_pairs": mean_us,
+                     "avg_launch_us": steady_ms * 1e3, "avg_launch_launches": k_steady,
+                     "avg_launch_us_timed_region": kernel_ms * 1e3,
+                     "launch_us_median_event_pairs": med_us, "launch_us_mean_event_pairs": mean_us,
                      "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                      "cache_resident": fits,
-                     "note": "avg_launch_us = HIP events around the K timed launches / K; launch_us_median = median of "
-                             "event-to-event durations of single launches, measured right after.  Resident arrays %.0f MB "
+                     "note": "avg_launch_us = HIP events around max(K, 256) launches enqueued behind a 16-launch lead-in (device "
+                             "busy when the first event fires), per launch; avg_launch_us_timed_region = the same bracket over the timed "
+                             "region itself (includes the idle device's pick-up of the first launch); "
+                             "launch_us_median_event_pairs = median event-to-event time of single launches (each pair adds "
+                             "its own ~2.5 us of packet gaps).  Resident arrays %.0f MB "
                              "(state streams + %d action batches): %s the 256 MiB Infinity Cache%s" % (
                                  resident / 1e6, RING, "fits" if fits else "exceeds",
                                  " -- the HBM-resident figure is the hbm_resident sub-record" if fits else "")},
@@ -422,7 +454,7 @@ def main():
         rows = 4
         eb = make_env(gf, torch, args.config, big, 0, with_returns, False, args.v4_stored)
         eb.reset()
-        ab = make_actions(torch, cfg, big, rows, g)
+        ab = make_actions(torch, cfg, big, rows)
         eb.step_many(ab, 12)
         us, _ = timed_steps(torch, eb, ab, 40)
         out["hbm_resident"] = {"n_envs": big, "steps": 40, "bytes_per_env_step": bytes_per, "avg_launch_us": us,
@@ -439,7 +471,7 @@ def main():
             nn = 1 << ln
             ef = make_env(gf, torch, args.config, nn, 0, with_returns, False, args.v4_stored)
             ef.reset()
-            af = make_actions(torch, cfg, nn, RING, g)
+            af = make_actions(torch, cfg, nn, RING)
             rows_r = torch.empty((101, nn), dtype=torch.float32, device="cuda")
             rows_d = torch.empty((101, nn), dtype=torch.uint8, device="cuda")
             ef.step_many(af, 101, fused=True, rewards_out=rows_r, dones_out=rows_d)
@@ -487,7 +519,7 @@ def main():
             nn = 1 << ln
             e3 = make_env(gf, torch, args.config, nn, 0, False, False, args.v4_stored)
             e3.reset()
-            acts = make_actions(torch, cfg, nn, 4, g)
+            acts = make_actions(torch, cfg, nn, 4)
             k = max(20, min(400, (1 << 31) // nn))
             e3.step_many(acts, k)
             us, _ = timed_steps(torch, e3, acts, k)

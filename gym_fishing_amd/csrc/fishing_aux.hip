@@ -131,7 +131,7 @@ reset_normals_kernel(const int64_t n, const uint64_t env_offset, const uint64_t 
          i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t env = env_offset + (uint64_t)i;
         uint32_t w0, w1;
-        philox2x32_10((uint32_t)env, (uint32_t)counter, param_key(seed, env, counter, stream_tag), w0, w1);
+        param_block(seed, env, counter, stream_tag == kStreamReset, w0, w1);
         float a, c;
         box_muller(w0, w1, a, c);
         if (zK) zK[i] = a;

@@ -86,13 +86,23 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
     o1 = c1;
 }
 
-// Key of the per-env parameter draw: counter = {env[31:0], counter[31:0]}; the 32-bit key folds in the
-// seed, the stream tag and the high halves of env index and counter (odd multipliers: each term is a
-// bijection of its input, so streams differ whenever exactly one ingredient differs; mirrored in
-// oracle/fishing_oracle.py: param_words).
-__device__ __forceinline__ uint32_t param_key(uint64_t seed, uint64_t env, uint64_t counter, uint32_t stream) {
-    return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu) ^ (stream * 0xC2B2AE35u) ^
-           ((uint32_t)(env >> 32) * 0x27D4EB2Fu) ^ ((uint32_t)(counter >> 32) * 0x165667B1u);
+// Block of the per-env parameter draw (mirrored in oracle/fishing_oracle.py: param_words):
+//   key = seed[31:0] ^ seed[63:32] * 0x85EBCA6B                                  -- wave-uniform: the ten round keys
+//                                                                                   stay in SGPRs, like the noise block's
+//   c0  = env[31:0]     ^ bitreverse(counter[63:32])
+//   c1  = counter[31:0] ^ bitreverse(env[63:32]) ^ (stream == kStreamReset ? 0x5851F42D : 0x2545F491)
+// The high halves (zero until 2^32 envs or steps) and the stream tag are folded into the counter words with
+// full-rate ops; everything per-lane sits in the counter, so a round costs one multiply and two xors.
+constexpr uint32_t kParamTagReset = 0x5851F42Du, kParamTagAuto = 0x2545F491u;
+__device__ __forceinline__ uint32_t param_key(uint64_t seed) {
+    return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
+}
+__device__ __forceinline__ void param_block(uint64_t seed, uint64_t env, uint64_t counter, bool reset_stream, uint32_t& w0,
+                                            uint32_t& w1) {
+    const uint32_t c0 = (uint32_t)env ^ __builtin_bitreverse32((uint32_t)(counter >> 32));
+    const uint32_t c1 = (uint32_t)counter ^ __builtin_bitreverse32((uint32_t)(env >> 32)) ^
+                        (reset_stream ? kParamTagReset : kParamTagAuto);
+    philox2x32_10(c0, c1, param_key(seed), w0, w1);
 }
 
 // Two standard normals from two words.  u1 in (0, 1], u2 = fraction of a turn in [0, 1].
@@ -602,17 +612,22 @@ __device__ __forceinline__ T reset_obs(T x0, T K) {
 // fishing-v4 (K, r) draw of ONE env (fishing_model_error.py:37-38 / :42-43: K first, then r): one
 // Philox2x32-10 block keyed by (seed, env, counter, stream) -> Box-Muller (zK, zr).
 //   stream kStreamReset,     counter = reset counter          : reset()
-//   stream kStreamAutoReset, counter = step counter of the step that finished the episode : auto-reset
+//   any other stream tag (kStreamAutoReset), counter = step counter of the step that finished the episode
 template <typename T>
-__device__ __forceinline__ void draw_model_error(uint64_t seed, uint64_t env, uint64_t counter,
-                                                 uint32_t stream, T K_mean, T r_mean, T sigma_p,
-                                                 T& K, T& r) {
+__device__ __forceinline__ void draw_model_error_block(uint64_t seed, uint64_t env, uint64_t counter, bool reset_stream,
+                                                       T K_mean, T r_mean, T sigma_p, T& K, T& r) {
     uint32_t w0, w1;
-    philox2x32_10((uint32_t)env, (uint32_t)counter, param_key(seed, env, counter, stream), w0, w1);
+    param_block(seed, env, counter, reset_stream, w0, w1);
     float zK, zr;
     box_muller(w0, w1, zK, zr);
     K = clip_param<T>(K_mean + sigma_p * (T)zK);
     r = clip_param<T>(r_mean + sigma_p * (T)zr);
+}
+template <typename T>
+__device__ __forceinline__ void draw_model_error(uint64_t seed, uint64_t env, uint64_t counter,
+                                                 uint32_t stream, T K_mean, T r_mean, T sigma_p,
+                                                 T& K, T& r) {
+    draw_model_error_block<T>(seed, env, counter, stream == kStreamReset, K_mean, r_mean, sigma_p, K, r);
 }
 
 // The (K, r) in force for an env are a pure function of where its episode began, and that is readable
@@ -629,8 +644,7 @@ __device__ __forceinline__ void derive_model_error(uint64_t seed, uint64_t env, 
                                                    T r_mean, T sigma_p, T& K, T& r) {
     const uint64_t since = step_counter - (uint64_t)(int64_t)t;
     const bool from_reset = since == origin_step;
-    draw_model_error<T>(seed, env, from_reset ? origin_counter : since - 1,
-                        from_reset ? kStreamReset : kStreamAutoReset, K_mean, r_mean, sigma_p, K, r);
+    draw_model_error_block<T>(seed, env, from_reset ? origin_counter : since - 1, from_reset, K_mean, r_mean, sigma_p, K, r);
 }
 
 // Redraw (K, r) and restart the finished envs of one thread's 4-env tile (`base` = global index of

@@ -40,6 +40,12 @@ namespace fishing {
 #ifndef FISHING_LEAN_BATCH_ARGS
 #define FISHING_LEAN_BATCH_ARGS 1
 #endif
+#ifndef FISHING_LEAN_LOCAL_KEYS
+#define FISHING_LEAN_LOCAL_KEYS 1
+#endif
+#ifndef FISHING_LEAN_DIVK
+#define FISHING_LEAN_DIVK 0      // x / K as the exact multiply x * (1 / K) when the scalar K is a power of two (same bits)
+#endif
 #ifndef FISHING_STEP_MAXTHREADS
 #define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
 #endif
@@ -314,6 +320,7 @@ struct LeanArgs {
     GrowthT<T> growth;       // fishing-v5..v10: the growth function's parameter set (unused, hence never
                              // loaded, by the v0/v1/v2/v4 instantiations)
     T alpha;                 // DRIFT
+    DivK dk;                 // FISHING_LEAN_DIVK: the scalar K's exact-reciprocal shortcut
 };
 
 #ifndef FISHING_LEAN_ATTRS
@@ -375,6 +382,14 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         // 16.5 us), and even a run-time switch costs the returns variant 2.5 % there: own instantiations.
         const int64_t tile = (ZZ && (step_counter & 1)) ? (ntiles - 1 - it) : it;
         const int64_t base = (tile * 256 + threadIdx.x) * kEnvsPerThread;
+        // The Philox round keys (seed + i * Weyl) are wave-uniform; hoisted out of this loop they sit in 20-30 SGPRs
+        // for the whole kernel, which pushes the fishing-v4 variants (two generators) past 100 SGPRs = 7 instead of
+        // 8 waves per SIMD.  Laundering the seed per tile keeps the key schedule next to its rounds (a scalar add
+        // each): fishing-v4 derived 10.7 -> 10.2 us at N = 2^21, 78.2 -> 74.6 us at 2^24, stored arrays 16.5 -> 16.1;
+        // the single-generator kernels prefer the hoisted keys (fishing-v1 bare 16.16 vs 16.5 us), so only
+        // fishing-v4 launders (profiles/r02_ab_variants.jsonl).
+        uint64_t seed_it = seed;
+        if constexpr (FISHING_LEAN_LOCAL_KEYS != 0 && kPerEnv) asm volatile("" : "+s"(seed_it));
         T obs[4], rr[4], KK[4], z[4], er[4], sg[4];
         int32_t t[4], a_i[4];
         float a_f[4];
@@ -447,7 +462,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
         if (noise == kNoisePhilox) {
             float zq[4];
-            noise_quad(seed, (env_offset + (uint64_t)base) >> 2, step_counter, zq);
+            noise_quad(seed_it, (env_offset + (uint64_t)base) >> 2, step_counter, zq);
 #pragma unroll
             for (int j = 0; j < 4; ++j) z[j] = (T)zq[j];
             // ... and the generator (which needs none of the loaded data) runs under their latency:
@@ -457,8 +472,15 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         if (DERIVED) {      // needs the year counters: after the noise block, which hid their latency
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
+                derive_model_error<T>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
                                       a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+        }
+        // envs that were finished before this step (only possible without auto-reset): packed now, so that obs / t
+        // need not stay live until the record
+        uint32_t stale = 0;
+        if (RET && !auto_reset) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stale |= (uint32_t)was_done<T>(obs[j], t[j], KK[j], a.Tmax) << j;
         }
         T obs_next[4], rew[4];
         int32_t t_next[4];
@@ -480,8 +502,13 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                                                      rew[j], dn[j], t_next[j]);
                 }
             } else {
+#if FISHING_LEAN_DIVK
+                env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
+                                   dn[j], t_next[j], kPerEnv ? DivK{false, 0.0f, 0.0} : a.dk);
+#else
                 env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
                                    dn[j], t_next[j]);
+#endif
             }
         }
         {
@@ -511,7 +538,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
             if (__any(lane_done)) {          // wave-ballot: only waves with a finished env record
                 bool fresh[4];               // the episode ended on THIS step (not: stepped on after its end)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fresh[j] = dn[j] && (auto_reset || !was_done<T>(obs[j], t[j], KK[j], a.Tmax));
+                for (int j = 0; j < 4; ++j) fresh[j] = dn[j] && !((stale >> j) & 1u);
                 record_tile<T>(fresh, er, t_next, acc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
@@ -524,7 +551,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         if (kPerEnv && !DERIVED) {
             if (auto_reset && __any(lane_done)) {
                 const bool redrawn =
-                    redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, a.K_mean,
+                    redraw_tile<T, MODEL>(seed_it, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, a.K_mean,
                                           a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs_next, t_next);
                 if (redrawn) {
                     Vec4<T> qk, qr;
@@ -731,7 +758,10 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
         }
     }
 #ifndef FISHING_NO_ZOO_HOT
-    if constexpr (sizeof(T) == 4 && is_zoo_tag(MODEL)) {
+    // float32 zoo (one growth function each) and the float64 parity layout of fishing-v0/v1/v2: bare / with the
+    // return record.  Measured against their catch-alls at N = 2^22: fishing-v9 16.05 vs 17.7 us, float64
+    // fishing-v1 24.4 vs 26.9 us (profiles/r02_ab_variants.jsonl).
+    if constexpr ((sizeof(T) == 4 && is_zoo_tag(MODEL)) || (sizeof(T) == 8 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4)) {
         switch (req) {
             FISHING_LEAN_CASE(P);
             FISHING_LEAN_CASE(P | RET);
@@ -767,7 +797,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
                   bt.counter, bt.sigma, bt.terminal_obs, bt.done_bits, bt.z_ext, pt.r, pt.K, pt.sigma, pt.C, pt.x0,
                   pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET),
                   noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, pt.origin_step, pt.origin_counter, pt.growth,
-                  pt.alpha};
+                  pt.alpha, make_divk((double)pt.K)};
     // up to 4096 workgroups = one tile each at N = 2^22: 21.39 -> 21.13 us with returns against a cap of
     // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl)
     int cap = p->launch_blocks ? p->launch_blocks : kMaxBlocks;

@@ -7,6 +7,9 @@ producing the same `[time, state, action, reward, rep]` table.
   (policies.msy / policies.escapement, or the strings "random" / ("constant", a)) runs inside
   the fused rollout kernel and the table is cut from its `[T][4][N]` record; any other model
   is driven step by step with batched predict().
+* simulate_mdp_vec: the reference's own N-env helper (shared_env.py:57-79), row for row: Tmax + 1 rows per env
+  and batch, time-major, no break on done (the batch auto-resets like SB3's VecEnv), the RAW ACTION of the
+  previous step in the action column (pinned by tests/golden/reference_vec_sims.npz).
 Returns a pandas DataFrame when pandas is importable, else a dict of NumPy columns.
 """
 import numpy as np
@@ -37,9 +40,9 @@ def _kernel_policy(model):
 
 
 def simulate_mdp(env, model, reps=1):
-    """shared_env.py:29-54."""
+    """shared_env.py:29-54.  With an N-env batch every env of every batch is one rep of that table."""
     if not env._scalar:
-        return simulate_mdp_vec(env, model, reps * env.num_envs)
+        return _simulate_mdp_batched(env, model, reps * env.num_envs)
     rows = []
     for rep in range(reps):
         obs = env.reset()
@@ -79,8 +82,66 @@ def _cut_tables(env, traj, rep0):
 
 
 def simulate_mdp_vec(env, model, n_eval_episodes):
-    """shared_env.py:57-79 in spirit: n_eval_episodes must be a multiple of num_envs; each env
-    of each batch is one rep.  Rows follow simulate_mdp's convention (at most Tmax per rep)."""
+    """shared_env.py:57-79, row for row.  `env` is an N-env batch (auto-reset is switched on for the call: the
+    reference relies on the VecEnv's).  Per batch ("rep" in the reference's loop) and t in range(Tmax): one row per
+    env [t, population of obs_i, action_i, reward_i, rep * N + i] BEFORE acting -- action / reward are the previous
+    step's (initially action_space.low[0] and 0) -- then a final block of rows at t = Tmax; no break on done.
+    The action column holds the raw action (not the quota simulate_mdp records).  A model with `kernel_policy`
+    runs inside the fused rollout kernel; any other is driven step by step with batched predict().
+    fishing-v0: the reference's version needs action_space.low and fails on Discrete; here the initial action is 0."""
+    N = env.num_envs
+    if n_eval_episodes % N:
+        raise AssertionError("number of evaluations needs to be divisible by the number of parallel environments")
+    if env._scalar:
+        raise ValueError("simulate_mdp_vec needs an N-env batch (make(id, num_envs=N))")
+    batches = n_eval_episodes // N
+    Tmax = int(env.get_attr("Tmax")[0])
+    kp = _kernel_policy(model)
+    discrete = env.MODEL == 0
+    a0 = 0.0 if discrete else float(env.action_space.low[0])
+    f64 = torch.float64
+    out = []
+    saved = env.auto_reset
+    env.auto_reset = True
+    try:
+        for b in range(batches):
+            obs = env.reset().reshape(-1).to(f64).clone()
+            if kp is not None and N % 4 == 0 and not env._np_rng:
+                traj = env.rollout(Tmax, policy=kp[0], param=kp[1], record=True).to(f64)     # [T, 4, N]
+                obs_rows = torch.cat([traj[:, 0], env.state.reshape(1, N).to(f64)])               # obs before each step + after the last
+                act_rows = torch.cat([torch.full((1, N), a0, dtype=f64, device=env.device), traj[:, 1]])
+                rew_rows = torch.cat([torch.zeros((1, N), dtype=f64, device=env.device), traj[:, 2]])
+            else:
+                obs_rows = torch.empty((Tmax + 1, N), dtype=f64, device=env.device)
+                act_rows = torch.full((Tmax + 1, N), a0, dtype=f64, device=env.device)
+                rew_rows = torch.zeros((Tmax + 1, N), dtype=f64, device=env.device)
+                state = None
+                done = torch.zeros(N, dtype=torch.bool, device=env.device)
+                o = env.state
+                for t in range(Tmax):
+                    obs_rows[t] = o.reshape(-1).to(f64)
+                    try:
+                        action, state = model.predict(o, state=state, mask=done)
+                    except TypeError:                   # a predict(obs) without the SB3 keywords
+                        action, state = model.predict(o)
+                    a = torch.as_tensor(action, device=env.device).reshape(-1)
+                    o, rew, done, _ = env.step(a)
+                    act_rows[t + 1] = a.to(f64)
+                    rew_rows[t + 1] = rew.to(f64)
+                obs_rows[Tmax] = o.reshape(-1).to(f64)
+            K = env._K_view().to(f64).reshape(1, N) if env._per_env else float(env.params["K"])
+            pop = (obs_rows + 1.0) * K                              # get_fish_population :158-160
+            t_idx = torch.arange(Tmax + 1, device=env.device, dtype=f64).reshape(-1, 1).expand(Tmax + 1, N)
+            rep = (b * N + torch.arange(N, device=env.device, dtype=f64)).reshape(1, N).expand(Tmax + 1, N)
+            out.append(torch.stack([t_idx, pop, act_rows, rew_rows, rep], dim=-1).reshape(-1, 5).cpu().numpy())
+    finally:
+        env.auto_reset = saved
+    return _table(np.concatenate(out) if out else np.zeros((0, 5)))
+
+
+def _simulate_mdp_batched(env, model, n_eval_episodes):
+    """simulate_mdp's table (shared_env.py:29-54: break on done, at most Tmax rows per rep, quota column) from an
+    N-env batch: n_eval_episodes must be a multiple of num_envs; each env of each batch is one rep."""
     if n_eval_episodes % env.num_envs:
         raise AssertionError("number of evaluations needs to be divisible by the number of parallel environments")
     batches = n_eval_episodes // env.num_envs

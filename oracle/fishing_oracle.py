@@ -375,18 +375,28 @@ def philox2x32_10(c0, c1, k):
     return c0, c1
 
 
+def _bitrev32(v):
+    v = np.asarray(v, dtype=np.uint32)
+    v = ((v >> np.uint32(1)) & np.uint32(0x55555555)) | ((v & np.uint32(0x55555555)) << np.uint32(1))
+    v = ((v >> np.uint32(2)) & np.uint32(0x33333333)) | ((v & np.uint32(0x33333333)) << np.uint32(2))
+    v = ((v >> np.uint32(4)) & np.uint32(0x0F0F0F0F)) | ((v & np.uint32(0x0F0F0F0F)) << np.uint32(4))
+    v = ((v >> np.uint32(8)) & np.uint32(0x00FF00FF)) | ((v & np.uint32(0x00FF00FF)) << np.uint32(8))
+    return (v >> np.uint32(16)) | (v << np.uint32(16))
+
+
 def param_words(seed, env_index, counter, stream):
-    """The two words behind fishing-v4's (K, r) draw of env `env_index` (fishing_common.h: draw_model_error,
-    param_key): Philox2x32-10 with counter {env[31:0], counter[31:0]} and a 32-bit key folded from the seed,
-    the stream tag and the high halves of env index and counter."""
+    """The two words behind fishing-v4's (K, r) draw of env `env_index` (fishing_common.h: param_block):
+    Philox2x32-10 with key = seed[31:0] ^ seed[63:32] * 0x85EBCA6B and counter words
+    c0 = env[31:0] ^ bitreverse(counter[63:32]),
+    c1 = counter[31:0] ^ bitreverse(env[63:32]) ^ (0x5851F42D on the reset stream, 0x2545F491 otherwise)."""
     env = np.asarray(env_index, dtype=np.uint64)
     counter, seed, stream = int(counter), int(seed), int(stream)
     m32 = 0xFFFFFFFF
-    key0 = ((seed & m32) ^ (((seed >> 32) * 0x85EBCA6B) & m32) ^ ((stream * 0xC2B2AE35) & m32)
-            ^ ((((counter >> 32) & m32) * 0x165667B1) & m32))
-    with np.errstate(over="ignore"):
-        key = np.uint32(key0) ^ (((env >> np.uint64(32)) * np.uint64(0x27D4EB2F)) & _MASK).astype(np.uint32)
-    return philox2x32_10((env & _MASK).astype(np.uint32), np.uint32(counter & m32), key)
+    key = ((seed & m32) ^ (((seed >> 32) * 0x85EBCA6B) & m32))
+    tag = 0x5851F42D if stream == STREAM_RESET else 0x2545F491
+    c0 = (env & _MASK).astype(np.uint32) ^ _bitrev32(np.uint32((counter >> 32) & m32))
+    c1 = np.uint32((counter & m32) ^ tag) ^ _bitrev32((env >> np.uint64(32)).astype(np.uint32))
+    return philox2x32_10(c0, c1, np.uint32(key))
 
 
 def reset_normals(seed, env_index, counter, stream):

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 CSVs of scripts/profile_bench.sh into the committed summaries:
 
-    python scripts/summarize_profile.py gpurun_out/<tag> profiles/<name> [--n-envs N] [--with-returns 0|1] [--latest]
+    python scripts/summarize_profile.py gpurun_out/<tag> profiles/<name> [--latest]
+
+The kernel, N and the algorithmic bytes per env-step are read from the bench line the traced run printed
+(gpurun_out/<tag>/bench_trace.json: roofline.kernel, config.envs_per_gpu, roofline.bytes_per_env_step).
 
 Writes <name>_kernel_stats.csv (rocprofv3 --stats table, our kernels + top others),
 <name>_summary.json (avg duration, PMC bytes per launch with the gfx950 correction:
@@ -32,13 +35,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("raw")
     ap.add_argument("out")
-    ap.add_argument("--kernel", default="step_kernel")
-    ap.add_argument("--n-envs", type=int, default=1 << 22)
-    ap.add_argument("--with-returns", type=int, default=1)
+    ap.add_argument("--kernel", default=None, help="substring of the kernel name (default: roofline.kernel of the bench line)")
+    ap.add_argument("--n-envs", type=int, default=None)
+    ap.add_argument("--bytes", type=int, default=None, help="algorithmic bytes per env-step")
     ap.add_argument("--latest", action="store_true")
     a = ap.parse_args()
     full = None
-    summ = {"raw_dir": a.raw, "kernel_filter": a.kernel, "n_envs": a.n_envs, "with_returns": bool(a.with_returns)}
+    line = None
+    bj = os.path.join(a.raw, "bench_trace.json")
+    if os.path.exists(bj):
+        try:
+            line = json.loads(open(bj).read().strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001
+            pass
+    if line:
+        a.kernel = a.kernel or line["roofline"]["kernel"]
+        a.n_envs = a.n_envs or line["config"]["envs_per_gpu"]
+        a.bytes = a.bytes or line["roofline"]["bytes_per_env_step"]
+    a.kernel = a.kernel or "step_kernel"
+    a.n_envs = a.n_envs or (1 << 22)
+    a.bytes = a.bytes or 33
+    summ = {"raw_dir": a.raw, "kernel_filter": a.kernel, "n_envs": a.n_envs, "bytes_per_env_step": a.bytes,
+            "workload": line["config"]["workload"] if line else None}
 
     stats = find(os.path.join(a.raw, "trace"), "*kernel_stats.csv")
     if stats:
@@ -88,27 +106,31 @@ def main():
         summ["read_bytes_per_launch_corrected"] = rd
         summ["write_bytes_per_launch"] = wr
         summ["hbm_bytes_per_launch"] = rd + wr
-        per = 25 + (8 if a.with_returns else 0)
+        per = a.bytes
         summ["algorithmic_bytes_per_launch"] = per * a.n_envs
         summ["traffic_over_algorithmic"] = (rd + wr) / (per * a.n_envs)
         if "avg_ns" in summ:        # achieved HBM rate from rocprofv3 alone: bytes per launch / average duration
             summ["achieved_GBps_algorithmic"] = per * a.n_envs / summ["avg_ns"]
             summ["achieved_GBps_pmc_traffic"] = (rd + wr) / summ["avg_ns"]
             summ["frac_of_8TBps_peak"] = summ["achieved_GBps_algorithmic"] / 8000.0
-    bj = os.path.join(a.raw, "bench_trace.json")
-    if os.path.exists(bj):
-        try:
-            summ["bench_line_under_profiler"] = json.loads(open(bj).read().strip().splitlines()[-1])
-        except Exception:  # noqa: BLE001
-            pass
+    if line:
+        summ["bench_line_under_profiler"] = line
     with open(a.out + "_summary.json", "w") as f:
         json.dump(summ, f, indent=1)
     if a.latest and "hbm_bytes_per_launch" in summ:
-        with open(os.path.join(os.path.dirname(a.out), "pmc_latest.json"), "w") as f:
-            json.dump({"n_envs": a.n_envs, "with_returns": bool(a.with_returns),
-                       "hbm_bytes_per_launch": summ["hbm_bytes_per_launch"],
-                       "source": os.path.basename(a.out) + "_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                 "separate passes; FETCH_SIZE x2 gfx950 correction)"}, f, indent=1)
+        # profiles/pmc_latest.json: a list, one record per (kernel, N), read by bench.py for roofline.traffic
+        path = os.path.join(os.path.dirname(a.out), "pmc_latest.json")
+        try:
+            recs = json.load(open(path))
+            recs = recs if isinstance(recs, list) else []
+        except Exception:  # noqa: BLE001
+            recs = []
+        recs = [r for r in recs if not (r.get("kernel") == summ.get("kernel") and r.get("n_envs") == a.n_envs)]
+        recs.append({"kernel": summ.get("kernel"), "n_envs": a.n_envs, "hbm_bytes_per_launch": summ["hbm_bytes_per_launch"],
+                     "source": os.path.basename(a.out) + "_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                               "separate passes; FETCH_SIZE x2 gfx950 correction)"})
+        with open(path, "w") as f:
+            json.dump(recs, f, indent=1)
     print(json.dumps({k: v for k, v in summ.items() if k != "bench_line_under_profiler"}, indent=1))
 
 

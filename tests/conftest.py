@@ -87,3 +87,14 @@ def load_seeded_sims():
         meta = json.loads(str(z[key + "/meta"]))
         out.append(dict(key=key, table=z[key + "/table"], **meta))
     return out
+
+
+def load_vec_sims():
+    """Reference simulate_mdp_vec tables (tests/golden/make_golden.py): N reference envs behind a DummyVecEnv-shaped
+    harness, np.random.seed(11) right before the call."""
+    z = np.load(os.path.join(GOLDEN, "reference_vec_sims.npz"))
+    out = []
+    for key in sorted(k[:-5] for k in z.files if k.endswith("/meta")):
+        meta = json.loads(str(z[key + "/meta"]))
+        out.append(dict(key=key, table=z[key + "/table"], **meta))
+    return out

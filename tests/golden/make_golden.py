@@ -328,6 +328,77 @@ def main():
                                                          "S": float(model.S),
                                                          "msy": float(model.msy) if pname == "msy" else None}))
     np.savez_compressed(os.path.join(OUT, "reference_seeded_sims.npz"), **seeded)
+    # --- simulate_mdp_vec (shared_env.py:57-79): the reference's only code written against an N-env object.  It is
+    # driven UNMODIFIED over N reference envs behind a minimal harness with the SB3-DummyVecEnv behaviour it relies
+    # on (envs stepped in order, a finished env reset at once and its post-reset observation returned, env_method /
+    # get_attr fan-out).  The policy adapter calls the reference policy per env and keeps the fixtures' action
+    # convention (float32 value, float64 arithmetic).  Recorded: the table (Tmax + 1 rows per env and rep, no break
+    # on done, raw action of the previous step in the action column).
+    from gym_fishing.envs.shared_env import simulate_mdp_vec
+
+    class MiniVecEnv:
+        def __init__(self, envs):
+            self.envs, self.num_envs = envs, len(envs)
+            self.action_space = envs[0].action_space
+
+        def reset(self):
+            return np.stack([e.reset() for e in self.envs])
+
+        def step(self, actions):
+            obs, rews, dones, infos = [], [], [], []
+            for e, a in zip(self.envs, actions):
+                o, r, d, info = e.step(a)
+                if d:
+                    info = dict(info, terminal_observation=o)
+                    o = e.reset()
+                obs.append(o)
+                rews.append(r)
+                dones.append(d)
+                infos.append(info)
+            return np.stack(obs), np.array(rews), np.array(dones), infos
+
+        def env_method(self, name, *args, indices=None, **kw):
+            idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+            return [getattr(self.envs[i], name)(*args, **kw) for i in idx]
+
+        def get_attr(self, name, indices=None):
+            idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+            return [getattr(self.envs[i], name) for i in idx]
+
+    class VecPolicy:
+        def __init__(self, model):
+            self.model = model
+
+        def predict(self, obs, state=None, mask=None):
+            acts = [np.array([self.model.predict(o)[0]], dtype=np.float32).astype(np.float64) for o in obs]
+            return np.stack(acts), state
+
+    class constant:                     # a fixed action: fishes the stock out every other step -> auto-resets mid-table
+        S = float("nan")
+
+        def __init__(self, env, a=-0.45):
+            self.a = a
+
+        def predict(self, obs, **kw):
+            return self.a, obs
+
+    vec = {}
+    for env_id, kw, pname, cls, n_envs, episodes in (
+            ("fishing-v1", {"sigma": 0.1, "Tmax": 15}, "constant", constant, 4, 4),
+            ("fishing-v1", {"sigma": 0.1, "Tmax": 15}, "escapement", escapement, 3, 6),
+            ("fishing-v1", {"sigma": 0.1, "Tmax": 15}, "msy", msy, 3, 3),
+            ("fishing-v1", {"sigma": 0.2, "Tmax": 9, "r": 0.5, "K": 2.0, "init_state": 1.1}, "escapement", escapement, 4, 8),
+            ("fishing-v2", {"sigma": 0.05, "Tmax": 12}, "escapement", escapement, 3, 6)):
+        envs = [gym.make(env_id, **kw) for _ in range(n_envs)]
+        model = cls(envs[0])            # the sweep runs at sigma = 0: S (and msy) do not depend on the stream
+        np.random.seed(11)              # from here on the N envs share the global stream, stepped in order
+        df = simulate_mdp_vec(MiniVecEnv(envs), VecPolicy(model), n_eval_episodes=episodes)
+        key = "%s_%s_%d" % (env_id.replace("fishing-", ""), pname, len(vec) // 2)
+        vec[key + "/table"] = df.to_numpy(dtype=np.float64)
+        vec[key + "/meta"] = np.array(json.dumps({"id": env_id, "kwargs": kw, "policy": pname, "seed": 11, "num_envs": n_envs,
+                                                  "n_eval_episodes": episodes, "S": float(model.S),
+                                                  "msy": float(model.msy) if pname == "msy" else None}))
+    np.savez_compressed(os.path.join(OUT, "reference_vec_sims.npz"), **vec)
     # get_action / get_quota round trips (base_fishing_env.py:135-156)
     env0 = gym.make("fishing-v0")
     env1 = gym.make("fishing-v1")

@@ -19,7 +19,7 @@ def test_fixtures_regenerate_bit_for_bit(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     for name in ("reference_trajectories.npz", "reference_policy_sims.npz", "reference_zoo_trajectories.npz",
-                 "reference_seeded_sims.npz"):
+                 "reference_seeded_sims.npz", "reference_vec_sims.npz"):
         new, old = np.load(tmp_path / name), np.load(os.path.join(GOLDEN, name))
         assert sorted(new.files) == sorted(old.files), name
         for k in old.files:
@@ -44,4 +44,5 @@ def test_fixtures_hold_numbers_only():
                 if k.endswith("/meta"):
                     meta = json.loads(str(z[k]))
                     assert set(meta) in ({"id", "kwargs", "seeds", "nsteps", "auto_reset", "init_reset"},
-                                         {"id", "kwargs", "policy", "seed", "reps", "S", "msy"}), (name, k)
+                                         {"id", "kwargs", "policy", "seed", "reps", "S", "msy"},
+                                         {"id", "kwargs", "policy", "seed", "num_envs", "n_eval_episodes", "S", "msy"}), (name, k)

@@ -1,0 +1,63 @@
+"""bench.py end to end on the GPU box: the --gpus N entry point starts its own ranks, and a sharded run measures
+exactly the single-process workload (noise AND actions are keyed by the global env index)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*flags, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
+                          env=e, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout            # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_launches_its_own_ranks_and_matches_one_rank_of_twice_the_envs():
+    """`python bench.py --gpus 2` with no torch.distributed.run parent: the script starts two ranks as child
+    processes (RCCL when the box has two devices; on a one-GPU box the gloo + single-device rehearsal knobs),
+    prints one JSON line with n_gpus = 2 and the collective named, and its all-reduced episode record equals a
+    one-rank run over twice the envs."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; none visible")
+    common = ["--steps", "30", "--warmup", "5", "--spinup-ms", "0", "--no-cpu-baseline", "--no-subrecords"]
+    knobs = {} if torch.cuda.device_count() >= 2 else {"FISHING_BENCH_BACKEND": "gloo", "FISHING_BENCH_SINGLE_DEVICE": "1"}
+    two = run_bench("--gpus", "2", "--n-envs", str(1 << 17), *common, env=knobs)
+    assert two["n_gpus"] == 2 and two["config"]["global_envs"] == 1 << 18
+    assert "all-reduce" in two["config"]["collective"]
+    assert two["scaling"] == "weak" and two["steps"] == 30 and two["unit"] == "env-steps/s"
+    one = run_bench("--gpus", "1", "--n-envs", str(1 << 18), *common)
+    assert one["n_gpus"] == 1 and one["config"]["collective"] == "none"
+    a, b = two["episode_stats"], one["episode_stats"]
+    assert a["n_episodes"] == b["n_episodes"] > (1 << 18)           # every env finished at least once in 35 steps
+    assert abs(a["mean_return"] - b["mean_return"]) <= 1e-9 * abs(b["mean_return"])
+    assert abs(a["mean_length"] - b["mean_length"]) <= 1e-12 * b["mean_length"]
+    # the roofline record names the kernel the dispatch picked
+    assert one["roofline"]["kernel"] == "fishing::step_kernel_lean<float, 1, 6>"
+    assert one["roofline"]["bytes_per_env_step"] == 33
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("config,kernel,nbytes", [("v0", "fishing::step_kernel_lean<float, 0, 6>", 33),
+                                                  ("v2", "fishing::step_kernel_lean<float, 2, 6>", 33),
+                                                  ("v4", "fishing::step_kernel_lean<float, 4, 270>", 37)])
+def test_bench_configs_name_their_workload(config, kernel, nbytes):
+    out = run_bench("--config", config, "--steps", "20", "--warmup", "5", "--spinup-ms", "5", "--no-cpu-baseline",
+                    "--no-subrecords", "--n-envs", str(1 << 18))
+    assert out["config"]["name"] == config and out["roofline"]["kernel"] == kernel
+    assert out["roofline"]["bytes_per_env_step"] == nbytes and out["value"] > 1e9
+    assert out["episode_stats"]["n_episodes"] > 0

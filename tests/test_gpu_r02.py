@@ -418,3 +418,64 @@ def test_v10_population_draw_drifts_r_like_the_reference(hh):
         want = fo.zoo_population_draw(fo.KIND_OF_MODEL[fo.MODEL_V10], x, np.zeros(3), dict(r=r, K=1.0, sigma=0.0))
         assert np.allclose(got, want, rtol=1e-12, atol=0), (k, got, want)
         assert np.isclose(env.r, r)
+
+
+# ------------------------------------------------------------------ simulate_mdp_vec, row for row
+from conftest import load_vec_sims  # noqa: E402
+
+
+@pytest.mark.parametrize("case", load_vec_sims(), ids=lambda c: c["key"])
+def test_simulate_mdp_vec_reproduces_the_reference_table(hh, case):
+    """shared_env.py:57-79 driven unmodified over N reference envs (tests/golden/reference_vec_sims.npz) against
+    rollout.simulate_mdp_vec over the N-env batch seeded the same way (rng="numpy": one np.random.normal(0, 1, N) per
+    step is the order in which a DummyVecEnv steps N reference envs): same row count and order (Tmax + 1 rows per env
+    and batch, no break on done, auto-reset mid-table), same numbers -- bit for bit for fishing-v1, within the
+    transcendental tolerance for fishing-v2."""
+    import gym_fishing_amd as gf
+    from gym_fishing_amd import policies, rollout
+    env = gf.make(case["id"], num_envs=case["num_envs"], rng="numpy", dtype=__import__("torch").float64, **case["kwargs"])
+    if case["policy"] == "constant":
+        class Const:
+            def predict(self, obs, **kw):
+                import torch
+                return torch.full((env.num_envs, 1), -0.45, dtype=torch.float32), obs
+        model = Const()
+    else:
+        model = getattr(policies, case["policy"])(env)
+        if case["id"] == "fishing-v2":
+            # the tipping-point growth curve is flat at its maximum and the device's exp differs from np.exp in the last
+            # bit: the float32 sweep's argmax lands a few grid points (of 10001) away.  Take the reference's S so that
+            # the table compares the rollout, not the sweep.
+            assert abs(model.S - case["S"]) < 2e-3
+            model.S = case["S"]
+        else:
+            assert model.S == case["S"]
+        if case["msy"] is not None:
+            assert model.msy == case["msy"]
+    np.random.seed(case["seed"])
+    df = rollout.simulate_mdp_vec(env, model, case["n_eval_episodes"])
+    got = df.to_numpy(dtype=np.float64) if hasattr(df, "to_numpy") else np.stack([df[c] for c in rollout.COLUMNS], 1)
+    want = case["table"]
+    assert got.shape == want.shape == (case["n_eval_episodes"] * (case["kwargs"]["Tmax"] + 1), 5)
+    assert np.array_equal(got[:, [0, 4]], want[:, [0, 4]])              # time and rep columns: the row order
+    if case["id"] == "fishing-v2":
+        assert np.allclose(got, want, rtol=0, atol=1e-9)
+    else:
+        same(got, want, case["key"])
+
+
+def test_simulate_mdp_vec_fused_path_equals_the_step_loop(hh):
+    """With the Philox streams a model that names a kernel policy runs inside the fused rollout kernel; the table
+    must equal the one the step-by-step loop builds from the same seed (same counters, same arithmetic)."""
+    import gym_fishing_amd as gf
+    from gym_fishing_amd import policies, rollout
+    tabs = []
+    for fused in (True, False):
+        env = gf.make("fishing-v1", num_envs=8, sigma=0.1, Tmax=12, seed=3)
+        model = policies.escapement(env)
+        if not fused:
+            del model.kernel_policy
+        df = rollout.simulate_mdp_vec(env, model, 16)
+        tabs.append(df.to_numpy(dtype=np.float64))
+    assert tabs[0].shape == (16 * 13, 5)
+    same(tabs[0], tabs[1], "fused vs step loop")
