@@ -197,7 +197,7 @@ def pmc_traffic(kernel, n_envs):
 ACTION_CHUNK = 1 << 16
 
 
-def make_actions(torch, cfg, n, rows, env_offset=0, pad=3072, seed=4321):
+def make_actions(torch, cfg, n, rows, env_offset=0, pad=3072, seed=4321, device="cuda"):
     """[rows, n] action ring of the envs [env_offset, env_offset + n).  The random policy's actions are a function
     of the GLOBAL env index -- chunk c = envs [c * 2^16, (c + 1) * 2^16) is drawn from torch's generator seeded
     seed + c -- so a sharded run steps exactly the workload of the single-process run over all envs.  Rows are
@@ -205,17 +205,17 @@ def make_actions(torch, cfg, n, rows, env_offset=0, pad=3072, seed=4321):
     reason the env staggers its own streams)."""
     kind, lo, hi = cfg["actions"]
     dtype = torch.int32 if kind == "int" else torch.float32
-    ring = torch.empty((rows, n + pad), device="cuda", dtype=dtype)
+    ring = torch.empty((rows, n + pad), device=device, dtype=dtype)
     view = ring[:, :n]
-    g = torch.Generator(device="cuda")
+    g = torch.Generator(device=device)
     first = env_offset // ACTION_CHUNK
     last = (env_offset + n - 1) // ACTION_CHUNK
     for c in range(first, last + 1):
         g.manual_seed(seed + c)
         if kind == "int":
-            blk = torch.randint(lo, hi, (rows, ACTION_CHUNK), device="cuda", generator=g, dtype=torch.int32)
+            blk = torch.randint(lo, hi, (rows, ACTION_CHUNK), device=device, generator=g, dtype=torch.int32)
         else:
-            blk = torch.rand((rows, ACTION_CHUNK), device="cuda", generator=g, dtype=torch.float32) * (hi - lo) + lo
+            blk = torch.rand((rows, ACTION_CHUNK), device=device, generator=g, dtype=torch.float32) * (hi - lo) + lo
         a = max(c * ACTION_CHUNK, env_offset)
         b = min((c + 1) * ACTION_CHUNK, env_offset + n)
         view[:, a - env_offset:b - env_offset] = blk[:, a - c * ACTION_CHUNK:b - c * ACTION_CHUNK]

@@ -43,6 +43,9 @@ namespace fishing {
 #ifndef FISHING_LEAN_LOCAL_KEYS
 #define FISHING_LEAN_LOCAL_KEYS 1
 #endif
+#ifndef FISHING_LEAN_BLOCKED_TILES
+#define FISHING_LEAN_BLOCKED_TILES 0
+#endif
 #ifndef FISHING_LEAN_DIVK
 #define FISHING_LEAN_DIVK 0      // x / K as the exact multiply x * (1 / K) when the scalar K is a power of two (same bits)
 #endif
@@ -293,6 +296,8 @@ constexpr int ZZ = 1 << 7;         // zig-zag tile walk (N >= 2^25); never under
 constexpr int DERIVED = 1 << 8;    // fishing-v4: (K, r) re-derived from the Philox streams, no r / K arrays
 constexpr int DRIFT = 1 << 9;      // fishing-v10: per-env r, drifting by alpha every draw
 constexpr int OPT = 1 << 10;
+constexpr int LATCH = 1 << 11;     // RET without auto-reset: a finished env that is stepped on must not enter the record
+                                   // again.  Catch-all only -- the exact RET instantiations are the auto-reset ones.
 }  // namespace feat
 
 template <typename T>
@@ -339,6 +344,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
     static_assert(!(F & feat::DRIFT) || MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT, "DRIFT is fishing-v10");
     static_assert(!(F & feat::DERIVED) || kPerEnv, "DERIVED is fishing-v4");
     static_assert(!((F & feat::ZZ) && kOpt), "ZZ has exact instantiations only");
+    static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || a.ep_return != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -371,11 +377,21 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         if constexpr ((F & feat::DRIFT) != 0) asm volatile("" ::"s"(a.r), "s"(a.alpha));
     }
     const uint64_t step_counter = a.counter ? (*a.counter + step_counter_arg) : step_counter_arg;
-    const bool auto_reset = a.auto_reset != 0;
+    // an exact RET instantiation is only ever launched with auto-reset on (the dispatch sends RET without it to the
+    // catch-all, which carries the LATCH): the flag is a compile-time fact there
+    const bool auto_reset = (kExact && (F & feat::RET)) ? true : a.auto_reset != 0;
+    const bool LATCH = (F & feat::LATCH) && !auto_reset;
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
     const T robs_scalar = reset_obs<T, MODEL>(a.x0, a.pK);
 
+#if FISHING_LEAN_BLOCKED_TILES
+    // experiment: a workgroup walks a CONTIGUOUS run of tiles instead of every gridDim-th one
+    const int64_t per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t it_end = ((int64_t)blockIdx.x + 1) * per_wg < ntiles ? ((int64_t)blockIdx.x + 1) * per_wg : ntiles;
+    for (int64_t it = (int64_t)blockIdx.x * per_wg; it < it_end; ++it) {
+#else
     for (int64_t it = blockIdx.x; it < ntiles; it += gridDim.x) {
+#endif
         // ZZ (launched for N >= 2^25, far outside the 256 MiB Infinity Cache): odd steps walk the tiles
         // backwards, so what the previous step touched last is still cached when this one starts there
         // (N = 2^26: 331 -> 297 us).  Inside the cache the forward walk is the faster one (2^22: 16.1 vs
@@ -475,13 +491,9 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                 derive_model_error<T>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
                                       a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
         }
-        // envs that were finished before this step (only possible without auto-reset): packed now, so that obs / t
-        // need not stay live until the record
-        uint32_t stale = 0;
-        if (RET && !auto_reset) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) stale |= (uint32_t)was_done<T>(obs[j], t[j], KK[j], a.Tmax) << j;
-        }
+        // LATCH: envs that were finished before this step (only possible without auto-reset) must not be recorded
+        // again.  The test reuses the population env_step computes anyway.
+        bool stale[4] = {false, false, false, false};
         T obs_next[4], rew[4];
         int32_t t_next[4];
         bool dn[4];
@@ -489,6 +501,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         for (int j = 0; j < 4; ++j) {
             const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
                                                         : quota_cts<T>((T)a_f[j], KK[j]);
+            if (RET && LATCH) stale[j] = was_done<T>(obs[j], t[j], KK[j], a.Tmax);
             if constexpr (kZoo) {
                 GrowthT<T> P = a.growth;
                 if (SIGARR) P.sigma = sg[j];
@@ -538,7 +551,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
             if (__any(lane_done)) {          // wave-ballot: only waves with a finished env record
                 bool fresh[4];               // the episode ended on THIS step (not: stepped on after its end)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fresh[j] = dn[j] && !((stale >> j) & 1u);
+                for (int j = 0; j < 4; ++j) fresh[j] = dn[j] && !stale[j];
                 record_tile<T>(fresh, er, t_next, acc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
@@ -716,7 +729,7 @@ int lean_launch(const LeanCall<T>& c) {
 // the catch-all mask of a (T, MODEL): every optional stream "may be there", noise mode at run time
 template <int MODEL>
 constexpr int catch_all_mask() {
-    int f = feat::kNoiseRT | feat::RET | feat::SIGARR | feat::T8 | feat::TERM | feat::BITS | feat::OPT;
+    int f = feat::kNoiseRT | feat::RET | feat::SIGARR | feat::T8 | feat::TERM | feat::BITS | feat::OPT | feat::LATCH;
     if (MODEL == FISHING_MODEL_V4) f |= feat::DERIVED;
     if (MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT) f |= feat::DRIFT;
     return f;
@@ -799,12 +812,16 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
                   noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, pt.origin_step, pt.origin_counter, pt.growth,
                   pt.alpha, make_divk((double)pt.K)};
     // up to 4096 workgroups = one tile each at N = 2^22: 21.39 -> 21.13 us with returns against a cap of
-    // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl)
-    int cap = p->launch_blocks ? p->launch_blocks : kMaxBlocks;
+    // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl).  From N = 2^24 on (state streams beyond
+    // the Infinity Cache) FEWER workgroups looping over more tiles stream better from HBM -- 768 = 3 per CU:
+    // N = 2^26 299 -> 287 us bare, 403 -> 391 us with returns; 2^27 666 -> 610 / 842 -> 785 us; 2^24 equal
+    // (profiles/r02_caps_large_n.jsonl).
+    int cap = p->launch_blocks ? p->launch_blocks : (ntiles >= (1 << 14) ? 768 : kMaxBlocks);
     if (cap > kMaxBlocks) cap = kMaxBlocks;
     const int lb = (int)(ntiles < cap ? ntiles : cap);
     int req = noise;
     if (b->ep_return) req |= feat::RET;
+    if (b->ep_return && !(p->flags & FISHING_FLAG_AUTO_RESET)) req |= feat::LATCH;
     if (b->sigma) req |= feat::SIGARR;
     if (t8) req |= feat::T8;
     if (b->terminal_obs) req |= feat::TERM;

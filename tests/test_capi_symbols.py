@@ -85,9 +85,12 @@ def test_argument_errors_need_no_gpu(lib):
     name = ctypes.create_string_buffer(128)
     bo = _capi.make_buffers(obs=4096, t=8192, action=12288, reward=16384, done=20480)
     assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
-    assert name.value == b"fishing::step_kernel_lean<float, 1, 1151>"        # sigma = 0 (no generator): the catch-all
+    assert name.value == b"fishing::step_kernel_lean<float, 1, 3199>"        # sigma = 0 (no generator): the catch-all
     p.sigma = 0.1
     bo.ep_return = 24576
+    assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
+    assert name.value == b"fishing::step_kernel_lean<float, 1, 3199>"        # a record without auto-reset: the catch-all's latch
+    p.flags = _capi.FLAG_AUTO_RESET
     assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
     assert name.value == b"fishing::step_kernel_lean<float, 1, 6>"           # Philox (2) | RET (4)
     assert lib.fishing_step_kernel_name_f32(p, 1000, bo, name, 128) == 0
