@@ -450,7 +450,7 @@ def main():
         # 256 MiB Infinity Cache
         del env
         torch.cuda.empty_cache()
-        big = 1 << (26 if args.config != "v4" else 25)
+        big = 1 << (26 if args.config != "v4" else 24)       # (config 5's whole N = 2^24 on one GPU: 620 MB of streams)
         rows = 4
         eb = make_env(gf, torch, args.config, big, 0, with_returns, False, args.v4_stored)
         eb.reset()

@@ -368,6 +368,9 @@ struct FusedArgs {
 };
 
 constexpr int kPrefetch = 4;
+#ifndef FISHING_FUSED_LOCAL_KEYS
+#define FISHING_FUSED_LOCAL_KEYS 1
+#endif
 
 template <typename T, int MODEL>
 __global__ void __launch_bounds__(256)
@@ -458,9 +461,15 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
                 if (s + kPrefetch < a.n_steps) load_action(s + kPrefetch, pf_f[u], pf_i[u]);
                 const uint64_t step_counter = step_counter0 + (uint64_t)s;
                 T z[4] = {(T)0, (T)0, (T)0, (T)0};
+#if FISHING_FUSED_LOCAL_KEYS
+                uint64_t seed_s = seed;     // keep the Philox key schedule next to its rounds instead of in 20 SGPRs
+                asm volatile("" : "+s"(seed_s));    // held across the whole step loop (the kernel is short of them)
+#else
+                const uint64_t seed_s = seed;
+#endif
                 if (a.noise == kNoisePhilox) {
                     float zq[4];
-                    noise_quad(seed, quad, step_counter, zq);
+                    noise_quad(seed_s, quad, step_counter, zq);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[j] = (T)zq[j];
                 }
@@ -517,7 +526,7 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
                     }
                     if (auto_reset) {
                         if (kPerEnv) {      // the next episode's (K, r): the draw a later derivation would re-make
-                            if (redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
+                            if (redraw_tile<T, MODEL>(seed_s, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
                                                       a.K_mean, a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs, t))
                                 kr_dirty = true;
                         } else {

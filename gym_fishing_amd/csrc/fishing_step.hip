@@ -812,11 +812,12 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
                   noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, pt.origin_step, pt.origin_counter, pt.growth,
                   pt.alpha, make_divk((double)pt.K)};
     // up to 4096 workgroups = one tile each at N = 2^22: 21.39 -> 21.13 us with returns against a cap of
-    // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl).  From N = 2^24 on (state streams beyond
+    // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl).  From N = 2^25 on (state streams far beyond
     // the Infinity Cache) FEWER workgroups looping over more tiles stream better from HBM -- 768 = 3 per CU:
     // N = 2^26 299 -> 287 us bare, 403 -> 391 us with returns; 2^27 666 -> 610 / 842 -> 785 us; 2^24 equal
-    // (profiles/r02_caps_large_n.jsonl).
-    int cap = p->launch_blocks ? p->launch_blocks : (ntiles >= (1 << 14) ? 768 : kMaxBlocks);
+    // (profiles/r02_caps_large_n.jsonl).  Not for fishing-v4 with derived parameters, which is as much VALU- as
+    // HBM-bound and needs the occupancy: 95 -> 101 us at N = 2^24 (profiles/r02_step_v4_24_*).
+    int cap = p->launch_blocks ? p->launch_blocks : ((ntiles >= (1 << 15) && !derived) ? 768 : kMaxBlocks);
     if (cap > kMaxBlocks) cap = kMaxBlocks;
     const int lb = (int)(ntiles < cap ? ntiles : cap);
     int req = noise;
