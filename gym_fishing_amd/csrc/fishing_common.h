@@ -581,12 +581,18 @@ __device__ __forceinline__ void env_step(T obs, int32_t t, T quota, T z, T r, T 
     done = (t_next > Tmax) || (x <= (T)0);    //                      :76-79
 }
 
-// fishing_model_error.py:37-38 / :42-43: K = clip(K_mean + sigma_p * zK, 0, 1e6), then r.
+// fishing_model_error.py:37-38 / :42-43: K = clip(K_mean + sigma_p * zK, 0, 1e6), then r.  The argument is never NaN here:
+// zK is finite (|z| <= 6.76) and the host refuses non-finite K_mean / r_mean / sigma_p for fishing-v4 (check_common), so
+// np.clip is one v_med3_f32 (float) or max + min (double) instead of two compare + select pairs.
 template <typename T>
-__device__ __forceinline__ T clip_param(T v) {
-    v = (v < (T)0) ? (T)0 : v;
-    v = (v > (T)1e6) ? (T)1e6 : v;
-    return v;
+__device__ __forceinline__ T clip_param(T v);
+template <>
+__device__ __forceinline__ float clip_param<float>(float v) {
+    return __builtin_amdgcn_fmed3f(v, 0.0f, 1e6f);
+}
+template <>
+__device__ __forceinline__ double clip_param<double>(double v) {
+    return __builtin_fmin(__builtin_fmax(v, 0.0), 1e6);
 }
 // fishing-v11 (growth_models.py:187,200): a new growth function for the finished envs of one thread's
 // 4-env tile.  One Philox block per env quad on the reset streams, word j -> env 4q + j.  Returns
@@ -638,13 +644,34 @@ __device__ __forceinline__ void draw_model_error(uint64_t seed, uint64_t env, ui
 // (FISHING_FLAG_V4_DERIVED; 8 B/env-step of reads and, on the random-policy workload where nearly every
 // 128-byte line holds a finished env, 8 B/env-step of redraw writes saved).  Same values bit for bit
 // as the stored-array path, which draws from the same blocks at the moment of the reset.
-template <typename T>
+template <typename T, bool NARROW = false>
 __device__ __forceinline__ void derive_model_error(uint64_t seed, uint64_t env, uint64_t step_counter, int32_t t,
                                                    uint64_t origin_step, uint64_t origin_counter, T K_mean,
                                                    T r_mean, T sigma_p, T& K, T& r) {
-    const uint64_t since = step_counter - (uint64_t)(int64_t)t;
-    const bool from_reset = since == origin_step;
-    draw_model_error_block<T>(seed, env, from_reset ? origin_counter : since - 1, from_reset, K_mean, r_mean, sigma_p, K, r);
+    if constexpr (NARROW) {
+        // every counter and env index of the wave fits 32 bits (derive_fits_32): the same block with half the
+        // integer work -- param_block's folded-in high halves are zero
+        const uint32_t since = (uint32_t)step_counter - (uint32_t)t;
+        const bool from_reset = since == (uint32_t)origin_step;
+        uint32_t w0, w1;
+        philox2x32_10((uint32_t)env, (from_reset ? (uint32_t)origin_counter : since - 1u) ^ (from_reset ? kParamTagReset : kParamTagAuto),
+                      param_key(seed), w0, w1);
+        float zK, zr;
+        box_muller(w0, w1, zK, zr);
+        K = clip_param<T>(K_mean + sigma_p * (T)zK);
+        r = clip_param<T>(r_mean + sigma_p * (T)zr);
+    } else {
+        const uint64_t since = step_counter - (uint64_t)(int64_t)t;
+        const bool from_reset = since == origin_step;
+        draw_model_error_block<T>(seed, env, from_reset ? origin_counter : since - 1, from_reset, K_mean, r_mean, sigma_p, K, r);
+    }
+}
+// wave-uniform: may this launch's derivations of the envs [env_first, env_last] use the 32-bit form?  (An env whose
+// years_passed exceeds the step count is out of contract -- the host advances both together -- so since - 1 cannot wrap
+// except as the unused arm of the from_reset select.)
+__device__ __forceinline__ bool derive_fits_32(uint64_t env_last, uint64_t step_counter, uint64_t origin_step,
+                                               uint64_t origin_counter) {
+    return ((env_last | step_counter | origin_step | origin_counter) >> 32) == 0;
 }
 
 // Redraw (K, r) and restart the finished envs of one thread's 4-env tile (`base` = global index of

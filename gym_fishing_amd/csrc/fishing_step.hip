@@ -486,10 +486,18 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
             if (FISHING_LEAN_FENCE & 2) __builtin_amdgcn_sched_barrier(0);
         }
         if (DERIVED) {      // needs the year counters: after the noise block, which hid their latency
+            // (tile-uniform: the last env of this workgroup's tile and the counters all below 2^32 -> 32-bit integer work)
+            if (derive_fits_32(env_offset + (uint64_t)(tile + 1) * 1024u - 1u, step_counter, a.origin_step, a.origin_counter)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                derive_model_error<T>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
-                                      a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+                for (int j = 0; j < 4; ++j)
+                    derive_model_error<T, true>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
+                                                a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    derive_model_error<T>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
+                                          a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+            }
         }
         // LATCH: envs that were finished before this step (only possible without auto-reset) must not be recorded
         // again.  The test reuses the population env_step computes anyway.
@@ -632,6 +640,9 @@ int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     const bool derived = p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED);
     if (derived && (p->flags & FISHING_FLAG_T_U8)) return FISHING_ERR_SIZE;    // a saturating counter cannot date an episode
     if (p->model == FISHING_MODEL_V4 && !derived && (!b->r || !b->K)) return FISHING_ERR_NULL;
+    // (clip_param relies on it; the reference turns a non-finite mean into NaN populations)
+    if (p->model == FISHING_MODEL_V4 && !(std::isfinite(p->K_mean) && std::isfinite(p->r_mean) && std::isfinite(p->sigma_p)))
+        return FISHING_ERR_SIZE;
     if (b->return_partials && !b->ep_return) return FISHING_ERR_NULL;
     if (b->counter && (((uintptr_t)b->counter) & 7u)) return FISHING_ERR_ALIGN;
     const void* ptrs[] = {b->obs,  b->action, b->reward, b->done,         b->done_bits, b->t,           b->r,

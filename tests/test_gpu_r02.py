@@ -484,3 +484,76 @@ def test_simulate_mdp_vec_fused_path_equals_the_step_loop(hh):
         tabs.append(df.to_numpy(dtype=np.float64))
     assert tabs[0].shape == (16 * 13, 5)
     same(tabs[0], tabs[1], "fused vs step loop")
+
+
+# ------------------------------------------------------------------ randomised differential test of the three step paths
+def _bits_equal(x, y):
+    import torch
+    it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]
+    return torch.equal(x.view(it), y.view(it))
+
+
+@pytest.mark.parametrize("trial", range(48))
+def test_randomised_requests_agree_across_dispatch_general_and_fused(hh, trial):
+    """48 random requests -- model (v0 / v1 / v2 / v4 stored / v4 derived / three zoo kinds incl. the drifting v10),
+    layout, N in [1, 7000] (whole tiles + ragged tails + sub-tile batches), auto-reset, return record, sigma array,
+    one-byte year counter, noise mode (Philox / none / external) -- each stepped 7 times three ways: whatever
+    instantiation the dispatch picks, the general kernel (diagnostic flag), and -- where it applies -- ONE fused
+    launch.  Every stream must agree bit for bit (NaNs included), the return records to double rounding."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    rng = np.random.default_rng(9000 + trial)
+    kind = ["v0", "v1", "v2", "v4s", "v4d", "v6", "v9", "v10"][trial % 8]
+    model = {"v0": fo.MODEL_V0, "v1": fo.MODEL_V1, "v2": fo.MODEL_V2, "v4s": fo.MODEL_V4, "v4d": fo.MODEL_V4, "v6": fo.MODEL_V6,
+             "v9": fo.MODEL_V9, "v10": fo.MODEL_V10}[kind]
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    n = int(rng.choice([rng.integers(1, 1024), 1024, 2048, rng.integers(1025, 7000), 4096 + 3]))
+    auto = bool(rng.random() < 0.6)
+    ret = bool(rng.random() < 0.6)
+    sigarr = bool(rng.random() < 0.35)
+    derived = kind == "v4d"
+    t8 = bool(rng.random() < 0.25) and not derived
+    noise = rng.choice(["philox", "philox", "none", "ext"])
+    T, off, seed, c0 = 7, 4 * int(rng.integers(0, 50)), int(rng.integers(1, 1 << 40)), int(rng.integers(0, 300))
+    kw = dict(sigma=0.0 if noise == "none" else 0.12, C=0.5, Tmax=4, sigma_p=0.15, auto_reset=auto, t_u8=t8)
+    if kind == "v10":
+        kw.update(r=0.8, alpha=-0.01)
+    per_env, drift = model == fo.MODEL_V4, model == fo.MODEL_V10
+    sig = rng.uniform(0.02, 0.2, n) if sigarr else None
+    zz = [rng.standard_normal(n) for _ in range(T)] if noise == "ext" else None
+    if model == fo.MODEL_V0:
+        ring = rng.integers(0, 100, (T, n)).astype(np.int32)
+    else:
+        ring = rng.uniform(-1.15, 0.3, (T, n)).astype(np.float32)
+    fn = lib.fishing_step_f32 if dtype == np.float32 else lib.fishing_step_f64
+
+    def run(mode):
+        p = hh.params(model, general=(mode == "general"), derived=derived, origin=(c0, 0), **kw)
+        st = hh.State(n, dtype, model, np.zeros(n), r=(np.full(n, kw.get("r", 0.3)) if (per_env and not derived) or drift else None),
+                      K=np.full(n, 1.0) if per_env and not derived else None, sigma=sig, ep_return=ret, t_u8=t8)
+        st.reset(p, seed=seed, counter=0, env_offset=off)
+        if mode == "fused":
+            st.step_fused(p, ring, T, seed=seed, step_counter=c0, env_offset=off, per_step=bool(trial & 1))
+        else:
+            dev_ring = st.ring_tensor(ring)
+            for s in range(T):
+                z = hh.dev(zz[s].astype(dtype)) if zz is not None else None
+                assert fn(p, n, off, st.buffers(dev_ring[s], z), seed, c0 + s, None) == 0
+            torch.cuda.synchronize()
+        return st
+    A, B = run("dispatch"), run("general")
+    names = ["obs", "t", "reward", "done"] + (["ep_return"] if ret else []) + (["K", "r"] if per_env and not derived else []) + (["r"] if drift else [])
+    what = (kind, np.dtype(dtype).name, n, auto, ret, sigarr, t8, noise)
+    for name in names:
+        assert _bits_equal(getattr(A, name), getattr(B, name)), (name, "dispatch vs general") + what
+    if ret:
+        ra, rb = A.record(), B.record()
+        assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True), what
+    if noise != "ext":
+        C = run("fused")
+        for name in names:
+            assert _bits_equal(getattr(A, name), getattr(C, name)), (name, "dispatch vs fused") + what
+        if ret:
+            rc = C.record()
+            assert ra[2] == rc[2] and ra[3] == rc[3] and np.allclose(ra[:2], rc[:2], rtol=1e-12, equal_nan=True), what
