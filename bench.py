@@ -455,9 +455,9 @@ def main():
         eb = make_env(gf, torch, args.config, big, 0, with_returns, False, args.v4_stored)
         eb.reset()
         ab = make_actions(torch, cfg, big, rows)
-        eb.step_many(ab, 12)
-        us, _ = timed_steps(torch, eb, ab, 40)
-        out["hbm_resident"] = {"n_envs": big, "steps": 40, "bytes_per_env_step": bytes_per, "avg_launch_us": us,
+        eb.step_many(ab, 24)
+        us, _ = timed_steps(torch, eb, ab, 100)
+        out["hbm_resident"] = {"n_envs": big, "steps": 100, "bytes_per_env_step": bytes_per, "avg_launch_us": us,
                                "achieved_GBps": big * bytes_per / us / 1e3, "frac": big * bytes_per / us / 1e3 / HBM_PEAK_GBS,
                                "env_steps_per_s": big / us * 1e6, "kernel": eb.step_kernel_name(ab[0]),
                                "resident_MB": (big * (bytes_per - 1 - 4) / 2 + big * 5 + rows * big * 4) / 1e6,

@@ -67,9 +67,10 @@ typedef void* fishing_stream_t; /* hipStream_t */
                                 read or written (may be NULL); every kernel re-derives an env's (K, r)
                                 from (seed, env index, the step or reset() that began its episode), which
                                 it reads off years_passed -- see v4_origin_step below.  Same values as the
-                                stored-array mode bit for bit.  Not with FISHING_FLAG_T_U8, z-less
-                                user-supplied parameters, or after a masked reset (the host then calls
-                                fishing_v4_params_* once and continues with arrays).                 */
+                                stored-array mode bit for bit.  Not with FISHING_FLAG_T_U8 (a saturating
+                                counter cannot date an episode), user-supplied parameters, or after a
+                                masked reset (the host then calls fishing_v4_params_* once and continues
+                                with arrays).                                                        */
 /* diagnostic (tests, A/B timing): route step() to the general kernel even where a lean instantiation applies */
 #define FISHING_FLAG_DIAG_GENERAL_KERNEL 0x80000000u
 
@@ -98,7 +99,8 @@ typedef struct FishingParams {
     double r, K, sigma; /* scalars; ignored where the per-env array in FishingBuffers is set */
     double C;          /* fishing-v2 tipping point                                      */
     double x0;         /* init_state                                                    */
-    double r_mean, K_mean, sigma_p; /* fishing-v4 redraw at reset                       */
+    double r_mean, K_mean, sigma_p; /* fishing-v4 redraw at reset; must be finite (else
+                                       FISHING_ERR_SIZE: the reference would produce NaN stocks) */
     int32_t launch_blocks;  /* 0 = auto; else cap on workgroups (tuning knob)           */
     int32_t launch_threads; /* 0 = auto (256); 64..256, multiple of 64                  */
     /* zoo extras (fishing-v5..v11) */

@@ -23,7 +23,7 @@ import statistics
 
 def find(d, pattern):
     hits = glob.glob(os.path.join(d, "**", pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None       # (a re-run merges into the same directory: newest wins)
 
 
 def short(name):

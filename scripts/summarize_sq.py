@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, statistics, sys
 
 def main():
     raw, out = sys.argv[1], sys.argv[2]
-    f = glob.glob(os.path.join(raw, "pmc_sq", "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(raw, "pmc_sq", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     per = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].replace("void ", "").split("(")[0]
@@ -23,7 +23,7 @@ def main():
     dur = {}
     tf = glob.glob(os.path.join(raw, "pmc_sq", "**", "*kernel_trace.csv"), recursive=True)
     if tf:
-        for r in csv.DictReader(open(tf[0])):
+        for r in csv.DictReader(open(max(tf, key=os.path.getmtime))):
             dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     res = {}
     for name, disp in per.items():

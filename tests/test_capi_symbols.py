@@ -72,6 +72,12 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.fishing_step_f32(p, 4, 0, b, 0, 0, None) == -2             # unknown model
     p.model = _capi.MODEL_V4
     assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -1      # v4 needs r, K arrays
+    bv4 = _capi.make_buffers(obs=4096, t=8192, action=12288, r=16384, K=20480)
+    p.K_mean, p.r_mean, p.sigma_p = float("nan"), 0.3, 0.1
+    assert lib.fishing_reset_f32(p, 4, 0, bv4, None, 0, 0, None) == -4    # fishing-v4's means must be finite
+    p.K_mean, p.sigma_p = 1.0, float("inf")
+    assert lib.fishing_step_f32(p, 4, 0, bv4, 0, 0, None) == -4
+    p.sigma_p = 0.1
     p.flags = _capi.FLAG_V4_DERIVED | _capi.FLAG_T_U8
     assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -4      # derived parameters need the int32 year counter
     p.flags = 0
