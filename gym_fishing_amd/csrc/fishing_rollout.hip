@@ -17,10 +17,14 @@
 
 namespace fishing {
 
+#ifndef FISHING_ROLLOUT_LOCAL_KEYS
+#define FISHING_ROLLOUT_LOCAL_KEYS 1
+#endif
+
 template <typename T, int MODEL, int POLICY, bool AUTO>
 __global__ void __launch_bounds__(256)
 rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
-               const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed,
+               const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed_arg,
                const uint64_t step_counter_arg, const int noise_on, const int policy_rt, const DivK dk_arg) {
     const uint64_t step_counter0 = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
@@ -76,7 +80,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         if (derived) {      // once per launch; the redraws below keep (K, r) current from then on
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter0, t[j], p.origin_step,
+                derive_model_error<T>(seed_arg, env_offset + (uint64_t)base + j, step_counter0, t[j], p.origin_step,
                                       p.origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
         }
         bool kind_dirty = false;
@@ -88,6 +92,12 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             const uint64_t step_counter = step_counter0 + (uint64_t)s;
             T z[4] = {(T)0, (T)0, (T)0, (T)0};
             uint32_t aw[4] = {0u, 0u, 0u, 0u};
+#if FISHING_ROLLOUT_LOCAL_KEYS
+            uint64_t seed = seed_arg;       // Philox key schedule next to its rounds, not in long-lived SGPRs (see the
+            asm volatile("" : "+s"(seed));  // fused step kernel below)
+#else
+            const uint64_t seed = seed_arg;
+#endif
             if (noise_on) {         // one block for the tile's four normals
                 float zq[4];
                 noise_quad(seed, quad, step_counter, zq);

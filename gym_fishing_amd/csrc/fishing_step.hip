@@ -64,7 +64,7 @@ __device__ __forceinline__ bool was_done(T obs, int32_t t, T K, int32_t Tmax) {
 template <typename T, int MODEL>
 __global__ void __launch_bounds__(FISHING_STEP_MAXTHREADS) FISHING_STEP_ATTRS
 step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
-            const uint64_t seed, const uint64_t step_counter_arg, const int noise) {
+            const uint64_t seed_arg, const uint64_t step_counter_arg, const int noise) {
     // graph-replay safety: with a device-resident counter the launch arguments can stay frozen
     // in a captured hipGraph while the noise key still advances (wave-uniform scalar load)
     const uint64_t step_counter = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
@@ -86,6 +86,11 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
         const bool active = base < n;
         const bool full = base + kEnvsPerThread <= n;
+        // (keeps the Philox key schedule next to its rounds instead of in 20-30 long-lived SGPRs: this kernel, with
+        // every argument a run-time decision, is the one shortest of them)
+        uint64_t seed_it = seed_arg;
+        asm volatile("" : "+s"(seed_it));
+        const uint64_t seed = seed_it;
 
         T obs[4], rr[4], KK[4], sg[4], z[4];
         int32_t t[4];
@@ -405,7 +410,8 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         // the single-generator kernels prefer the hoisted keys (fishing-v1 bare 16.16 vs 16.5 us), so only
         // fishing-v4 launders (profiles/r02_ab_variants.jsonl).
         uint64_t seed_it = seed;
-        if constexpr (FISHING_LEAN_LOCAL_KEYS != 0 && kPerEnv) asm volatile("" : "+s"(seed_it));
+        // (... and the float32 catch-alls, which sit at the 106-SGPR ceiling: 26 -> 2 SGPR-to-VGPR-lane spills)
+        if constexpr (FISHING_LEAN_LOCAL_KEYS != 0 && (kPerEnv || (kOpt && sizeof(T) == 4))) asm volatile("" : "+s"(seed_it));
         T obs[4], rr[4], KK[4], z[4], er[4], sg[4];
         int32_t t[4], a_i[4];
         float a_f[4];
