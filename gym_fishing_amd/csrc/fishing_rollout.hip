@@ -318,6 +318,10 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     if (rc != FISHING_OK) return rc;
     if (policy < FISHING_POLICY_RANDOM || policy > FISHING_POLICY_MSY) return FISHING_ERR_POLICY;
     if (Tsteps < 0) return FISHING_ERR_SIZE;
+    // Without auto-reset the rollout FREEZES a finished env -- its year counter stops while the step counter runs on,
+    // and with it the rule that dates the env's episode (derive_model_error): such a rollout needs the r / K arrays.
+    if (p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED) && !(p->flags & FISHING_FLAG_AUTO_RESET))
+        return FISHING_ERR_SIZE;
     if (traj && (((uintptr_t)traj) & 15u)) return FISHING_ERR_ALIGN;
     if (traj && (n & 3)) return FISHING_ERR_ALIGN;  // rows of the record must stay 16-byte aligned
     if (n == 0 || Tsteps == 0) return FISHING_OK;

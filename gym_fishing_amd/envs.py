@@ -728,6 +728,9 @@ class BaseFishingEnv(_gym_env_base()):
         if isinstance(policy, tuple):                 # ("constant", a) or a policies.* kernel_policy pair
             policy, param = policy
         pol = POLICIES[policy] if isinstance(policy, str) else int(policy)
+        if not self.auto_reset:
+            # a rollout without auto-reset freezes finished envs: their year counters stop dating their episodes
+            self._leave_derived_mode()
         traj = None
         if record:
             if self.num_envs % 4:

@@ -186,7 +186,8 @@ int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, con
  * traffic).  Equivalent to T fishing_step_* calls with auto-reset and the policy's
  * actions.  Updates obs, t, (r, K), ep_return, return_partials; writes the LAST step's
  * reward/done if those pointers are set.  Without FISHING_FLAG_AUTO_RESET a finished env is
- * frozen (its episode is over, as in simulate_mdp's `break`, shared_env.py:51-52).
+ * frozen (its episode is over, as in simulate_mdp's `break`, shared_env.py:51-52) -- its year counter stops, so this
+ * form is not available under FISHING_FLAG_V4_DERIVED (FISHING_ERR_SIZE: call fishing_v4_params_* and pass arrays).
  * traj (nullable): real[T][4][n] recording per step {obs before acting, action, reward,
  * done} -- the raw material of the simulate_mdp table (shared_env.py:37-49); needs n % 4 == 0. */
 int fishing_rollout_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,

@@ -557,3 +557,68 @@ def test_randomised_requests_agree_across_dispatch_general_and_fused(hh, trial):
         if ret:
             rc = C.record()
             assert ra[2] == rc[2] and ra[3] == rc[3] and np.allclose(ra[:2], rc[:2], rtol=1e-12, equal_nan=True), what
+
+
+@pytest.mark.parametrize("where", ["step_counter_crosses_2^32", "env_index_crosses_2^32", "both_far_beyond_2^32"])
+def test_v4_derived_parameters_across_the_32_bit_boundaries(hh, where):
+    """The derivation does its integer work in 32 bits while every counter and env index of a tile fits, in 64 bits
+    otherwise (fishing_common.h: derive_fits_32) -- the two must be the same function.  Stored vs derived parameters
+    over 160 auto-resetting steps with the step counter running through 2^32, with the shard's env indices
+    straddling 2^32 (some tiles narrow, some wide, in one launch), and with both far beyond."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n, seed = 4 * 1024 + 40, 31337
+    c0, off = {"step_counter_crosses_2^32": ((1 << 32) - 70, 16), "env_index_crosses_2^32": (5, (1 << 32) - 2048),
+               "both_far_beyond_2^32": ((1 << 40) + 11, (1 << 36) + 4096)}[where]
+    kw = dict(sigma=0.1, Tmax=6, K_mean=1.0, r_mean=0.3, sigma_p=0.2, auto_reset=True)
+    ps = hh.params(fo.MODEL_V4, **kw)
+    pd = hh.params(fo.MODEL_V4, derived=True, origin=(c0, 3), **kw)
+    S = hh.State(n, np.float32, fo.MODEL_V4, np.zeros(n), r=np.full(n, 0.3), K=np.full(n, 1.0), ep_return=True)
+    D = hh.State(n, np.float32, fo.MODEL_V4, np.zeros(n), ep_return=True)
+    S.reset(ps, seed=seed, counter=3, env_offset=off)
+    D.reset(pd, seed=seed, counter=3, env_offset=off)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for s in range(160):
+        a = (torch.rand(n, device="cuda", generator=g) * 1.3 - 1.15).float()
+        if s % 20 == 0:
+            Kd, rd = D.v4_params(pd, seed=seed, step_counter=c0 + s, env_offset=off)
+            same(Kd, S.K.cpu().numpy(), "K before step %d" % s)
+            same(rd, S.r.cpu().numpy(), "r before step %d" % s)
+        assert lib.fishing_step_f32(ps, n, off, S.buffers(a), seed, c0 + s, None) == 0
+        assert lib.fishing_step_f32(pd, n, off, D.buffers(a), seed, c0 + s, None) == 0
+        torch.cuda.synchronize()
+        for name in ("obs", "reward", "done", "t", "ep_return"):
+            assert _bits_equal(getattr(S, name), getattr(D, name)), (name, s, where)
+    assert S.record()[2] == D.record()[2] > 10 * n
+    # the oracle's restatement of the block (param_words) agrees with the device's on these indices too
+    env = np.arange(off, off + 64, dtype=np.uint64)
+    _, zK, zr = hh.device_noise(64, seed, c0 + 17, fo.STREAM_AUTORESET, off)
+    eK, er = fo.reset_normals(seed, env, c0 + 17, fo.STREAM_AUTORESET)
+    assert np.abs(zK - eK).max() < 2e-5 and np.abs(zr - er).max() < 2e-5
+
+
+def test_v4_rollout_without_auto_reset_leaves_the_derived_mode(hh):
+    """A fused rollout without auto-reset freezes finished envs (simulate_mdp's `break`): their year counters stop,
+    so the rule that dates an episode from them no longer holds.  The C ABI refuses that combination; the host
+    mirror stores the parameters first.  env.simulate() over a fishing-v4 batch then gives the same table from a
+    derived-mode env and from a stored-mode env, and env.K stays what it was for the frozen envs."""
+    import torch
+    import gym_fishing_amd as gf
+    from gym_fishing_amd import _capi, policies
+    p = hh.params(fo.MODEL_V4, sigma=0.05, derived=True, auto_reset=False)
+    st = hh.State(2048, np.float32, fo.MODEL_V4, np.zeros(2048))
+    rc = _capi.lib().fishing_rollout_f32(p, 2048, 0, st.buffers(), _capi.POLICY_RANDOM, 0.0, 5, None, 0, 0, None)
+    assert rc == -4                                      # FISHING_ERR_SIZE
+    tabs, Ks = [], []
+    for derived in (None, False):
+        env = gf.make("fishing-v4", num_envs=64, sigma=0.05, sigma_p=0.2, Tmax=12, seed=4, derived_params=derived)
+        model = policies.escapement(env)
+        df = env.simulate(model, reps=2)
+        tabs.append(df.to_numpy(dtype=np.float64))
+        Ks.append(env.K.clone())
+        assert env._derived is False                 # (the no-auto-reset rollout stored the parameters)
+        env.reset()
+        assert env._derived is (derived is None)     # a full reset returns to the derived mode
+    same(tabs[0], tabs[1], "simulate table: derived vs stored")
+    assert torch.equal(Ks[0], Ks[1])
