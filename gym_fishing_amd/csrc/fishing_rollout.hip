@@ -386,7 +386,12 @@ constexpr int kPrefetch = 4;
 #define FISHING_FUSED_LOCAL_KEYS 1
 #endif
 
-template <typename T, int MODEL>
+// RAGGED = false: n is a whole number of 1024-env tiles -- every access an unconditional 16-byte one.  That is not
+// only shorter: with the per-thread `full ? vector : element-wise` choice in the code, the compiler merges the two
+// paths' results right behind each prefetch load and has to wait for it there (`s_waitcnt vmcnt(0)` after every
+// global_load: the prefetch hid nothing, waves sat 36 % of their cycles on s_waitcnt).  RAGGED = true is the same
+// body for the < 1024-env tail, one workgroup.
+template <typename T, int MODEL, bool RAGGED>
 __global__ void __launch_bounds__(256)
 step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offset, const uint64_t seed,
                   const uint64_t step_counter_arg) {
@@ -407,8 +412,8 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
-        const bool active = base < n;
-        const bool full = base + kEnvsPerThread <= n;
+        const bool active = RAGGED ? base < n : true;
+        const bool full = RAGGED ? base + kEnvsPerThread <= n : true;
         T obs[4], rr[4], KK[4], sg[4], er[4], rew[4];
         int32_t t[4];
         bool dn[4];
@@ -511,7 +516,7 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
                         env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, o2[j], rew[j], dn[j],
                                            t2[j], dk);
                     }
-                    dn[j] = dn[j] && (base + j < n);
+                    if (RAGGED) dn[j] = dn[j] && (base + j < n);
                     fresh[j] = fresh[j] && dn[j];
                     er[j] = er[j] + rew[j];
                     obs[j] = o2[j];
@@ -602,15 +607,39 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
                          noise, pt.origin_step, pt.origin_counter, pt.growth, pt.alpha,
                          // x / K as an exact multiply changes no bit, so the per-step kernels' true division agrees
                          per_env ? DivK{false, 0.0f, 0.0} : make_divk((double)pt.K)};
-    int blocks, threads;
-    launch_shape(p, n, blocks, threads);
+    // whole tiles through the unconditional instantiation, the < 1024-env tail through one workgroup of the ragged one
+    const int64_t tile = 256 * kEnvsPerThread;
+    const int64_t n_full = (n / tile) * tile;
+    const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
     return with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
-        if constexpr (kTag != kModelZooMixed)
-            return launch_kernel(step_fused_kernel<T, kTag>, blocks, 256, (hipStream_t)stream, a, n, (uint64_t)env_offset,
-                                 seed, step_counter);
-        else
+        if constexpr (kTag != kModelZooMixed) {
+            if (n_full > 0) {
+                int blocks, threads;
+                launch_shape(p, n_full, blocks, threads);
+                const int rc2 = launch_kernel(step_fused_kernel<T, kTag, false>, blocks, 256, (hipStream_t)stream, a, n_full,
+                                              (uint64_t)env_offset, seed, step_counter);
+                if (rc2 != 0 || n_full == n) return rc2;
+            }
+            FusedArgs<T> tl = a;
+            const int64_t o = n_full;
+            tl.obs = a.obs + o;
+            tl.action = (const char*)a.action + 4 * o;
+            tl.reward = a.reward ? a.reward + o : nullptr;
+            tl.done = a.done ? a.done + o : nullptr;
+            tl.t = t8 ? reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(a.t) + o) : a.t + o;
+            tl.r = a.r ? a.r + o : nullptr;
+            tl.K = a.K ? a.K + o : nullptr;
+            tl.ep_return = a.ep_return ? a.ep_return + o : nullptr;
+            tl.sigma_arr = a.sigma_arr ? a.sigma_arr + o : nullptr;
+            tl.reward_steps = a.reward_steps ? a.reward_steps + o : nullptr;
+            tl.done_steps = a.done_steps ? a.done_steps + o : nullptr;
+            // (the tail adds its record to workgroup slot 0, as the per-step path.s tail launch does)
+            return launch_kernel(step_fused_kernel<T, kTag, true>, 1, 256, (hipStream_t)stream, tl, n - n_full,
+                                 (uint64_t)(env_offset + n_full), seed, step_counter);
+        } else {
             return (int)FISHING_ERR_MODEL;
+        }
     });
 }
 

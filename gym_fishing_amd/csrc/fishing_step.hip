@@ -788,10 +788,11 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
         }
     }
 #ifndef FISHING_NO_ZOO_HOT
-    // float32 zoo (one growth function each) and the float64 parity layout of fishing-v0/v1/v2: bare / with the
-    // return record.  Measured against their catch-alls at N = 2^22: fishing-v9 16.05 vs 17.7 us, float64
-    // fishing-v1 24.4 vs 26.9 us (profiles/r02_ab_variants.jsonl).
-    if constexpr ((sizeof(T) == 4 && is_zoo_tag(MODEL)) || (sizeof(T) == 8 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4)) {
+    // float32 zoo (one growth function each): bare / with the return record.  Measured against the catch-all at
+    // N = 2^22: fishing-v9 16.05 vs 17.7 us.  (The float64 parity layout gains under 1 % from exact instantiations --
+    // 26.65 vs 26.87 us, it is bound by its 32-byte-per-lane access shape -- and runs on its catch-alls:
+    // profiles/r02_ab_variants.jsonl.)
+    if constexpr (sizeof(T) == 4 && is_zoo_tag(MODEL)) {
         switch (req) {
             FISHING_LEAN_CASE(P);
             FISHING_LEAN_CASE(P | RET);

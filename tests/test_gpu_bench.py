@@ -61,3 +61,28 @@ def test_bench_configs_name_their_workload(config, kernel, nbytes):
     assert out["config"]["name"] == config and out["roofline"]["kernel"] == kernel
     assert out["roofline"]["bytes_per_env_step"] == nbytes and out["value"] > 1e9
     assert out["episode_stats"]["n_episodes"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_bench_under_torch_distributed_run_with_one_rccl_rank():
+    """The driver's launch form with one rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`
+    creates the RCCL communicator (backend "nccl"), runs the record's all-reduce and the barriers through it, and still
+    prints exactly one JSON line on stdout (RCCL's banner goes to stderr)."""
+    import socket
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; none visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                           "--gpus", "1", "--steps", "20", "--warmup", "5", "--spinup-ms", "5", "--n-envs", str(1 << 18),
+                           "--no-cpu-baseline", "--no-subrecords"], capture_output=True, text=True, env=e, timeout=500)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["episode_stats"]["n_episodes"] > 0 and out["value"] > 1e9

@@ -285,8 +285,7 @@ def test_kernel_names_follow_the_dispatch(hh):
     assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 130>"
     assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, terminal_obs=True, done_bits=True) == "fishing::step_kernel_lean<float, 1, 3199>"
-    assert name(p1, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 2>"
-    assert name(p1, dtype=np.float64, terminal_obs=True) == "fishing::step_kernel_lean<double, 1, 3199>"
+    assert name(p1, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 3199>"
     assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 4, 3455>"
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 18>"
     assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 2>"
