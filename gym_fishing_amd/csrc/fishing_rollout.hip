@@ -391,7 +391,11 @@ constexpr int kPrefetch = 4;
 // paths' results right behind each prefetch load and has to wait for it there (`s_waitcnt vmcnt(0)` after every
 // global_load: the prefetch hid nothing, waves sat 36 % of their cycles on s_waitcnt).  RAGGED = true is the same
 // body for the < 1024-env tail, one workgroup.
-template <typename T, int MODEL, bool RAGGED>
+// KP2 = true: the scalar K is a power of two, x / K is the exact multiply x * (1 / K) -- as a compile-time fact, so that
+// the four envs' arithmetic is one basic block the scheduler can interleave (a run-time flag puts a uniform branch
+// around every division and the envs' chains execute one after the other: it is the latency-bound small batches,
+// two waves per SIMD at N = 2^19, that pay for that).
+template <typename T, int MODEL, bool RAGGED, bool KP2 = false>
 __global__ void __launch_bounds__(256)
 step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offset, const uint64_t seed,
                   const uint64_t step_counter_arg) {
@@ -404,7 +408,7 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
     const bool derived = kPerEnv && a.derived != 0;
     const bool drift = kZoo && a.drift != 0;
     const bool t8 = a.t8 != 0;
-    const DivK dk = a.dk;
+    const DivK dk = RAGGED ? a.dk : (KP2 ? DivK{true, a.dk.inv_f, a.dk.inv_d} : DivK{false, 0.0f, 0.0});
     const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
@@ -617,8 +621,16 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
             if (n_full > 0) {
                 int blocks, threads;
                 launch_shape(p, n_full, blocks, threads);
-                const int rc2 = launch_kernel(step_fused_kernel<T, kTag, false>, blocks, 256, (hipStream_t)stream, a, n_full,
-                                              (uint64_t)env_offset, seed, step_counter);
+                int rc2;
+                if constexpr (kTag != FISHING_MODEL_V4 && !is_zoo_tag(kTag)) {
+                    rc2 = a.dk.pow2 ? launch_kernel(step_fused_kernel<T, kTag, false, true>, blocks, 256, (hipStream_t)stream, a,
+                                                    n_full, (uint64_t)env_offset, seed, step_counter)
+                                    : launch_kernel(step_fused_kernel<T, kTag, false, false>, blocks, 256, (hipStream_t)stream, a,
+                                                    n_full, (uint64_t)env_offset, seed, step_counter);
+                } else {    // per-env K (fishing-v4) and the zoo (x / K only in the obs map: its growth functions divide by their own K)
+                    rc2 = launch_kernel(step_fused_kernel<T, kTag, false, false>, blocks, 256, (hipStream_t)stream, a, n_full,
+                                        (uint64_t)env_offset, seed, step_counter);
+                }
                 if (rc2 != 0 || n_full == n) return rc2;
             }
             FusedArgs<T> tl = a;
