@@ -29,7 +29,10 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     const uint64_t step_counter0 = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     const bool derived = kPerEnv && (p.flags & FISHING_FLAG_V4_DERIVED) != 0;   // no r / K arrays (derive_model_error)
-    const DivK dk = kPerEnv ? DivK{false, 0.0f, 0.0} : dk_arg;      // per-env K keeps the true division
+    // per-env K keeps the true division.  (The power-of-two flag stays a run-time one here: at N = 2^22 this kernel is
+    // VALU-bound with 5-6 waves per SIMD to interleave, and a compile-time flag measured no gain -- unlike in the
+    // fused step kernel's two-waves-per-SIMD regime.)
+    const DivK dk = kPerEnv ? DivK{false, 0.0f, 0.0} : dk_arg;
     // POLICY >= 0: compile-time policy (v0/v1/v2/v4); POLICY < 0: wave-uniform run-time policy (zoo,
     // to keep the number of instantiations of the transcendental-heavy bodies small)
     const int policy = (POLICY >= 0) ? POLICY : policy_rt;
