@@ -265,15 +265,22 @@ def per_launch_us(torch, env, actions, launches):
     return statistics.median(d), statistics.fmean(d)
 
 
-def timed_steps(torch, env, actions, steps, **kw):
+def timed_steps(torch, env, actions, steps, spin_ms=60.0, repeats=1, **kw):
+    """HIP events around `steps` launches (or one fused launch of `steps` steps), after `spin_ms` of the same work:
+    every sub-record follows allocations and host work during which the device idled and its clocks dropped."""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < spin_ms:
+        env.step_many(actions, steps, **kw)
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e0.record()
-    env.step_many(actions, steps, **kw)
+    for _ in range(repeats):
+        env.step_many(actions, steps, **kw)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / steps, time.perf_counter() - t0
+    return e0.elapsed_time(e1) * 1e3 / (steps * repeats), time.perf_counter() - t0
 
 
 def main():
@@ -437,7 +444,7 @@ def main():
         bare = make_env(gf, torch, args.config, n, 0, False, False, args.v4_stored)
         bare.reset()
         bare.step_many(actions, min(max(args.warmup, 50), 200))
-        kb = max(20, min(args.steps, 2020))
+        kb = max(256, min(args.steps, 2020))
         us, wall = timed_steps(torch, bare, actions, kb)
         bb = bytes_per_env_step(args.config, False, False, args.v4_stored)
         out["bare_step"] = {"value": n * kb / wall, "unit": "env-steps/s", "steps": kb, "bytes_per_env_step": bb,
@@ -477,8 +484,8 @@ def main():
             ef.step_many(af, 101, fused=True, rewards_out=rows_r, dones_out=rows_d)
             ef.step_many(af, 202)
             us_l, _ = timed_steps(torch, ef, af, 1010)
-            us_f, _ = timed_steps(torch, ef, af, 101, fused=True, rewards_out=rows_r, dones_out=rows_d)
-            us_f2, _ = timed_steps(torch, ef, af, 101, fused=True)
+            us_f, _ = timed_steps(torch, ef, af, 101, repeats=8, fused=True, rewards_out=rows_r, dones_out=rows_d)
+            us_f2, _ = timed_steps(torch, ef, af, 101, repeats=8, fused=True)
             fb = 9 + (BYTES_SIGMA_ARRAY if args.config == "v4" else 0) * 0
             fused["2^%d" % ln] = {
                 "per_step_launches": {"us_per_step": us_l, "env_steps_per_s": nn / us_l * 1e6,
