@@ -755,17 +755,31 @@ constexpr int catch_all_mask() {
 // `req` = the exact mask of the request.  The hot requests (what bench.py and a training loop issue) have
 // their own instantiation; everything else takes the catch-all of its (T, MODEL).
 template <typename T, int MODEL>
-int lean_dispatch(int req, const LeanCall<T>& c) {
+int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     using namespace feat;
     constexpr int P = kNoisePhilox;
 #define FISHING_LEAN_CASE(MASK) \
     case (MASK): return lean_launch<T, MODEL, (MASK)>(c)
     if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL)) {
-        switch (req) {          // fishing-v0/v1/v2/v4, float32, in-kernel noise: bare / with the return record,
-            FISHING_LEAN_CASE(P);               // forward and zig-zag tile walk
+        if (zigzag) {           // N >= 2^25: the requests that have a zig-zag instantiation
+            switch (req | ZZ) {
+                FISHING_LEAN_CASE(P | ZZ);
+                FISHING_LEAN_CASE(P | RET | ZZ);
+                default: break;
+            }
+            if constexpr (MODEL == FISHING_MODEL_V4) {
+                switch (req | ZZ) {
+                    FISHING_LEAN_CASE(P | DERIVED | ZZ);
+                    FISHING_LEAN_CASE(P | DERIVED | RET | ZZ);
+                    FISHING_LEAN_CASE(P | DERIVED | SIGARR | ZZ);
+                    FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET | ZZ);
+                    default: break;
+                }
+            }
+        }
+        switch (req) {          // fishing-v0/v1/v2/v4, float32, in-kernel noise: bare / with the return record
+            FISHING_LEAN_CASE(P);
             FISHING_LEAN_CASE(P | RET);
-            FISHING_LEAN_CASE(P | ZZ);
-            FISHING_LEAN_CASE(P | RET | ZZ);
             default: break;
         }
         if constexpr (MODEL == FISHING_MODEL_V1) {
@@ -849,12 +863,11 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     if (drift) req |= feat::DRIFT;
     // N >= 2^25 (the state streams alone are far beyond the Infinity Cache): the zig-zag walk, for the requests
     // that have such an instantiation
-    if (ntiles >= (1 << 15) && (req & ~feat::RET) == kNoisePhilox && sizeof(T) == 4 && is_core_model(p->model))
-        req |= feat::ZZ;
+    const bool zigzag = ntiles >= (1 << 15);
     const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
-        if constexpr (kTag != kModelZooMixed) return lean_dispatch<T, kTag>(req, call);
+        if constexpr (kTag != kModelZooMixed) return lean_dispatch<T, kTag>(req, zigzag, call);
         else return (int)FISHING_ERR_MODEL;
     });
     if (rc != 0 || n_full == n || name) return rc;
