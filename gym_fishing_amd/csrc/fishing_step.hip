@@ -43,6 +43,9 @@ namespace fishing {
 #ifndef FISHING_LEAN_LOCAL_KEYS
 #define FISHING_LEAN_LOCAL_KEYS 1
 #endif
+#ifndef FISHING_ZZ_MIN_BYTES
+#define FISHING_ZZ_MIN_BYTES (500ll << 20)  // bytes one step streams, from which the tile walk alternates direction
+#endif
 #ifndef FISHING_LEAN_BLOCKED_TILES
 #define FISHING_LEAN_BLOCKED_TILES 0
 #endif
@@ -861,9 +864,12 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     if (b->done_bits) req |= feat::BITS;
     if (derived) req |= feat::DERIVED;
     if (drift) req |= feat::DRIFT;
-    // N >= 2^25 (the state streams alone are far beyond the Infinity Cache): the zig-zag walk, for the requests
-    // that have such an instantiation
-    const bool zigzag = ntiles >= (1 << 15);
+    // The zig-zag walk once a step's streams are about twice the 256 MiB Infinity Cache (for the requests that have such
+    // an instantiation): every size from N = 2^25 on, at 2^24 the variants with the return accumulator (33 B x 2^24 =
+    // 554 MB: 85.6 -> 82.8 us; the bare 25 B step, 420 MB, still prefers the forward walk: 62.9 vs 63.7 us).
+    const int64_t step_bytes = n_full * (int64_t)(sizeof(T) == 4 ? 25 + (b->ep_return ? 8 : 0) + (b->sigma ? 4 : 0)
+                                                                 : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0));
+    const bool zigzag = step_bytes >= FISHING_ZZ_MIN_BYTES;
     const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;

@@ -283,6 +283,9 @@ def test_kernel_names_follow_the_dispatch(hh):
     assert name(p1) == "fishing::step_kernel_lean<float, 1, 2>"
     assert name(p1, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 6>"
     assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 130>"
+    # the zig-zag walk starts where one step streams ~twice the Infinity Cache: with returns (33 B) already at N = 2^24
+    assert name(p1, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 2>"
+    assert name(p1, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 134>"
     assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, terminal_obs=True, done_bits=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 3199>"
