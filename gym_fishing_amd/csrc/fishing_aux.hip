@@ -172,7 +172,7 @@ int v4_params_impl(const FishingParams* p, int64_t n, int64_t env_offset, const 
     if (!p || !t) return FISHING_ERR_NULL;
     if (p->model != FISHING_MODEL_V4) return FISHING_ERR_MODEL;
     if (n < 0 || env_offset < 0) return FISHING_ERR_SIZE;
-    if (!(std::isfinite(p->K_mean) && std::isfinite(p->r_mean) && std::isfinite(p->sigma_p))) return FISHING_ERR_SIZE;
+    if (!(std::isfinite(p->K_mean) && std::isfinite(p->r_mean) && std::isfinite(p->sigma_p))) return FISHING_ERR_VALUE;
     if (n == 0) return FISHING_OK;
     const ParamsT<T> pt = narrow_params<T>(*p);
     return launch_kernel(v4_params_kernel<T>, grid_for(n, 2048), 256, (hipStream_t)stream, pt, n, (uint64_t)env_offset, t,
@@ -215,6 +215,8 @@ const char* fishing_error_string(int code) {
         case FISHING_ERR_SIZE: return "bad size / count / offset argument";
         case FISHING_ERR_POLICY: return "unknown in-kernel policy";
         case FISHING_ERR_NO_DEVICE: return "no usable HIP device";
+        case FISHING_ERR_UNSUPPORTED: return "this entry point does not serve this combination of flags / streams";
+        case FISHING_ERR_VALUE: return "a parameter value outside its domain";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }

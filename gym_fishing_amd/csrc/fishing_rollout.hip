@@ -324,7 +324,7 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     // Without auto-reset the rollout FREEZES a finished env -- its year counter stops while the step counter runs on,
     // and with it the rule that dates the env's episode (derive_model_error): such a rollout needs the r / K arrays.
     if (p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED) && !(p->flags & FISHING_FLAG_AUTO_RESET))
-        return FISHING_ERR_SIZE;
+        return FISHING_ERR_UNSUPPORTED;
     if (traj && (((uintptr_t)traj) & 15u)) return FISHING_ERR_ALIGN;
     if (traj && (n & 3)) return FISHING_ERR_ALIGN;  // rows of the record must stay 16-byte aligned
     if (n == 0 || Tsteps == 0) return FISHING_OK;
@@ -599,8 +599,8 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
     if ((reward_steps || done_steps) && (out_stride < n || (out_stride & 15))) return FISHING_ERR_ALIGN;
     if (misaligned(reward_steps) || misaligned(done_steps)) return FISHING_ERR_ALIGN;
     // the streams only the per-step kernels produce
-    if (b->z_ext || b->terminal_obs || b->done_bits || p->model == FISHING_MODEL_V11) return FISHING_ERR_MODEL;
-    if (p->launch_threads != 0 && p->launch_threads != 256) return FISHING_ERR_SIZE;
+    if (b->z_ext || b->terminal_obs || b->done_bits || p->model == FISHING_MODEL_V11) return FISHING_ERR_UNSUPPORTED;
+    if (p->launch_threads != 0 && p->launch_threads != 256) return FISHING_ERR_UNSUPPORTED;
     if (n == 0 || n_steps == 0) return FISHING_OK;
     const ParamsT<T> pt = narrow_params<T>(*p);
     const BuffersT<T> bt = typed_buffers<T>(*b);

@@ -647,11 +647,11 @@ int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     if ((p->flags & FISHING_FLAG_T_U8) && (p->Tmax < 0 || p->Tmax > 254)) return FISHING_ERR_SIZE;
     if (!b->obs || !b->t) return FISHING_ERR_NULL;
     const bool derived = p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED);
-    if (derived && (p->flags & FISHING_FLAG_T_U8)) return FISHING_ERR_SIZE;    // a saturating counter cannot date an episode
+    if (derived && (p->flags & FISHING_FLAG_T_U8)) return FISHING_ERR_UNSUPPORTED;     // a saturating counter cannot date an episode
     if (p->model == FISHING_MODEL_V4 && !derived && (!b->r || !b->K)) return FISHING_ERR_NULL;
     // (clip_param relies on it; the reference turns a non-finite mean into NaN populations)
     if (p->model == FISHING_MODEL_V4 && !(std::isfinite(p->K_mean) && std::isfinite(p->r_mean) && std::isfinite(p->sigma_p)))
-        return FISHING_ERR_SIZE;
+        return FISHING_ERR_VALUE;
     if (b->return_partials && !b->ep_return) return FISHING_ERR_NULL;
     if (b->counter && (((uintptr_t)b->counter) & 7u)) return FISHING_ERR_ALIGN;
     const void* ptrs[] = {b->obs,  b->action, b->reward, b->done,         b->done_bits, b->t,           b->r,

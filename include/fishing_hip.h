@@ -82,6 +82,10 @@ typedef void* fishing_stream_t; /* hipStream_t */
 #define FISHING_ERR_SIZE -4      /* n < 0, T < 0, n_actions <= 0, ...             */
 #define FISHING_ERR_POLICY -5    /* unknown in-kernel policy                      */
 #define FISHING_ERR_NO_DEVICE -6 /* no HIP device / wrong architecture            */
+#define FISHING_ERR_UNSUPPORTED -7 /* this entry point does not serve this combination of flags / streams
+                                      (e.g. fishing_step_fused_* with z_ext, derived fishing-v4 parameters with
+                                      a one-byte year counter or a rollout without auto-reset)          */
+#define FISHING_ERR_VALUE -8     /* a parameter value outside its domain (non-finite fishing-v4 mean) */
 
 /* Scalar parameters of one env family: the constructor kwargs of the reference
  * (envs/fishing_env.py:7-16, fishing_cts_env.py:5-7, fishing_tipping_env.py:7-16,
@@ -100,7 +104,7 @@ typedef struct FishingParams {
     double C;          /* fishing-v2 tipping point                                      */
     double x0;         /* init_state                                                    */
     double r_mean, K_mean, sigma_p; /* fishing-v4 redraw at reset; must be finite (else
-                                       FISHING_ERR_SIZE: the reference would produce NaN stocks) */
+                                       FISHING_ERR_VALUE: the reference would produce NaN stocks) */
     int32_t launch_blocks;  /* 0 = auto; else cap on workgroups (tuning knob)           */
     int32_t launch_threads; /* 0 = auto (256); 64..256, multiple of 64                  */
     /* zoo extras (fishing-v5..v11) */
@@ -187,7 +191,7 @@ int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, con
  * actions.  Updates obs, t, (r, K), ep_return, return_partials; writes the LAST step's
  * reward/done if those pointers are set.  Without FISHING_FLAG_AUTO_RESET a finished env is
  * frozen (its episode is over, as in simulate_mdp's `break`, shared_env.py:51-52) -- its year counter stops, so this
- * form is not available under FISHING_FLAG_V4_DERIVED (FISHING_ERR_SIZE: call fishing_v4_params_* and pass arrays).
+ * form is not available under FISHING_FLAG_V4_DERIVED (FISHING_ERR_UNSUPPORTED: call fishing_v4_params_* and pass arrays).
  * traj (nullable): real[T][4][n] recording per step {obs before acting, action, reward,
  * done} -- the raw material of the simulate_mdp table (shared_env.py:37-49); needs n % 4 == 0. */
 int fishing_rollout_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
@@ -203,7 +207,8 @@ int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, c
  * and done_steps + k * out_stride (u8).  The launch-bound regime's fast path (n <= 2^20: a dependent
  * launch costs ~2.7 us whatever it moves).  Bit-identical to n_steps fishing_step_* calls with the same
  * step_counter: same Philox counters, same arithmetic; FishingBuffers.reward / .done receive the last
- * step's values, return_partials the same record.  Not for z_ext / terminal_obs / done_bits (use step()). */
+ * step's values, return_partials the same record.  Not for z_ext / terminal_obs / done_bits / fishing-v11
+ * (FISHING_ERR_UNSUPPORTED: use step()). */
 int fishing_step_fused_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                            int64_t action_stride, int32_t ring_len, int32_t n_steps, void* reward_steps,
                            uint8_t* done_steps, int64_t out_stride, uint64_t seed, uint64_t step_counter,

@@ -50,7 +50,7 @@ def test_abi_version_and_struct_layout(lib):
 
 def test_error_strings(lib):
     assert lib.fishing_error_string(0) == b"ok"
-    for code in (-1, -2, -3, -4, -5, -6):
+    for code in (-1, -2, -3, -4, -5, -6, -7, -8):
         assert lib.fishing_error_string(code) not in (b"ok", b"unknown error")
 
 
@@ -74,12 +74,12 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -1      # v4 needs r, K arrays
     bv4 = _capi.make_buffers(obs=4096, t=8192, action=12288, r=16384, K=20480)
     p.K_mean, p.r_mean, p.sigma_p = float("nan"), 0.3, 0.1
-    assert lib.fishing_reset_f32(p, 4, 0, bv4, None, 0, 0, None) == -4    # fishing-v4's means must be finite
+    assert lib.fishing_reset_f32(p, 4, 0, bv4, None, 0, 0, None) == -8    # fishing-v4's means must be finite
     p.K_mean, p.sigma_p = 1.0, float("inf")
-    assert lib.fishing_step_f32(p, 4, 0, bv4, 0, 0, None) == -4
+    assert lib.fishing_step_f32(p, 4, 0, bv4, 0, 0, None) == -8
     p.sigma_p = 0.1
     p.flags = _capi.FLAG_V4_DERIVED | _capi.FLAG_T_U8
-    assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -4      # derived parameters need the int32 year counter
+    assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -7      # derived parameters need the int32 year counter
     p.flags = 0
     assert lib.fishing_v4_params_f32(p, 4, 0, None, None, None, 0, 0, None) == -1
     p.model = _capi.MODEL_V1
@@ -87,7 +87,7 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.fishing_step_fused_f32(p, 4, 0, b, 4, 0, 3, None, None, 0, 0, 0, None) == -4   # ring_len <= 0
     assert lib.fishing_step_fused_f32(p, 4, 0, b, 4, 2, 3, 4096, None, 2, 0, 0, None) == -3   # out_stride < n
     bz = _capi.make_buffers(obs=4096, t=8192, action=12288, z_ext=16384)
-    assert lib.fishing_step_fused_f32(p, 4, 0, bz, 4, 2, 3, None, None, 0, 0, 0, None) == -2  # external noise: step() only
+    assert lib.fishing_step_fused_f32(p, 4, 0, bz, 4, 2, 3, None, None, 0, 0, 0, None) == -7  # external noise: step() only
     name = ctypes.create_string_buffer(128)
     bo = _capi.make_buffers(obs=4096, t=8192, action=12288, reward=16384, done=20480)
     assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0

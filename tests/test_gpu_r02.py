@@ -611,7 +611,7 @@ def test_v4_rollout_without_auto_reset_leaves_the_derived_mode(hh):
     p = hh.params(fo.MODEL_V4, sigma=0.05, derived=True, auto_reset=False)
     st = hh.State(2048, np.float32, fo.MODEL_V4, np.zeros(2048))
     rc = _capi.lib().fishing_rollout_f32(p, 2048, 0, st.buffers(), _capi.POLICY_RANDOM, 0.0, 5, None, 0, 0, None)
-    assert rc == -4                                      # FISHING_ERR_SIZE
+    assert rc == -7                                      # FISHING_ERR_UNSUPPORTED
     tabs, Ks = [], []
     for derived in (None, False):
         env = gf.make("fishing-v4", num_envs=64, sigma=0.05, sigma_p=0.2, Tmax=12, seed=4, derived_params=derived)
