@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU session 1 of round 2: new tests, the driver's bench command, per-config lines, A/B against the round-1 tree.
+# GPU session 1 of round 2: new tests, the driver's bench command, per-config lines, A/B against the round-1 tree
+# (a `git worktree add --detach .r01_baseline <round-1 head>` with its own built library, removed at the end of the round).
 set -u
 O=gpurun_out/r02_s1
 mkdir -p $O
