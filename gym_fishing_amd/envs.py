@@ -759,9 +759,9 @@ class BaseFishingEnv(_gym_env_base()):
             rc = self._lib.fishing_reduce_returns(self._partials.data_ptr(), self._record.data_ptr(), self._stream())
         _capi.check(rc, "fishing_reduce_returns")
         from .sharding import all_reduce_record
-        rec = self._record
+        rec = self._record              # scratch: rewritten from the partials by every call, so reduced in place
         if all_reduce:
-            rec = all_reduce_record(rec.clone())
+            rec = all_reduce_record(rec)
         return rec
 
     def episode_stats(self, all_reduce=True):
