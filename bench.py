@@ -486,7 +486,18 @@ def main():
             us_l, _ = timed_steps(torch, ef, af, 1010)
             us_f, _ = timed_steps(torch, ef, af, 101, repeats=8, fused=True, rewards_out=rows_r, dones_out=rows_d)
             us_f2, _ = timed_steps(torch, ef, af, 101, repeats=8, fused=True)
-            fb = 9 + (BYTES_SIGMA_ARRAY if args.config == "v4" else 0) * 0
+            # ... and the fused rollout with the policy drawn in-kernel (no action traffic at all): BASELINE config 2 is
+            # "N = 2^20, random-policy rollout"
+            ef.rollout(101, policy="random")
+            torch.cuda.synchronize()
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record()
+            for _ in range(8):
+                ef.rollout(101, policy="random")
+            r1.record()
+            torch.cuda.synchronize()
+            us_r = r0.elapsed_time(r1) * 1e3 / (8 * 101)
+            fb = 9
             fused["2^%d" % ln] = {
                 "per_step_launches": {"us_per_step": us_l, "env_steps_per_s": nn / us_l * 1e6,
                                       "frac_of_25B_roofline_rate": nn / us_l * 1e6 * BYTES_STEP / (HBM_PEAK_GBS * 1e9)},
@@ -495,6 +506,8 @@ def main():
                                                 "frac_of_25B_roofline_rate": nn / us_f * 1e6 * BYTES_STEP / (HBM_PEAK_GBS * 1e9)},
                 "fused_last_step_outputs_only": {"us_per_step": us_f2, "env_steps_per_s": nn / us_f2 * 1e6,
                                                  "bytes_per_env_step": 4},
+                "fused_rollout_in_kernel_random_policy": {"us_per_step": us_r, "env_steps_per_s": nn / us_r * 1e6,
+                                                          "bytes_per_env_step": 0},
             }
             del ef, af, rows_r, rows_d
             torch.cuda.empty_cache()
