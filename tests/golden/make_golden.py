@@ -328,6 +328,24 @@ def main():
                                                          "S": float(model.S),
                                                          "msy": float(model.msy) if pname == "msy" else None}))
     np.savez_compressed(os.path.join(OUT, "reference_seeded_sims.npz"), **seeded)
+    # --- estimate_policyfn (shared_env.py:82-102): the policy's quota over a grid of 50 observations, through the
+    # reference's own env.policyfn(); same action convention as the tables above (RefEra).
+    pf = {}
+    for env_id, kw in (("fishing-v1", {}), ("fishing-v0", {}), ("fishing-v1", {"r": 0.5, "K": 2.0, "init_state": 1.1}),
+                       ("fishing-v0", {"n_actions": 37, "r": 0.4})):
+        tag = env_id[-2:] + ("_params" if kw else "")
+        for pname, cls in (("msy", msy), ("escapement", escapement)):
+            env = gym.make(env_id, sigma=0.0, **kw)
+            model = RefEra(cls(env), env_id == "fishing-v0")
+            # The grid's dtype comes from the observation Box (float32), and `float32 scalar + Python int` is float32
+            # under NumPy 2 but float64 under the reference's NumPy 1.19: asking for a float64 grid makes every sum
+            # float64 under both, so the table pins the function (grid, predict, population and quota maps, row
+            # layout) and not a NumPy version.
+            env.observation_space.dtype = np.dtype(np.float64)
+            df = env.policyfn(model, reps=2)
+            pf["policyfn_%s_%s" % (tag, pname)] = df.to_numpy(dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "reference_policyfn.npz"), **pf)
+
     # --- simulate_mdp_vec (shared_env.py:57-79): the reference's only code written against an N-env object.  It is
     # driven UNMODIFIED over N reference envs behind a minimal harness with the SB3-DummyVecEnv behaviour it relies
     # on (envs stepped in order, a finished env reset at once and its post-reset observation returned, env_method /

@@ -624,3 +624,28 @@ def test_v4_rollout_without_auto_reset_leaves_the_derived_mode(hh):
         assert env._derived is (derived is None)     # a full reset returns to the derived mode
     same(tabs[0], tabs[1], "simulate table: derived vs stored")
     assert torch.equal(Ks[0], Ks[1])
+
+
+# ------------------------------------------------------------------ estimate_policyfn against the reference's table
+def _policyfn_cases():
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "reference_policyfn.npz"))
+    return [(k, z[k]) for k in sorted(z.files)]
+
+
+@pytest.mark.parametrize("key,table", _policyfn_cases(), ids=[k for k, _ in _policyfn_cases()])
+def test_policyfn_reproduces_the_reference_table(hh, key, table):
+    """env.policyfn(model, reps=2) (shared_env.py:82-102) on the reference with msy / escapement policies, for
+    fishing-v0 / v1 with default and non-default parameters, against the same call here (scalar protocol, fp64
+    kernels): 100 rows [population, quota, rep] bit for bit.  Both sides use a float64 observation grid (see
+    tests/golden/make_golden.py for why)."""
+    import gym_fishing_amd as gf
+    from gym_fishing_amd import policies
+    _, tag, pname = key.split("_", 2) if key.count("_") == 2 else (None, key.split("_")[1] + "_params", key.split("_")[3])
+    env_id = "fishing-" + tag[:2]
+    kw = {"v1_params": {"r": 0.5, "K": 2.0, "init_state": 1.1}, "v0_params": {"n_actions": 37, "r": 0.4}}.get(tag, {})
+    env = gf.make(env_id, sigma=0.0, **kw)
+    model = getattr(policies, pname)(env)
+    env.observation_space.dtype = np.dtype(np.float64)
+    df = env.policyfn(model, reps=2)
+    got = df.to_numpy(dtype=np.float64) if hasattr(df, "to_numpy") else np.stack([df[c] for c in ("state", "action", "rep")], 1)
+    same(got, table, key)
