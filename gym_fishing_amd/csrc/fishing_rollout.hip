@@ -620,7 +620,13 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
     const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
     return with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
-        if constexpr (kTag != kModelZooMixed) {
+        if constexpr (kTag != kModelZooMixed && sizeof(T) == 8) {
+            // the float64 parity layout is not the fast path: one ragged-capable instantiation over the whole batch
+            int blocks, threads;
+            launch_shape(p, n, blocks, threads);
+            return launch_kernel(step_fused_kernel<T, kTag, true>, blocks, 256, (hipStream_t)stream, a, n, (uint64_t)env_offset,
+                                 seed, step_counter);
+        } else if constexpr (kTag != kModelZooMixed) {
             if (n_full > 0) {
                 int blocks, threads;
                 launch_shape(p, n_full, blocks, threads);
