@@ -49,9 +49,6 @@ namespace fishing {
 #ifndef FISHING_LEAN_BLOCKED_TILES
 #define FISHING_LEAN_BLOCKED_TILES 0
 #endif
-#ifndef FISHING_LEAN_DIVK
-#define FISHING_LEAN_DIVK 0      // x / K as the exact multiply x * (1 / K) when the scalar K is a power of two (same bits)
-#endif
 #ifndef FISHING_STEP_MAXTHREADS
 #define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
 #endif
@@ -306,6 +303,9 @@ constexpr int DRIFT = 1 << 9;      // fishing-v10: per-env r, drifting by alpha 
 constexpr int OPT = 1 << 10;
 constexpr int LATCH = 1 << 11;     // RET without auto-reset: a finished env that is stepped on must not enter the record
                                    // again.  Catch-all only -- the exact RET instantiations are the auto-reset ones.
+constexpr int KP2 = 1 << 12;       // the scalar K is a power of two (K = 1 included): x / K is the exact multiply x * (1 / K),
+                                   // same bits, a third of the instructions.  Exact instantiations of fishing-v0/v1/v2 only;
+                                   // any other K takes the catch-all's correctly rounded division.
 }  // namespace feat
 
 template <typename T>
@@ -333,7 +333,7 @@ struct LeanArgs {
     GrowthT<T> growth;       // fishing-v5..v10: the growth function's parameter set (unused, hence never
                              // loaded, by the v0/v1/v2/v4 instantiations)
     T alpha;                 // DRIFT
-    DivK dk;                 // FISHING_LEAN_DIVK: the scalar K's exact-reciprocal shortcut
+    DivK dk;                 // KP2: the scalar K's exact reciprocal
 };
 
 #ifndef FISHING_LEAN_ATTRS
@@ -353,6 +353,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
     static_assert(!(F & feat::DERIVED) || kPerEnv, "DERIVED is fishing-v4");
     static_assert(!((F & feat::ZZ) && kOpt), "ZZ has exact instantiations only");
     static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
+    static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo), "KP2: exact fishing-v0/v1/v2 instantiations");
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || a.ep_return != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -532,13 +533,8 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                                                      rew[j], dn[j], t_next[j]);
                 }
             } else {
-#if FISHING_LEAN_DIVK
                 env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
-                                   dn[j], t_next[j], kPerEnv ? DivK{false, 0.0f, 0.0} : a.dk);
-#else
-                env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
-                                   dn[j], t_next[j]);
-#endif
+                                   dn[j], t_next[j], (F & feat::KP2) ? DivK{true, a.dk.inv_f, a.dk.inv_d} : DivK{false, 0.0f, 0.0});
             }
         }
         {
@@ -763,45 +759,53 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     constexpr int P = kNoisePhilox;
 #define FISHING_LEAN_CASE(MASK) \
     case (MASK): return lean_launch<T, MODEL, (MASK)>(c)
-    if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL)) {
-        if (zigzag) {           // N >= 2^25: the requests that have a zig-zag instantiation
+    if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
+        // fishing-v0/v1/v2, float32, in-kernel noise, K a power of two: bare / with the return record, forward and
+        // zig-zag tile walk (another K: the catch-all)
+        if (zigzag) {
             switch (req | ZZ) {
-                FISHING_LEAN_CASE(P | ZZ);
-                FISHING_LEAN_CASE(P | RET | ZZ);
+                FISHING_LEAN_CASE(P | KP2 | ZZ);
+                FISHING_LEAN_CASE(P | KP2 | RET | ZZ);
                 default: break;
             }
-            if constexpr (MODEL == FISHING_MODEL_V4) {
-                switch (req | ZZ) {
-                    FISHING_LEAN_CASE(P | DERIVED | ZZ);
-                    FISHING_LEAN_CASE(P | DERIVED | RET | ZZ);
-                    FISHING_LEAN_CASE(P | DERIVED | SIGARR | ZZ);
-                    FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET | ZZ);
-                    default: break;
-                }
-            }
         }
-        switch (req) {          // fishing-v0/v1/v2/v4, float32, in-kernel noise: bare / with the return record
-            FISHING_LEAN_CASE(P);
-            FISHING_LEAN_CASE(P | RET);
+        switch (req) {
+            FISHING_LEAN_CASE(P | KP2);
+            FISHING_LEAN_CASE(P | KP2 | RET);
             default: break;
         }
         if constexpr (MODEL == FISHING_MODEL_V1) {
             switch (req) {      // the compact layout bench.py --compact measures
-                FISHING_LEAN_CASE(P | T8);
-                FISHING_LEAN_CASE(P | T8 | RET);
+                FISHING_LEAN_CASE(P | KP2 | T8);
+                FISHING_LEAN_CASE(P | KP2 | T8 | RET);
                 default: break;
             }
         }
-        if constexpr (MODEL == FISHING_MODEL_V4) {
-            switch (req) {      // BASELINE config 5: per-env sigma array; stored or derived (K, r)
-                FISHING_LEAN_CASE(P | SIGARR);
-                FISHING_LEAN_CASE(P | SIGARR | RET);
-                FISHING_LEAN_CASE(P | DERIVED);
-                FISHING_LEAN_CASE(P | DERIVED | RET);
-                FISHING_LEAN_CASE(P | DERIVED | SIGARR);
-                FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET);
+    }
+    if constexpr (sizeof(T) == 4 && MODEL == FISHING_MODEL_V4) {
+        // fishing-v4 (per-env K: always the true division): stored or derived (K, r), sigma scalar or array (BASELINE
+        // config 5), bare / with the return record; the derived ones also with the zig-zag walk
+        if (zigzag) {
+            switch (req | ZZ) {
+                FISHING_LEAN_CASE(P | ZZ);
+                FISHING_LEAN_CASE(P | RET | ZZ);
+                FISHING_LEAN_CASE(P | DERIVED | ZZ);
+                FISHING_LEAN_CASE(P | DERIVED | RET | ZZ);
+                FISHING_LEAN_CASE(P | DERIVED | SIGARR | ZZ);
+                FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET | ZZ);
                 default: break;
             }
+        }
+        switch (req) {
+            FISHING_LEAN_CASE(P);
+            FISHING_LEAN_CASE(P | RET);
+            FISHING_LEAN_CASE(P | SIGARR);
+            FISHING_LEAN_CASE(P | SIGARR | RET);
+            FISHING_LEAN_CASE(P | DERIVED);
+            FISHING_LEAN_CASE(P | DERIVED | RET);
+            FISHING_LEAN_CASE(P | DERIVED | SIGARR);
+            FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET);
+            default: break;
         }
     }
 #ifndef FISHING_NO_ZOO_HOT
@@ -864,6 +868,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     if (b->done_bits) req |= feat::BITS;
     if (derived) req |= feat::DERIVED;
     if (drift) req |= feat::DRIFT;
+    if (sizeof(T) == 4 && a.dk.pow2 && is_core_model(p->model) && p->model != FISHING_MODEL_V4) req |= feat::KP2;
     // The zig-zag walk once a step's streams are about twice the 256 MiB Infinity Cache (for the requests that have such
     // an instantiation): every size from N = 2^25 on, at 2^24 the variants with the return accumulator (33 B x 2^24 =
     // 554 MB: 85.6 -> 82.8 us; the bare 25 B step, 420 MB, still prefers the forward walk: 62.9 vs 63.7 us).

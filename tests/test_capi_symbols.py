@@ -89,6 +89,7 @@ def test_argument_errors_need_no_gpu(lib):
     bz = _capi.make_buffers(obs=4096, t=8192, action=12288, z_ext=16384)
     assert lib.fishing_step_fused_f32(p, 4, 0, bz, 4, 2, 3, None, None, 0, 0, 0, None) == -7  # external noise: step() only
     name = ctypes.create_string_buffer(128)
+    p.K = 1.0
     bo = _capi.make_buffers(obs=4096, t=8192, action=12288, reward=16384, done=20480)
     assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
     assert name.value == b"fishing::step_kernel_lean<float, 1, 3199>"        # sigma = 0 (no generator): the catch-all
@@ -98,7 +99,11 @@ def test_argument_errors_need_no_gpu(lib):
     assert name.value == b"fishing::step_kernel_lean<float, 1, 3199>"        # a record without auto-reset: the catch-all's latch
     p.flags = _capi.FLAG_AUTO_RESET
     assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
-    assert name.value == b"fishing::step_kernel_lean<float, 1, 6>"           # Philox (2) | RET (4)
+    assert name.value == b"fishing::step_kernel_lean<float, 1, 4102>"        # Philox (2) | RET (4) | KP2 (4096): K = 1
+    p.K = 1.5
+    assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
+    assert name.value == b"fishing::step_kernel_lean<float, 1, 3199>"        # K not a power of two: the catch-all's division
+    p.K = 1.0
     assert lib.fishing_step_kernel_name_f32(p, 1000, bo, name, 128) == 0
     assert name.value == b"fishing::step_kernel<float, 1>"                   # below one tile: the general kernel
     p.sigma = 0.0

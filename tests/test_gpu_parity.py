@@ -964,7 +964,7 @@ def test_zigzag_walk_at_large_n_agrees_with_general_kernel(hh, ret, which):
     a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
     lib = __import__("gym_fishing_amd")._capi.lib()
     assert hh.kernel_name(pa, n, hh.State(4096, np.float32, model, np.float32(-0.25), ep_return=ret).buffers(a)).endswith(
-        ", %d>" % ((2 | 128) | (4 if ret else 0) | (256 if derived else 0)))
+        ", %d>" % ((2 | 128) | (4 if ret else 0) | (256 if derived else 4096)))       # ZZ, RET, DERIVED / KP2 (K = 1)
     outs = []
     for p in (pa, pb):
         st = hh.State(n, np.float32, model, np.float32(-0.25), ep_return=ret)

@@ -280,18 +280,21 @@ def test_kernel_names_follow_the_dispatch(hh):
                 setattr(b, k, None)
         return hh.kernel_name(p, n, b, dtype)
     p1 = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True)
-    assert name(p1) == "fishing::step_kernel_lean<float, 1, 2>"
-    assert name(p1, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 6>"
-    assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 130>"
+    assert name(p1) == "fishing::step_kernel_lean<float, 1, 4098>"                 # Philox (2) | KP2 (4096): K = 1
+    assert name(p1, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 4102>"
+    assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 4226>"
     # the zig-zag walk starts where one step streams ~twice the Infinity Cache: with returns (33 B) already at N = 2^24
-    assert name(p1, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 2>"
-    assert name(p1, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 134>"
+    assert name(p1, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 4098>"
+    assert name(p1, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 4230>"
     assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, terminal_obs=True, done_bits=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 3199>"
     assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 4, 3455>"
-    assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 18>"
-    assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 2>"
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 4114>"
+    assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 4098>"
+    # a K that is not a power of two keeps the correctly rounded division: the catch-all
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5)) == "fishing::step_kernel_lean<float, 1, 3199>"
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=0.25)) == "fishing::step_kernel_lean<float, 1, 4098>"
     assert name(hh.params(fo.MODEL_V9, sigma=0.1)) == "fishing::step_kernel_lean<float, 104, 2>"
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, general=True)) == "fishing::step_kernel<float, 1>"
     # the return record without auto-reset needs the latch, which only the catch-all carries
@@ -519,6 +522,9 @@ def test_randomised_requests_agree_across_dispatch_general_and_fused(hh, trial):
     noise = rng.choice(["philox", "philox", "none", "ext"])
     T, off, seed, c0 = 7, 4 * int(rng.integers(0, 50)), int(rng.integers(1, 1 << 40)), int(rng.integers(0, 300))
     kw = dict(sigma=0.0 if noise == "none" else 0.12, C=0.5, Tmax=4, sigma_p=0.15, auto_reset=auto, t_u8=t8)
+    if kind in ("v0", "v1", "v2"):      # K = 2^k takes the exact-multiply instantiations, any other K the true division
+        kw["K"] = float(rng.choice([1.0, 1.0, 2.0, 0.5, 1.5, 3.0]))
+        kw["x0"] = 0.75 * kw["K"]
     if kind == "v10":
         kw.update(r=0.8, alpha=-0.01)
     per_env, drift = model == fo.MODEL_V4, model == fo.MODEL_V10
