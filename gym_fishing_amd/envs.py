@@ -97,6 +97,7 @@ class BaseFishingEnv(_gym_env_base()):
 
     metadata = {"render.modes": ["human"]}
     MODEL = MODEL_V1
+    _STREAM_STAGGER = 12288      # bytes between the arena's stream starts beyond their sizes (see __init__)
 
     def __init__(self, params=None, Tmax=100, file=None, *, num_envs=None, device=None, seed=0,
                  dtype=None, auto_reset=None, env_offset=0, record_terminal_obs=False,
@@ -174,11 +175,12 @@ class BaseFishingEnv(_gym_env_base()):
                  (torch.uint8, N)]
         if track_returns:
             sizes.append((dtype, N * esz))
-        stagger = 0 if self._host_mapped else 12288  # host-mapped: nothing to de-alias, keep the arena small
+        stagger = 0 if self._host_mapped else self._STREAM_STAGGER  # host-mapped: nothing to de-alias, keep the arena small
         offs, off = [], 0
         for k, (_, nbytes) in enumerate(sizes):
             offs.append(off)
-            off = (off + nbytes + stagger * (k + 1) + 255) & ~255
+            gap = stagger[k] if isinstance(stagger, (tuple, list)) else stagger * (k + 1)
+            off = (off + nbytes + gap + 255) & ~255
         self._arena_offs = offs
         if self._host_mapped:
             # scalar protocol: the single env's streams (+ its action) live in pinned, device-mapped
