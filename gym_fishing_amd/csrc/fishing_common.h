@@ -451,61 +451,83 @@ __device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const Gr
 
 // fishing-v11: the growth function differs per env, so a straight per-lane switch runs all five
 // functions for every one of a thread's four envs (20 masked passes per wave, most lanes idle in
-// each).  Instead each wave regroups its 256 envs BY KIND through a wave-private LDS window: for kind
-// k the envs of that kind are compacted (ballot + mbcnt ranks) into consecutive slots, the wave
-// evaluates growth function k on full 64-lane chunks with wave-uniform parameters, and every env
-// reads its result back from its slot -- about ceil(n_k / 64) passes per kind, 5-7 in total.  Same
+// each).  Instead each wave regroups its 256 envs BY KIND through a wave-private LDS window, ONCE for
+// all kinds: every env gets a slot = start of its kind's segment + its rank inside the kind (ballot +
+// mbcnt; segments are padded to whole 64-slot chunks, so a chunk never mixes kinds), (x, z) pairs go
+// to their slots in one write phase, the wave evaluates growth function k on the chunks of segment k
+// with wave-uniform parameters (ceil(n_k / 64) passes per kind, 5-7 in total), and every env reads
+// its result back from its slot: three LDS phases per tile whatever the number of kinds.  Same
 // function on the same inputs as zoo_population_draw<T, k>: identical bits.
 // Must be called by all 64 lanes of the wave (envs that do not take part pass kind < 0).
-// `win` is this wave's window: 2 * 256 elements of T.
+// `win` is this wave's window: kZooWindowSlots pairs.  256 envs in 5 padded segments fill at most
+// 512 slots (the padded total is a multiple of 64 below 256 + 5 * 63).
+constexpr int kZooWindowSlots = 512;
+template <typename T>
+struct alignas(2 * sizeof(T)) ZooSlot {
+    T x, z;
+};
+
 template <typename T, int K>
-__device__ __forceinline__ void zoo_draw_kind_pass(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
-                                                   const GrowthT<T>& P, T (&out)[4], T* __restrict__ win, int lane) {
-    bool mine[4];
-    int pos[4];
+__device__ __forceinline__ void zoo_rank_kind(const int (&kind)[4], int (&slot)[4], int& begin, int& count, int& next) {
     int total = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        mine[j] = kind[j] == K;
-        const uint64_t bal = __ballot(mine[j]);
-        pos[j] = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        total += __popcll(bal);
+        const bool mine = kind[j] == K;
+        const uint64_t bal = __ballot(mine);
+        const int pos = next + total +
+                        (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        slot[j] = mine ? pos : slot[j];
+        total += __popcll(bal);                   // wave-uniform
     }
-    if (total == 0) return;                       // wave-uniform
-    T* wx = win;
-    T* wz = win + 256;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (mine[j]) {
-            wx[pos[j]] = x[j];
-            wz[pos[j]] = z[j];
+    begin = next;
+    count = total;
+    next += (total + kWave - 1) & ~(kWave - 1);
+}
+
+template <typename T, int K>
+__device__ __forceinline__ void zoo_eval_kind(ZooSlot<T>* __restrict__ win, int begin, int count, const GrowthT<T>& P,
+                                              int lane) {
+    for (int c = 0; c < count; c += kWave) {      // wave-uniform trip count
+        if (c + lane < count) {
+            const ZooSlot<T> v = win[begin + c + lane];
+            win[begin + c + lane].x = zoo_population_draw<T, K, false>(K, v.x, v.z, P);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int c = 0; c < total; c += kWave) {      // wave-uniform trip count
-        const int p = c + lane;
-        if (p < total) wx[p] = zoo_population_draw<T, K, false>(K, wx[p], wz[p], P);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = mine[j] ? wx[pos[j]] : out[j];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();              // the next kind reuses the window
 }
 
 template <typename T>
 __device__ __forceinline__ void zoo_draw_regrouped(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
                                                    const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[4],
-                                                   T* __restrict__ win, int lane) {
-    zoo_draw_kind_pass<T, FISHING_KIND_ALLEN>(kind, x, z, zoo[FISHING_KIND_ALLEN], out, win, lane);
-    zoo_draw_kind_pass<T, FISHING_KIND_BEVERTON_HOLT>(kind, x, z, zoo[FISHING_KIND_BEVERTON_HOLT], out, win, lane);
-    zoo_draw_kind_pass<T, FISHING_KIND_MYERS>(kind, x, z, zoo[FISHING_KIND_MYERS], out, win, lane);
-    zoo_draw_kind_pass<T, FISHING_KIND_MAY>(kind, x, z, zoo[FISHING_KIND_MAY], out, win, lane);
-    zoo_draw_kind_pass<T, FISHING_KIND_RICKER>(kind, x, z, zoo[FISHING_KIND_RICKER], out, win, lane);
+                                                   ZooSlot<T>* __restrict__ win, int lane) {
+    int slot[4] = {-1, -1, -1, -1};
+    int begin[FISHING_N_KINDS], count[FISHING_N_KINDS];
+    int next = 0;
+    zoo_rank_kind<T, FISHING_KIND_ALLEN>(kind, slot, begin[0], count[0], next);
+    zoo_rank_kind<T, FISHING_KIND_BEVERTON_HOLT>(kind, slot, begin[1], count[1], next);
+    zoo_rank_kind<T, FISHING_KIND_MYERS>(kind, slot, begin[2], count[2], next);
+    zoo_rank_kind<T, FISHING_KIND_MAY>(kind, slot, begin[3], count[3], next);
+    zoo_rank_kind<T, FISHING_KIND_RICKER>(kind, slot, begin[4], count[4], next);
+    static_assert(FISHING_KIND_ALLEN == 0 && FISHING_KIND_BEVERTON_HOLT == 1 && FISHING_KIND_MYERS == 2 &&
+                      FISHING_KIND_MAY == 3 && FISHING_KIND_RICKER == 4 && FISHING_N_KINDS == 5,
+                  "segment order = kind order");
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (slot[j] >= 0) win[slot[j]] = ZooSlot<T>{x[j], z[j]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    zoo_eval_kind<T, FISHING_KIND_ALLEN>(win, begin[0], count[0], zoo[FISHING_KIND_ALLEN], lane);
+    zoo_eval_kind<T, FISHING_KIND_BEVERTON_HOLT>(win, begin[1], count[1], zoo[FISHING_KIND_BEVERTON_HOLT], lane);
+    zoo_eval_kind<T, FISHING_KIND_MYERS>(win, begin[2], count[2], zoo[FISHING_KIND_MYERS], lane);
+    zoo_eval_kind<T, FISHING_KIND_MAY>(win, begin[3], count[3], zoo[FISHING_KIND_MAY], lane);
+    zoo_eval_kind<T, FISHING_KIND_RICKER>(win, begin[4], count[4], zoo[FISHING_KIND_RICKER], lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (slot[j] >= 0) ? win[slot[j]].x : out[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();              // the next tile reuses the window
 }
 
 // step() with a zoo growth function: quota / obs maps use the env's K (K_obs), the growth its

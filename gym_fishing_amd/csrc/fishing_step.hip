@@ -144,7 +144,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         bool stepped = false;
         if constexpr (zoo_mixed) {
             if (!b.sigma) {     // wave-uniform.  fishing-v11: regroup the wave's envs by growth function
-                __shared__ T win[(FISHING_STEP_MAXTHREADS / kWave) * 512];
+                __shared__ ZooSlot<T> win[(FISHING_STEP_MAXTHREADS / kWave) * kZooWindowSlots];
                 T xh[4], hv[4], xn[4];
                 int kk[4];
 #pragma unroll
@@ -157,7 +157,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                     xn[j] = (T)0;
                     kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                 }
-                zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * 512, lane);
+                zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     obs_next[j] = xn[j] / KK[j] - (T)1;
