@@ -464,7 +464,15 @@ def main():
         ab = make_actions(torch, cfg, big, rows)
         eb.step_many(ab, 24)
         us, _ = timed_steps(torch, eb, ab, 100)
+        # the same env once more in a second allocation (made while the first is alive): at this size the launch time
+        # follows the allocation the arena landed in; reported beside the first, never instead
+        eb2 = make_env(gf, torch, args.config, big, 0, with_returns, False, args.v4_stored)
+        eb2.reset()
+        eb2.step_many(ab, 24)
+        us2, _ = timed_steps(torch, eb2, ab, 100)
+        del eb2
         out["hbm_resident"] = {"n_envs": big, "steps": 100, "bytes_per_env_step": bytes_per, "avg_launch_us": us,
+                               "avg_launch_us_second_allocation": us2,
                                "achieved_GBps": big * bytes_per / us / 1e3, "frac": big * bytes_per / us / 1e3 / HBM_PEAK_GBS,
                                "env_steps_per_s": big / us * 1e6, "kernel": eb.step_kernel_name(ab[0]),
                                "resident_MB": (big * (bytes_per - 1 - 4) / 2 + big * 5 + rows * big * 4) / 1e6,
