@@ -384,6 +384,19 @@ struct FusedArgs {
     DivK dk;                 // exact x / K as a multiply when the scalar K is a power of two (never for per-env K)
 };
 
+// fishing-v11 only: the growth kind in force per env, the model list it is redrawn from and the per-kind parameters.
+// Every other model passes the empty struct (one byte of kernel arguments).
+template <typename T>
+struct FusedMixedArgs {
+    int32_t* model_idx;
+    int32_t n_models;
+    int32_t kinds[FISHING_N_KINDS];
+    GrowthT<T> zoo[FISHING_N_KINDS];
+};
+struct FusedNoExtra {};
+template <typename T, int MODEL>
+using FusedExtra = std::conditional_t<MODEL == kModelZooMixed, FusedMixedArgs<T>, FusedNoExtra>;
+
 constexpr int kPrefetch = 4;
 #ifndef FISHING_FUSED_LOCAL_KEYS
 #define FISHING_FUSED_LOCAL_KEYS 1
@@ -400,12 +413,14 @@ constexpr int kPrefetch = 4;
 // two waves per SIMD at N = 2^19, that pay for that).
 template <typename T, int MODEL, bool RAGGED, bool KP2 = false>
 __global__ void __launch_bounds__(256)
-step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offset, const uint64_t seed,
-                  const uint64_t step_counter_arg) {
+step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int64_t n, const uint64_t env_offset,
+                  const uint64_t seed, const uint64_t step_counter_arg) {
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     constexpr bool kZoo = is_zoo_tag(MODEL);
-    constexpr int kZooKind = kZoo ? (MODEL - kModelZoo) : -1;
-    static_assert(MODEL != kModelZooMixed && MODEL != kModelZooRT, "fishing-v11 steps through the per-step kernels");
+    constexpr bool zoo_mixed = (MODEL == kModelZooMixed);              // fishing-v11: growth kind per env
+    constexpr int kZooKind = (kZoo && !zoo_mixed) ? (MODEL - kModelZoo) : -1;
+    static_assert(MODEL != kModelZooRT, "the run-time-kind tag belongs to the general step kernel");
+    const int lane = threadIdx.x & (kWave - 1);
     const uint64_t step_counter0 = a.counter ? (*a.counter + step_counter_arg) : step_counter_arg;
     const bool auto_reset = a.auto_reset != 0;
     const bool derived = kPerEnv && a.derived != 0;
@@ -423,11 +438,13 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
         const bool full = RAGGED ? base + kEnvsPerThread <= n : true;
         T obs[4], rr[4], KK[4], sg[4], er[4], rew[4];
         int32_t t[4];
+        int32_t kind[4];
         bool dn[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             obs[j] = (T)0;
             t[j] = 0;
+            kind[j] = FISHING_KIND_BEVERTON_HOLT;
             rr[j] = a.pr;
             KK[j] = a.pK;
             sg[j] = a.sigma;
@@ -443,6 +460,7 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
                 load4<T>(a.K, base, n, full, KK, a.pK);
             }
             if (drift) load4<T>(a.r, base, n, full, rr, a.pr);
+            if constexpr (zoo_mixed) load4<int32_t>(ex.model_idx, base, n, full, kind, FISHING_KIND_BEVERTON_HOLT);
             if (a.sigma_arr) load4<T>(a.sigma_arr, base, n, full, sg, a.sigma);
             if (a.ep_return) load4<T>(a.ep_return, base, n, full, er, (T)0);
         }
@@ -471,6 +489,7 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
         }
         const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
         bool kr_dirty = false;
+        bool kind_dirty = false;
 
         for (int32_t s0 = 0; s0 < a.n_steps; s0 += kPrefetch) {
 #pragma unroll
@@ -502,12 +521,52 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
                 T o2[4];
                 int32_t t2[4];
                 bool fresh[4];
+                bool stepped = false;
+                if constexpr (zoo_mixed) {
+                    if (!a.sigma_arr) {     // wave-uniform: regroup the wave's envs by growth function, as the per-step kernel
+                        __shared__ ZooSlot<T> win[4 * kZooWindowSlots];
+                        T xh[4], hv[4], xn[4];
+                        int kk[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const T quota = quota_cts<T>((T)a_f[j], KK[j]);
+                            fresh[j] = auto_reset || !((t[j] > a.Tmax) || ((obs[j] + (T)1) * KK[j] <= (T)0));
+                            const T x = (obs[j] + (T)1) * KK[j];
+                            hv[j] = (quota < x) ? quota : x;
+                            const T d = x - hv[j];
+                            xh[j] = ((T)0 > d) ? (T)0 : d;
+                            xn[j] = (T)0;
+                            kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+                        }
+                        zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            o2[j] = xn[j] / KK[j] - (T)1;
+                            rew[j] = ((T)0 > hv[j]) ? (T)0 : hv[j];
+                            t2[j] = t[j] + 1;
+                            dn[j] = (t2[j] > a.Tmax) || (xn[j] <= (T)0);
+                            if (RAGGED) dn[j] = dn[j] && (base + j < n);
+                            fresh[j] = fresh[j] && dn[j];
+                            er[j] = er[j] + rew[j];
+                            obs[j] = o2[j];
+                            t[j] = t2[j];
+                        }
+                        stepped = true;
+                    }
+                }
+                if (!stepped) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
                                                                 : quota_cts<T>((T)a_f[j], KK[j]);
                     fresh[j] = auto_reset || !((t[j] > a.Tmax) || ((obs[j] + (T)1) * KK[j] <= (T)0));
-                    if constexpr (kZoo) {
+                    if constexpr (zoo_mixed) {          // per-env sigma: a straight per-lane switch over the growth functions
+                        const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+                        GrowthT<T> P = ex.zoo[kk];
+                        P.sigma = sg[j];
+                        env_step_zoo<T, -1, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], a.Tmax, o2[j], rew[j], dn[j],
+                                                   t2[j]);
+                    } else if constexpr (kZoo) {
                         GrowthT<T> P = a.growth;
                         if (a.sigma_arr) P.sigma = sg[j];
                         if (drift) {                     // growth_models.py:151: drift first, then draw
@@ -528,6 +587,7 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
                     er[j] = er[j] + rew[j];
                     obs[j] = o2[j];
                     t[j] = t2[j];
+                }
                 }
                 if (active) {
                     if (a.reward_steps) store4<T, 1>(a.reward_steps + (int64_t)s * a.out_stride, base, n, full, rew);
@@ -551,6 +611,11 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
                         for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
                     }
                     if (auto_reset) {
+                        if constexpr (zoo_mixed) {      // growth_models.py:200: a new model for the next episode
+                            if (redraw_kinds(seed_s, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, ex.kinds,
+                                             ex.n_models, dn, kind))
+                                kind_dirty = true;
+                        }
                         if (kPerEnv) {      // the next episode's (K, r): the draw a later derivation would re-make
                             if (redraw_tile<T, MODEL>(seed_s, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
                                                       a.K_mean, a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs, t))
@@ -577,6 +642,9 @@ step_fused_kernel(const FusedArgs<T> a, const int64_t n, const uint64_t env_offs
                 store4<T>(a.r, base, n, full, rr);
             }
             if (drift) store4<T>(a.r, base, n, full, rr);
+            if constexpr (zoo_mixed) {
+                if (kind_dirty) store4<int32_t>(ex.model_idx, base, n, full, kind);
+            }
             if (a.done) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -599,7 +667,8 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
     if ((reward_steps || done_steps) && (out_stride < n || (out_stride & 15))) return FISHING_ERR_ALIGN;
     if (misaligned(reward_steps) || misaligned(done_steps)) return FISHING_ERR_ALIGN;
     // the streams only the per-step kernels produce
-    if (b->z_ext || b->terminal_obs || b->done_bits || p->model == FISHING_MODEL_V11) return FISHING_ERR_UNSUPPORTED;
+    if (b->z_ext || b->terminal_obs || b->done_bits) return FISHING_ERR_UNSUPPORTED;
+    if (p->model == FISHING_MODEL_V11 && !b->model_idx) return FISHING_ERR_NULL;
     if (p->launch_threads != 0 && p->launch_threads != 256) return FISHING_ERR_UNSUPPORTED;
     if (n == 0 || n_steps == 0) return FISHING_OK;
     const ParamsT<T> pt = narrow_params<T>(*p);
@@ -620,25 +689,34 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
     const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
     return with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
-        if constexpr (kTag != kModelZooMixed && sizeof(T) == 8) {
+        FusedExtra<T, kTag> ex{};
+        if constexpr (kTag == kModelZooMixed) {
+            ex.model_idx = bt.model_idx;
+            ex.n_models = pt.n_models;
+            for (int k = 0; k < FISHING_N_KINDS; ++k) {
+                ex.kinds[k] = pt.kinds[k];
+                ex.zoo[k] = pt.zoo[k];
+            }
+        }
+        if constexpr (sizeof(T) == 8) {
             // the float64 parity layout is not the fast path: one ragged-capable instantiation over the whole batch
             int blocks, threads;
             launch_shape(p, n, blocks, threads);
-            return launch_kernel(step_fused_kernel<T, kTag, true>, blocks, 256, (hipStream_t)stream, a, n, (uint64_t)env_offset,
-                                 seed, step_counter);
-        } else if constexpr (kTag != kModelZooMixed) {
+            return launch_kernel(step_fused_kernel<T, kTag, true>, blocks, 256, (hipStream_t)stream, a, ex, n,
+                                 (uint64_t)env_offset, seed, step_counter);
+        } else {
             if (n_full > 0) {
                 int blocks, threads;
                 launch_shape(p, n_full, blocks, threads);
                 int rc2;
                 if constexpr (kTag != FISHING_MODEL_V4 && !is_zoo_tag(kTag)) {
                     rc2 = a.dk.pow2 ? launch_kernel(step_fused_kernel<T, kTag, false, true>, blocks, 256, (hipStream_t)stream, a,
-                                                    n_full, (uint64_t)env_offset, seed, step_counter)
+                                                    ex, n_full, (uint64_t)env_offset, seed, step_counter)
                                     : launch_kernel(step_fused_kernel<T, kTag, false, false>, blocks, 256, (hipStream_t)stream, a,
-                                                    n_full, (uint64_t)env_offset, seed, step_counter);
+                                                    ex, n_full, (uint64_t)env_offset, seed, step_counter);
                 } else {    // per-env K (fishing-v4) and the zoo (x / K only in the obs map: its growth functions divide by their own K)
-                    rc2 = launch_kernel(step_fused_kernel<T, kTag, false, false>, blocks, 256, (hipStream_t)stream, a, n_full,
-                                        (uint64_t)env_offset, seed, step_counter);
+                    rc2 = launch_kernel(step_fused_kernel<T, kTag, false, false>, blocks, 256, (hipStream_t)stream, a, ex,
+                                        n_full, (uint64_t)env_offset, seed, step_counter);
                 }
                 if (rc2 != 0 || n_full == n) return rc2;
             }
@@ -655,11 +733,10 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
             tl.sigma_arr = a.sigma_arr ? a.sigma_arr + o : nullptr;
             tl.reward_steps = a.reward_steps ? a.reward_steps + o : nullptr;
             tl.done_steps = a.done_steps ? a.done_steps + o : nullptr;
+            if constexpr (kTag == kModelZooMixed) ex.model_idx = ex.model_idx + o;
             // (the tail adds its record to workgroup slot 0, as the per-step path.s tail launch does)
-            return launch_kernel(step_fused_kernel<T, kTag, true>, 1, 256, (hipStream_t)stream, tl, n - n_full,
+            return launch_kernel(step_fused_kernel<T, kTag, true>, 1, 256, (hipStream_t)stream, tl, ex, n - n_full,
                                  (uint64_t)(env_offset + n_full), seed, step_counter);
-        } else {
-            return (int)FISHING_ERR_MODEL;
         }
     });
 }

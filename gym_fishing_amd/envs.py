@@ -652,8 +652,7 @@ class BaseFishingEnv(_gym_env_base()):
         fused=True runs them in ONE kernel launch (fishing_step_fused_*: state in registers, action rows
         prefetched) -- bit-identical results, and the fast path while a launch per step is latency-bound
         (N <= 2^20); `rewards_out` [n_steps, N] (env dtype) / `dones_out` [n_steps, N] (uint8 or bool) then receive every
-        step's reward / done rows.  Not available with terminal-observation / done_bits records, fishing-v11 or
-        rng="numpy"."""
+        step's reward / done rows.  Not available with terminal-observation / done_bits records or rng="numpy"."""
         want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
         if not (isinstance(actions, torch.Tensor) and actions.device == self.device and actions.dtype == want
                 and actions.dim() == 2 and actions.shape[1] == self.num_envs and actions.stride(1) == 1

@@ -207,8 +207,8 @@ int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, c
  * and done_steps + k * out_stride (u8).  The launch-bound regime's fast path (n <= 2^20: a dependent
  * launch costs ~2.7 us whatever it moves).  Bit-identical to n_steps fishing_step_* calls with the same
  * step_counter: same Philox counters, same arithmetic; FishingBuffers.reward / .done receive the last
- * step's values, return_partials the same record.  Not for z_ext / terminal_obs / done_bits / fishing-v11
- * (FISHING_ERR_UNSUPPORTED: use step()). */
+ * step's values, return_partials the same record.  Every model id (fishing-v11 needs model_idx, as step()).
+ * Not for z_ext / terminal_obs / done_bits (FISHING_ERR_UNSUPPORTED: use step()). */
 int fishing_step_fused_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                            int64_t action_stride, int32_t ring_len, int32_t n_steps, void* reward_steps,
                            uint8_t* done_steps, int64_t out_stride, uint64_t seed, uint64_t step_counter,

@@ -32,3 +32,25 @@ for policy, param in (("random", 0.0), ("escapement", 0.5)):
         ts.append(e0.elapsed_time(e1))
     ms = statistics.median(ts)
     print(json.dumps({"id": "fishing-v11", "rollout": policy, "env_steps_per_s": "%.3e" % (n * 505 / ms * 1e3)}), flush=True)
+# caller-driven steps: a launch per step vs fishing_step_fused_f32 (101 steps per launch), launch-bound sizes
+for ln in (19, 20):
+    nn = 1 << ln
+    ring2 = torch.empty((8, nn + 3072), device="cuda"); a2 = ring2[:, :nn]; a2.copy_(torch.rand((8, nn), device="cuda") * 0.4 - 1.0)
+    env = gf.make("fishing-v11", num_envs=nn, seed=1, track_returns=True)
+    for d in env.model_params.values():
+        d["sigma"] = 0.1
+    env.reset(); env.step_many(a2, 202); env.step_many(a2, 101, fused=True); torch.cuda.synchronize()
+    res = {}
+    for fused in (False, True):
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                env.step_many(a2, 101, fused=fused)
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / 404)
+        res["fused" if fused else "per_step"] = round(statistics.median(ts), 3)
+    print(json.dumps({"id": "fishing-v11", "log2_n": ln, "us_per_step": res,
+                      "env_steps_per_s_fused": "%.3e" % (nn / res["fused"] * 1e6)}), flush=True)
+    del env

@@ -143,6 +143,8 @@ FUSED_CASES = [
     ("v6", fo.MODEL_V6, dict(sigma=0.1), False),
     ("v7", fo.MODEL_V7, dict(sigma=0.1, r=0.7, K=1.5, M=1.5, q=3.0, b=0.15, a=0.2), False),
     ("v10", fo.MODEL_V10, dict(sigma=0.1, r=0.8, alpha=-0.007), False),
+    ("v11", fo.MODEL_V11, dict(sigma=0.0), False),             # growth function per env, redrawn per episode
+    ("v11_sigma_array", fo.MODEL_V11, dict(sigma=0.0), False),   # ... with a per-env sigma (the per-lane switch path)
 ]
 
 
@@ -157,11 +159,14 @@ def test_fused_step_many_equals_per_step_launches(hh, case, auto, dtype):
     import torch
     from gym_fishing_amd import _capi
     lib = _capi.lib()
-    _, model, kw, derived = case
+    case_name, model, kw, derived = case
     n, off, seed, T, R, c0 = 2 * 1024 + 37, 12, 4242, 23, 5, 100
     per_env = model == fo.MODEL_V4
     drift = model == fo.MODEL_V10
+    mixed = model == fo.MODEL_V11
     kw = dict(kw, Tmax=6, auto_reset=auto)
+    if mixed:
+        kw.update(models=[4, 0, 3, 1, 2], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE])
     pk = dict(derived=True, origin=(c0, 0)) if derived else {}
     p = hh.params(model, **kw, **pk)
     rng = np.random.default_rng(5)
@@ -172,7 +177,9 @@ def test_fused_step_many_equals_per_step_launches(hh, case, auto, dtype):
 
     def mk():
         st = hh.State(n, dtype, model, np.zeros(n), r=(np.full(n, kw.get("r", 0.3)) if (per_env and not derived) or drift else None),
-                      K=np.full(n, 1.0) if per_env and not derived else None, ep_return=True)
+                      K=np.full(n, 1.0) if per_env and not derived else None, ep_return=True,
+                      model_idx=np.zeros(n, np.int32) if mixed else None,
+                      sigma=np.linspace(0.02, 0.2, n) if case_name == "v11_sigma_array" else None)
         st.reset(p, seed=seed, counter=0, env_offset=off)
         return st
     A, B = mk(), mk()
@@ -188,7 +195,8 @@ def test_fused_step_many_equals_per_step_launches(hh, case, auto, dtype):
     for s in range(T):
         same(rs[s], rows_r[s], "reward row %d" % s)
         assert np.array_equal(ds[s], rows_d[s]), "done row %d" % s
-    names = ["obs", "t", "reward", "done", "ep_return"] + (["K", "r"] if per_env and not derived else []) + (["r"] if drift else [])
+    names = (["obs", "t", "reward", "done", "ep_return"] + (["K", "r"] if per_env and not derived else []) + (["r"] if drift else [])
+             + (["model_idx"] if mixed else []))
     for name in names:
         assert torch.equal(getattr(A, name), getattr(B, name)), name
     ra, rb = A.record(), B.record()
@@ -202,7 +210,7 @@ def test_fused_step_many_equals_per_step_launches(hh, case, auto, dtype):
     # ... and without the per-step rows (only the last step's reward / done are written)
     C = mk()
     C.step_fused(p, ring, T, seed=seed, step_counter=c0, env_offset=off, per_step=False)
-    for name in ("obs", "t", "reward", "done", "ep_return"):
+    for name in ("obs", "t", "reward", "done", "ep_return") + (("model_idx",) if mixed else ()):
         assert torch.equal(getattr(A, name), getattr(C, name)), name
 
 

@@ -273,6 +273,48 @@ def test_zoo_simulate_uses_the_fused_rollout(hh):
     assert fused.shape == stepwise.shape == (800, 5) and np.array_equal(fused, stepwise)
 
 
+@pytest.mark.parametrize("env_id", ["fishing-v6", "fishing-v10", "fishing-v11"])
+def test_zoo_env_step_many_fused_equals_launch_per_step(hh, env_id):
+    """env.step_many(fused=True) for the zoo, fishing-v11 (growth function per env, redrawn at every auto-reset inside
+    the launch) included: every per-step reward / done row and the final state equal a launch per step."""
+    import torch
+    import gym_fishing_amd as gf
+    n, K = 3 * 1024 + 5, 37
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    buf = torch.rand((6, n + 7), device="cuda", generator=g) * 1.2 - 1.1      # row stride: a multiple of 4 elements
+    acts = buf[:, :n]
+
+    def mk():
+        kw = {} if env_id == "fishing-v11" else dict(sigma=0.1)
+        env = gf.make(env_id, num_envs=n, seed=11, Tmax=9, track_returns=True, **kw)
+        if env_id == "fishing-v11":
+            for d in env.model_params.values():
+                d["sigma"] = 0.1
+        env.reset()
+        return env
+    A, B = mk(), mk()
+    rows_r, rows_d = [], []
+    for k in range(K):
+        _, r, d, _ = A.step(acts[k % 6])
+        rows_r.append(r.clone())
+        rows_d.append(d.clone())
+    stride = (n + 15) // 16 * 16
+    rr = torch.empty((K, stride), device="cuda")[:, :n]
+    dd = torch.empty((K, stride), dtype=torch.uint8, device="cuda")[:, :n]
+    B.step_many(acts, K, fused=True, rewards_out=rr, dones_out=dd)
+    for k in range(K):
+        assert torch.equal(rr[k].view(torch.int32), rows_r[k].view(torch.int32)), (env_id, k)
+        assert torch.equal(dd[k].bool(), rows_d[k].bool()), (env_id, k)
+    for key in ("_obs", "_t"):
+        assert torch.equal(getattr(A, key).view(torch.int32), getattr(B, key).view(torch.int32)), key
+    if env_id == "fishing-v11":
+        assert torch.equal(A._model_idx, B._model_idx)
+        assert len(set(A._model_idx.cpu().tolist())) == 5
+    ea, eb = A.episode_stats(), B.episode_stats()
+    assert ea["n_episodes"] == eb["n_episodes"] > n
+
+
 @pytest.mark.parametrize("model", [fo.MODEL_V5, fo.MODEL_V6, fo.MODEL_V7, fo.MODEL_V8, fo.MODEL_V9, fo.MODEL_V10])
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
