@@ -6,7 +6,9 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "_build", "libfishing_oracle.so")
+# FISHING_ORACLE_LIB: another build of the same source, e.g. `make -C oracle sanitize` (ASan + UBSan; run the tests with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0)
+LIB = os.environ.get("FISHING_ORACLE_LIB") or os.path.join(HERE, "_build", "libfishing_oracle.so")
 
 c_i32, c_i64, c_u64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p
 _lib = None
