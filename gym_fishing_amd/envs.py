@@ -524,6 +524,12 @@ class BaseFishingEnv(_gym_env_base()):
         then launch with frozen arguments plus a one-thread counter bump, so a hipGraph that
         captured them (torch.cuda.CUDAGraph, or gym_fishing_amd.graphs.GraphedSteps) draws
         fresh noise on every replay.  Same noise stream as the host-counter mode."""
+        if self._derived_capable:
+            # A captured launch freezes FishingParams, and with them the (step count, reset counter) origin that the derived
+            # fishing-v4 parameters date episodes from: a reset() after the capture would leave the graph deriving from a
+            # stale origin.  Graph mode therefore keeps the r / K arrays (same draws, same bits), for good.
+            self._leave_derived_mode()
+            self._derived_capable = False
         if self._counter is None:
             self._counter = torch.tensor([self._step_count], dtype=torch.int64, device=self.device)
             self._cbuf = None

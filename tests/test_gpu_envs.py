@@ -482,6 +482,34 @@ def test_graph_replay_draws_fresh_noise_and_matches_eager(gf):
     assert torch.equal(graphed.state, eager.state)
 
 
+def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
+    """fishing-v4 normally re-derives (K, r) from an origin carried in the launch arguments; a captured launch would keep
+    the origin of capture time.  enable_graph_replay() therefore switches the env to stored r / K arrays: replays before
+    AND after a later reset() equal an eager env (which stays in the derived mode) bit for bit."""
+    import torch
+    from gym_fishing_amd.graphs import GraphedSteps
+    n = 2048 + 24
+    acts = torch.rand((4, n), device="cuda") * 1.4 - 1.2
+    mk = lambda: gf.make("fishing-v4", sigma=0.05, sigma_p=0.2, num_envs=n, seed=5, Tmax=7)  # noqa: E731
+    eager, graphed = mk(), mk()
+    eager.reset()
+    graphed.reset()
+    assert eager._derived and graphed._derived
+    g = GraphedSteps(graphed, acts)                  # 4 steps per replay
+    assert not graphed._derived and graphed._K_arr is not None
+    for rnd in range(2):
+        for _ in range(3):
+            g.replay()
+            eager.step_many(acts, 4)
+        assert torch.equal(graphed.state, eager.state), rnd
+        assert torch.equal(graphed.K, eager.K) and torch.equal(graphed.r, eager.r), rnd
+        if rnd == 0:                                 # a reset of all envs between replays: new origin for the eager env
+            graphed.reset()
+            eager.reset()
+            assert eager._derived and not graphed._derived
+            assert torch.equal(graphed.K, eager.K)
+
+
 def test_bmsy_does_not_disturb_the_env_noise_level(gf):
     """BMSY()/msy() evaluate population_draw at sigma = 0 (models/policies.py:61-65) and must
     leave the env's own sigma in force afterwards."""
