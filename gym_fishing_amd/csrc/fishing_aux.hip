@@ -152,7 +152,12 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
     if (n == 0) return FISHING_OK;
     const ParamsT<T> pt = narrow_params<T>(*p);
     BuffersT<T> bt = typed_buffers<T>(*b);
-    if (p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED)) bt.K = bt.r = nullptr;
+    if (p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED)) {
+        // envs reset one by one no longer share the origin the derivation dates episodes from: the caller
+        // materialises the parameters (fishing_v4_params_*) and continues with arrays
+        if (mask) return FISHING_ERR_UNSUPPORTED;
+        bt.K = bt.r = nullptr;
+    }
     const int blocks = grid_for(n, 2048);
     hipStream_t s = (hipStream_t)stream;
     return with_model_tag(p->model, [&](auto tag) {

@@ -180,7 +180,8 @@ int fishing_step_many_f64(const FishingParams* p, int64_t n, int64_t env_offset,
 
 /* BaseFishingEnv.reset (envs/base_fishing_env.py:83-91) / FishingModelError.reset
  * (envs/fishing_model_error.py:41-48).  mask: u8[n], nullable => reset every env.
- * Writes obs, t = 0, ep_return = 0 (and K, r for v4). */
+ * Writes obs, t = 0, ep_return = 0 (and K, r for v4; under FISHING_FLAG_V4_DERIVED nothing more -- and only a
+ * reset of every env is served: a mask returns FISHING_ERR_UNSUPPORTED). */
 int fishing_reset_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                       const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream);
 int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,

@@ -80,6 +80,8 @@ def test_argument_errors_need_no_gpu(lib):
     p.sigma_p = 0.1
     p.flags = _capi.FLAG_V4_DERIVED | _capi.FLAG_T_U8
     assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -7      # derived parameters need the int32 year counter
+    p.flags = _capi.FLAG_V4_DERIVED
+    assert lib.fishing_reset_f32(p, 4, 0, b, 24576, 0, 0, None) == -7     # ... and a reset of ALL envs (no mask)
     p.flags = 0
     assert lib.fishing_v4_params_f32(p, 4, 0, None, None, None, 0, 0, None) == -1
     p.model = _capi.MODEL_V1
