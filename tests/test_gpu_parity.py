@@ -259,7 +259,7 @@ def test_device_philox_words_bit_exact_and_normals_close(hh):
         for k in range(4):
             assert (words[:, k] == w[k]).all(), "philox word %d" % k
         e0, e1 = fo.box_muller(w[0], w[1])
-        if tag != fo.STREAM_NOISE:    # (zK, zr) of the fishing-v4 redraw: one block per env pair
+        if tag != fo.STREAM_NOISE:    # (zK, zr) of the fishing-v4 redraw: one Philox2x32 block per env
             e0, e1 = fo.reset_normals(seed, np.arange(off, off + n, dtype=np.uint64), counter, tag)
             assert not np.array_equal(e0[0::2], e0[1::2])
         # hardware log2/sqrt/sin/cos vs libm in float64: absolute error of a few 1e-6
