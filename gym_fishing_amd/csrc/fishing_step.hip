@@ -297,7 +297,7 @@ constexpr int SIGARR = 1 << 3;     // per-env noise scale
 constexpr int T8 = 1 << 4;         // compact layout: one-byte year counters
 constexpr int TERM = 1 << 5;       // terminal_obs: the observation before the fused auto-reset (SB3)
 constexpr int BITS = 1 << 6;       // done_bits: wave-ballot termination mask
-constexpr int ZZ = 1 << 7;         // zig-zag tile walk (N >= 2^25); never under OPT
+constexpr int ZZ = 1 << 7;         // zig-zag tile walk (N >= 2^25); never under OPT (the catch-alls read LeanArgs::zz_rt)
 constexpr int DERIVED = 1 << 8;    // fishing-v4: (K, r) re-derived from the Philox streams, no r / K arrays
 constexpr int DRIFT = 1 << 9;      // fishing-v10: per-env r, drifting by alpha every draw
 constexpr int OPT = 1 << 10;
@@ -329,6 +329,7 @@ struct LeanArgs {
     uint32_t auto_reset;
     int32_t noise_rt;        // feat::kNoiseRT: the noise mode of this launch
     uint32_t t8_rt, derived_rt, drift_rt;    // feat::OPT: run-time values of T8 / DERIVED / DRIFT
+    uint32_t zz_rt;          // feat::OPT: zig-zag tile walk for this launch (the exact instantiations carry feat::ZZ instead)
     uint64_t origin_step, origin_counter;    // DERIVED (derive_model_error)
     GrowthT<T> growth;       // fishing-v5..v10: the growth function's parameter set (unused, hence never
                              // loaded, by the v0/v1/v2/v4 instantiations)
@@ -362,7 +363,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
     const bool BITS = (F & feat::BITS) && (kExact || a.done_bits != nullptr);
     const bool DERIVED = (F & feat::DERIVED) && (kExact || a.derived_rt != 0);
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
-    constexpr bool ZZ = (F & feat::ZZ) != 0;
+    const bool ZZ = (F & feat::ZZ) != 0 || (kOpt && a.zz_rt != 0);
     const int noise = ((F & feat::kNoiseMask) == feat::kNoiseRT) ? a.noise_rt : (F & feat::kNoiseMask);
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
@@ -404,7 +405,8 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         // ZZ (launched for N >= 2^25, far outside the 256 MiB Infinity Cache): odd steps walk the tiles
         // backwards, so what the previous step touched last is still cached when this one starts there
         // (N = 2^26: 331 -> 297 us).  Inside the cache the forward walk is the faster one (2^22: 16.1 vs
-        // 16.5 us), and even a run-time switch costs the returns variant 2.5 % there: own instantiations.
+        // 16.5 us), and even a run-time switch costs the returns variant 2.5 % there: own instantiations.  The
+        // catch-alls (every fp64 request among them) take the direction as a run-time flag, zz_rt.
         const int64_t tile = (ZZ && (step_counter & 1)) ? (ntiles - 1 - it) : it;
         const int64_t base = (tile * 256 + threadIdx.x) * kEnvsPerThread;
         // The Philox round keys (seed + i * Weyl) are wave-uniform; hoisted out of this loop they sit in 20-30 SGPRs
@@ -848,7 +850,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     LeanArgs<T> a{bt.obs,   bt.action, bt.reward, bt.done,  bt.t,    bt.r,     bt.K,     bt.ep_return, bt.partials,
                   bt.counter, bt.sigma, bt.terminal_obs, bt.done_bits, bt.z_ext, pt.r, pt.K, pt.sigma, pt.C, pt.x0,
                   pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET),
-                  noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, pt.origin_step, pt.origin_counter, pt.growth,
+                  noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, pt.origin_step, pt.origin_counter, pt.growth,
                   pt.alpha, make_divk((double)pt.K)};
     // up to 4096 workgroups = one tile each at N = 2^22: 21.39 -> 21.13 us with returns against a cap of
     // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl).  From N = 2^25 on (state streams far beyond
@@ -875,6 +877,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     const int64_t step_bytes = n_full * (int64_t)(sizeof(T) == 4 ? 25 + (b->ep_return ? 8 : 0) + (b->sigma ? 4 : 0)
                                                                  : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0));
     const bool zigzag = step_bytes >= FISHING_ZZ_MIN_BYTES;
+    a.zz_rt = zigzag ? 1u : 0u;          // (read by the catch-alls only)
     const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;

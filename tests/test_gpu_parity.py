@@ -947,6 +947,39 @@ def test_lean_done_bits_variant_agrees_with_general_kernel_and_the_byte_mask(hh,
     assert seen > n
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_zigzag_walk_of_the_catch_all_kernels_agrees_with_general_kernel(hh, dtype):
+    """The catch-all instantiations (here: the terminal-observation stream in float32, and any float64 request) take the
+    walk direction as a run-time flag once a step streams ~500 MB: N = 2^25 + 3077 in float32, 2^24 + 3077 in float64.
+    Three steps (even, odd, even counters) against the general kernel, every stream bit-for-bit."""
+    import torch
+    n = (1 << (25 if dtype == np.float32 else 24)) + 3077
+    kw = dict(sigma=0.1, Tmax=2, auto_reset=True, K=1.5)
+    pa, pb = hh.params(fo.MODEL_V1, **kw), hh.params(fo.MODEL_V1, general=True, **kw)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    fn = lib.fishing_step_f32 if dtype == np.float32 else lib.fishing_step_f64
+    assert hh.kernel_name(pa, n, hh.State(4096, dtype, fo.MODEL_V1, dtype(-0.25), ep_return=True, terminal=True).buffers(a),
+                          dtype=dtype).endswith(", 3199>")
+    outs = []
+    for p in (pa, pb):
+        st = hh.State(n, dtype, fo.MODEL_V1, dtype(-0.25), ep_return=True, terminal=True)
+        for s in range(3):
+            assert fn(p, n, 0, st.buffers(a), 11, s, None) == 0
+        torch.cuda.synchronize()
+        outs.append(st)
+    A, B = outs
+    for name in ("obs", "reward", "done", "t", "ep_return", "terminal"):
+        x, y = getattr(A, name), getattr(B, name)
+        it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]
+        assert torch.equal(x.view(it), y.view(it)), name
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True) and ra[2] > n // 2
+    del A, B, outs
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 @pytest.mark.parametrize("which", ["v1", "v4_derived"])
 def test_zigzag_walk_at_large_n_agrees_with_general_kernel(hh, ret, which):
