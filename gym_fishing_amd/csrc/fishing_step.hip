@@ -337,24 +337,38 @@ struct LeanArgs {
     DivK dk;                 // KP2: the scalar K's exact reciprocal
 };
 
+// fishing-v11 only (MODEL == kModelZooMixed): the growth kind in force per env, the model list it is redrawn from and
+// the per-kind parameters.  Every other model passes the empty struct (one byte of kernel arguments).
+template <typename T>
+struct LeanMixedArgs {
+    int32_t* model_idx;
+    int32_t n_models;
+    int32_t kinds[FISHING_N_KINDS];
+    GrowthT<T> zoo[FISHING_N_KINDS];
+};
+struct LeanNoExtra {};
+template <typename T, int MODEL>
+using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, LeanNoExtra>;
+
 #ifndef FISHING_LEAN_ATTRS
 #define FISHING_LEAN_ATTRS
 #endif
 template <typename T, int MODEL, int F>
 __global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
-step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_offset, const uint64_t seed,
-                 const uint64_t step_counter_arg) {
+step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_t ntiles, const uint64_t env_offset,
+                 const uint64_t seed, const uint64_t step_counter_arg) {
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
-    constexpr bool kZoo = is_zoo_tag(MODEL);              // one growth function of the zoo, compile-time kind
+    constexpr bool kMixed = (MODEL == kModelZooMixed);    // fishing-v11: growth function per env
+    constexpr bool kZoo = is_zoo_tag(MODEL) && !kMixed;   // one growth function of the zoo, compile-time kind
     constexpr int kZooKind = kZoo ? (MODEL - kModelZoo) : -1;
     constexpr bool kOpt = (F & feat::OPT) != 0;
     constexpr bool kExact = !kOpt;
-    static_assert(MODEL != kModelZooMixed && MODEL != kModelZooRT, "fishing-v11 runs on the general kernel");
+    static_assert(MODEL != kModelZooRT, "the run-time-kind tag belongs to the general kernel");
     static_assert(!(F & feat::DRIFT) || MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT, "DRIFT is fishing-v10");
     static_assert(!(F & feat::DERIVED) || kPerEnv, "DERIVED is fishing-v4");
     static_assert(!((F & feat::ZZ) && kOpt), "ZZ has exact instantiations only");
     static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
-    static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo), "KP2: exact fishing-v0/v1/v2 instantiations");
+    static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || a.ep_return != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -420,12 +434,19 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         if constexpr (FISHING_LEAN_LOCAL_KEYS != 0 && (kPerEnv || (kOpt && sizeof(T) == 4))) asm volatile("" : "+s"(seed_it));
         T obs[4], rr[4], KK[4], z[4], er[4], sg[4];
         int32_t t[4], a_i[4];
+        int32_t kind[4] = {FISHING_KIND_BEVERTON_HOLT, FISHING_KIND_BEVERTON_HOLT, FISHING_KIND_BEVERTON_HOLT,
+                           FISHING_KIND_BEVERTON_HOLT};
         float a_f[4];
         {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 sg[j] = a.sigma;
                 er[j] = (T)0;
+            }
+            if constexpr (kMixed) {
+                const Vec4<int32_t> qk = *reinterpret_cast<const Vec4<int32_t>*>(ex.model_idx + base);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kind[j] = qk.v[j];
             }
             if (SIGARR) {
                 const Vec4<T> qs = *reinterpret_cast<const Vec4<T>*>(a.sigma_arr + base);
@@ -517,12 +538,48 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
         T obs_next[4], rew[4];
         int32_t t_next[4];
         bool dn[4];
+        bool stepped = false;
+        if constexpr (kMixed) {
+            if (!SIGARR) {      // wave-uniform: regroup the wave's envs by growth function (fishing_common.h: zoo_draw_regrouped)
+                __shared__ ZooSlot<T> win[4 * kZooWindowSlots];
+                T xh[4], hv[4], xn[4];
+                int kk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const T quota = quota_cts<T>((T)a_f[j], KK[j]);
+                    if (RET && LATCH) stale[j] = was_done<T>(obs[j], t[j], KK[j], a.Tmax);
+                    const T x = (obs[j] + (T)1) * KK[j];
+                    hv[j] = (quota < x) ? quota : x;
+                    const T d = x - hv[j];
+                    xh[j] = ((T)0 > d) ? (T)0 : d;
+                    xn[j] = (T)0;
+                    kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+                }
+                zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots,
+                                      (int)(threadIdx.x & (kWave - 1)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    obs_next[j] = xn[j] / KK[j] - (T)1;
+                    rew[j] = ((T)0 > hv[j]) ? (T)0 : hv[j];
+                    t_next[j] = t[j] + 1;
+                    dn[j] = (t_next[j] > a.Tmax) || (xn[j] <= (T)0);
+                }
+                stepped = true;
+            }
+        }
+        if (!stepped) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
                                                         : quota_cts<T>((T)a_f[j], KK[j]);
             if (RET && LATCH) stale[j] = was_done<T>(obs[j], t[j], KK[j], a.Tmax);
-            if constexpr (kZoo) {
+            if constexpr (kMixed) {         // per-env sigma: a straight per-lane switch over the growth functions
+                const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+                GrowthT<T> P = ex.zoo[kk];
+                P.sigma = sg[j];
+                env_step_zoo<T, -1, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], a.Tmax, obs_next[j], rew[j], dn[j],
+                                           t_next[j]);
+            } else if constexpr (kZoo) {
                 GrowthT<T> P = a.growth;
                 if (SIGARR) P.sigma = sg[j];
                 if (DRIFT) {                             // growth_models.py:151: drift first, then draw
@@ -538,6 +595,7 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
                 env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
                                    dn[j], t_next[j], (F & feat::KP2) ? DivK{true, a.dk.inv_f, a.dk.inv_d} : DivK{false, 0.0f, 0.0});
             }
+        }
         }
         {
             // reward and done are write-only streams nobody re-reads inside the step loop: nontemporal
@@ -575,6 +633,17 @@ step_kernel_lean(const LeanArgs<T> a, const int64_t ntiles, const uint64_t env_o
 #pragma unroll
             for (int j = 0; j < 4; ++j) qe.v[j] = er[j];
             *reinterpret_cast<Vec4<T>*>(a.ep_return + base) = qe;
+        }
+        if constexpr (kMixed) {     // growth_models.py:200: a new model for the next episode
+            if (auto_reset && __any(lane_done)) {
+                if (redraw_kinds(seed_it, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, ex.kinds, ex.n_models, dn,
+                                 kind)) {
+                    Vec4<int32_t> qk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qk.v[j] = kind[j];
+                    *reinterpret_cast<Vec4<int32_t>*>(ex.model_idx + base) = qk;
+                }
+            }
         }
         if (kPerEnv && !DERIVED) {
             if (auto_reset && __any(lane_done)) {
@@ -730,6 +799,7 @@ struct LeanCall {
     int blocks;
     hipStream_t s;
     std::string* name;
+    const void* extra;       // LeanMixedArgs<T> for fishing-v11, unused otherwise
 };
 
 template <typename T, int MODEL, int F>
@@ -740,7 +810,9 @@ int lean_launch(const LeanCall<T>& c) {
         *c.name = buf;
         return FISHING_OK;
     }
-    return launch_kernel(step_kernel_lean<T, MODEL, F>, c.blocks, 256, c.s, c.a, c.ntiles, c.env_offset, c.seed,
+    LeanExtra<T, MODEL> ex{};
+    if constexpr (MODEL == kModelZooMixed) ex = *static_cast<const LeanMixedArgs<T>*>(c.extra);
+    return launch_kernel(step_kernel_lean<T, MODEL, F>, c.blocks, 256, c.s, c.a, ex, c.ntiles, c.env_offset, c.seed,
                          c.step_counter);
 }
 
@@ -815,6 +887,7 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     // N = 2^22: fishing-v9 16.05 vs 17.7 us.  (The float64 parity layout gains under 1 % from exact instantiations --
     // 26.65 vs 26.87 us, it is bound by its 32-byte-per-lane access shape -- and runs on its catch-alls:
     // profiles/r02_ab_variants.jsonl.)
+    // (fishing-v11 included: growth function per env, regrouped by kind inside the wave)
     if constexpr (sizeof(T) == 4 && is_zoo_tag(MODEL)) {
         switch (req) {
             FISHING_LEAN_CASE(P);
@@ -837,8 +910,10 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
     const bool derived = p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED);
     const int64_t tile = 256 * kEnvsPerThread;
-    const bool lean = p->model != FISHING_MODEL_V11 && !(p->flags & FISHING_FLAG_DIAG_GENERAL_KERNEL) && b->reward &&
-                      b->done && (p->launch_threads == 0 || p->launch_threads == 256) && n >= tile;
+    // (fishing-v11 in float64 stays on the general kernel: its lean catch-all would spill to scratch memory)
+    const bool lean = !(p->flags & FISHING_FLAG_DIAG_GENERAL_KERNEL) && b->reward && b->done &&
+                      (p->launch_threads == 0 || p->launch_threads == 256) && n >= tile &&
+                      !(p->model == FISHING_MODEL_V11 && sizeof(T) == 8);
     if (!lean) {
         int blocks, threads;
         launch_shape(p, n, blocks, threads);
@@ -878,11 +953,20 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
                                                                  : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0));
     const bool zigzag = step_bytes >= FISHING_ZZ_MIN_BYTES;
     a.zz_rt = zigzag ? 1u : 0u;          // (read by the catch-alls only)
-    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name};
+    LeanMixedArgs<T> mixed{};
+    if (p->model == FISHING_MODEL_V11) {
+        mixed.model_idx = bt.model_idx;
+        mixed.n_models = pt.n_models;
+        for (int k = 0; k < FISHING_N_KINDS; ++k) {
+            mixed.kinds[k] = pt.kinds[k];
+            mixed.zoo[k] = pt.zoo[k];
+        }
+    }
+    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name, &mixed};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
-        if constexpr (kTag != kModelZooMixed) return lean_dispatch<T, kTag>(req, zigzag, call);
-        else return (int)FISHING_ERR_MODEL;
+        if constexpr (kTag == kModelZooMixed && sizeof(T) == 8) return (int)FISHING_ERR_MODEL;     // (not reached: see `lean`)
+        else return lean_dispatch<T, kTag>(req, zigzag, call);
     });
     if (rc != 0 || n_full == n || name) return rc;
     // ragged tail (< 1024 envs): one workgroup of the general kernel

@@ -274,8 +274,8 @@ def test_finished_envs_stepped_on_are_recorded_once(hh, kernel):
 # ------------------------------------------------------------------ which kernel runs what
 def test_kernel_names_follow_the_dispatch(hh):
     """fishing_step_kernel_name_* reports the instantiation the launch code picks: exact masks for the hot
-    requests, the catch-all of the (T, MODEL) for everything else, the general kernel for fishing-v11, batches
-    below one tile and the diagnostic flag."""
+    requests, the catch-all of the (T, MODEL) for everything else, the general kernel for fishing-v11 in float64,
+    batches below one tile and the diagnostic flag."""
     n = 1 << 22
     st = hh.State(4096, np.float32, fo.MODEL_V1, np.zeros(4096), ep_return=True, terminal=True, done_bits=True)
     full = st.buffers(st.action_tensor(np.zeros(4096, np.float32)))
@@ -310,6 +310,12 @@ def test_kernel_names_follow_the_dispatch(hh):
         "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, n=1000) == "fishing::step_kernel<float, 1>"
     assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True)) == "fishing::step_kernel_lean<float, 4, 258>"
+    # fishing-v11 (growth function per env): float32 on the lean kernel, float64 on the general one
+    p11 = hh.params(fo.MODEL_V11, sigma=0.1, models=[0, 1, 2, 3, 4], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE], auto_reset=True)
+    b11 = hh.State(4096, np.float32, fo.MODEL_V11, np.zeros(4096), model_idx=np.zeros(4096, np.int32), ep_return=True)
+    full11 = b11.buffers(b11.action_tensor(np.zeros(4096, np.float32)))
+    assert hh.kernel_name(p11, n, full11) == "fishing::step_kernel_lean<float, 105, 6>"
+    assert hh.kernel_name(p11, n, full11, np.float64) == "fishing::step_kernel<double, 105>"
 
 
 # ------------------------------------------------------------------ the host mirror in the derived mode
