@@ -895,6 +895,14 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
             default: break;
         }
     }
+    // fishing-v10 = Beverton-Holt with the per-env drifting r stream
+    if constexpr (sizeof(T) == 4 && MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT) {
+        switch (req) {
+            FISHING_LEAN_CASE(P | DRIFT);
+            FISHING_LEAN_CASE(P | DRIFT | RET);
+            default: break;
+        }
+    }
 #endif
 #undef FISHING_LEAN_CASE
     return lean_launch<T, MODEL, catch_all_mask<MODEL>()>(c);
