@@ -300,8 +300,8 @@ def test_kernel_names_follow_the_dispatch(hh):
     assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 4, 3455>"
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 4114>"
     assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 4098>"
-    # a K that is not a power of two keeps the correctly rounded division: the catch-all
-    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5)) == "fishing::step_kernel_lean<float, 1, 3199>"
+    # a K that is not a power of two keeps the correctly rounded division
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5)) == "fishing::step_kernel_lean<float, 1, 2>"
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=0.25)) == "fishing::step_kernel_lean<float, 1, 4098>"
     assert name(hh.params(fo.MODEL_V9, sigma=0.1)) == "fishing::step_kernel_lean<float, 104, 2>"
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, general=True)) == "fishing::step_kernel<float, 1>"
