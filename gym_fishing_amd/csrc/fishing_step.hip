@@ -846,11 +846,16 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
         switch (req) {
             FISHING_LEAN_CASE(P | KP2);
             FISHING_LEAN_CASE(P | KP2 | RET);
-            // any other K: the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns against the
-            // catch-all at N = 2^22)
-            FISHING_LEAN_CASE(P);
-            FISHING_LEAN_CASE(P | RET);
             default: break;
+        }
+        if (!zigzag) {      // (at the zig-zag sizes the catch-all, which can walk zig-zag, is the better choice)
+            switch (req) {
+                // any other K: the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns against
+                // the catch-all at N = 2^22)
+                FISHING_LEAN_CASE(P);
+                FISHING_LEAN_CASE(P | RET);
+                default: break;
+            }
         }
         if constexpr (MODEL == FISHING_MODEL_V1) {
             switch (req) {      // the compact layout bench.py --compact measures
@@ -892,19 +897,25 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     // 26.65 vs 26.87 us, it is bound by its 32-byte-per-lane access shape -- and runs on its catch-alls:
     // profiles/r02_ab_variants.jsonl.)
     // (fishing-v11 included: growth function per env, regrouped by kind inside the wave)
+    // At the zig-zag sizes their catch-alls, which can walk zig-zag, are the better choice (N = 2^26: fishing-v9 289 vs
+    // 314 us: profiles/r02_zz_catch_all.jsonl).
     if constexpr (sizeof(T) == 4 && is_zoo_tag(MODEL)) {
-        switch (req) {
-            FISHING_LEAN_CASE(P);
-            FISHING_LEAN_CASE(P | RET);
-            default: break;
+        if (!zigzag) {
+            switch (req) {
+                FISHING_LEAN_CASE(P);
+                FISHING_LEAN_CASE(P | RET);
+                default: break;
+            }
         }
     }
     // fishing-v10 = Beverton-Holt with the per-env drifting r stream
     if constexpr (sizeof(T) == 4 && MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT) {
-        switch (req) {
-            FISHING_LEAN_CASE(P | DRIFT);
-            FISHING_LEAN_CASE(P | DRIFT | RET);
-            default: break;
+        if (!zigzag) {
+            switch (req) {
+                FISHING_LEAN_CASE(P | DRIFT);
+                FISHING_LEAN_CASE(P | DRIFT | RET);
+                default: break;
+            }
         }
     }
 #endif
