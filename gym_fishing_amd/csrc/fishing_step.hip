@@ -900,7 +900,7 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     // At the zig-zag sizes their catch-alls, which can walk zig-zag, are the better choice (N = 2^26: fishing-v9 289 vs
     // 314 us: profiles/r02_zz_catch_all.jsonl).
     if constexpr (sizeof(T) == 4 && is_zoo_tag(MODEL)) {
-        if (!zigzag) {
+        if (!zigzag || MODEL == kModelZooMixed) {       // (fishing-v11 is VALU-bound: its exact kernels win at every size)
             switch (req) {
                 FISHING_LEAN_CASE(P);
                 FISHING_LEAN_CASE(P | RET);
