@@ -879,6 +879,7 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
                 default: break;
             }
         }
+        if (!zigzag || !(req & SIGARR) || (req & DERIVED))     // (stored arrays + sigma array have no zig-zag twin)
         switch (req) {
             FISHING_LEAN_CASE(P);
             FISHING_LEAN_CASE(P | RET);
