@@ -833,9 +833,15 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     constexpr int P = kNoisePhilox;
 #define FISHING_LEAN_CASE(MASK) \
     case (MASK): return lean_launch<T, MODEL, (MASK)>(c)
+    // Once a step streams ~500 MB the tiles are walked zig-zag (see the kernel).  Requests whose exact instantiation has
+    // a zig-zag twin take it; every other request goes to its catch-all there, which walks zig-zag by a run-time flag --
+    // measured better than an exact kernel walking forward (N = 2^26 zoo: 289 vs 314 us; fishing-v4 stored + sigma array
+    // at 2^24: 145 vs 156-177 us: profiles/r02_zz_catch_all.jsonl).  fishing-v11 is VALU-bound and keeps its exact kernels.
+    const bool forward = !zigzag || MODEL == kModelZooMixed;
     if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
-        // fishing-v0/v1/v2, float32, in-kernel noise, K a power of two: bare / with the return record, forward and
-        // zig-zag tile walk (another K: the catch-all)
+        // fishing-v0/v1/v2, float32, in-kernel noise: bare / with the return record.  K a power of two (KP2): forward and
+        // zig-zag; any other K keeps the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns
+        // against the catch-all at N = 2^22).
         if (zigzag) {
             switch (req | ZZ) {
                 FISHING_LEAN_CASE(P | KP2 | ZZ);
@@ -843,31 +849,26 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
                 default: break;
             }
         }
-        switch (req) {
-            FISHING_LEAN_CASE(P | KP2);
-            FISHING_LEAN_CASE(P | KP2 | RET);
-            default: break;
-        }
-        if (!zigzag) {      // (at the zig-zag sizes the catch-all, which can walk zig-zag, is the better choice)
+        if (forward) {
             switch (req) {
-                // any other K: the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns against
-                // the catch-all at N = 2^22)
+                FISHING_LEAN_CASE(P | KP2);
+                FISHING_LEAN_CASE(P | KP2 | RET);
                 FISHING_LEAN_CASE(P);
                 FISHING_LEAN_CASE(P | RET);
                 default: break;
             }
-        }
-        if constexpr (MODEL == FISHING_MODEL_V1) {
-            switch (req) {      // the compact layout bench.py --compact measures
-                FISHING_LEAN_CASE(P | KP2 | T8);
-                FISHING_LEAN_CASE(P | KP2 | T8 | RET);
-                default: break;
+            if constexpr (MODEL == FISHING_MODEL_V1) {
+                switch (req) {      // the compact layout bench.py --compact measures
+                    FISHING_LEAN_CASE(P | KP2 | T8);
+                    FISHING_LEAN_CASE(P | KP2 | T8 | RET);
+                    default: break;
+                }
             }
         }
     }
     if constexpr (sizeof(T) == 4 && MODEL == FISHING_MODEL_V4) {
         // fishing-v4 (per-env K: always the true division): stored or derived (K, r), sigma scalar or array (BASELINE
-        // config 5), bare / with the return record; the derived ones also with the zig-zag walk
+        // config 5), bare / with the return record; zig-zag twins for the derived ones and for stored + scalar sigma
         if (zigzag) {
             switch (req | ZZ) {
                 FISHING_LEAN_CASE(P | ZZ);
@@ -879,29 +880,27 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
                 default: break;
             }
         }
-        if (!zigzag || !(req & SIGARR) || (req & DERIVED))     // (stored arrays + sigma array have no zig-zag twin)
-        switch (req) {
-            FISHING_LEAN_CASE(P);
-            FISHING_LEAN_CASE(P | RET);
-            FISHING_LEAN_CASE(P | SIGARR);
-            FISHING_LEAN_CASE(P | SIGARR | RET);
-            FISHING_LEAN_CASE(P | DERIVED);
-            FISHING_LEAN_CASE(P | DERIVED | RET);
-            FISHING_LEAN_CASE(P | DERIVED | SIGARR);
-            FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET);
-            default: break;
+        if (forward) {
+            switch (req) {
+                FISHING_LEAN_CASE(P);
+                FISHING_LEAN_CASE(P | RET);
+                FISHING_LEAN_CASE(P | SIGARR);
+                FISHING_LEAN_CASE(P | SIGARR | RET);
+                FISHING_LEAN_CASE(P | DERIVED);
+                FISHING_LEAN_CASE(P | DERIVED | RET);
+                FISHING_LEAN_CASE(P | DERIVED | SIGARR);
+                FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET);
+                default: break;
+            }
         }
     }
 #ifndef FISHING_NO_ZOO_HOT
-    // float32 zoo (one growth function each): bare / with the return record.  Measured against the catch-all at
-    // N = 2^22: fishing-v9 16.05 vs 17.7 us.  (The float64 parity layout gains under 1 % from exact instantiations --
-    // 26.65 vs 26.87 us, it is bound by its 32-byte-per-lane access shape -- and runs on its catch-alls:
-    // profiles/r02_ab_variants.jsonl.)
-    // (fishing-v11 included: growth function per env, regrouped by kind inside the wave)
-    // At the zig-zag sizes their catch-alls, which can walk zig-zag, are the better choice (N = 2^26: fishing-v9 289 vs
-    // 314 us: profiles/r02_zz_catch_all.jsonl).
+    // float32 zoo (one growth function each; fishing-v11: growth function per env, regrouped by kind inside the wave):
+    // bare / with the return record.  Measured against the catch-all at N = 2^22: fishing-v9 16.05 vs 17.7 us.  (The
+    // float64 parity layout gains under 1 % from exact instantiations -- 26.65 vs 26.87 us, it is bound by its
+    // 32-byte-per-lane access shape -- and runs on its catch-alls: profiles/r02_ab_variants.jsonl.)
     if constexpr (sizeof(T) == 4 && is_zoo_tag(MODEL)) {
-        if (!zigzag || MODEL == kModelZooMixed) {       // (fishing-v11 is VALU-bound: its exact kernels win at every size)
+        if (forward) {
             switch (req) {
                 FISHING_LEAN_CASE(P);
                 FISHING_LEAN_CASE(P | RET);
@@ -911,7 +910,7 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     }
     // fishing-v10 = Beverton-Holt with the per-env drifting r stream
     if constexpr (sizeof(T) == 4 && MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT) {
-        if (!zigzag) {
+        if (forward) {
             switch (req) {
                 FISHING_LEAN_CASE(P | DRIFT);
                 FISHING_LEAN_CASE(P | DRIFT | RET);
