@@ -39,6 +39,25 @@ def _kernel_policy(model):
     return getattr(model, "kernel_policy", None)
 
 
+class _StringPolicy:
+    """predict() for the policy strings the fused kernel understands, for the step-by-step path: a constant action, or
+    uniform random actions from torch's generator (NOT the in-kernel Philox policy stream)."""
+
+    def __init__(self, env, kp):
+        self.env, self.kp = env, kp
+
+    def predict(self, obs, **kw):
+        env, (pol, param) = self.env, self.kp
+        n = env.num_envs
+        if pol == POLICY_CONSTANT:
+            if env.MODEL == 0:
+                return torch.full((n,), int(param), dtype=torch.int32, device=env.device), None
+            return torch.full((n,), float(param), dtype=torch.float32, device=env.device), None
+        if env.MODEL == 0:
+            return torch.randint(0, env.n_actions, (n,), dtype=torch.int32, device=env.device), None
+        return torch.rand(n, device=env.device) * 2.0 - 1.0, None
+
+
 def simulate_mdp(env, model, reps=1):
     """shared_env.py:29-54.  With an N-env batch every env of every batch is one rep of that table."""
     if not env._scalar:
@@ -87,7 +106,9 @@ def simulate_mdp_vec(env, model, n_eval_episodes):
     env [t, population of obs_i, action_i, reward_i, rep * N + i] BEFORE acting -- action / reward are the previous
     step's (initially action_space.low[0] and 0) -- then a final block of rows at t = Tmax; no break on done.
     The action column holds the raw action (not the quota simulate_mdp records).  A model with `kernel_policy`
-    runs inside the fused rollout kernel; any other is driven step by step with batched predict().
+    runs inside the fused rollout kernel; any other -- and fishing-v4, whose K changes at every auto-reset inside the
+    table, so that each row needs the K in force at that row (df_entry_vec asks the env itself, shared_env.py:15-26) --
+    is driven step by step with batched predict().
     fishing-v0: the reference's version needs action_space.low and fails on Discrete; here the initial action is 0."""
     N = env.num_envs
     if n_eval_episodes % N:
@@ -106,7 +127,8 @@ def simulate_mdp_vec(env, model, n_eval_episodes):
     try:
         for b in range(batches):
             obs = env.reset().reshape(-1).to(f64).clone()
-            if kp is not None and N % 4 == 0 and not env._np_rng:
+            K_rows = None
+            if kp is not None and N % 4 == 0 and not env._np_rng and not env._per_env:
                 traj = env.rollout(Tmax, policy=kp[0], param=kp[1], record=True).to(f64)     # [T, 4, N]
                 obs_rows = torch.cat([traj[:, 0], env.state.reshape(1, N).to(f64)])               # obs before each step + after the last
                 act_rows = torch.cat([torch.full((1, N), a0, dtype=f64, device=env.device), traj[:, 1]])
@@ -118,8 +140,16 @@ def simulate_mdp_vec(env, model, n_eval_episodes):
                 state = None
                 done = torch.zeros(N, dtype=torch.bool, device=env.device)
                 o = env.state
+                if not hasattr(model, "predict"):       # "random" / ("constant", a) outside the fused kernel
+                    if kp is None:
+                        raise ValueError("model needs a predict() method (or be 'random' / ('constant', a))")
+                    model = _StringPolicy(env, kp)
+                if env._per_env:    # fishing-v4 redraws K at every (auto-)reset: a row's population uses the K in force THEN
+                    K_rows = torch.empty((Tmax + 1, N), dtype=f64, device=env.device)
                 for t in range(Tmax):
                     obs_rows[t] = o.reshape(-1).to(f64)
+                    if K_rows is not None:
+                        K_rows[t] = env._K_view().to(f64)
                     try:
                         action, state = model.predict(o, state=state, mask=done)
                     except TypeError:                   # a predict(obs) without the SB3 keywords
@@ -129,8 +159,10 @@ def simulate_mdp_vec(env, model, n_eval_episodes):
                     act_rows[t + 1] = a.to(f64)
                     rew_rows[t + 1] = rew.to(f64)
                 obs_rows[Tmax] = o.reshape(-1).to(f64)
-            K = env._K_view().to(f64).reshape(1, N) if env._per_env else float(env.params["K"])
-            pop = (obs_rows + 1.0) * K                              # get_fish_population :158-160
+                if K_rows is not None:
+                    K_rows[Tmax] = env._K_view().to(f64)
+            K = K_rows if K_rows is not None else float(env.params["K"])
+            pop = (obs_rows + 1.0) * K                              # get_fish_population :158-160 (the env's K at that row)
             t_idx = torch.arange(Tmax + 1, device=env.device, dtype=f64).reshape(-1, 1).expand(Tmax + 1, N)
             rep = (b * N + torch.arange(N, device=env.device, dtype=f64)).reshape(1, N).expand(Tmax + 1, N)
             out.append(torch.stack([t_idx, pop, act_rows, rew_rows, rep], dim=-1).reshape(-1, 5).cpu().numpy())
