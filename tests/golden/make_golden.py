@@ -417,6 +417,32 @@ def main():
                                                   "n_eval_episodes": episodes, "S": float(model.S),
                                                   "msy": float(model.msy) if pname == "msy" else None}))
     np.savez_compressed(os.path.join(OUT, "reference_vec_sims.npz"), **vec)
+
+    # fishing-v4 through the same helper: K is redrawn at every reset, and df_entry_vec (shared_env.py:15-26) asks the
+    # env itself for each row's population -- so a row after an auto-reset inside the table uses the NEW K.  The harness
+    # logs the observation and the env's K at every get_fish_population call next to the table.
+    class LoggingVecEnv(MiniVecEnv):
+        def __init__(self, envs):
+            super().__init__(envs)
+            self.log = []
+
+        def env_method(self, name, *args, indices=None, **kw):
+            if name == "get_fish_population":
+                i = indices if isinstance(indices, int) else indices[0]
+                self.log.append((float(np.asarray(args[0]).reshape(-1)[0]), float(self.envs[i].K)))
+            return super().env_method(name, *args, indices=indices, **kw)
+
+    kw4 = {"sigma": 0.05, "sigma_p": 0.2, "Tmax": 7}
+    envs = [gym.make("fishing-v4", **kw4) for _ in range(3)]
+    np.random.seed(11)
+    lv = LoggingVecEnv(envs)
+    df = simulate_mdp_vec(lv, VecPolicy(constant(envs[0], a=0.2)), n_eval_episodes=6)
+    v4 = {"v4_constant/table": df.to_numpy(dtype=np.float64),
+          "v4_constant/obs_rows": np.array([o for o, _ in lv.log], dtype=np.float64),
+          "v4_constant/K_rows": np.array([k for _, k in lv.log], dtype=np.float64),
+          "v4_constant/meta": np.array(json.dumps({"id": "fishing-v4", "kwargs": kw4, "policy": "constant", "seed": 11,
+                                                   "num_envs": 3, "n_eval_episodes": 6, "S": float("nan"), "msy": None}))}
+    np.savez_compressed(os.path.join(OUT, "reference_vec_sims_v4.npz"), **v4)
     # get_action / get_quota round trips (base_fishing_env.py:135-156)
     env0 = gym.make("fishing-v0")
     env1 = gym.make("fishing-v1")

@@ -293,3 +293,49 @@ def test_zoo_single_step_bit_exact(c):
     assert_bit_equal(obs, c.obs, c.name + " obs")
     assert_bit_equal(rew, c.reward, c.name + " reward")
     assert (done == c.done).all() and (t == c.t).all()
+
+
+# ------------------------------------------------------------------ simulate_mdp_vec over fishing-v4 (K per row)
+def test_reference_vec_sim_of_fishing_v4_uses_the_K_in_force_at_each_row():
+    """tests/golden/reference_vec_sims_v4.npz: the reference's simulate_mdp_vec (shared_env.py:57-79) over three
+    FishingModelError envs, with the observation and the env's K logged at every get_fish_population call
+    (df_entry_vec, shared_env.py:15-26).  Facts of the reference this pins: a row's population is (obs + 1) * K with
+    the K the env holds AT THAT ROW -- after an auto-reset inside the table that is the redrawn K -- and the first obs
+    of an episode is x0 un-normalised (quirk B8).  The oracle's scalar envs behind the same harness, seeded the same
+    way, reproduce the table bit for bit."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from oracle import scalar_env
+    z = np.load(os.path.join(GOLDEN, "reference_vec_sims_v4.npz"))
+    tab, obs_rows, K_rows = z["v4_constant/table"], z["v4_constant/obs_rows"], z["v4_constant/K_rows"]
+    meta = json.loads(str(z["v4_constant/meta"]))
+    n, Tmax, reps = meta["num_envs"], meta["kwargs"]["Tmax"], meta["n_eval_episodes"] // meta["num_envs"]
+    assert tab.shape == (reps * (Tmax + 1) * n, 5)
+    assert np.array_equal(tab[:, 1], (obs_rows + 1.0) * K_rows)
+    K = K_rows.reshape(reps, Tmax + 1, n)
+    assert (K[:, 1:] != K[:, :-1]).any(axis=(0, 1)).all()          # every env changed its K inside a table
+    assert np.array_equal(obs_rows.reshape(reps, Tmax + 1, n)[:, 0], np.full((reps, n), 0.75))
+    # the oracle's scalar envs behind a DummyVecEnv-shaped loop (envs stepped in order, finished envs reset at once)
+    envs = [scalar_env.ScalarFishingEnv("fishing-v4", **meta["kwargs"]) for _ in range(n)]
+    np.random.seed(meta["seed"])
+    rows = []
+    for rep in range(reps):
+        obs = [e.reset() for e in envs]
+        action, reward = [-1.0] * n, [0.0] * n
+        for t in range(Tmax + 1):
+            for i, e in enumerate(envs):
+                rows.append([t, (obs[i][0] + 1) * e.K, action[i], reward[i], rep * n + i])
+            if t == Tmax:
+                break
+            for i, e in enumerate(envs):
+                a = np.array([0.2], dtype=np.float32).astype(np.float64)
+                o, r, d, _ = e.step(a)
+                if d:
+                    o = e.reset()
+                obs[i], action[i], reward[i] = o, 0.2, r
+    got = np.array(rows, dtype=np.float64)
+    assert np.array_equal(got[:, [0, 4]], tab[:, [0, 4]])
+    assert np.array_equal(got[:, 1], tab[:, 1]) and np.array_equal(got[:, 3], tab[:, 3])
+    assert np.allclose(got[:, 2], tab[:, 2], rtol=0, atol=1e-7)     # the raw action column (float32(0.2) in the reference's table)
