@@ -21,6 +21,7 @@ N_KINDS = 5
 FLAG_AUTO_RESET = 1
 FLAG_T_U8 = 4
 FLAG_V4_DERIVED = 8                  # fishing-v4: (K, r) re-derived in-kernel, no r / K arrays
+FLAG_PADDED_TILES = 16               # state buffers hold whole 1024-env tiles: a ragged batch steps in one launch
 FLAG_GENERAL_KERNEL = 0x80000000     # FISHING_FLAG_DIAG_GENERAL_KERNEL (tests, A/B timing)
 POLICY_RANDOM, POLICY_CONSTANT, POLICY_ESCAPEMENT, POLICY_MSY = 0, 1, 2, 3
 STREAM_NOISE, STREAM_AUTORESET, STREAM_RESET, STREAM_POLICY = 0, 1, 2, 3

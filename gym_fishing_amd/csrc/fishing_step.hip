@@ -330,6 +330,7 @@ struct LeanArgs {
     int32_t noise_rt;        // feat::kNoiseRT: the noise mode of this launch
     uint32_t t8_rt, derived_rt, drift_rt;    // feat::OPT: run-time values of T8 / DERIVED / DRIFT
     uint32_t zz_rt;          // feat::OPT: zig-zag tile walk for this launch (the exact instantiations carry feat::ZZ instead)
+    int64_t n_live;          // FISHING_FLAG_PADDED_TILES: the number of envs that exist (a multiple of 4); INT64_MAX otherwise
     uint64_t origin_step, origin_counter;    // DERIVED (derive_model_error)
     GrowthT<T> growth;       // fishing-v5..v10: the growth function's parameter set (unused, hence never
                              // loaded, by the v0/v1/v2/v4 instantiations)
@@ -423,6 +424,13 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         // catch-alls (every fp64 request among them) take the direction as a run-time flag, zz_rt.
         const int64_t tile = (ZZ && (step_counter & 1)) ? (ntiles - 1 - it) : it;
         const int64_t base = (tile * 256 + threadIdx.x) * kEnvsPerThread;
+        // FISHING_FLAG_PADDED_TILES: the state buffers have room for whole tiles, so a batch that is not a multiple of 1024
+        // envs still runs in this ONE launch (no second, one-workgroup launch for the tail: 3.7-4.2 us per step).  The
+        // envs behind the last one are scratch: stepped like any other, but they never finish (neither recorded nor
+        // redrawn), and the streams the CALLER owns -- actions, external noise -- are read at the last quad that exists
+        // instead of past their end.  One 64-bit compare and two selects per tile; `live` is true everywhere otherwise.
+        const bool live = base < a.n_live;
+        const int64_t cbase = live ? base : a.n_live - kEnvsPerThread;
         // The Philox round keys (seed + i * Weyl) are wave-uniform; hoisted out of this loop they sit in 20-30 SGPRs
         // for the whole kernel, which pushes the fishing-v4 variants (two generators) past 100 SGPRs = 7 instead of
         // 8 waves per SIMD.  Laundering the seed per tile keeps the key schedule next to its rounds (a scalar add
@@ -473,11 +481,11 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 a_f[j] = 0.0f;
             }
             if (MODEL == FISHING_MODEL_V0) {
-                const Vec4<int32_t> qa = *reinterpret_cast<const Vec4<int32_t>*>((const int32_t*)a.action + base);
+                const Vec4<int32_t> qa = *reinterpret_cast<const Vec4<int32_t>*>((const int32_t*)a.action + cbase);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a_i[j] = qa.v[j];
             } else {
-                const Vec4<float> qa = *reinterpret_cast<const Vec4<float>*>((const float*)a.action + base);
+                const Vec4<float> qa = *reinterpret_cast<const Vec4<float>*>((const float*)a.action + cbase);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a_f[j] = qa.v[j];
             }
@@ -501,7 +509,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 for (int j = 0; j < 4; ++j) er[j] = qe.v[j];
             }
             if (noise == kNoiseExt) {
-                const Vec4<T> qz = *reinterpret_cast<const Vec4<T>*>(a.z_ext + base);
+                const Vec4<T> qz = *reinterpret_cast<const Vec4<T>*>(a.z_ext + cbase);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) z[j] = qz.v[j];
             }
@@ -597,6 +605,8 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
             }
         }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dn[j] = dn[j] && live;       // (scratch envs never finish)
         {
             // reward and done are write-only streams nobody re-reads inside the step loop: nontemporal
             // stores (0.5-0.7 % at N = 2^22, 1.5 % at 2^24 / 2^26; profiles/r01g_lean_nt_stores.txt)
@@ -942,14 +952,18 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
         launch_shape(p, n, blocks, threads);
         return launch_general<T>(pt, bt, noise, n, env_offset, seed, step_counter, blocks, threads, s, name);
     }
-    const int64_t ntiles = n / tile;
-    const int64_t n_full = ntiles * tile;
+    // FISHING_FLAG_PADDED_TILES: the caller's state buffers have room for whole tiles -> the last, partial tile runs in
+    // the same launch (its scratch envs are stepped but never finish) instead of a second launch of the general kernel.
+    // (Whole quads only: the caller-owned action stream is read 16 bytes at a time.)
+    const bool padded = (p->flags & FISHING_FLAG_PADDED_TILES) != 0 && (n % tile) != 0 && (n % kEnvsPerThread) == 0;
+    const int64_t ntiles = padded ? (n + tile - 1) / tile : n / tile;
+    const int64_t n_full = padded ? n : ntiles * tile;
     const bool drift = p->model == FISHING_MODEL_V10;
     LeanArgs<T> a{bt.obs,   bt.action, bt.reward, bt.done,  bt.t,    bt.r,     bt.K,     bt.ep_return, bt.partials,
                   bt.counter, bt.sigma, bt.terminal_obs, bt.done_bits, bt.z_ext, pt.r, pt.K, pt.sigma, pt.C, pt.x0,
                   pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET),
-                  noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, pt.origin_step, pt.origin_counter, pt.growth,
-                  pt.alpha, make_divk((double)pt.K)};
+                  noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, padded ? n : INT64_MAX, pt.origin_step,
+                  pt.origin_counter, pt.growth, pt.alpha, make_divk((double)pt.K)};
     // up to 4096 workgroups = one tile each at N = 2^22: 21.39 -> 21.13 us with returns against a cap of
     // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl).  From N = 2^25 on (state streams far beyond
     // the Infinity Cache) FEWER workgroups looping over more tiles stream better from HBM -- 768 = 3 per CU:

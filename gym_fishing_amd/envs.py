@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import (FLAG_AUTO_RESET, FLAG_T_U8, FLAG_V4_DERIVED, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
+from ._capi import (FLAG_AUTO_RESET, FLAG_PADDED_TILES, FLAG_T_U8, FLAG_V4_DERIVED, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
                     MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11, POLICY_CONSTANT, POLICY_ESCAPEMENT,
                     POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
 from .spaces import is_discrete, space_classes
@@ -171,10 +171,18 @@ class BaseFishingEnv(_gym_env_base()):
         # HBM channel hash (measured at N = 2^22: 16.6 us unstaggered -> 16.1 us; profiles/
         # r01c_stream_stagger_experiment.jsonl).
         esz = torch.empty(0, dtype=dtype).element_size()
-        sizes = [(dtype, N * esz), (torch.uint8, N) if self.compact else (torch.int32, N * 4), (dtype, N * esz),
-                 (torch.uint8, N)]
+        # FISHING_FLAG_PADDED_TILES: with room for whole 1024-env tiles behind every state stream, a batch that is not a
+        # multiple of 1024 envs steps in ONE launch instead of two (N = 10^6: 9.3 -> 5.1 us per step).  The envs behind
+        # the N-th are scratch; every tensor the env hands out is the [:N] view.
+        self._cap = N
+        if not self._host_mapped and N > 1024 and N % 1024 and N % 4 == 0:
+            self._cap = (N + 1023) // 1024 * 1024
+        self._padded = self._cap != N
+        C = self._cap
+        sizes = [(dtype, C * esz), (torch.uint8, C) if self.compact else (torch.int32, C * 4), (dtype, C * esz),
+                 (torch.uint8, C)]
         if track_returns:
-            sizes.append((dtype, N * esz))
+            sizes.append((dtype, C * esz))
         stagger = 0 if self._host_mapped else self._STREAM_STAGGER  # host-mapped: nothing to de-alias, keep the arena small
         offs, off = [], 0
         for k, (_, nbytes) in enumerate(sizes):
@@ -191,12 +199,13 @@ class BaseFishingEnv(_gym_env_base()):
             self._arena_np = self._arena.numpy()
         else:
             self._arena = torch.zeros(off, dtype=torch.uint8, device=dev)
-        views = [self._arena[o:o + nb].view(dt) for o, (dt, nb) in zip(offs, sizes)]
+        views = [self._arena[o:o + nb].view(dt)[:N] for o, (dt, nb) in zip(offs, sizes)]
         self._obs, self._t, self._reward, self._done = views[:4]
         self._r_arr = self._K_arr = self._sigma_arr = None
         sigma = params["sigma"]
         if isinstance(sigma, (torch.Tensor, np.ndarray, list, tuple)):
-            self._sigma_arr = torch.as_tensor(sigma).to(device=dev, dtype=dtype).reshape(N).contiguous()
+            self._sigma_arr = self._per_env_buffer(dtype)
+            self._sigma_arr.copy_(torch.as_tensor(sigma).to(device=dev, dtype=dtype).reshape(N))
             self._sigma_scalar = float(self._sigma_arr[0])
         else:
             self._sigma_scalar = float(sigma)
@@ -212,16 +221,17 @@ class BaseFishingEnv(_gym_env_base()):
         self._derived = self._derived_capable
         self._origin = (0, 0)            # (step count, reset counter) of the last reset() of all envs
         if self._per_env and not self._derived:
-            self._r_arr = torch.full((N,), float(params["r"]), dtype=dtype, device=dev)
-            self._K_arr = torch.full((N,), float(params["K"]), dtype=dtype, device=dev)
+            self._r_arr = self._per_env_buffer(dtype, float(params["r"]))
+            self._K_arr = self._per_env_buffer(dtype, float(params["K"]))
         if self.MODEL == MODEL_V10:      # the drifting growth rate is per-env state (growth_models.py:151)
-            self._r_arr = torch.full((N,), float(params["r"]), dtype=dtype, device=dev)
-        self._model_idx = torch.zeros(N, dtype=torch.int32, device=dev) if self.MODEL == MODEL_V11 else None
+            self._r_arr = self._per_env_buffer(dtype, float(params["r"]))
+        self._model_idx = self._per_env_buffer(torch.int32) if self.MODEL == MODEL_V11 else None
         self._terminal_obs = None
         if record_terminal_obs:
             self._terminal_obs = (torch.empty(N, dtype=dtype).pin_memory() if self._host_mapped
-                                  else torch.empty(N, dtype=dtype, device=dev))
-        self._done_bits = (torch.zeros((N + 63) // 64, dtype=torch.int64, device=dev) if done_bits else None)
+                                  else self._per_env_buffer(dtype))
+        self._done_bits = (torch.zeros((self._cap + 63) // 64, dtype=torch.int64, device=dev)[:(N + 63) // 64]
+                           if done_bits else None)
         self._ep_return = self._partials = self._record = None
         if track_returns:
             self._ep_return = views[4]
@@ -280,8 +290,8 @@ class BaseFishingEnv(_gym_env_base()):
     @sigma.setter
     def sigma(self, v):
         if isinstance(v, (torch.Tensor, np.ndarray, list, tuple)):
-            self._sigma_arr = torch.as_tensor(v).to(device=self.device, dtype=self.dtype).reshape(
-                self.num_envs).contiguous()
+            self._sigma_arr = self._per_env_buffer(self.dtype)
+            self._sigma_arr.copy_(torch.as_tensor(v).to(device=self.device, dtype=self.dtype).reshape(self.num_envs))
         else:
             self._sigma_arr = None
             self._sigma_scalar = float(v)
@@ -290,10 +300,17 @@ class BaseFishingEnv(_gym_env_base()):
                 # reference: growth_models.py:208-261)
                 self.params["sigma"] = v
 
+    def _per_env_buffer(self, dtype, fill=None):
+        """A [N] device tensor with room for whole 1024-env tiles behind it (FISHING_FLAG_PADDED_TILES; self._cap == N
+        when the batch needs no padding).  Every per-env stream handed to the kernels comes from here or from the arena."""
+        buf = (torch.zeros(self._cap, dtype=dtype, device=self.device) if fill is None
+               else torch.full((self._cap,), fill, dtype=dtype, device=self.device))
+        return buf[:self.num_envs]
+
     def _derive_params(self):
         """(K, r) tensors of a fishing-v4 env in the derived mode, materialised by fishing_v4_params_*."""
-        K = torch.empty(self.num_envs, dtype=self.dtype, device=self.device)
-        r = torch.empty_like(K)
+        K = self._per_env_buffer(self.dtype)
+        r = self._per_env_buffer(self.dtype)
         with torch.cuda.device(self.device):
             rc = getattr(self._lib, "fishing_v4_params_" + self._suffix)(
                 self._c_params(), self.num_envs, self.env_offset, self._t.data_ptr(), K.data_ptr(), r.data_ptr(),
@@ -354,7 +371,7 @@ class BaseFishingEnv(_gym_env_base()):
         cp.n_actions = int(getattr(self, "n_actions", 0) or 0)
         cp.Tmax = int(self.Tmax)
         cp.flags = ((FLAG_AUTO_RESET if self.auto_reset else 0) | (FLAG_T_U8 if self.compact else 0)
-                    | (FLAG_V4_DERIVED if self._derived else 0))
+                    | (FLAG_V4_DERIVED if self._derived else 0) | (FLAG_PADDED_TILES if self._padded else 0))
         cp.v4_origin_step, cp.v4_origin_counter = self._origin
         cp.r = float(p["r"])
         cp.K = float(p["K"])
@@ -494,8 +511,8 @@ class BaseFishingEnv(_gym_env_base()):
                 self._derived, self._K_arr, self._r_arr = True, None, None
             elif self._derived:
                 self._derived = False
-                self._K_arr = torch.empty(self.num_envs, dtype=self.dtype, device=self.device)
-                self._r_arr = torch.empty_like(self._K_arr)
+                self._K_arr = self._per_env_buffer(self.dtype)
+                self._r_arr = self._per_env_buffer(self.dtype)
             self._origin = tuple(sd.get("v4_origin", (0, 0)))
             self._cbuf = None
         for k in self._STATE_TENSORS:

@@ -20,7 +20,7 @@ def dev(a, dtype=None):
 
 def params(model, r=0.3, K=1.0, sigma=0.0, C=0.5, x0=0.75, Tmax=100, n_actions=100, K_mean=1.0, r_mean=0.3,
            sigma_p=0.1, auto_reset=False, launch_blocks=0, launch_threads=0, M=0.0, theta=0.0, q=0.0, b=0.0, a=0.0,
-           alpha=0.0, models=None, zoo_table=None, general=False, t_u8=False, derived=False, origin=(0, 0)):
+           alpha=0.0, models=None, zoo_table=None, general=False, t_u8=False, derived=False, origin=(0, 0), padded=False):
     p = _capi.FishingParams()
     p.M, p.theta, p.q, p.b, p.a, p.alpha = M, theta, q, b, a, alpha
     if models is not None:                      # fishing-v11: list of kind indices + per-kind dicts
@@ -32,7 +32,8 @@ def params(model, r=0.3, K=1.0, sigma=0.0, C=0.5, x0=0.75, Tmax=100, n_actions=1
                 setattr(p.zoo[k], name, float(d.get(name, 0.0)))
     p.model, p.n_actions, p.Tmax = model, n_actions, Tmax
     p.flags = ((_capi.FLAG_AUTO_RESET if auto_reset else 0) | (_capi.FLAG_GENERAL_KERNEL if general else 0)
-               | (_capi.FLAG_T_U8 if t_u8 else 0) | (_capi.FLAG_V4_DERIVED if derived else 0))
+               | (_capi.FLAG_T_U8 if t_u8 else 0) | (_capi.FLAG_V4_DERIVED if derived else 0)
+               | (_capi.FLAG_PADDED_TILES if padded else 0))
     p.v4_origin_step, p.v4_origin_counter = origin
     p.r, p.K, p.sigma, p.C, p.x0 = r, K, sigma, C, x0
     p.r_mean, p.K_mean, p.sigma_p = r_mean, K_mean, sigma_p

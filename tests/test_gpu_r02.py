@@ -536,6 +536,93 @@ def test_simulate_mdp_vec_fishing_v4_rows_use_the_K_in_force(hh):
     assert np.array_equal(tab[n:, 2], np.full(n * Tmax, np.float64(np.float32(0.9))))       # the raw action of the previous step
 
 
+# ------------------------------------------------------------------ FISHING_FLAG_PADDED_TILES: a ragged batch in one launch
+PADDED_CASES = [("v1", fo.MODEL_V1, {}), ("v0", fo.MODEL_V0, {}), ("v2", fo.MODEL_V2, {}), ("v1_K3", fo.MODEL_V1, dict(K=3.0)),
+                ("v4_stored", fo.MODEL_V4, {}), ("v4_derived", fo.MODEL_V4, dict(derived=True, origin=(7, 0))),
+                ("v9", fo.MODEL_V9, {}), ("v10", fo.MODEL_V10, dict(r=0.8, alpha=-0.01)), ("v11", fo.MODEL_V11, {})]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case", PADDED_CASES, ids=[c[0] for c in PADDED_CASES])
+def test_padded_tiles_flag_steps_a_ragged_batch_like_the_two_launch_path(hh, case, dtype):
+    """With FISHING_FLAG_PADDED_TILES (state buffers hold whole 1024-env tiles) a batch of 4 * 1024 + 612 envs takes ONE
+    lean launch; without it, the lean launch plus a one-workgroup launch of the general kernel for the tail.  Same bits
+    for the n envs on every stream, same return record (the scratch envs behind the n-th never finish), 9 auto-resetting
+    steps, every model family; the action tensor holds exactly n elements."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    _, model, kw = case
+    n, cap, off, seed, c0 = 4 * 1024 + 612, 5 * 1024, 8, 77, 7
+    per_env, drift, mixed = model == fo.MODEL_V4, model == fo.MODEL_V10, model == fo.MODEL_V11
+    derived = kw.get("derived", False)
+    kw = dict(dict(sigma=0.1, Tmax=3, auto_reset=True, sigma_p=0.2), **kw)
+    if mixed:
+        kw.update(models=[2, 0, 4], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE])
+    fn = lib.fishing_step_f32 if dtype == np.float32 else lib.fishing_step_f64
+    rng = np.random.default_rng(3)
+    acts = [rng.integers(0, 100, n).astype(np.int32) if model == fo.MODEL_V0 else rng.uniform(-1.1, 0.3, n).astype(np.float32)
+            for _ in range(9)]
+    outs = []
+    for padded in (True, False):
+        p = hh.params(model, padded=padded, **kw)
+        st = hh.State(cap, dtype, model, np.zeros(cap), r=(np.full(cap, kw.get("r", 0.3)) if (per_env and not derived) or drift else None),
+                      K=np.full(cap, 1.0) if per_env and not derived else None, ep_return=True, terminal=True,
+                      model_idx=np.zeros(cap, np.int32) if mixed else None)
+        assert getattr(lib, "fishing_reset_" + st.suffix)(p, n, off, st.buffers(), None, seed, 0, None) == 0
+        for s_, a in enumerate(acts):
+            at = torch.as_tensor(a).cuda()                   # exactly n elements: nothing may be read behind them
+            assert fn(p, n, off, st.buffers(at), seed, c0 + s_, None) == 0
+        torch.cuda.synchronize()
+        outs.append(st)
+    A, B = outs
+    names = ["obs", "t", "reward", "done", "ep_return", "terminal"] + (["K", "r"] if per_env and not derived else []) + \
+        (["r"] if drift else []) + (["model_idx"] if mixed else [])
+    for name in names:
+        assert _bits_equal(getattr(A, name)[:n], getattr(B, name)[:n]), (name, case[0])
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] > 0 and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("env_id", ["fishing-v1", "fishing-v4", "fishing-v11"])
+def test_env_pads_its_streams_so_that_any_batch_size_steps_in_one_launch(hh, env_id):
+    """make(id, num_envs=N) with N not a multiple of 1024 allocates room for whole tiles behind every per-env stream and
+    sets FISHING_FLAG_PADDED_TILES; what the caller sees (shapes, results, episode statistics, state_dict round trip)
+    is unchanged: equal to an env forced onto the general kernel (launch_threads=128), which needs no padding."""
+    import torch
+    import gym_fishing_amd as gf
+    n = 3 * 1024 + 100
+    kw = dict(num_envs=n, seed=9, Tmax=5, track_returns=True)
+    if env_id != "fishing-v11":
+        kw["sigma"] = 0.1
+    A = gf.make(env_id, **kw)
+    B = gf.make(env_id, launch_threads=128, **kw)
+    assert A._padded and A._cap == 4 * 1024 and A._obs.shape == (n,) and A.state.shape == (n, 1)
+    assert A._c_params().flags & 16 and B._c_params().flags & 16          # (the flag is the env's; the general kernel ignores it)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = torch.rand((7, n), device="cuda", generator=g) * 1.4 - 1.2
+    for e in (A, B):
+        e.reset()
+    for k in range(23):
+        oa, ra, da, _ = A.step(acts[k % 7])
+        ob, rb, db, _ = B.step(acts[k % 7])
+        assert oa.shape == (n, 1) and ra.shape == (n,) and da.shape == (n,)
+        assert _bits_equal(oa.reshape(-1), ob.reshape(-1)) and _bits_equal(ra, rb) and torch.equal(da, db), k
+    sa, sb = A.episode_stats(), B.episode_stats()
+    assert sa["n_episodes"] == sb["n_episodes"] > n and abs(sa["mean_return"] - sb["mean_return"]) < 1e-9
+    # a padded env resumes from its own checkpoint
+    sd = A.state_dict()
+    C = gf.make(env_id, **kw)
+    C.load_state_dict(sd)
+    for k in range(5):
+        oa, _, _, _ = A.step(acts[k])
+        oc, _, _, _ = C.step(acts[k])
+        assert _bits_equal(oa.reshape(-1), oc.reshape(-1)), k
+    A.step_many(acts, 9, fused=True)
+    C.step_many(acts, 9)
+    assert _bits_equal(A.state.reshape(-1), C.state.reshape(-1))
+
+
 # ------------------------------------------------------------------ randomised differential test of the three step paths
 def _bits_equal(x, y):
     import torch
