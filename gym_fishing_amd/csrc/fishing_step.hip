@@ -606,7 +606,10 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dn[j] = dn[j] && live;       // (scratch envs never finish)
+        for (int j = 0; j < 4; ++j) {       // scratch envs never finish, and their year counter stays put (no overflow, ever)
+            dn[j] = dn[j] && live;
+            t_next[j] = live ? t_next[j] : 0;
+        }
         {
             // reward and done are write-only streams nobody re-reads inside the step loop: nontemporal
             // stores (0.5-0.7 % at N = 2^22, 1.5 % at 2^24 / 2^26; profiles/r01g_lean_nt_stores.txt)
