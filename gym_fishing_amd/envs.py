@@ -175,7 +175,7 @@ class BaseFishingEnv(_gym_env_base()):
         # multiple of 1024 envs steps in ONE launch instead of two (N = 10^6: 9.3 -> 5.1 us per step).  The envs behind
         # the N-th are scratch; every tensor the env hands out is the [:N] view.
         self._cap = N
-        if not self._host_mapped and N > 1024 and N % 1024 and N % 4 == 0:
+        if not self._host_mapped and N % 1024 and N % 4 == 0:      # (also batches below one tile: the lean kernel then)
             self._cap = (N + 1023) // 1024 * 1024
         self._padded = self._cap != N
         C = self._cap

@@ -75,7 +75,8 @@ typedef void* fishing_stream_t; /* hipStream_t */
                                 r, K, sigma, terminal_obs, ep_return, model_idx -- not action, not z_ext) has room for
                                 ceil(n / 1024) * 1024 elements; the elements behind the n-th are scratch the library may
                                 overwrite.  fishing_step_* then runs a batch that is not a multiple of 1024 envs in ONE
-                                launch instead of two (3.7-4.2 us per step less).  Same results for the n envs.
+                                launch instead of two (3.7-4.2 us per step less), and a batch below one tile on the lean
+                                kernel.  Same results for the n envs.
                                 Honoured when n is a multiple of 4 (else ignored: two launches as without it).    */
 /* diagnostic (tests, A/B timing): route step() to the general kernel even where a lean instantiation applies */
 #define FISHING_FLAG_DIAG_GENERAL_KERNEL 0x80000000u
