@@ -537,7 +537,7 @@ def test_simulate_mdp_vec_fishing_v4_rows_use_the_K_in_force(hh):
 
 
 # ------------------------------------------------------------------ FISHING_FLAG_PADDED_TILES: a ragged batch in one launch
-PADDED_CASES = [("v1", fo.MODEL_V1, {}), ("v0", fo.MODEL_V0, {}), ("v2", fo.MODEL_V2, {}), ("v1_K3", fo.MODEL_V1, dict(K=3.0)),
+PADDED_CASES = [("v1", fo.MODEL_V1, {}), ("v1_ext_noise", fo.MODEL_V1, {}), ("v0", fo.MODEL_V0, {}), ("v2", fo.MODEL_V2, {}), ("v1_K3", fo.MODEL_V1, dict(K=3.0)),
                 ("v4_stored", fo.MODEL_V4, {}), ("v4_derived", fo.MODEL_V4, dict(derived=True, origin=(7, 0))),
                 ("v9", fo.MODEL_V9, {}), ("v10", fo.MODEL_V10, dict(r=0.8, alpha=-0.01)), ("v11", fo.MODEL_V11, {})]
 
@@ -563,6 +563,7 @@ def test_padded_tiles_flag_steps_a_ragged_batch_like_the_two_launch_path(hh, cas
     rng = np.random.default_rng(3)
     acts = [rng.integers(0, 100, n).astype(np.int32) if model == fo.MODEL_V0 else rng.uniform(-1.1, 0.3, n).astype(np.float32)
             for _ in range(9)]
+    zs = [rng.standard_normal(n) for _ in range(9)]
     outs = []
     for padded in (True, False):
         p = hh.params(model, padded=padded, **kw)
@@ -572,7 +573,8 @@ def test_padded_tiles_flag_steps_a_ragged_batch_like_the_two_launch_path(hh, cas
         assert getattr(lib, "fishing_reset_" + st.suffix)(p, n, off, st.buffers(), None, seed, 0, None) == 0
         for s_, a in enumerate(acts):
             at = torch.as_tensor(a).cuda()                   # exactly n elements: nothing may be read behind them
-            assert fn(p, n, off, st.buffers(at), seed, c0 + s_, None) == 0
+            zt = hh.dev(zs[s_].astype(dtype)) if case[0] == "v1_ext_noise" else None       # (the same for external noise)
+            assert fn(p, n, off, st.buffers(at, zt), seed, c0 + s_, None) == 0
         torch.cuda.synchronize()
         outs.append(st)
     A, B = outs
