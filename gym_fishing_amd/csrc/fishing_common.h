@@ -884,7 +884,7 @@ __device__ __forceinline__ double row_sum_fields(const double (&acc)[kPartialFie
 // waves -> thread k adds field k.  One owner thread per slot and a fixed addition order, so the sums
 // are bitwise reproducible for a fixed launch shape.  Must be reached by every thread of the
 // workgroup with all lanes active (it contains a barrier and whole-wave DPP moves).
-template <int MAX_WAVES>
+template <int MAX_WAVES, int STATIC_WAVES = 0>
 __device__ __forceinline__ void add_block_partials(const double (&acc)[kPartialFields], double* partials) {
     constexpr int kRows = kWave / 16;
     __shared__ double red[MAX_WAVES * kRows][kPartialFields];
@@ -894,7 +894,8 @@ __device__ __forceinline__ void add_block_partials(const double (&acc)[kPartialF
     __syncthreads();
     if (threadIdx.x < kPartialFields) {
         double tot = 0.0;
-        const int nrows = blockDim.x >> 4;
+        const int nrows = STATIC_WAVES ? STATIC_WAVES * kRows : (int)(blockDim.x >> 4);
+#pragma unroll
         for (int w = 0; w < nrows; ++w) tot += red[w][threadIdx.x];
         // The slot belongs to this workgroup alone, so a hardware no-return atomic add gives the same
         // bits as a read-modify-write (one add per slot per launch, launches are stream-ordered) without

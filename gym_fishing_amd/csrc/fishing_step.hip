@@ -52,6 +52,15 @@ namespace fishing {
 #ifndef FISHING_STEP_MAXTHREADS
 #define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
 #endif
+#ifndef FISHING_X_ONE
+#define FISHING_X_ONE 0      // experiment: bit 0 = no tile loop (grid == ntiles), bit 1 = record + partials before the stores
+#endif
+#ifndef FISHING_X_STATIC_ROWS
+#define FISHING_X_STATIC_ROWS 0   // experiment: 4 = the workgroup size is a compile-time fact in the partial-sum reduction
+#endif
+#ifndef FISHING_X_NO_LIVE
+#define FISHING_X_NO_LIVE 0  // experiment: no padded-tile selects
+#endif
 
 // An env that was already finished BEFORE this step (stepped on without a reset: years_passed beyond Tmax, or
 // no fish left) must not enter the episodic-return record a second time.
@@ -414,6 +423,9 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
     const int64_t per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
     const int64_t it_end = ((int64_t)blockIdx.x + 1) * per_wg < ntiles ? ((int64_t)blockIdx.x + 1) * per_wg : ntiles;
     for (int64_t it = (int64_t)blockIdx.x * per_wg; it < it_end; ++it) {
+#elif (FISHING_X_ONE & 1)
+    {
+        const int64_t it = blockIdx.x;
 #else
     for (int64_t it = blockIdx.x; it < ntiles; it += gridDim.x) {
 #endif
@@ -429,8 +441,13 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         // envs behind the last one are scratch: stepped like any other, but they never finish (neither recorded nor
         // redrawn), and the streams the CALLER owns -- actions, external noise -- are read at the last quad that exists
         // instead of past their end.  One 64-bit compare and two selects per tile; `live` is true everywhere otherwise.
+#if FISHING_X_NO_LIVE
+        const bool live = true;
+        const int64_t cbase = base;
+#else
         const bool live = base < a.n_live;
         const int64_t cbase = live ? base : a.n_live - kEnvsPerThread;
+#endif
         // The Philox round keys (seed + i * Weyl) are wave-uniform; hoisted out of this loop they sit in 20-30 SGPRs
         // for the whole kernel, which pushes the fishing-v4 variants (two generators) past 100 SGPRs = 7 instead of
         // 8 waves per SIMD.  Laundering the seed per tile keeps the key schedule next to its rounds (a scalar add
@@ -610,7 +627,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
             dn[j] = dn[j] && live;
             t_next[j] = live ? t_next[j] : 0;
         }
-        {
+        auto store_outputs = [&]() {
             // reward and done are write-only streams nobody re-reads inside the step loop: nontemporal
             // stores (0.5-0.7 % at N = 2^22, 1.5 % at 2^24 / 2^26; profiles/r01g_lean_nt_stores.txt)
             typedef T nt4 __attribute__((ext_vector_type(4)));
@@ -629,7 +646,8 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 const int64_t wave_env0 = (tile * 256 + (threadIdx.x & ~(kWave - 1))) * kEnvsPerThread;
                 if (lane < 4) a.done_bits[(wave_env0 >> 6) + lane] = word;
             }
-        }
+        };
+        if (!(FISHING_X_ONE & 2) || !RET) store_outputs();
         const bool lane_done = dn[0] | dn[1] | dn[2] | dn[3];
         if (RET) {
 #pragma unroll
@@ -641,6 +659,10 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 record_tile<T>(fresh, er, t_next, acc);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
+            }
+            if (FISHING_X_ONE & 2) {
+                if (a.partials) add_block_partials<4, 4>(acc, a.partials);
+                store_outputs();
             }
             Vec4<T> qe;
 #pragma unroll
@@ -702,8 +724,8 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         }
     }
 
-    if (RET) {
-        if (a.partials) add_block_partials<4>(acc, a.partials);
+    if (RET && !(FISHING_X_ONE & 2)) {
+        if (a.partials) add_block_partials<4, FISHING_X_STATIC_ROWS>(acc, a.partials);
     }
 }
 

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, session 2: small-N shape sweep with return-record variants; kernarg placement
+set -u
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"
+OUT="$REPO/gpurun_out/r03_s02"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="$REPO/scripts/exp/_build/small_n_shapes"
+timeout -k 10 240 "$B" 400 18 21 > "$OUT/events.jsonl" 2> "$OUT/events.err" || exit 1
+HIP_FORCE_DEV_KERNARG=0 timeout -k 10 240 "$B" 400 19 19 product > "$OUT/events_kernarg0.jsonl" 2>> "$OUT/events.err" || exit 1
+HIP_FORCE_DEV_KERNARG=1 timeout -k 10 240 "$B" 400 19 19 product > "$OUT/events_kernarg1.jsonl" 2>> "$OUT/events.err" || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -- "$B" 100 18 21 > "$OUT/events_under_prof.jsonl" 2> "$OUT/trace.err" || exit 2
+python3 "$REPO/scripts/exp/small_n_trace.py" "$OUT/trace" > "$OUT/trace.jsonl" || exit 3
+rm -rf "$OUT/trace"
+echo done
