@@ -24,6 +24,11 @@ ARCH = "gfx950"
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
                "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# Per translation unit.  fishing_step.hip: no SLP vectorizer -- it splits the tile's 16-byte loads into 8-byte halves
+# and sinks them next to their first use, behind the Philox block and (the return accumulator) behind the first
+# s_waitcnt; without it the loads are issued together at the top of the tile, ahead of the scheduling fence, as the
+# kernel is written (N = 2^21 with returns: 9.8 -> 8.7 us per step; profiles/r03_small_n/).
+TU_FLAGS = {"fishing_step.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -68,7 +73,7 @@ def _compile(out_path, verbose, extra_flags):
     objs = ["%s.%d.o" % (tmp, i) for i in range(len(srcs))]
     # one hipcc per translation unit, side by side (the two kernel files take about as long as each other),
     # then one link step
-    cmds = [[hipcc] + flags + ["-c", src, "-o", obj] for src, obj in zip(srcs, objs)]
+    cmds = [[hipcc] + flags + TU_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj] for src, obj in zip(srcs, objs)]
     procs = []
     for cmd in cmds:
         if verbose:

@@ -46,20 +46,8 @@ namespace fishing {
 #ifndef FISHING_ZZ_MIN_BYTES
 #define FISHING_ZZ_MIN_BYTES (500ll << 20)  // bytes one step streams, from which the tile walk alternates direction
 #endif
-#ifndef FISHING_LEAN_BLOCKED_TILES
-#define FISHING_LEAN_BLOCKED_TILES 0
-#endif
 #ifndef FISHING_STEP_MAXTHREADS
 #define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
-#endif
-#ifndef FISHING_X_ONE
-#define FISHING_X_ONE 0      // experiment: bit 0 = no tile loop (grid == ntiles), bit 1 = record + partials before the stores
-#endif
-#ifndef FISHING_X_STATIC_ROWS
-#define FISHING_X_STATIC_ROWS 0   // experiment: 4 = the workgroup size is a compile-time fact in the partial-sum reduction
-#endif
-#ifndef FISHING_X_NO_LIVE
-#define FISHING_X_NO_LIVE 0  // experiment: no padded-tile selects
 #endif
 
 // An env that was already finished BEFORE this step (stepped on without a reset: years_passed beyond Tmax, or
@@ -312,6 +300,10 @@ constexpr int DRIFT = 1 << 9;      // fishing-v10: per-env r, drifting by alpha 
 constexpr int OPT = 1 << 10;
 constexpr int LATCH = 1 << 11;     // RET without auto-reset: a finished env that is stepped on must not enter the record
                                    // again.  Catch-all only -- the exact RET instantiations are the auto-reset ones.
+constexpr int ONE = 1 << 13;       // one tile per workgroup (grid == ntiles; every launch up to N = 2^22): no tile loop, and with RET the
+                                   // return record -- workgroup reduction + its atomic -- is issued BEFORE the tile's stores, so the
+                                   // atomic's round trip runs under theirs.  Exact instantiations only.  Per step at N = 2^19 / 2^20 /
+                                   // 2^21, back to back: 4.75 -> 4.09, 6.15 -> 5.71, 9.78 -> 8.15 us (profiles/r03_small_n/).
 constexpr int KP2 = 1 << 12;       // the scalar K is a power of two (K = 1 included): x / K is the exact multiply x * (1 / K),
                                    // same bits, a third of the instructions.  Exact instantiations of fishing-v0/v1/v2 only;
                                    // any other K takes the catch-all's correctly rounded division.
@@ -379,6 +371,8 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
     static_assert(!((F & feat::ZZ) && kOpt), "ZZ has exact instantiations only");
     static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
+    static_assert(!(F & feat::ONE) || (kExact && !(F & feat::ZZ)), "ONE: exact instantiations, no tile walk");
+    constexpr bool kOne = (F & feat::ONE) != 0;
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || a.ep_return != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -410,7 +404,15 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                          "s"(a.growth.logA), "s"(a.growth.B));
         if constexpr ((F & feat::DRIFT) != 0) asm volatile("" ::"s"(a.r), "s"(a.alpha));
     }
-    const uint64_t step_counter = a.counter ? (*a.counter + step_counter_arg) : step_counter_arg;
+    // graph-replay mode keeps the step counter in device memory (wave-uniform: one scalar load).  With a tile loop it is
+    // read here; a one-tile launch reads it AFTER issuing the tile's loads, which do not depend on it.
+    auto read_counter = [&]() -> uint64_t {
+        if (!a.counter) return step_counter_arg;
+        uint64_t c;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "s"(a.counter) : "memory");
+        return c + step_counter_arg;
+    };
+    uint64_t step_counter = kOne ? step_counter_arg : read_counter();
     // an exact RET instantiation is only ever launched with auto-reset on (the dispatch sends RET without it to the
     // catch-all, which carries the LATCH): the flag is a compile-time fact there
     const bool auto_reset = (kExact && (F & feat::RET)) ? true : a.auto_reset != 0;
@@ -418,17 +420,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
     const T robs_scalar = reset_obs<T, MODEL>(a.x0, a.pK);
 
-#if FISHING_LEAN_BLOCKED_TILES
-    // experiment: a workgroup walks a CONTIGUOUS run of tiles instead of every gridDim-th one
-    const int64_t per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int64_t it_end = ((int64_t)blockIdx.x + 1) * per_wg < ntiles ? ((int64_t)blockIdx.x + 1) * per_wg : ntiles;
-    for (int64_t it = (int64_t)blockIdx.x * per_wg; it < it_end; ++it) {
-#elif (FISHING_X_ONE & 1)
-    {
-        const int64_t it = blockIdx.x;
-#else
-    for (int64_t it = blockIdx.x; it < ntiles; it += gridDim.x) {
-#endif
+    auto do_tile = [&](const int64_t it) {
         // ZZ (launched for N >= 2^25, far outside the 256 MiB Infinity Cache): odd steps walk the tiles
         // backwards, so what the previous step touched last is still cached when this one starts there
         // (N = 2^26: 331 -> 297 us).  Inside the cache the forward walk is the faster one (2^22: 16.1 vs
@@ -440,14 +432,13 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         // envs still runs in this ONE launch (no second, one-workgroup launch for the tail: 3.7-4.2 us per step).  The
         // envs behind the last one are scratch: stepped like any other, but they never finish (neither recorded nor
         // redrawn), and the streams the CALLER owns -- actions, external noise -- are read at the last quad that exists
-        // instead of past their end.  One 64-bit compare and two selects per tile; `live` is true everywhere otherwise.
-#if FISHING_X_NO_LIVE
-        const bool live = true;
-        const int64_t cbase = base;
-#else
-        const bool live = base < a.n_live;
-        const int64_t cbase = live ? base : a.n_live - kEnvsPerThread;
-#endif
+        // instead of past their end.  `live` is true everywhere otherwise.
+        // (the tile's share of n_live is a scalar; per lane one 32-bit compare and one 32-bit select)
+        const int64_t tile_left = a.n_live - tile * 1024;                          // wave-uniform
+        const uint32_t left32 = tile_left >= 1024 ? 1024u : (uint32_t)tile_left;
+        const uint32_t lane_env = threadIdx.x * (uint32_t)kEnvsPerThread;
+        const bool live = lane_env < left32;
+        const int64_t cbase = tile * 1024 + (int64_t)(live ? lane_env : left32 - (uint32_t)kEnvsPerThread);
         // The Philox round keys (seed + i * Weyl) are wave-uniform; hoisted out of this loop they sit in 20-30 SGPRs
         // for the whole kernel, which pushes the fishing-v4 variants (two generators) past 100 SGPRs = 7 instead of
         // 8 waves per SIMD.  Laundering the seed per tile keeps the key schedule next to its rounds (a scalar add
@@ -534,6 +525,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         // the loads above must be in flight BEFORE the ~100-instruction Philox block starts: without
         // this fence the scheduler hoists the (independent) generator above them in some variants
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kOne) step_counter = read_counter();
         if (noise == kNoisePhilox) {
             float zq[4];
             noise_quad(seed_it, (env_offset + (uint64_t)base) >> 2, step_counter, zq);
@@ -647,7 +639,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 if (lane < 4) a.done_bits[(wave_env0 >> 6) + lane] = word;
             }
         };
-        if (!(FISHING_X_ONE & 2) || !RET) store_outputs();
+        if (!(kOne && RET)) store_outputs();
         const bool lane_done = dn[0] | dn[1] | dn[2] | dn[3];
         if (RET) {
 #pragma unroll
@@ -660,7 +652,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
             }
-            if (FISHING_X_ONE & 2) {
+            if constexpr (kOne) {       // the record's atomic first, the tile's stores behind it
                 if (a.partials) add_block_partials<4, 4>(acc, a.partials);
                 store_outputs();
             }
@@ -722,10 +714,15 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
             if (T8) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.t) + base) = pack_t4(t_next);
             else *reinterpret_cast<Vec4<int32_t>*>(a.t + base) = qt;
         }
-    }
+    };
 
-    if (RET && !(FISHING_X_ONE & 2)) {
-        if (a.partials) add_block_partials<4, FISHING_X_STATIC_ROWS>(acc, a.partials);
+    if constexpr (kOne) {
+        do_tile(blockIdx.x);
+    } else {
+        for (int64_t it = blockIdx.x; it < ntiles; it += gridDim.x) do_tile(it);
+        if (RET) {
+            if (a.partials) add_block_partials<4, 4>(acc, a.partials);
+        }
     }
 }
 
@@ -866,8 +863,13 @@ template <typename T, int MODEL>
 int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     using namespace feat;
     constexpr int P = kNoisePhilox;
-#define FISHING_LEAN_CASE(MASK) \
+    // every forward exact instantiation has a one-tile-per-workgroup twin (feat::ONE), taken whenever the grid covers the
+    // tiles one to one -- every launch up to 4096 tiles = N = 2^22
+    const bool one = (int64_t)c.blocks == c.ntiles;
+#define FISHING_LEAN_CASE_ZZ(MASK) \
     case (MASK): return lean_launch<T, MODEL, (MASK)>(c)
+#define FISHING_LEAN_CASE(MASK) \
+    case (MASK): return one ? lean_launch<T, MODEL, (MASK) | ONE>(c) : lean_launch<T, MODEL, (MASK)>(c)
     // Once a step streams ~500 MB the tiles are walked zig-zag (see the kernel).  Requests whose exact instantiation has
     // a zig-zag twin take it; every other request goes to its catch-all there, which walks zig-zag by a run-time flag --
     // measured better than an exact kernel walking forward (N = 2^26 zoo: 289 vs 314 us; fishing-v4 stored + sigma array
@@ -879,8 +881,8 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
         // against the catch-all at N = 2^22).
         if (zigzag) {
             switch (req | ZZ) {
-                FISHING_LEAN_CASE(P | KP2 | ZZ);
-                FISHING_LEAN_CASE(P | KP2 | RET | ZZ);
+                FISHING_LEAN_CASE_ZZ(P | KP2 | ZZ);
+                FISHING_LEAN_CASE_ZZ(P | KP2 | RET | ZZ);
                 default: break;
             }
         }
@@ -906,12 +908,12 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
         // config 5), bare / with the return record; zig-zag twins for the derived ones and for stored + scalar sigma
         if (zigzag) {
             switch (req | ZZ) {
-                FISHING_LEAN_CASE(P | ZZ);
-                FISHING_LEAN_CASE(P | RET | ZZ);
-                FISHING_LEAN_CASE(P | DERIVED | ZZ);
-                FISHING_LEAN_CASE(P | DERIVED | RET | ZZ);
-                FISHING_LEAN_CASE(P | DERIVED | SIGARR | ZZ);
-                FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET | ZZ);
+                FISHING_LEAN_CASE_ZZ(P | ZZ);
+                FISHING_LEAN_CASE_ZZ(P | RET | ZZ);
+                FISHING_LEAN_CASE_ZZ(P | DERIVED | ZZ);
+                FISHING_LEAN_CASE_ZZ(P | DERIVED | RET | ZZ);
+                FISHING_LEAN_CASE_ZZ(P | DERIVED | SIGARR | ZZ);
+                FISHING_LEAN_CASE_ZZ(P | DERIVED | SIGARR | RET | ZZ);
                 default: break;
             }
         }
@@ -955,6 +957,7 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     }
 #endif
 #undef FISHING_LEAN_CASE
+#undef FISHING_LEAN_CASE_ZZ
     return lean_launch<T, MODEL, catch_all_mask<MODEL>()>(c);
 }
 

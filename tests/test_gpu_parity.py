@@ -694,6 +694,60 @@ def test_lean_and_general_kernels_agree(hh, model, ret, n, dtype):
             assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True) and ra[2] > 0
 
 
+@pytest.mark.parametrize("case", ["v1", "v1_ret", "v0_ret", "v2_ret", "v1_K1.5_ret", "v4_derived_sig_ret", "v4_stored_ret", "v9_ret",
+                                  "v1_padded_ret", "v1_counter_ret"])
+def test_one_tile_and_tile_loop_instantiations_agree(hh, case):
+    """Round 3: every exact lean instantiation exists twice -- feat::ONE (a tile per workgroup: no loop, the return
+    record's atomic ahead of the tile's stores; what every launch up to N = 2^22 takes) and the tile-loop form (grids
+    capped below the tile count).  A capped grid (launch_blocks = 3) forces the loop form at a small N: same bits on
+    every stream over 10 auto-resetting steps, same episode counts, return sums equal to double rounding (the
+    partial sums land in different slots).  Also with a padded last tile and with the device-resident step counter."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n = 1024 * 9 + (512 if "padded" in case else 0)
+    cap = -(-n // 1024) * 1024          # room for whole tiles behind every state stream (FISHING_FLAG_PADDED_TILES)
+    model = {"v0": fo.MODEL_V0, "v1": fo.MODEL_V1, "v2": fo.MODEL_V2, "v4": fo.MODEL_V4, "v9": fo.MODEL_V9}[case.split("_")[0]]
+    ret = case.endswith("_ret")
+    derived = "derived" in case
+    kw = dict(sigma=0.1, C=0.5, Tmax=3, sigma_p=0.2, auto_reset=True, derived=derived, origin=(0, 0), padded="padded" in case,
+              K=1.5 if "K1.5" in case else 1.0)
+    pa, pb = hh.params(model, **kw), hh.params(model, launch_blocks=3, **kw)
+    per_env = model == fo.MODEL_V4
+    sig = np.random.default_rng(3).uniform(0.0, 0.3, cap) if "sig" in case else None
+    mk = lambda: hh.State(cap, np.float32, model, np.zeros(cap), r=np.full(cap, 0.3) if per_env and not derived else None,   # noqa: E731
+                          K=np.full(cap, 1.0) if per_env and not derived else None, sigma=sig, ep_return=ret)
+    A, B = mk(), mk()
+    if per_env and not derived:
+        for st, p in ((A, pa), (B, pb)):
+            assert lib.fishing_reset_f32(p, n, 8, st.buffers(), None, 5, 0, None) == 0
+    a0 = torch.zeros(n, device="cuda")
+    na = hh.kernel_name(pa, n, A.buffers(a0))
+    nb = hh.kernel_name(pb, n, B.buffers(a0))
+    mask_a, mask_b = int(na.rstrip(">").split(",")[-1]), int(nb.rstrip(">").split(",")[-1])
+    assert mask_a == mask_b | 8192 and not mask_b & 8192, (na, nb)
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda") if "counter" in case else None
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for s in range(10):
+        a = (torch.randint(0, 100, (n,), device="cuda", generator=g, dtype=torch.int32) if model == fo.MODEL_V0
+             else (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float())
+        if counter is not None:
+            counter.fill_(s)
+        for st, p in ((A, pa), (B, pb)):
+            b = _capi.FishingBuffers.from_buffer_copy(st.buffers(a))
+            if counter is not None:
+                b.counter = counter.data_ptr()
+            assert lib.fishing_step_f32(p, n, 8, b, 5, 0 if counter is not None else s, None) == 0
+        torch.cuda.synchronize()
+        for name in ("obs", "reward", "done", "t") + (("K", "r") if per_env and not derived else ()) + (("ep_return",) if ret else ()):
+            x, y = getattr(A, name)[:n], getattr(B, name)[:n]
+            it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]
+            assert torch.equal(x.view(it), y.view(it)), (name, s)
+    if ret:
+        ra, rb = A.record(), B.record()
+        assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True) and ra[2] > n
+
+
 def test_huge_batch_64bit_indexing(hh):
     """Maximum sizes: N = 2^29 + 1029 envs (2 GiB per float32 stream, byte offsets past 2^31 and
     element counts past 2^29; ragged tail behind the lean launch).  sigma = 0 and one shared

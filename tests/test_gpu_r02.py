@@ -82,17 +82,17 @@ def test_v4_derived_parameters_equal_stored_arrays(hh, dtype, kernel, sigarr):
     rs, rd_ = S.record(), D.record()
     assert rs[2] == rd_[2] == finished and np.array_equal(rs, rd_)
     if not general:
-        want = fo_mask(derived=True, sigarr=sigarr, ret=True) if dtype == np.float32 else None
+        want = fo_mask(derived=True, sigarr=sigarr, ret=True, one=True) if dtype == np.float32 else None
         name = hh.kernel_name(pd, n, D.buffers(a), dtype)
         assert name.startswith("fishing::step_kernel_lean<%s, 4, " % ("float" if dtype == np.float32 else "double")), name
         if want is not None:
             assert name.endswith(", %d>" % want), (name, want)
 
 
-def fo_mask(noise=2, ret=False, sigarr=False, t8=False, term=False, bits=False, zz=False, derived=False, drift=False):
-    """Feature mask of step_kernel_lean (csrc/fishing_step.hip: namespace feat)."""
+def fo_mask(noise=2, ret=False, sigarr=False, t8=False, term=False, bits=False, zz=False, derived=False, drift=False, one=False):
+    """Feature mask of step_kernel_lean (csrc/fishing_step.hip: namespace feat); `one` = a tile per workgroup (grid == tiles)."""
     return (noise | (4 if ret else 0) | (8 if sigarr else 0) | (16 if t8 else 0) | (32 if term else 0) | (64 if bits else 0)
-            | (128 if zz else 0) | (256 if derived else 0) | (512 if drift else 0))
+            | (128 if zz else 0) | (256 if derived else 0) | (512 if drift else 0) | (8192 if one else 0))
 
 
 def test_v4_derived_parameters_against_the_oracle(hh):
@@ -288,33 +288,34 @@ def test_kernel_names_follow_the_dispatch(hh):
                 setattr(b, k, None)
         return hh.kernel_name(p, n, b, dtype)
     p1 = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True)
-    assert name(p1) == "fishing::step_kernel_lean<float, 1, 4098>"                 # Philox (2) | KP2 (4096): K = 1
-    assert name(p1, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 4102>"
+    assert name(p1) == "fishing::step_kernel_lean<float, 1, 12290>"                # Philox (2) | KP2 (4096): K = 1 | ONE (8192): a tile per workgroup
+    assert name(p1, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 12294>"
     assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 4226>"
     # the zig-zag walk starts where one step streams ~twice the Infinity Cache: with returns (33 B) already at N = 2^24
-    assert name(p1, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 4098>"
+    assert name(p1, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 4098>"                       # (more tiles than workgroups: the tile loop)
+    assert name(p1, n=1 << 20) == "fishing::step_kernel_lean<float, 1, 12290>"
     assert name(p1, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 4230>"
     assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, terminal_obs=True, done_bits=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 3199>"
     assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 4, 3455>"
-    assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 4114>"
-    assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 4098>"
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 12306>"
+    assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 12290>"
     # a K that is not a power of two keeps the correctly rounded division
-    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5)) == "fishing::step_kernel_lean<float, 1, 2>"
-    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=0.25)) == "fishing::step_kernel_lean<float, 1, 4098>"
-    assert name(hh.params(fo.MODEL_V9, sigma=0.1)) == "fishing::step_kernel_lean<float, 104, 2>"
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5)) == "fishing::step_kernel_lean<float, 1, 8194>"
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=0.25)) == "fishing::step_kernel_lean<float, 1, 12290>"
+    assert name(hh.params(fo.MODEL_V9, sigma=0.1)) == "fishing::step_kernel_lean<float, 104, 8194>"
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, general=True)) == "fishing::step_kernel<float, 1>"
     # the return record without auto-reset needs the latch, which only the catch-all carries
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=False), ep_return=True, return_partials=True) == \
         "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, n=1000) == "fishing::step_kernel<float, 1>"
-    assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True)) == "fishing::step_kernel_lean<float, 4, 258>"
+    assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True)) == "fishing::step_kernel_lean<float, 4, 8450>"
     # fishing-v11 (growth function per env): float32 on the lean kernel, float64 on the general one
     p11 = hh.params(fo.MODEL_V11, sigma=0.1, models=[0, 1, 2, 3, 4], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE], auto_reset=True)
     b11 = hh.State(4096, np.float32, fo.MODEL_V11, np.zeros(4096), model_idx=np.zeros(4096, np.int32), ep_return=True)
     full11 = b11.buffers(b11.action_tensor(np.zeros(4096, np.float32)))
-    assert hh.kernel_name(p11, n, full11) == "fishing::step_kernel_lean<float, 105, 6>"
+    assert hh.kernel_name(p11, n, full11) == "fishing::step_kernel_lean<float, 105, 8198>"
     assert hh.kernel_name(p11, n, full11, np.float64) == "fishing::step_kernel<double, 105>"
 
 

@@ -366,7 +366,7 @@ def test_v11_lean_and_general_kernels_agree(hh, ret):
     kw = dict(sigma=0.1, Tmax=4, auto_reset=True, models=[4, 0, 3], zoo_table=table)
     pa, pb = hh.params(fo.MODEL_V11, **kw), hh.params(fo.MODEL_V11, general=True, **kw)
     A, B = (hh.State(n, np.float32, fo.MODEL_V11, np.zeros(n), ep_return=ret, model_idx=np.zeros(n, np.int32)) for _ in range(2))
-    assert hh.kernel_name(pa, n, A.buffers(A.obs)) == "fishing::step_kernel_lean<float, 105, %d>" % (6 if ret else 2)
+    assert hh.kernel_name(pa, n, A.buffers(A.obs)) == "fishing::step_kernel_lean<float, 105, %d>" % (8198 if ret else 8194)
     assert hh.kernel_name(pb, n, B.buffers(B.obs)) == "fishing::step_kernel<float, 105>"
     A.reset(pa, seed=5, env_offset=12)
     B.reset(pb, seed=5, env_offset=12)
