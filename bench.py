@@ -36,6 +36,11 @@ import subprocess
 import sys
 import time
 
+# dmabuf IPC is what RCCL (and any cross-process device-memory sharing) needs on this driver; set before anything can
+# initialise HIP, in EVERY process that runs this file -- a rank started directly by torch.distributed.run (as the
+# driver's scaling run does) never passes through self_launch()
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -126,8 +131,12 @@ def cpu_baseline(seconds, cfg_name):
     n = int(max(50_000, min(rate * seconds, 5_000_000)))
     rate, _ = time_random_rollout(scalar_id, n, seed=1, **skw)
     out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
-           "sample": "oracle/scalar_env.py (per-env NumPy step(), same op sequence as the reference): "
-                     "%d env-steps of %s sigma=%g, random policy, reset on done, 1 core" % (n, scalar_id, skw["sigma"])}
+           "sample": "oracle/scalar_env.py (per-env NumPy step(): the reference's arithmetic with its five helper calls and "
+                     "the isinstance test inlined -- leaner than the reference it stands for): "
+                     "%d env-steps of %s sigma=%g, random policy, reset on done, 1 core" % (n, scalar_id, skw["sigma"]),
+           "reference_build_container": {"value": 1.1e5, "unit": "env-steps/s", "cores": 1,
+                                         "source": "SURVEY.md section 6: the unmodified reference's step() timed in the build "
+                                                   "container (it cannot travel to the GPU box); the port above runs ~2.7x that"}}
     try:    # the same Python port on every core of the box's CPU share;
         # independent `python -c` workers: nothing here depends on how this file was started
         procs = max(1, min(os.cpu_count() or 1, 16))
@@ -178,15 +187,24 @@ def cpu_baseline(seconds, cfg_name):
     return out
 
 
-def pmc_traffic(kernel, n_envs):
+def pmc_traffic(kernel, n_envs, built=None):
     """HBM bytes per launch from a committed rocprofv3 --pmc summary of this same command
-    (profiles/pmc_latest.json), or None.  bench.py cannot profile itself."""
+    (profiles/pmc_latest.json), or None.  bench.py cannot profile itself, so the figure is a lookup -- valid only while
+    the kernel that runs is the kernel that was profiled: the record carries that kernel's compile-time resources
+    (VGPRs / SGPRs / LDS / scratch / occupancy, from the build's own table) and is refused when the library built in
+    this tree reports different ones, or none."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if built is None:
+        from gym_fishing_amd import build
+        built = build.kernel_resources(kernel)
     try:
         with open(path) as f:
             rec = json.load(f)
         for r in rec if isinstance(rec, list) else [rec]:
             if r.get("n_envs") == n_envs and r.get("kernel") == kernel:
+                if not built or r.get("kernel_resources") != built:
+                    return None, "stale: %s was profiled with kernel resources %s, the built library has %s" % (
+                        r.get("source", "the committed record").split(" ")[0], r.get("kernel_resources"), built)
                 return r.get("hbm_bytes_per_launch"), r.get("source")
     except Exception:  # noqa: BLE001
         pass
@@ -283,6 +301,35 @@ def timed_steps(torch, env, actions, steps, spin_ms=60.0, repeats=1, **kw):
     return e0.elapsed_time(e1) * 1e3 / (steps * repeats), time.perf_counter() - t0
 
 
+def graph_region(torch, gf, args, n, actions):
+    """The timed region once more as ONE hipGraph: the same K launches + the record's reduce kernel captured once
+    (gym_fishing_amd.graphs.GraphedSteps; the step counter lives in device memory, so every replay draws fresh noise)
+    and replayed between synchronize() calls.  Beside the plain figure, never instead of it: what a caller gains who
+    can pre-record its loop."""
+    from gym_fishing_amd.graphs import GraphedSteps
+    try:
+        env = make_env(gf, torch, args.config, n, 0, True, False, args.v4_stored)
+        env.reset()
+        env.step_many(actions, max(args.warmup, 8))
+        g = GraphedSteps(env, actions, n_steps=args.steps, record=True)
+        walls = []
+        for _ in range(12):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g.replay()
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        w = statistics.median(walls[2:])
+        rec = g.record.tolist()
+        return {"steps": args.steps, "ms_per_step": w / max(args.steps, 1) * 1e3, "value": float(n) * args.steps / w,
+                "unit": "env-steps/s", "replays": len(walls), "ms_per_step_first_replay": walls[0] / max(args.steps, 1) * 1e3,
+                "kernel": env.step_kernel_name(actions[0]), "episodes_in_record": rec[2],
+                "note": "median wall time of one replay of a hipGraph holding the K step launches + the return record's "
+                        "reduce kernel, synchronize() on both sides"}
+    except Exception as e:  # noqa: BLE001 - a sub-record must not take the headline down
+        return {"error": repr(e)[:300]}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -298,10 +345,17 @@ def main():
         raise SystemExit("--gpus %d under torch.distributed.run needs %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    single_device = os.environ.get("FISHING_BENCH_SINGLE_DEVICE") == "1"
+    # (device_count() does not initialise the GPU on this image; no re-exec and no retry from here on, whatever fails)
+    if not single_device and torch.cuda.device_count() < local_rank + 1:
+        raise SystemExit("bench.py rank %d: LOCAL_RANK=%d but only %d HIP device(s) visible (HIP_VISIBLE_DEVICES=%r, "
+                         "ROCR_VISIBLE_DEVICES=%r): one rank per GPU needs --gpus <= the devices of this node" % (
+                             rank, local_rank, torch.cuda.device_count(), os.environ.get("HIP_VISIBLE_DEVICES"),
+                             os.environ.get("ROCR_VISIBLE_DEVICES")))
     # rehearsal knobs (not used by the driver): several ranks on ONE device over gloo, to run the
     # multi-rank control flow on a single-GPU box
     backend = os.environ.get("FISHING_BENCH_BACKEND", "nccl")
-    if os.environ.get("FISHING_BENCH_SINGLE_DEVICE") == "1":
+    if single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     # under torch.distributed.run (RANK set) the process group is created for any world size, so
@@ -319,13 +373,22 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             else:
                 dist.init_process_group(backend)
-            warm = torch.zeros(4, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(warm)
+            # every rank contributes a one: the sum is the number of ranks the collective library actually joined
+            ones = torch.ones(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(ones)
             torch.cuda.synchronize()
+            ranks_seen = int(round(float(ones.item())))
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+
+        if dist.get_world_size() != world or ranks_seen != world:
+            print("bench.py rank %d: the process group has %d ranks and the all-reduce of ones saw %d, WORLD_SIZE says %d"
+                  % (rank, dist.get_world_size(), ranks_seen, world), file=sys.stderr, flush=True)
+            raise SystemExit(3)
+    else:
+        ranks_seen = None
 
     import gym_fishing_amd as gf
     cfg = CONFIGS[args.config]
@@ -414,10 +477,12 @@ def main():
                    "name": args.config, "baseline_config": cfg["baseline_config"],
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-shard x%d" % world,
                    "collective": "1 all-reduce of 4 doubles per rollout (%s)" % ("RCCL" if backend == "nccl" else backend)
-                                 if world > 1 else "none"},
+                                 if world > 1 else "none",
+                   # ranks counted by an all-reduce of ones at start-up (null: no process group, i.e. a bare 1-GPU run)
+                   ("rccl_ranks_seen" if backend == "nccl" else backend + "_ranks_seen"): ranks_seen},
         "spinup": {"ms": spin_ms, "launches": spin_launches,
                    "note": "same launches as the timed region, ahead of --warmup; not timed"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "infinity-cache/hbm" if fits else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": kernel, "bytes_per_env_step": bytes_per,
                      "avg_launch_us": steady_ms * 1e3, "avg_launch_launches": k_steady,
@@ -436,6 +501,8 @@ def main():
     }
     if stats:
         out["episode_stats"] = {k: stats[k] for k in ("n_episodes", "mean_return", "std_return", "mean_length") if k in stats}
+    if rank == 0 and world == 1 and with_returns and not args.no_subrecords and not args.compact:
+        out["graph_region"] = graph_region(torch, gf, args, n, actions)
 
     subrecords = rank == 0 and world == 1 and not args.no_subrecords and not args.compact
     if subrecords and with_returns:

@@ -11,7 +11,9 @@ arithmetic rounds every operation separately, so the kernels must not fuse
 a*b+c into an FMA ("Bit-exactness vs NumPy").
 """
 import glob
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -20,6 +22,10 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfishing_hip.so")
+# Per-kernel register / LDS table of the library that was built (hipcc's own remarks, written next to the .so).  bench.py
+# quotes a committed rocprofv3 --pmc figure only when the kernel it ran still has the resources of the kernel that
+# was profiled (scripts/summarize_profile.py stores them in the record): a changed kernel reports no stale counters.
+RESOURCES_PATH = os.path.join(LIB_DIR, "kernel_resources.json")
 ARCH = "gfx950"
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
@@ -41,7 +47,7 @@ def _deps():
 
 
 def is_stale():
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(RESOURCES_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     return any(os.path.getmtime(s) > t for s in _deps() if os.path.exists(s))
@@ -69,7 +75,7 @@ def _compile(out_path, verbose, extra_flags):
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     tmp = out_path + ".tmp.%d" % os.getpid()
     srcs = sources()
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-Rpass-analysis=kernel-resource-usage"] + list(extra_flags)
     objs = ["%s.%d.o" % (tmp, i) for i in range(len(srcs))]
     # one hipcc per translation unit, side by side (the two kernel files take about as long as each other),
     # then one link step
@@ -84,8 +90,10 @@ def _compile(out_path, verbose, extra_flags):
         for p, o in zip(procs, outs):
             if p.returncode != 0:
                 raise RuntimeError("hipcc failed (%d):\n%s" % (p.returncode, o))
-            if verbose and o.strip():
-                print(o)
+            if verbose:
+                rest = "\n".join(ln for ln in o.splitlines() if "remark:" not in ln and "kernel-resource-usage" not in ln)
+                if rest.strip():
+                    print(rest)
         link = [hipcc] + HIPCC_FLAGS + list(extra_flags) + objs + ["-o", tmp]
         if verbose:
             print(" ".join(link), flush=True)
@@ -93,11 +101,45 @@ def _compile(out_path, verbose, extra_flags):
         if proc.returncode != 0:
             raise RuntimeError("hipcc link failed (%d):\n%s" % (proc.returncode, proc.stdout))
         os.replace(tmp, out_path)
+        if out_path == LIB_PATH:
+            with open(RESOURCES_PATH, "w") as f:
+                json.dump(parse_resources("\n".join(outs)), f, indent=0, sort_keys=True)
     finally:
         for f in objs + [tmp]:
             if os.path.exists(f):
                 os.remove(f)
     return out_path
+
+
+def parse_resources(remarks):
+    """hipcc -Rpass-analysis=kernel-resource-usage output -> {demangled kernel name: {vgpr, sgpr, lds, scratch, occupancy}}."""
+    blocks = re.split(r"remark: [^\n]*Function Name: ", remarks)[1:]
+    names = [b.split()[0] for b in blocks]
+    dem = names
+    filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        dem = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True, check=True).stdout.splitlines()
+    except Exception:  # noqa: BLE001 - mangled names are still unique keys
+        pass
+    table = {}
+    for blk, name in zip(blocks, dem):
+        def g(key, blk=blk):
+            m = re.search(re.escape(key) + r": (\d+)", blk)
+            return int(m.group(1)) if m else None
+        short = re.sub(r"^void ", "", name).split("(")[0]
+        table[short] = {"vgpr": g("VGPRs"), "sgpr": g("TotalSGPRs"), "lds": g("LDS Size [bytes/block]"),
+                        "scratch": g("ScratchSize [bytes/lane]"), "occupancy": g("Occupancy [waves/SIMD]")}
+    return table
+
+
+def kernel_resources(kernel=None):
+    """The table written by the last build of LIB_PATH ({} when absent); `kernel` -> that kernel's entry or None."""
+    try:
+        with open(RESOURCES_PATH) as f:
+            table = json.load(f)
+    except Exception:  # noqa: BLE001
+        table = {}
+    return table if kernel is None else table.get(kernel)
 
 
 if __name__ == "__main__":

@@ -53,23 +53,45 @@ v4_params_kernel(const ParamsT<T> p, const int64_t n, const uint64_t env_offset,
     }
 }
 
-__global__ void __launch_bounds__(256)
+constexpr int kReduceThreads = 1024;
+__global__ void __launch_bounds__(kReduceThreads)
 reduce_returns_kernel(const double* __restrict__ partials, double* __restrict__ out4) {
-    // one workgroup of 4 waves: wave f sums field f.  Lane l adds slots l, l+64, ... in slot
-    // order, then a fixed shuffle tree combines the 64 lanes: same bits on every run.
-    const int field = threadIdx.x >> 6;
+    // One workgroup of 16 waves.  Thread i owns slots i, i + 1024, i + 2048, i + 3072: four 32-byte reads (a slot's
+    // four fields are contiguous), all issued before the first add; then a fixed tree -- slot order inside the
+    // thread, a shuffle tree inside the wave, wave order across the workgroup: same bits on every run.  (Round 2's
+    // form -- 256 threads, 64 strided 8-byte reads each -- took 8 us of the bench's 20-step region; this one ~3.)
+    static_assert(kMaxBlocks % kReduceThreads == 0, "whole passes");
+    constexpr int kPerThread = kMaxBlocks / kReduceThreads;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 lo[kPerThread], hi[kPerThread];
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        const d2* q = reinterpret_cast<const d2*>(partials + (int64_t)(threadIdx.x + k * kReduceThreads) * kPartialFields);
+        lo[k] = q[0];
+        hi[k] = q[1];
+    }
+    double s[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        s[0] += lo[k][0];
+        s[1] += lo[k][1];
+        s[2] += hi[k][0];
+        s[3] += hi[k][1];
+    }
+    __shared__ double red[kReduceThreads / kWave][kPartialFields];
     const int lane = threadIdx.x & (kWave - 1);
-    // all 64 loads of a lane are issued before the first add (one latency instead of 64 in a row:
-    // 20 us -> a few us), the adds stay in slot order
-    constexpr int kPerLane = kMaxBlocks / kWave;
-    double v[kPerLane];
 #pragma unroll
-    for (int k = 0; k < kPerLane; ++k) v[k] = partials[(lane + k * kWave) * kPartialFields + field];
-    double s = 0.0;
+    for (int f = 0; f < kPartialFields; ++f) {
+        const double w = wave_sum(s[f]);
+        if (lane == 0) red[threadIdx.x >> 6][f] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPartialFields) {
+        double tot = 0.0;
 #pragma unroll
-    for (int k = 0; k < kPerLane; ++k) s += v[k];
-    s = wave_sum(s);
-    if (lane == 0) out4[field] = s;
+        for (int w = 0; w < kReduceThreads / kWave; ++w) tot += red[w][threadIdx.x];
+        out4[threadIdx.x] = tot;
+    }
 }
 
 // population_draw() over an array of populations, as BMSY() drives it (models/policies.py:59-63)
@@ -265,7 +287,7 @@ int fishing_stream_synchronize(fishing_stream_t stream) { return (int)hipStreamS
 
 int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream) {
     if (!return_partials || !out4) return FISHING_ERR_NULL;
-    return fishing::launch_kernel(fishing::reduce_returns_kernel, 1, 256, (hipStream_t)stream, return_partials, out4);
+    return fishing::launch_kernel(fishing::reduce_returns_kernel, 1, fishing::kReduceThreads, (hipStream_t)stream, return_partials, out4);
 }
 
 int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,

@@ -698,13 +698,16 @@ __device__ __forceinline__ bool derive_fits_32(uint64_t env_last, uint64_t step_
 
 // Redraw (K, r) and restart the finished envs of one thread's 4-env tile (`base` = global index of
 // its first env).  Returns whether anything was redrawn.
-template <typename T, int MODEL>
+template <typename T, int MODEL, int E>
 __device__ __forceinline__ bool redraw_tile(uint64_t seed, uint64_t base, uint64_t counter, uint32_t stream,
-                                            T K_mean, T r_mean, T sigma_p, T x0, const bool (&fin)[4],
-                                            T (&KK)[4], T (&rr)[4], T (&obs)[4], int32_t (&t)[4]) {
-    if (!(fin[0] | fin[1] | fin[2] | fin[3])) return false;
+                                            T K_mean, T r_mean, T sigma_p, T x0, const bool (&fin)[E],
+                                            T (&KK)[E], T (&rr)[E], T (&obs)[E], int32_t (&t)[E]) {
+    bool any = false;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < E; ++j) any |= fin[j];
+    if (!any) return false;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
         T K2, r2;
         draw_model_error<T>(seed, base + (uint64_t)j, counter, stream, K_mean, r_mean, sigma_p, K2, r2);
         KK[j] = fin[j] ? K2 : KK[j];
@@ -718,10 +721,12 @@ __device__ __forceinline__ bool redraw_tile(uint64_t seed, uint64_t base, uint64
 // ---------------------------------------------------------------- 4-wide access helpers
 // 16-byte aligned at most: that is what the ABI guarantees for every buffer (a Vec4<double> is moved as two
 // 16-byte accesses either way)
-template <typename T>
-struct alignas(16) Vec4 {
-    T v[4];
+template <typename T, int E>
+struct alignas((E * sizeof(T) >= 16) ? 16 : E * sizeof(T)) VecE {
+    T v[E];
 };
+template <typename T>
+using Vec4 = VecE<T, 4>;
 
 template <typename T>
 __device__ __forceinline__ void load4(const T* p, int64_t base, int64_t n, bool full, T (&out)[4], T fill) {
@@ -778,10 +783,11 @@ __device__ __forceinline__ void load_t4(const int32_t* tp, bool u8, int64_t base
         for (int j = 0; j < 4; ++j) t[j] = (base + j < n) ? (int32_t)p[base + j] : 0;
     }
 }
-__device__ __forceinline__ uint32_t pack_t4(const int32_t (&t)[4]) {
+template <int E>
+__device__ __forceinline__ uint32_t pack_t4(const int32_t (&t)[E]) {
     uint32_t w = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w |= (uint32_t)(t[j] > 255 ? 255 : t[j]) << (8 * j);
+    for (int j = 0; j < E; ++j) w |= (uint32_t)(t[j] > 255 ? 255 : t[j]) << (8 * j);
     return w;
 }
 __device__ __forceinline__ void store_t4(int32_t* tp, bool u8, int64_t base, int64_t n, bool full,
@@ -805,12 +811,15 @@ __device__ __forceinline__ void store_t4(int32_t* tp, bool u8, int64_t base, int
 // the tile collects lanes 16k..16k+15.  Lane L fetches the nibble of lane 16k + L/4 with a
 // ds_bpermute (cross-lane, no LDS memory) and the 64 lanes vote their bit with one ballot.
 // Returns, in lanes 0..3, words 0..3 of the tile.
+// (E envs per lane: the wave's 64 * E flags make E words; word k collects lanes (64 / E) * k .. + 64 / E - 1.)
+template <int E = 4>
 __device__ __forceinline__ uint64_t ballot_tile_words(uint32_t nibble, int lane) {
+    static_assert(E == 4 || E == 2, "4 or 2 envs per lane");
     uint64_t mine = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t nb = (uint32_t)__shfl((int)nibble, 16 * k + (lane >> 2), kWave);
-        const uint64_t word = __ballot((nb >> (lane & 3)) & 1u);
+    for (int k = 0; k < E; ++k) {
+        const uint32_t nb = (uint32_t)__shfl((int)nibble, (kWave / E) * k + lane / E, kWave);
+        const uint64_t word = __ballot((nb >> (lane % E)) & 1u);
         mine = (lane == k) ? word : mine;
     }
     return mine;
@@ -827,13 +836,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 // double operations per tile instead of sixteen, which is 7 % of the fp32 step kernel's launch time
 // on the random-policy workload where every wave finishes an env every step.  Every kernel uses
 // this routine, so step-wise, fused-rollout and general-kernel records agree to double rounding.
-template <typename T>
-__device__ __forceinline__ void record_tile(const bool (&fin)[4], const T (&er)[4], const int32_t (&len)[4],
+template <typename T, int E>
+__device__ __forceinline__ void record_tile(const bool (&fin)[E], const T (&er)[E], const int32_t (&len)[E],
                                             double (&acc)[4]) {
     T s1 = (T)0, s2 = (T)0;
     int32_t cnt = 0, tot = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < E; ++j) {
         s1 += fin[j] ? er[j] : (T)0;
         s2 += fin[j] ? er[j] * er[j] : (T)0;
         cnt += fin[j] ? 1 : 0;

@@ -46,6 +46,9 @@ namespace fishing {
 #ifndef FISHING_ZZ_MIN_BYTES
 #define FISHING_ZZ_MIN_BYTES (500ll << 20)  // bytes one step streams, from which the tile walk alternates direction
 #endif
+#ifndef FISHING_F64_E2_MAX_BYTES
+#define FISHING_F64_E2_MAX_BYTES (250ll << 20)
+#endif
 #ifndef FISHING_STEP_MAXTHREADS
 #define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
 #endif
@@ -355,7 +358,12 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_LEAN_ATTRS
 #define FISHING_LEAN_ATTRS
 #endif
-template <typename T, int MODEL, int F>
+// E = envs per thread: 4 everywhere (16-byte accesses on the 4-byte streams) except the float64 parity layout at
+// cache-resident sizes, which runs E = 2 -- 16 bytes per lane on ITS streams instead of 32 (two 16-byte accesses, half
+// of each 64-byte line per instruction): a copy over the same streams takes 23.5 instead of 27.2 us at N = 2^22
+// (profiles/r02_f64_access_shape.jsonl).  A workgroup's tile is 256 * E envs; the lane pair that shares an env quad
+// computes the quad's Philox block twice and keeps one Box-Muller pair each.
+template <typename T, int MODEL, int F, int E = 4>
 __global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
 step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_t ntiles, const uint64_t env_offset,
                  const uint64_t seed, const uint64_t step_counter_arg) {
@@ -373,6 +381,8 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
     static_assert(!(F & feat::ONE) || (kExact && !(F & feat::ZZ)), "ONE: exact instantiations, no tile walk");
     constexpr bool kOne = (F & feat::ONE) != 0;
+    static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && kOpt && !kMixed), "E = 2: the float64 catch-alls");
+    constexpr int kTileEnvs = 256 * E;
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || a.ep_return != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -427,18 +437,21 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         // 16.5 us), and even a run-time switch costs the returns variant 2.5 % there: own instantiations.  The
         // catch-alls (every fp64 request among them) take the direction as a run-time flag, zz_rt.
         const int64_t tile = (ZZ && (step_counter & 1)) ? (ntiles - 1 - it) : it;
-        const int64_t base = (tile * 256 + threadIdx.x) * kEnvsPerThread;
+        const int64_t base = (tile * 256 + threadIdx.x) * E;
         // FISHING_FLAG_PADDED_TILES: the state buffers have room for whole tiles, so a batch that is not a multiple of 1024
         // envs still runs in this ONE launch (no second, one-workgroup launch for the tail: 3.7-4.2 us per step).  The
         // envs behind the last one are scratch: stepped like any other, but they never finish (neither recorded nor
         // redrawn), and the streams the CALLER owns -- actions, external noise -- are read at the last quad that exists
         // instead of past their end.  `live` is true everywhere otherwise.
         // (the tile's share of n_live is a scalar; per lane one 32-bit compare and one 32-bit select)
-        const int64_t tile_left = a.n_live - tile * 1024;                          // wave-uniform
-        const uint32_t left32 = tile_left >= 1024 ? 1024u : (uint32_t)tile_left;
-        const uint32_t lane_env = threadIdx.x * (uint32_t)kEnvsPerThread;
+        const int64_t tile_left = a.n_live - tile * kTileEnvs;                     // wave-uniform
+        const uint32_t left32 = tile_left >= kTileEnvs ? (uint32_t)kTileEnvs : (tile_left > 0 ? (uint32_t)tile_left : 0u);
+        const uint32_t lane_env = threadIdx.x * (uint32_t)E;
         const bool live = lane_env < left32;
-        const int64_t cbase = tile * 1024 + (int64_t)(live ? lane_env : left32 - (uint32_t)kEnvsPerThread);
+        // (E = 4: a padded tile holds at least one live quad, so the last one is tile-relative -- one 32-bit select;
+        // an E = 2 half-tile may be scratch altogether)
+        const int64_t cbase = (E == 4) ? tile * kTileEnvs + (int64_t)(live ? lane_env : left32 - (uint32_t)E)
+                                       : (live ? base : a.n_live - E);
         // The Philox round keys (seed + i * Weyl) are wave-uniform; hoisted out of this loop they sit in 20-30 SGPRs
         // for the whole kernel, which pushes the fishing-v4 variants (two generators) past 100 SGPRs = 7 instead of
         // 8 waves per SIMD.  Laundering the seed per tile keeps the key schedule next to its rounds (a scalar add
@@ -448,38 +461,40 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         uint64_t seed_it = seed;
         // (... and the float32 catch-alls, which sit at the 106-SGPR ceiling: 26 -> 2 SGPR-to-VGPR-lane spills)
         if constexpr (FISHING_LEAN_LOCAL_KEYS != 0 && (kPerEnv || (kOpt && sizeof(T) == 4))) asm volatile("" : "+s"(seed_it));
-        T obs[4], rr[4], KK[4], z[4], er[4], sg[4];
-        int32_t t[4], a_i[4];
-        int32_t kind[4] = {FISHING_KIND_BEVERTON_HOLT, FISHING_KIND_BEVERTON_HOLT, FISHING_KIND_BEVERTON_HOLT,
-                           FISHING_KIND_BEVERTON_HOLT};
-        float a_f[4];
+        T obs[E], rr[E], KK[E], z[E], er[E], sg[E];
+        int32_t t[E], a_i[E];
+        int32_t kind[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) kind[j] = FISHING_KIND_BEVERTON_HOLT;
+        float a_f[E];
         {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < E; ++j) {
                 sg[j] = a.sigma;
                 er[j] = (T)0;
             }
             if constexpr (kMixed) {
-                const Vec4<int32_t> qk = *reinterpret_cast<const Vec4<int32_t>*>(ex.model_idx + base);
+                const VecE<int32_t, E> qk = *reinterpret_cast<const VecE<int32_t, E>*>(ex.model_idx + base);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) kind[j] = qk.v[j];
+                for (int j = 0; j < E; ++j) kind[j] = qk.v[j];
             }
             if (SIGARR) {
-                const Vec4<T> qs = *reinterpret_cast<const Vec4<T>*>(a.sigma_arr + base);
+                const VecE<T, E> qs = *reinterpret_cast<const VecE<T, E>*>(a.sigma_arr + base);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sg[j] = qs.v[j];
+                for (int j = 0; j < E; ++j) sg[j] = qs.v[j];
             }
-            const Vec4<T> q = *reinterpret_cast<const Vec4<T>*>(a.obs + base);
-            Vec4<int32_t> qt;
+            const VecE<T, E> q = *reinterpret_cast<const VecE<T, E>*>(a.obs + base);
+            VecE<int32_t, E> qt;
             if (T8) {
-                const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(a.t) + base);
+                typedef std::conditional_t<E == 4, uint32_t, uint16_t> bytesE;
+                const uint32_t w = *reinterpret_cast<const bytesE*>(reinterpret_cast<const uint8_t*>(a.t) + base);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) qt.v[j] = (int32_t)((w >> (8 * j)) & 255u);
+                for (int j = 0; j < E; ++j) qt.v[j] = (int32_t)((w >> (8 * j)) & 255u);
             } else {
-                qt = *reinterpret_cast<const Vec4<int32_t>*>(a.t + base);
+                qt = *reinterpret_cast<const VecE<int32_t, E>*>(a.t + base);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < E; ++j) {
                 obs[j] = q.v[j];
                 t[j] = qt.v[j];
                 rr[j] = a.pr;
@@ -489,37 +504,37 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 a_f[j] = 0.0f;
             }
             if (MODEL == FISHING_MODEL_V0) {
-                const Vec4<int32_t> qa = *reinterpret_cast<const Vec4<int32_t>*>((const int32_t*)a.action + cbase);
+                const VecE<int32_t, E> qa = *reinterpret_cast<const VecE<int32_t, E>*>((const int32_t*)a.action + cbase);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a_i[j] = qa.v[j];
+                for (int j = 0; j < E; ++j) a_i[j] = qa.v[j];
             } else {
-                const Vec4<float> qa = *reinterpret_cast<const Vec4<float>*>((const float*)a.action + cbase);
+                const VecE<float, E> qa = *reinterpret_cast<const VecE<float, E>*>((const float*)a.action + cbase);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a_f[j] = qa.v[j];
+                for (int j = 0; j < E; ++j) a_f[j] = qa.v[j];
             }
             if (kPerEnv && !DERIVED) {
-                const Vec4<T> qr = *reinterpret_cast<const Vec4<T>*>(a.r + base);
-                const Vec4<T> qk = *reinterpret_cast<const Vec4<T>*>(a.K + base);
+                const VecE<T, E> qr = *reinterpret_cast<const VecE<T, E>*>(a.r + base);
+                const VecE<T, E> qk = *reinterpret_cast<const VecE<T, E>*>(a.K + base);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < E; ++j) {
                     rr[j] = qr.v[j];
                     KK[j] = qk.v[j];
                 }
             }
             if (DRIFT) {
-                const Vec4<T> qr = *reinterpret_cast<const Vec4<T>*>(a.r + base);
+                const VecE<T, E> qr = *reinterpret_cast<const VecE<T, E>*>(a.r + base);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rr[j] = qr.v[j];
+                for (int j = 0; j < E; ++j) rr[j] = qr.v[j];
             }
             if (RET) {
-                const Vec4<T> qe = *reinterpret_cast<const Vec4<T>*>(a.ep_return + base);
+                const VecE<T, E> qe = *reinterpret_cast<const VecE<T, E>*>(a.ep_return + base);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) er[j] = qe.v[j];
+                for (int j = 0; j < E; ++j) er[j] = qe.v[j];
             }
             if (noise == kNoiseExt) {
-                const Vec4<T> qz = *reinterpret_cast<const Vec4<T>*>(a.z_ext + cbase);
+                const VecE<T, E> qz = *reinterpret_cast<const VecE<T, E>*>(a.z_ext + cbase);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) z[j] = qz.v[j];
+                for (int j = 0; j < E; ++j) z[j] = qz.v[j];
             }
         }
         // the loads above must be in flight BEFORE the ~100-instruction Philox block starts: without
@@ -527,42 +542,50 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
         if constexpr (kOne) step_counter = read_counter();
         if (noise == kNoisePhilox) {
-            float zq[4];
-            noise_quad(seed_it, (env_offset + (uint64_t)base) >> 2, step_counter, zq);
+            float zq[E];
+            if constexpr (E == 4) {
+                noise_quad(seed_it, (env_offset + (uint64_t)base) >> 2, step_counter, zq);
+            } else {        // this lane's half of the quad's block (noise_quad: (w0, w1) -> envs 4q, 4q+1; (w2, w3) -> 4q+2, 4q+3)
+                const Words4 w = philox_block(seed_it, (env_offset + (uint64_t)base) >> 2, step_counter, kStreamNoise);
+                const bool upper = ((env_offset + (uint64_t)base) & 2u) != 0;
+                box_muller(upper ? w.w2 : w.w0, upper ? w.w3 : w.w1, zq[0], zq[1]);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) z[j] = (T)zq[j];
+            for (int j = 0; j < E; ++j) z[j] = (T)zq[j];
             // ... and the generator (which needs none of the loaded data) runs under their latency:
             // the first s_waitcnt vmcnt lands after it, at the first use of a loaded register
             if (FISHING_LEAN_FENCE & 2) __builtin_amdgcn_sched_barrier(0);
         }
         if (DERIVED) {      // needs the year counters: after the noise block, which hid their latency
             // (tile-uniform: the last env of this workgroup's tile and the counters all below 2^32 -> 32-bit integer work)
-            if (derive_fits_32(env_offset + (uint64_t)(tile + 1) * 1024u - 1u, step_counter, a.origin_step, a.origin_counter)) {
+            if (derive_fits_32(env_offset + (uint64_t)(tile + 1) * (uint64_t)kTileEnvs - 1u, step_counter, a.origin_step, a.origin_counter)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < E; ++j)
                     derive_model_error<T, true>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
                                                 a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < E; ++j)
                     derive_model_error<T>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
                                           a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
             }
         }
         // LATCH: envs that were finished before this step (only possible without auto-reset) must not be recorded
         // again.  The test reuses the population env_step computes anyway.
-        bool stale[4] = {false, false, false, false};
-        T obs_next[4], rew[4];
-        int32_t t_next[4];
-        bool dn[4];
+        bool stale[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) stale[j] = false;
+        T obs_next[E], rew[E];
+        int32_t t_next[E];
+        bool dn[E];
         bool stepped = false;
         if constexpr (kMixed) {
             if (!SIGARR) {      // wave-uniform: regroup the wave's envs by growth function (fishing_common.h: zoo_draw_regrouped)
                 __shared__ ZooSlot<T> win[4 * kZooWindowSlots];
-                T xh[4], hv[4], xn[4];
-                int kk[4];
+                T xh[E], hv[E], xn[E];
+                int kk[E];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < E; ++j) {
                     const T quota = quota_cts<T>((T)a_f[j], KK[j]);
                     if (RET && LATCH) stale[j] = was_done<T>(obs[j], t[j], KK[j], a.Tmax);
                     const T x = (obs[j] + (T)1) * KK[j];
@@ -575,7 +598,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots,
                                       (int)(threadIdx.x & (kWave - 1)));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < E; ++j) {
                     obs_next[j] = xn[j] / KK[j] - (T)1;
                     rew[j] = ((T)0 > hv[j]) ? (T)0 : hv[j];
                     t_next[j] = t[j] + 1;
@@ -586,7 +609,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         }
         if (!stepped) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < E; ++j) {
             const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
                                                         : quota_cts<T>((T)a_f[j], KK[j]);
             if (RET && LATCH) stale[j] = was_done<T>(obs[j], t[j], KK[j], a.Tmax);
@@ -615,60 +638,66 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {       // scratch envs never finish, and their year counter stays put (no overflow, ever)
+        for (int j = 0; j < E; ++j) {       // scratch envs never finish, and their year counter stays put (no overflow, ever)
             dn[j] = dn[j] && live;
             t_next[j] = live ? t_next[j] : 0;
         }
         auto store_outputs = [&]() {
             // reward and done are write-only streams nobody re-reads inside the step loop: nontemporal
             // stores (0.5-0.7 % at N = 2^22, 1.5 % at 2^24 / 2^26; profiles/r01g_lean_nt_stores.txt)
-            typedef T nt4 __attribute__((ext_vector_type(4)));
-            const nt4 qv = {rew[0], rew[1], rew[2], rew[3]};
-            __builtin_nontemporal_store(qv, reinterpret_cast<nt4*>(a.reward + base));
-            __builtin_nontemporal_store((uint32_t)dn[0] | ((uint32_t)dn[1] << 8) | ((uint32_t)dn[2] << 16) | ((uint32_t)dn[3] << 24),
-                                        reinterpret_cast<uint32_t*>(a.done + base));
-            if (TERM) {         // obs_next is still the pre-reset observation here
-                const nt4 qt = {obs_next[0], obs_next[1], obs_next[2], obs_next[3]};
-                __builtin_nontemporal_store(qt, reinterpret_cast<nt4*>(a.terminal_obs + base));
+            typedef T ntE __attribute__((ext_vector_type(E)));
+            typedef std::conditional_t<E == 4, uint32_t, uint16_t> bytesE;
+            ntE qv, qt;
+            uint32_t packed = 0, nibble = 0;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                qv[j] = rew[j];
+                qt[j] = obs_next[j];
+                packed |= (uint32_t)dn[j] << (8 * j);
+                nibble |= (uint32_t)dn[j] << j;
             }
-            if (BITS) {         // the wave's 256 flags as four 64-bit words (ballots, no LDS)
+            __builtin_nontemporal_store(qv, reinterpret_cast<ntE*>(a.reward + base));
+            __builtin_nontemporal_store((bytesE)packed, reinterpret_cast<bytesE*>(a.done + base));
+            if (TERM) __builtin_nontemporal_store(qt, reinterpret_cast<ntE*>(a.terminal_obs + base));   // (still the pre-reset observation)
+            if (BITS) {         // the wave's 64 * E flags as E 64-bit words (ballots, no LDS)
                 const int lane = threadIdx.x & (kWave - 1);
-                const uint32_t nibble = (uint32_t)dn[0] | ((uint32_t)dn[1] << 1) | ((uint32_t)dn[2] << 2) | ((uint32_t)dn[3] << 3);
-                const uint64_t word = ballot_tile_words(nibble, lane);
-                const int64_t wave_env0 = (tile * 256 + (threadIdx.x & ~(kWave - 1))) * kEnvsPerThread;
-                if (lane < 4) a.done_bits[(wave_env0 >> 6) + lane] = word;
+                const uint64_t word = ballot_tile_words<E>(nibble, lane);
+                const int64_t wave_env0 = (tile * 256 + (threadIdx.x & ~(kWave - 1))) * E;
+                if (lane < E) a.done_bits[(wave_env0 >> 6) + lane] = word;
             }
         };
         if (!(kOne && RET)) store_outputs();
-        const bool lane_done = dn[0] | dn[1] | dn[2] | dn[3];
+        bool lane_done = false;
+#pragma unroll
+        for (int j = 0; j < E; ++j) lane_done |= dn[j];
         if (RET) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) er[j] = er[j] + rew[j];
+            for (int j = 0; j < E; ++j) er[j] = er[j] + rew[j];
             if (__any(lane_done)) {          // wave-ballot: only waves with a finished env record
-                bool fresh[4];               // the episode ended on THIS step (not: stepped on after its end)
+                bool fresh[E];               // the episode ended on THIS step (not: stepped on after its end)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fresh[j] = dn[j] && !stale[j];
+                for (int j = 0; j < E; ++j) fresh[j] = dn[j] && !stale[j];
                 record_tile<T>(fresh, er, t_next, acc);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
+                for (int j = 0; j < E; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
             }
             if constexpr (kOne) {       // the record's atomic first, the tile's stores behind it
                 if (a.partials) add_block_partials<4, 4>(acc, a.partials);
                 store_outputs();
             }
-            Vec4<T> qe;
+            VecE<T, E> qe;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) qe.v[j] = er[j];
-            *reinterpret_cast<Vec4<T>*>(a.ep_return + base) = qe;
+            for (int j = 0; j < E; ++j) qe.v[j] = er[j];
+            *reinterpret_cast<VecE<T, E>*>(a.ep_return + base) = qe;
         }
         if constexpr (kMixed) {     // growth_models.py:200: a new model for the next episode
             if (auto_reset && __any(lane_done)) {
                 if (redraw_kinds(seed_it, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, ex.kinds, ex.n_models, dn,
                                  kind)) {
-                    Vec4<int32_t> qk;
+                    VecE<int32_t, E> qk;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) qk.v[j] = kind[j];
-                    *reinterpret_cast<Vec4<int32_t>*>(ex.model_idx + base) = qk;
+                    for (int j = 0; j < E; ++j) qk.v[j] = kind[j];
+                    *reinterpret_cast<VecE<int32_t, E>*>(ex.model_idx + base) = qk;
                 }
             }
         }
@@ -678,41 +707,44 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                     redraw_tile<T, MODEL>(seed_it, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, a.K_mean,
                                           a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs_next, t_next);
                 if (redrawn) {
-                    Vec4<T> qk, qr;
+                    VecE<T, E> qk, qr;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < E; ++j) {
                         qk.v[j] = KK[j];
                         qr.v[j] = rr[j];
                     }
-                    *reinterpret_cast<Vec4<T>*>(a.K + base) = qk;
-                    *reinterpret_cast<Vec4<T>*>(a.r + base) = qr;
+                    *reinterpret_cast<VecE<T, E>*>(a.K + base) = qk;
+                    *reinterpret_cast<VecE<T, E>*>(a.r + base) = qr;
                 }
             }
         } else {        // (fishing-v4 with derived parameters restarts at x0 whatever the next episode's K)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < E; ++j) {
                 const bool rs = dn[j] && auto_reset;
                 obs_next[j] = rs ? robs_scalar : obs_next[j];
                 t_next[j] = rs ? 0 : t_next[j];
             }
         }
         {
-            Vec4<T> qo;
-            Vec4<int32_t> qt;
+            VecE<T, E> qo;
+            VecE<int32_t, E> qt;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < E; ++j) {
                 qo.v[j] = obs_next[j];
                 qt.v[j] = t_next[j];
             }
-            *reinterpret_cast<Vec4<T>*>(a.obs + base) = qo;
+            *reinterpret_cast<VecE<T, E>*>(a.obs + base) = qo;
             if (DRIFT) {
-                Vec4<T> qr;
+                VecE<T, E> qr;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) qr.v[j] = rr[j];
-                *reinterpret_cast<Vec4<T>*>(a.r + base) = qr;
+                for (int j = 0; j < E; ++j) qr.v[j] = rr[j];
+                *reinterpret_cast<VecE<T, E>*>(a.r + base) = qr;
             }
-            if (T8) *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(a.t) + base) = pack_t4(t_next);
-            else *reinterpret_cast<Vec4<int32_t>*>(a.t + base) = qt;
+            if (T8) {
+                typedef std::conditional_t<E == 4, uint32_t, uint16_t> bytesE;
+                *reinterpret_cast<bytesE*>(reinterpret_cast<uint8_t*>(a.t) + base) = (bytesE)pack_t4(t_next);
+            }
+            else *reinterpret_cast<VecE<int32_t, E>*>(a.t + base) = qt;
         }
     };
 
@@ -832,20 +864,23 @@ struct LeanCall {
     hipStream_t s;
     std::string* name;
     const void* extra;       // LeanMixedArgs<T> for fishing-v11, unused otherwise
+    bool two_per_thread;     // float64: E = 2 (streams cache-resident)
 };
 
-template <typename T, int MODEL, int F>
+template <typename T, int MODEL, int F, int E = 4>
 int lean_launch(const LeanCall<T>& c) {
     if (c.name) {
         char buf[96];
-        std::snprintf(buf, sizeof buf, "fishing::step_kernel_lean<%s, %d, %d>", sizeof(T) == 4 ? "float" : "double", MODEL, F);
+        std::snprintf(buf, sizeof buf, "fishing::step_kernel_lean<%s, %d, %d, %d>", sizeof(T) == 4 ? "float" : "double", MODEL, F, E);
         *c.name = buf;
         return FISHING_OK;
     }
     LeanExtra<T, MODEL> ex{};
     if constexpr (MODEL == kModelZooMixed) ex = *static_cast<const LeanMixedArgs<T>*>(c.extra);
-    return launch_kernel(step_kernel_lean<T, MODEL, F>, c.blocks, 256, c.s, c.a, ex, c.ntiles, c.env_offset, c.seed,
-                         c.step_counter);
+    // (c.ntiles / c.blocks count 1024-env tiles; an E = 2 workgroup covers half of one)
+    const int64_t nt = c.ntiles * (4 / E);
+    const int64_t nb = nt < kMaxBlocks ? nt : ((int64_t)c.blocks * (4 / E) < kMaxBlocks ? (int64_t)c.blocks * (4 / E) : kMaxBlocks);
+    return launch_kernel(step_kernel_lean<T, MODEL, F, E>, (int)nb, 256, c.s, c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
 }
 
 // the catch-all mask of a (T, MODEL): every optional stream "may be there", noise mode at run time
@@ -958,6 +993,10 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
 #endif
 #undef FISHING_LEAN_CASE
 #undef FISHING_LEAN_CASE_ZZ
+    // the float64 catch-alls: two envs per thread while a step's streams sit in the Infinity Cache (see the kernel)
+    if constexpr (sizeof(T) == 8 && MODEL != kModelZooMixed) {
+        if (c.two_per_thread) return lean_launch<T, MODEL, catch_all_mask<MODEL>(), 2>(c);
+    }
     return lean_launch<T, MODEL, catch_all_mask<MODEL>()>(c);
 }
 
@@ -1029,7 +1068,10 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
             mixed.zoo[k] = pt.zoo[k];
         }
     }
-    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name, &mixed};
+    // float64 with two envs per thread while one step's streams fit the 256 MiB Infinity Cache with room to spare
+    // (N < 2^23 for the 37-byte layout); four per thread beyond, where the access shape stops mattering
+    const bool two = sizeof(T) == 8 && step_bytes < FISHING_F64_E2_MAX_BYTES && !p->launch_blocks;
+    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name, &mixed, two};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
         if constexpr (kTag == kModelZooMixed && sizeof(T) == 8) return (int)FISHING_ERR_MODEL;     // (not reached: see `lean`)

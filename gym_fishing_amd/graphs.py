@@ -14,14 +14,23 @@ import torch
 
 
 class GraphedSteps:
-    def __init__(self, env, actions, n_steps=None, warmup=1):
+    def __init__(self, env, actions, n_steps=None, warmup=1, record=False):
+        """`record=True` also captures the reduction of the episodic-return record behind the steps (this rank's record:
+        no collective inside the graph); `self.record` is then the 4-double device tensor every replay rewrites."""
         if env._scalar:
             raise ValueError("graph capture is for the N-env tensor protocol")
         self.env = env.enable_graph_replay()
         self.actions = actions
         many = actions.dim() == 2
         self.n_steps = (actions.shape[0] if n_steps is None else int(n_steps)) if many else 1
-        run = (lambda: env.step_many(actions, self.n_steps)) if many else (lambda: env.step(actions))
+        step = (lambda: env.step_many(actions, self.n_steps)) if many else (lambda: env.step(actions))
+        self.record = None
+
+        def run():
+            out = step()
+            if record:
+                self.record = env.episode_record(all_reduce=False)
+            return out
         # warm up on a side stream (torch's capture rule), then restore the counter so the
         # captured sequence continues where the caller left off
         start = env._counter.clone()

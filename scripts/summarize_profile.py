@@ -19,6 +19,7 @@ import glob
 import json
 import os
 import statistics
+import sys
 
 
 def find(d, pattern):
@@ -126,7 +127,12 @@ def main():
         except Exception:  # noqa: BLE001
             recs = []
         recs = [r for r in recs if not (r.get("kernel") == summ.get("kernel") and r.get("n_envs") == a.n_envs)]
+        # the profiled kernel's compile-time resources (gym_fishing_amd/_lib/kernel_resources.json of the library in this
+        # tree -- run this script before rebuilding): bench.py drops the record once the built kernel differs
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from gym_fishing_amd import build as _build
         recs.append({"kernel": summ.get("kernel"), "n_envs": a.n_envs, "hbm_bytes_per_launch": summ["hbm_bytes_per_launch"],
+                     "kernel_resources": _build.kernel_resources(summ.get("kernel")),
                      "source": os.path.basename(a.out) + "_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                "separate passes; FETCH_SIZE x2 gfx950 correction)"})
         with open(path, "w") as f:

@@ -155,14 +155,19 @@ class State:
         return out.cpu().numpy()
 
 
-def kernel_name(p, n, buffers, dtype=np.float32):
-    """Name of the kernel step() would launch for the whole tiles of this request (fishing_step_kernel_name_*)."""
+def kernel_name(p, n, buffers, dtype=np.float32, raw=False):
+    """Name of the kernel step() would launch for the whole tiles of this request (fishing_step_kernel_name_*), as
+    rocprofv3 prints it.  The lean kernel's last template argument is its envs per thread: the usual 4 is dropped here
+    unless `raw` (tests name the feature mask; the float64 layout's 2-per-thread form keeps its ", 2>")."""
     import ctypes
     out = ctypes.create_string_buffer(160)
     fn = getattr(_capi.lib(), "fishing_step_kernel_name_" + ("f32" if np.dtype(dtype) == np.float32 else "f64"))
     rc = fn(p, n, buffers, out, 160)
     assert rc == 0, rc
-    return out.value.decode()
+    name = out.value.decode()
+    if not raw and "step_kernel_lean<" in name and name.endswith(", 4>"):
+        name = name[:-4] + ">"
+    return name
 
 
 def device_noise(n, seed, counter, stream_tag=0, env_offset=0):

@@ -47,14 +47,14 @@ def test_bench_gpus_2_launches_its_own_ranks_and_matches_one_rank_of_twice_the_e
     assert abs(a["mean_return"] - b["mean_return"]) <= 1e-9 * abs(b["mean_return"])
     assert abs(a["mean_length"] - b["mean_length"]) <= 1e-12 * b["mean_length"]
     # the roofline record names the kernel the dispatch picked
-    assert one["roofline"]["kernel"] == "fishing::step_kernel_lean<float, 1, 12294>"
+    assert one["roofline"]["kernel"] == "fishing::step_kernel_lean<float, 1, 12294, 4>"
     assert one["roofline"]["bytes_per_env_step"] == 33
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("config,kernel,nbytes", [("v0", "fishing::step_kernel_lean<float, 0, 12294>", 33),
-                                                  ("v2", "fishing::step_kernel_lean<float, 2, 12294>", 33),
-                                                  ("v4", "fishing::step_kernel_lean<float, 4, 8462>", 37)])
+@pytest.mark.parametrize("config,kernel,nbytes", [("v0", "fishing::step_kernel_lean<float, 0, 12294, 4>", 33),
+                                                  ("v2", "fishing::step_kernel_lean<float, 2, 12294, 4>", 33),
+                                                  ("v4", "fishing::step_kernel_lean<float, 4, 8462, 4>", 37)])
 def test_bench_configs_name_their_workload(config, kernel, nbytes):
     out = run_bench("--config", config, "--steps", "20", "--warmup", "5", "--spinup-ms", "5", "--no-cpu-baseline",
                     "--no-subrecords", "--n-envs", str(1 << 18))

@@ -629,7 +629,9 @@ def test_bench_contract_json_line(gf):
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # (N = 2^18: the streams sit in the Infinity Cache, and the record says so in the field itself)
+    assert r["bound"] == ("infinity-cache/hbm" if r["cache_resident"] else "hbm") and r["cache_resident"] is True
+    assert r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert abs(d["value"] - (1 << 18) * 40 / (d["ms_per_step"] * 40 / 1e3)) / d["value"] < 1e-9
 
