@@ -47,7 +47,8 @@ namespace fishing {
 #define FISHING_ZZ_MIN_BYTES (500ll << 20)  // bytes one step streams, from which the tile walk alternates direction
 #endif
 #ifndef FISHING_F64_E2_MAX_BYTES
-#define FISHING_F64_E2_MAX_BYTES (250ll << 20)
+#define FISHING_F64_E2_MAX_BYTES (250ll << 20)      // float64: two envs per thread below this many bytes per step ...
+#define FISHING_F64_E2_MIN_BYTES (105ll << 20)      // ... the catch-alls only above this many (profiles/r03_f64_two_per_thread.jsonl)
 #endif
 #ifndef FISHING_STEP_MAXTHREADS
 #define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
@@ -381,7 +382,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
     static_assert(!(F & feat::ONE) || (kExact && !(F & feat::ZZ)), "ONE: exact instantiations, no tile walk");
     constexpr bool kOne = (F & feat::ONE) != 0;
-    static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && kOpt && !kMixed), "E = 2: the float64 catch-alls");
+    static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
     constexpr int kTileEnvs = 256 * E;
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || a.ep_return != nullptr);
@@ -864,7 +865,8 @@ struct LeanCall {
     hipStream_t s;
     std::string* name;
     const void* extra;       // LeanMixedArgs<T> for fishing-v11, unused otherwise
-    bool two_per_thread;     // float64: E = 2 (streams cache-resident)
+    bool two_per_thread;     // float64: E = 2 for the exact instantiations (streams cache-resident)
+    bool two_per_thread_any; //          ... and for the catch-all
 };
 
 template <typename T, int MODEL, int F, int E = 4>
@@ -993,9 +995,22 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
 #endif
 #undef FISHING_LEAN_CASE
 #undef FISHING_LEAN_CASE_ZZ
-    // the float64 catch-alls: two envs per thread while a step's streams sit in the Infinity Cache (see the kernel)
+    // float64: two envs per thread while a step's streams sit in the Infinity Cache (see the kernel).  Relieved of the
+    // 32-byte access shape the layout feels its arithmetic -- two IEEE float64 divisions per env, ~25 instructions each --
+    // so fishing-v0/v1/v2 with K a power of two have exact instantiations there (no division, no option tests)
     if constexpr (sizeof(T) == 8 && MODEL != kModelZooMixed) {
-        if (c.two_per_thread) return lean_launch<T, MODEL, catch_all_mask<MODEL>(), 2>(c);
+        if (c.two_per_thread) {
+            if constexpr (!is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
+                switch (req) {
+                    case (P | KP2): return lean_launch<T, MODEL, (P | KP2), 2>(c);
+                    case (P | KP2 | RET): return lean_launch<T, MODEL, (P | KP2 | RET), 2>(c);
+                    default: break;
+                }
+            }
+            // (the catch-all pays for E = 2 with a third more instructions per env -- the lane pair's second Philox
+            // block, its option tests twice: worth it only from ~110 MB per step on, N = 2^22 and 2^21 with returns)
+            if (c.two_per_thread_any) return lean_launch<T, MODEL, catch_all_mask<MODEL>(), 2>(c);
+        }
     }
     return lean_launch<T, MODEL, catch_all_mask<MODEL>()>(c);
 }
@@ -1051,7 +1066,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     if (b->done_bits) req |= feat::BITS;
     if (derived) req |= feat::DERIVED;
     if (drift) req |= feat::DRIFT;
-    if (sizeof(T) == 4 && a.dk.pow2 && is_core_model(p->model) && p->model != FISHING_MODEL_V4) req |= feat::KP2;
+    if (a.dk.pow2 && is_core_model(p->model) && p->model != FISHING_MODEL_V4) req |= feat::KP2;
     // The zig-zag walk once a step's streams are about twice the 256 MiB Infinity Cache (for the requests that have such
     // an instantiation): every size from N = 2^25 on, at 2^24 the variants with the return accumulator (33 B x 2^24 =
     // 554 MB: 85.6 -> 82.8 us; the bare 25 B step, 420 MB, still prefers the forward walk: 62.9 vs 63.7 us).
@@ -1071,7 +1086,8 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     // float64 with two envs per thread while one step's streams fit the 256 MiB Infinity Cache with room to spare
     // (N < 2^23 for the 37-byte layout); four per thread beyond, where the access shape stops mattering
     const bool two = sizeof(T) == 8 && step_bytes < FISHING_F64_E2_MAX_BYTES && !p->launch_blocks;
-    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name, &mixed, two};
+    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name, &mixed, two,
+                           two && step_bytes >= FISHING_F64_E2_MIN_BYTES};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
         if constexpr (kTag == kModelZooMixed && sizeof(T) == 8) return (int)FISHING_ERR_MODEL;     // (not reached: see `lean`)
