@@ -86,23 +86,26 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
     o1 = c1;
 }
 
-// Block of the per-env parameter draw (mirrored in oracle/fishing_oracle.py: param_words):
-//   key = seed[31:0] ^ seed[63:32] * 0x85EBCA6B                                  -- wave-uniform: the ten round keys
-//                                                                                   stay in SGPRs, like the noise block's
-//   c0  = env[31:0]     ^ bitreverse(counter[63:32])
-//   c1  = counter[31:0] ^ bitreverse(env[63:32]) ^ (stream == kStreamReset ? 0x5851F42D : 0x2545F491)
-// The high halves (zero until 2^32 envs or steps) and the stream tag are folded into the counter words with
-// full-rate ops; everything per-lane sits in the counter, so a round costs one multiply and two xors.
-constexpr uint32_t kParamTagReset = 0x5851F42Du, kParamTagAuto = 0x2545F491u;
+// Block of the per-env parameter draw (mirrored in oracle/fishing_oracle.py: param_words; round 3 layout):
+//   c0  = env[31:0]
+//   c1  = counter[30:0] | (stream == kStreamReset ? 1 << 31 : 0)
+//   key = seed[31:0] ^ seed[63:32] * 0x85EBCA6B ^ counter[62:31] * 0x9E3779B1 ^ env[63:32] * 0xC2B2AE35
+// While env < 2^32 and counter < 2^31 -- every run so far: 2^31 steps are 15 hours at 25 us per step -- the block is an
+// injective function of (env, counter, stream): the reset() draws and the auto-reset draws can never meet, whatever the
+// two counters (round 2 told the streams apart by XOR-ing a tag into c1, which made reset counter a and step counter b
+// share a block whenever a ^ b equalled the difference of the tags, b ~ 2.1e9).  There the key is wave-uniform and its
+// ten round keys stay in SGPRs, like the noise block's; beyond, the high parts perturb the key per lane.
+// Key space: Philox2x32 takes ONE 32-bit key, so the 64-bit seed is folded -- two seeds share their parameter stream with
+// probability 2^-32 (the noise stream, Philox4x32, carries the full 64-bit seed and is not affected).
+constexpr uint32_t kParamResetBit = 0x80000000u;
 __device__ __forceinline__ uint32_t param_key(uint64_t seed) {
     return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x85EBCA6Bu);
 }
 __device__ __forceinline__ void param_block(uint64_t seed, uint64_t env, uint64_t counter, bool reset_stream, uint32_t& w0,
                                             uint32_t& w1) {
-    const uint32_t c0 = (uint32_t)env ^ __builtin_bitreverse32((uint32_t)(counter >> 32));
-    const uint32_t c1 = (uint32_t)counter ^ __builtin_bitreverse32((uint32_t)(env >> 32)) ^
-                        (reset_stream ? kParamTagReset : kParamTagAuto);
-    philox2x32_10(c0, c1, param_key(seed), w0, w1);
+    const uint32_t c1 = ((uint32_t)counter & ~kParamResetBit) | (reset_stream ? kParamResetBit : 0u);
+    const uint32_t key = param_key(seed) ^ ((uint32_t)(counter >> 31) * 0x9E3779B1u) ^ ((uint32_t)(env >> 32) * 0xC2B2AE35u);
+    philox2x32_10((uint32_t)env, c1, key, w0, w1);
 }
 
 // Two standard normals from two words.  u1 in (0, 1], u2 = fraction of a turn in [0, 1].
@@ -671,13 +674,12 @@ __device__ __forceinline__ void derive_model_error(uint64_t seed, uint64_t env, 
                                                    uint64_t origin_step, uint64_t origin_counter, T K_mean,
                                                    T r_mean, T sigma_p, T& K, T& r) {
     if constexpr (NARROW) {
-        // every counter and env index of the wave fits 32 bits (derive_fits_32): the same block with half the
-        // integer work -- param_block's folded-in high halves are zero
+        // every env index of the wave fits 32 bits and every counter 31 (derive_fits_32): the same block with half the
+        // integer work -- param_block's key terms of the high parts are zero, the key is wave-uniform
         const uint32_t since = (uint32_t)step_counter - (uint32_t)t;
         const bool from_reset = since == (uint32_t)origin_step;
         uint32_t w0, w1;
-        philox2x32_10((uint32_t)env, (from_reset ? (uint32_t)origin_counter : since - 1u) ^ (from_reset ? kParamTagReset : kParamTagAuto),
-                      param_key(seed), w0, w1);
+        philox2x32_10((uint32_t)env, from_reset ? ((uint32_t)origin_counter | kParamResetBit) : since - 1u, param_key(seed), w0, w1);
         float zK, zr;
         box_muller(w0, w1, zK, zr);
         K = clip_param<T>(K_mean + sigma_p * (T)zK);
@@ -688,12 +690,21 @@ __device__ __forceinline__ void derive_model_error(uint64_t seed, uint64_t env, 
         draw_model_error_block<T>(seed, env, from_reset ? origin_counter : since - 1, from_reset, K_mean, r_mean, sigma_p, K, r);
     }
 }
+// FishingBuffers.counter under FISHING_FLAG_V4_DERIVED: {step counter, origin step, origin counter} in device memory, so
+// that a launch captured in a hipGraph (frozen arguments) sees the origin of the LAST reset().  Wave-uniform scalar loads.
+__device__ __forceinline__ void device_origin(const uint64_t* counter, uint64_t& origin_step, uint64_t& origin_counter) {
+    if (counter) {
+        origin_step = counter[1];
+        origin_counter = counter[2];
+    }
+}
+
 // wave-uniform: may this launch's derivations of the envs [env_first, env_last] use the 32-bit form?  (An env whose
 // years_passed exceeds the step count is out of contract -- the host advances both together -- so since - 1 cannot wrap
 // except as the unused arm of the from_reset select.)
 __device__ __forceinline__ bool derive_fits_32(uint64_t env_last, uint64_t step_counter, uint64_t origin_step,
                                                uint64_t origin_counter) {
-    return ((env_last | step_counter | origin_step | origin_counter) >> 32) == 0;
+    return ((env_last >> 32) | ((step_counter | origin_step | origin_counter) >> 31)) == 0;
 }
 
 // Redraw (K, r) and restart the finished envs of one thread's 4-env tile (`base` = global index of

@@ -29,6 +29,8 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     const uint64_t step_counter0 = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     const bool derived = kPerEnv && (p.flags & FISHING_FLAG_V4_DERIVED) != 0;   // no r / K arrays (derive_model_error)
+    uint64_t origin_step = p.origin_step, origin_counter = p.origin_counter;
+    if (derived) device_origin(b.counter, origin_step, origin_counter);
     // per-env K keeps the true division.  (The power-of-two flag stays a run-time one here: at N = 2^22 this kernel is
     // VALU-bound with 5-6 waves per SIMD to interleave, and a compile-time flag measured no gain -- unlike in the
     // fused step kernel's two-waves-per-SIMD regime.)
@@ -83,8 +85,8 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         if (derived) {      // once per launch; the redraws below keep (K, r) current from then on
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                derive_model_error<T>(seed_arg, env_offset + (uint64_t)base + j, step_counter0, t[j], p.origin_step,
-                                      p.origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
+                derive_model_error<T>(seed_arg, env_offset + (uint64_t)base + j, step_counter0, t[j], origin_step,
+                                      origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
         }
         bool kind_dirty = false;
         const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
@@ -424,6 +426,8 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
     const uint64_t step_counter0 = a.counter ? (*a.counter + step_counter_arg) : step_counter_arg;
     const bool auto_reset = a.auto_reset != 0;
     const bool derived = kPerEnv && a.derived != 0;
+    uint64_t origin_step = a.origin_step, origin_counter = a.origin_counter;
+    if (derived) device_origin(a.counter, origin_step, origin_counter);
     const bool drift = kZoo && a.drift != 0;
     const bool t8 = a.t8 != 0;
     const DivK dk = RAGGED ? a.dk : (KP2 ? DivK{true, a.dk.inv_f, a.dk.inv_d} : DivK{false, 0.0f, 0.0});
@@ -484,8 +488,8 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
         if (derived) {      // once per launch; the redraws below keep (K, r) current from then on
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter0, t[j], a.origin_step,
-                                      a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+                derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter0, t[j], origin_step,
+                                      origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
         }
         const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
         bool kr_dirty = false;

@@ -77,6 +77,8 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
     const bool auto_reset = (p.flags & FISHING_FLAG_AUTO_RESET) != 0;
     const bool derived = kPerEnv && (p.flags & FISHING_FLAG_V4_DERIVED) != 0;
+    uint64_t origin_step = p.origin_step, origin_counter = p.origin_counter;
+    if (derived) device_origin(b.counter, origin_step, origin_counter);
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
     // zoo (fishing-v5..v11): wave-uniform facts about the family
     const bool zoo_drift = kZoo && p.model == FISHING_MODEL_V10;       // r += alpha every draw
@@ -135,8 +137,8 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         if (derived) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter, t[j], p.origin_step,
-                                      p.origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
+                derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter, t[j], origin_step,
+                                      origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
         }
 
         T obs_next[4], rew[4];
@@ -424,6 +426,8 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         return c + step_counter_arg;
     };
     uint64_t step_counter = kOne ? step_counter_arg : read_counter();
+    uint64_t origin_step = a.origin_step, origin_counter = a.origin_counter;
+    if (DERIVED) device_origin(a.counter, origin_step, origin_counter);
     // an exact RET instantiation is only ever launched with auto-reset on (the dispatch sends RET without it to the
     // catch-all, which carries the LATCH): the flag is a compile-time fact there
     const bool auto_reset = (kExact && (F & feat::RET)) ? true : a.auto_reset != 0;
@@ -559,16 +563,16 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         }
         if (DERIVED) {      // needs the year counters: after the noise block, which hid their latency
             // (tile-uniform: the last env of this workgroup's tile and the counters all below 2^32 -> 32-bit integer work)
-            if (derive_fits_32(env_offset + (uint64_t)(tile + 1) * (uint64_t)kTileEnvs - 1u, step_counter, a.origin_step, a.origin_counter)) {
+            if (derive_fits_32(env_offset + (uint64_t)(tile + 1) * (uint64_t)kTileEnvs - 1u, step_counter, origin_step, origin_counter)) {
 #pragma unroll
                 for (int j = 0; j < E; ++j)
-                    derive_model_error<T, true>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
-                                                a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+                    derive_model_error<T, true>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], origin_step,
+                                                origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < E; ++j)
-                    derive_model_error<T>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], a.origin_step,
-                                          a.origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+                    derive_model_error<T>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], origin_step,
+                                          origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
             }
         }
         // LATCH: envs that were finished before this step (only possible without auto-reset) must not be recorded

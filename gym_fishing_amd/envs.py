@@ -92,6 +92,12 @@ def _gym_env_base():
         return object
 
 
+# state_dict() format.  2: carries `format` and `v4_param_stream` (what draws fishing-v4's (K, r): one Philox2x32-10 block
+# per env, fishing_common.h: param_block); _counter holds {step counter, v4 origin step, v4 origin counter}.
+STATE_FORMAT = 2
+V4_PARAM_STREAM = "philox2x32-10/env"
+
+
 class BaseFishingEnv(_gym_env_base()):
     """base_fishing_env.py:16-164, vectorised.  See the module docstring."""
 
@@ -268,7 +274,31 @@ class BaseFishingEnv(_gym_env_base()):
 
     # ------------------------------------------------------------------ parameters
     @property
+    def years_passed(self):
+        """base_fishing_env.py:75.  One env: the int.  num_envs: the live int32 year-counter tensor -- except for
+        fishing-v4 in the derived-parameter mode, where the counter also dates each env's episode and with it its (K, r):
+        there a COPY is returned, and an assignment (env.years_passed = ..., set_attr) first switches the env to stored
+        r / K arrays, so that an outside write can move the Tmax check but never silently re-key an env's parameters."""
+        if self._scalar:
+            return self._years_scalar
+        return self._t.clone() if self._derived else self._t
+
+    @years_passed.setter
+    def years_passed(self, v):
+        if self._scalar:
+            self._years_scalar = v
+            return
+        if v is self._t:
+            return
+        self._leave_derived_mode()
+        self._t.copy_(torch.as_tensor(v).to(device=self.device, dtype=self._t.dtype).reshape(self.num_envs))
+
+    @property
     def K(self):
+        """Carrying capacity.  fishing-v4 with num_envs: the per-env tensor -- in the default derived-parameter mode a
+        SNAPSHOT materialised by this access (the env keeps no K / r arrays: in-place edits of the returned tensor are
+        lost, and every access costs a small kernel); assign through `env.K = ...` / `env.r = ...`, which switches the
+        env to stored arrays until the next full reset()."""
         return self._K_view() if self._per_env else self.params["K"]
 
     @K.setter
@@ -307,10 +337,10 @@ class BaseFishingEnv(_gym_env_base()):
                else torch.full((self._cap,), fill, dtype=dtype, device=self.device))
         return buf[:self.num_envs]
 
-    def _derive_params(self):
-        """(K, r) tensors of a fishing-v4 env in the derived mode, materialised by fishing_v4_params_*."""
-        K = self._per_env_buffer(self.dtype)
-        r = self._per_env_buffer(self.dtype)
+    def _derive_params(self, out=None):
+        """(K, r) tensors of a fishing-v4 env in the derived mode, materialised by fishing_v4_params_* (into the pair
+        `out` when given: callers that ask every step reuse one pair instead of allocating two streams per call)."""
+        K, r = out if out is not None else (self._per_env_buffer(self.dtype), self._per_env_buffer(self.dtype))
         with torch.cuda.device(self.device):
             rc = getattr(self._lib, "fishing_v4_params_" + self._suffix)(
                 self._c_params(), self.num_envs, self.env_offset, self._t.data_ptr(), K.data_ptr(), r.data_ptr(),
@@ -328,9 +358,9 @@ class BaseFishingEnv(_gym_env_base()):
             self._derived = False
             self._cbuf = None
 
-    def _K_view(self):
+    def _K_view(self, out=None):
         if self._derived:
-            return self._derive_params()[0]
+            return self._derive_params(out)[0]
         return float(self._K_arr[0]) if self._scalar else self._K_arr
 
     def _r_view(self):
@@ -460,12 +490,11 @@ class BaseFishingEnv(_gym_env_base()):
 
     def _publish_scalar_state(self):
         if self._scalar:
-            self.state, self.years_passed, self._last_reward, self._last_done = self._read_scalar()
+            self.state, self._years_scalar, self._last_reward, self._last_done = self._read_scalar()
             self.fish_population = float((self.state[0] + 1.0) * float(self._K_view() if self._per_env else self.params["K"]))
         else:
             self.state = self._obs_view
             self.reward = self._reward
-            self.years_passed = self._t
 
     def seed(self, seed=None):
         """The reference has no seed() (base_fishing_env.py:13); this keys the Philox streams and, for
@@ -491,7 +520,8 @@ class BaseFishingEnv(_gym_env_base()):
         if self._scalar:
             torch.cuda.current_stream(self.device).synchronize()
         sd = {k: getattr(self, k).clone() for k in self._STATE_TENSORS if getattr(self, k) is not None}
-        sd.update(seed=self._seed, step_count=self._step_count, reset_count=self._reset_count,
+        sd.update(format=STATE_FORMAT, v4_param_stream=V4_PARAM_STREAM,
+                  seed=self._seed, step_count=self._step_count, reset_count=self._reset_count,
                   params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state,
                   v4_derived=self._derived, v4_origin=tuple(self._origin), auto_reset=self.auto_reset,
                   attrs={k: getattr(self, k) for k in self._STATE_ATTRS if hasattr(self, k)})
@@ -502,12 +532,23 @@ class BaseFishingEnv(_gym_env_base()):
         return sd
 
     def load_state_dict(self, sd):
+        # everything that can refuse the state is checked BEFORE the first field changes: a failed load leaves the env as it was
+        if self._per_env and sd.get("v4_param_stream") != V4_PARAM_STREAM:
+            # fishing-v4 redraws (K, r) at every reset from a generator that is part of the state's meaning: a checkpoint
+            # written under another scheme (round 1: one Philox4x32 block per env PAIR; no tag at all before format 2)
+            # would load and then continue on different parameters
+            raise ValueError("fishing-v4 state was written with parameter stream %r, this library draws %r: it cannot "
+                             "resume bit-for-bit" % (sd.get("v4_param_stream"), V4_PARAM_STREAM))
+        if self._per_env and sd.get("v4_derived", False) and not self._derived_capable:
+            raise ValueError("state was saved in the derived-parameter mode, which this env cannot run")
+        v4_arrays = self._per_env and not sd.get("v4_derived", False)
+        for k in self._STATE_TENSORS:
+            if k in sd and getattr(self, k) is None and k != "_counter" and not (k in ("_r_arr", "_K_arr") and v4_arrays):
+                raise ValueError("state has %s but this env was built without it" % k)
         if self._host_mapped:
             torch.cuda.current_stream(self.device).synchronize()
         if self._per_env:                       # fishing-v4: same parameter mode as the saved env
             if sd.get("v4_derived", False):
-                if not self._derived_capable:
-                    raise ValueError("state was saved in the derived-parameter mode, which this env cannot run")
                 self._derived, self._K_arr, self._r_arr = True, None, None
             elif self._derived:
                 self._derived = False
@@ -517,12 +558,12 @@ class BaseFishingEnv(_gym_env_base()):
             self._cbuf = None
         for k in self._STATE_TENSORS:
             if k in sd:
-                if getattr(self, k) is None:
-                    if k == "_counter":
-                        self.enable_graph_replay()
-                    else:
-                        raise ValueError("state has %s but this env was built without it" % k)
-                getattr(self, k).copy_(sd[k])
+                if getattr(self, k) is None and k == "_counter":
+                    self.enable_graph_replay()
+                if k == "_counter":         # (format 1 kept the step counter alone; the origin words follow _origin below)
+                    self._counter[:sd[k].numel()].copy_(sd[k])
+                else:
+                    getattr(self, k).copy_(sd[k])
         self._seed, self._step_count, self._reset_count = sd["seed"], sd["step_count"], sd["reset_count"]
         self.params.update(sd["params"])
         self.Tmax, self.init_state = sd["Tmax"], sd["init_state"]
@@ -533,6 +574,8 @@ class BaseFishingEnv(_gym_env_base()):
             self._sigma_scalar = float(self.params["sigma"])
         if self._np_rng and "numpy_rng_state" in sd:
             np.random.set_state(sd["numpy_rng_state"])
+        if self._per_env:
+            self._set_origin(*self._origin)
         self._publish_scalar_state()
         return self
 
@@ -541,16 +584,23 @@ class BaseFishingEnv(_gym_env_base()):
         then launch with frozen arguments plus a one-thread counter bump, so a hipGraph that
         captured them (torch.cuda.CUDAGraph, or gym_fishing_amd.graphs.GraphedSteps) draws
         fresh noise on every replay.  Same noise stream as the host-counter mode."""
-        if self._derived_capable:
-            # A captured launch freezes FishingParams, and with them the (step count, reset counter) origin that the derived
-            # fishing-v4 parameters date episodes from: a reset() after the capture would leave the graph deriving from a
-            # stale origin.  Graph mode therefore keeps the r / K arrays (same draws, same bits), for good.
-            self._leave_derived_mode()
-            self._derived_capable = False
         if self._counter is None:
-            self._counter = torch.tensor([self._step_count], dtype=torch.int64, device=self.device)
+            # {step counter, v4 origin step, v4 origin counter}: a captured launch freezes FishingParams, and with them the
+            # origin that the derived fishing-v4 parameters date episodes from -- so in this mode the kernels read the
+            # origin from these words (include/fishing_hip.h: FishingBuffers.counter), which reset() rewrites.  fishing-v4
+            # stays in the derived mode under graph replay (ABI 4; round 2 fell back to r / K arrays for good).
+            self._counter = torch.tensor([self._step_count, self._origin[0], self._origin[1]], dtype=torch.int64,
+                                         device=self.device)
             self._cbuf = None
         return self
+
+    def _set_origin(self, step_count, reset_count):
+        """(step count, reset counter) of the reset() of ALL envs that dates every running episode; mirrored into the
+        device-resident counter words in graph-replay mode (two fills on the current stream)."""
+        self._origin = (int(step_count), int(reset_count))
+        if self._counter is not None:
+            self._counter[1].fill_(self._origin[0])
+            self._counter[2].fill_(self._origin[1])
 
     def reset(self, mask=None, *, seed=None, options=None):
         """base_fishing_env.py:83-91 (v4: fishing_model_error.py:41-48).  `mask` (bool[N]) resets
@@ -565,7 +615,7 @@ class BaseFishingEnv(_gym_env_base()):
             m = torch.as_tensor(mask).to(device=self.device).reshape(self.num_envs).to(torch.uint8).contiguous()
         elif self._derived_capable:         # a reset of ALL envs: its counters date every episode from here on
             self._derived, self._K_arr, self._r_arr, self._cbuf = True, None, None, None
-            self._origin = (self._current_step_count(), self._reset_count)
+            self._set_origin(self._current_step_count(), self._reset_count)
         with torch.cuda.device(self.device):
             rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
                                 self._c_buffers(with_outputs=False), m.data_ptr() if m is not None else None,
@@ -772,11 +822,14 @@ class BaseFishingEnv(_gym_env_base()):
             self._publish_scalar_state()
         return traj
 
-    def episode_record(self, all_reduce=True):
+    def episode_record(self, all_reduce=True, copy=False):
         """The episodic-return record {sum R, sum R^2, n, sum length} as a 4-double DEVICE tensor: reduced on the
         device in slot order and -- when torch.distributed is initialised -- summed across ranks (one RCCL
         all-reduce).  Everything is enqueued on the current stream; nothing here waits for the GPU (with a
-        non-RCCL backend the all-reduce goes through a 32-byte host copy)."""
+        non-RCCL backend the all-reduce goes through a 32-byte host copy).
+        The tensor returned is the env's own scratch: VALID UNTIL THE NEXT episode_record() / episode_stats() call,
+        which rewrites it.  `copy=True` returns a private copy (one 32-byte device copy on the same stream) for
+        callers that keep records of several points of a run side by side."""
         if self._partials is None:
             raise RuntimeError("construct the env with track_returns=True")
         with torch.cuda.device(self.device):
@@ -786,7 +839,7 @@ class BaseFishingEnv(_gym_env_base()):
         rec = self._record              # scratch: rewritten from the partials by every call, so reduced in place
         if all_reduce:
             rec = all_reduce_record(rec)
-        return rec
+        return rec.clone() if copy else rec
 
     def episode_stats(self, all_reduce=True):
         """episode_record() read back to the host, with mean / std of the return and mean episode length."""
@@ -989,7 +1042,7 @@ class FishingModelError(BaseFishingEnv):
     def _set_initial_state(self):
         # constructor: draw (K, r) once (fishing_model_error.py:37-38) but keep the base
         # class's obs = x0 / K_mean - 1 (base_fishing_env.py:46) until the first reset()
-        self._origin = (self._step_count, self._reset_count)
+        self._set_origin(self._step_count, self._reset_count)
         with torch.cuda.device(self.device):
             rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
                                 self._c_buffers(with_outputs=False), None, self._seed, self._reset_count,

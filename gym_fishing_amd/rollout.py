@@ -146,10 +146,11 @@ def simulate_mdp_vec(env, model, n_eval_episodes):
                     model = _StringPolicy(env, kp)
                 if env._per_env:    # fishing-v4 redraws K at every (auto-)reset: a row's population uses the K in force THEN
                     K_rows = torch.empty((Tmax + 1, N), dtype=f64, device=env.device)
+                    kr_buf = (env._per_env_buffer(env.dtype), env._per_env_buffer(env.dtype))     # one pair for all Tmax + 1 asks
                 for t in range(Tmax):
                     obs_rows[t] = o.reshape(-1).to(f64)
                     if K_rows is not None:
-                        K_rows[t] = env._K_view().to(f64)
+                        K_rows[t] = env._K_view(kr_buf)[:N].to(f64)
                     try:
                         action, state = model.predict(o, state=state, mask=done)
                     except TypeError:                   # a predict(obs) without the SB3 keywords
@@ -160,7 +161,7 @@ def simulate_mdp_vec(env, model, n_eval_episodes):
                     rew_rows[t + 1] = rew.to(f64)
                 obs_rows[Tmax] = o.reshape(-1).to(f64)
                 if K_rows is not None:
-                    K_rows[Tmax] = env._K_view().to(f64)
+                    K_rows[Tmax] = env._K_view(kr_buf)[:N].to(f64)
             K = K_rows if K_rows is not None else float(env.params["K"])
             pop = (obs_rows + 1.0) * K                              # get_fish_population :158-160 (the env's K at that row)
             t_idx = torch.arange(Tmax + 1, device=env.device, dtype=f64).reshape(-1, 1).expand(Tmax + 1, N)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FISHING_ABI_VERSION 3
+#define FISHING_ABI_VERSION 4
 
 typedef void* fishing_stream_t; /* hipStream_t */
 
@@ -153,7 +153,12 @@ typedef struct FishingBuffers {
                                 noise of fishing_step_* / fishing_rollout_* is keyed by
                                 *counter + step_counter instead of step_counter alone, so a
                                 hipGraph that captured the launch draws fresh noise on every
-                                replay; advance it with fishing_counter_add (also capturable).  */
+                                replay; advance it with fishing_counter_add (also capturable).
+                                With FISHING_FLAG_V4_DERIVED the buffer is u64[3] = {step counter,
+                                v4_origin_step, v4_origin_counter}: the kernels take the episode origin
+                                from counter[1..2] and ignore FishingParams.v4_origin_* -- a captured
+                                launch (frozen arguments) keeps deriving the right (K, r) after a
+                                reset() of all envs, which only rewrites those two words (ABI 4).  */
 } FishingBuffers;
 
 /* In-kernel policies for the fused rollout (callers of step(): shared_env.py:29-54,

@@ -386,17 +386,19 @@ def _bitrev32(v):
 
 def param_words(seed, env_index, counter, stream):
     """The two words behind fishing-v4's (K, r) draw of env `env_index` (fishing_common.h: param_block):
-    Philox2x32-10 with key = seed[31:0] ^ seed[63:32] * 0x85EBCA6B and counter words
-    c0 = env[31:0] ^ bitreverse(counter[63:32]),
-    c1 = counter[31:0] ^ bitreverse(env[63:32]) ^ (0x5851F42D on the reset stream, 0x2545F491 otherwise)."""
+    Philox2x32-10 with counter words c0 = env[31:0], c1 = counter[30:0] | (1 << 31 on the reset stream) and
+    key = seed[31:0] ^ seed[63:32] * 0x85EBCA6B ^ counter[62:31] * 0x9E3779B1 ^ env[63:32] * 0xC2B2AE35 (all mod 2^32):
+    injective in (env, counter, stream) while env < 2^32 and counter < 2^31, so the reset() draws and the auto-reset
+    draws never share a block."""
     env = np.asarray(env_index, dtype=np.uint64)
     counter, seed, stream = int(counter), int(seed), int(stream)
     m32 = 0xFFFFFFFF
-    key = ((seed & m32) ^ (((seed >> 32) * 0x85EBCA6B) & m32))
-    tag = 0x5851F42D if stream == STREAM_RESET else 0x2545F491
-    c0 = (env & _MASK).astype(np.uint32) ^ _bitrev32(np.uint32((counter >> 32) & m32))
-    c1 = np.uint32((counter & m32) ^ tag) ^ _bitrev32((env >> np.uint64(32)).astype(np.uint32))
-    return philox2x32_10(c0, c1, np.uint32(key))
+    key0 = ((seed & m32) ^ (((seed >> 32) * 0x85EBCA6B) & m32)) ^ ((((counter >> 31) & m32) * 0x9E3779B1) & m32)
+    env_hi = (env >> np.uint64(32)).astype(np.uint64)
+    key = (np.uint64(key0) ^ ((env_hi * np.uint64(0xC2B2AE35)) & np.uint64(m32))).astype(np.uint32)
+    c0 = (env & _MASK).astype(np.uint32)
+    c1 = np.uint32((counter & 0x7FFFFFFF) | (0x80000000 if stream == STREAM_RESET else 0))
+    return philox2x32_10(c0, np.broadcast_to(c1, c0.shape), key)
 
 
 def reset_normals(seed, env_index, counter, stream):

@@ -459,7 +459,7 @@ def test_graph_replay_draws_fresh_noise_and_matches_eager(gf):
     graphed.reset()
     static = acts[0].clone()
     g = GraphedSteps(graphed, static)
-    assert int(graphed._counter) == 0 and torch.equal(graphed.state, eager.state)
+    assert int(graphed._counter[0]) == 0 and torch.equal(graphed.state, eager.state)
     prev = None
     for k in range(7):
         static.copy_(acts[k % 5])
@@ -469,13 +469,13 @@ def test_graph_replay_draws_fresh_noise_and_matches_eager(gf):
         if prev is not None:
             assert not torch.equal(prev, rew)
         prev = rew.clone()
-    assert int(graphed._counter) == 7
+    assert int(graphed._counter[0]) == 7
     # multi-step graph
     g2 = GraphedSteps(graphed, acts)
     for _ in range(3):
         g2.replay()
         eager.step_many(acts, 5)
-    assert torch.equal(graphed.state, eager.state) and int(graphed._counter) == 7 + 15
+    assert torch.equal(graphed.state, eager.state) and int(graphed._counter[0]) == 7 + 15
     # eager calls on a graph-mode env keep the same stream of noise
     graphed.step(acts[1])
     eager.step(acts[1])
@@ -483,9 +483,10 @@ def test_graph_replay_draws_fresh_noise_and_matches_eager(gf):
 
 
 def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
-    """fishing-v4 normally re-derives (K, r) from an origin carried in the launch arguments; a captured launch would keep
-    the origin of capture time.  enable_graph_replay() therefore switches the env to stored r / K arrays: replays before
-    AND after a later reset() equal an eager env (which stays in the derived mode) bit for bit."""
+    """fishing-v4 re-derives (K, r) from the origin of the last reset() of all envs.  A captured launch freezes its
+    arguments, so in graph-replay mode the origin lives next to the step counter in device memory (FishingBuffers.counter
+    = u64[3], ABI 4) and reset() rewrites it: the env STAYS in the derived mode (no r / K arrays), and replays before AND
+    after a later reset() equal an eager env bit for bit -- state, and the (K, r) in force."""
     import torch
     from gym_fishing_amd.graphs import GraphedSteps
     n = 2048 + 24
@@ -496,18 +497,34 @@ def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
     graphed.reset()
     assert eager._derived and graphed._derived
     g = GraphedSteps(graphed, acts)                  # 4 steps per replay
-    assert not graphed._derived and graphed._K_arr is not None
-    for rnd in range(2):
+    assert graphed._derived and graphed._K_arr is None and graphed._counter.numel() == 3
+    assert graphed.step_kernel_name(acts[0]) == eager.step_kernel_name(acts[0]) == "fishing::step_kernel_lean<float, 4, 8450, 4>"
+    for rnd in range(3):
         for _ in range(3):
             g.replay()
             eager.step_many(acts, 4)
         assert torch.equal(graphed.state, eager.state), rnd
         assert torch.equal(graphed.K, eager.K) and torch.equal(graphed.r, eager.r), rnd
-        if rnd == 0:                                 # a reset of all envs between replays: new origin for the eager env
+        if rnd < 2:                                  # a reset of all envs between replays: a new origin for both
             graphed.reset()
             eager.reset()
-            assert eager._derived and not graphed._derived
+            assert eager._derived and graphed._derived
+            assert graphed._counter.tolist() == [graphed._step_count, graphed._origin[0], graphed._origin[1]]
             assert torch.equal(graphed.K, eager.K)
+    # a checkpoint of the graph-mode env resumes in an env that never saw the capture
+    sd = graphed.state_dict()
+    assert sd["format"] == 2 and sd["_counter"].numel() == 3
+    fresh = mk()
+    fresh.load_state_dict(sd)
+    fresh.step_many(acts, 4)
+    g.replay()
+    assert torch.equal(fresh.state, graphed.state) and torch.equal(fresh.K, graphed.K)
+    # ... and a fishing-v4 state without the parameter-stream tag (format 1) is refused before anything changes
+    old = {k: v for k, v in sd.items() if k not in ("format", "v4_param_stream")}
+    before = fresh.state.clone()
+    with pytest.raises(ValueError, match="parameter stream"):
+        fresh.load_state_dict(old)
+    assert torch.equal(fresh.state, before) and fresh._derived
 
 
 def test_bmsy_does_not_disturb_the_env_noise_level(gf):

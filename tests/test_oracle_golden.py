@@ -177,6 +177,19 @@ def test_v4_parameter_draw_statistics_and_origin_rule():
                   fo.param_words(99, env[:64] + np.uint64(1 << 32), 5, fo.STREAM_RESET),
                   fo.param_words(99, env[:64], 5 + (1 << 32), fo.STREAM_RESET)):
         assert not np.array_equal(base, other[0])
+    # the reset() stream and the auto-reset stream can never meet while counters stay below 2^31 (bit 31 of the second
+    # counter word is the stream's): not for equal counters, not for the pair round 2's XOR tags made collide
+    # (a ^ b == 0x5851F42D ^ 0x2545F491), not across a sample of the range
+    rng = np.random.default_rng(0)
+    a_cnt = rng.integers(0, 1 << 31, 200)
+    for a_, b_ in list(zip(a_cnt, a_cnt)) + [(int(x), int(x) ^ (0x5851F42D ^ 0x2545F491)) for x in a_cnt[:50]]:
+        b_ &= 0x7FFFFFFF
+        w_r = fo.param_words(99, env[:8], int(a_), fo.STREAM_RESET)
+        w_a = fo.param_words(99, env[:8], int(b_), fo.STREAM_AUTORESET)
+        assert not np.array_equal(w_r[0], w_a[0]) and not np.array_equal(w_r[1], w_a[1])
+    # ... and beyond 2^31 steps the counter's high part moves to the key: still distinct blocks
+    assert not np.array_equal(fo.param_words(99, env[:8], 5, fo.STREAM_AUTORESET)[0],
+                              fo.param_words(99, env[:8], 5 + (1 << 31), fo.STREAM_AUTORESET)[0])
     # an env that has run since the reset made at step count 40 (reset counter 3); one auto-reset by step 57
     stream, counter = fo.v4_origin(step_counter=60, t=np.array([20, 2]), origin_step=40, origin_counter=3)
     assert stream.tolist() == [fo.STREAM_RESET, fo.STREAM_AUTORESET] and counter.tolist() == [3, 57]
