@@ -43,14 +43,25 @@ def env_class(env_id):
     return getattr(envs, ENTRY_POINTS[env_id])
 
 
-def make(env_id, **kwargs):
+def make(env_id, api="gym", **kwargs):
     """gym.make(id, **ctor_kwargs) equivalent.  Extra kwargs: num_envs, device, seed, dtype,
-    auto_reset, env_offset, record_terminal_obs, track_returns, done_bits, compact."""
-    return env_class(env_id)(**kwargs)
+    auto_reset, env_offset, record_terminal_obs, track_returns, done_bits, compact.
+    api="gym" (default): the reference's protocol -- reset() -> obs, step() -> (obs, reward, done, info).
+    api="gymnasium": reset() -> (obs, info), step() -> (obs, reward, terminated, truncated, info) with
+    truncated = years_passed > Tmax and terminated = fish_population <= 0 (gym_fishing_amd.gymnasium_api)."""
+    if api == "gym":
+        return env_class(env_id)(**kwargs)
+    if api != "gymnasium":
+        raise ValueError("api must be 'gym' or 'gymnasium', not %r" % (api,))
+    env_class(env_id)       # unknown ids fail here, with the list of ids
+    from .gymnasium_api import GymnasiumFishingEnv
+    return GymnasiumFishingEnv(env_id, **kwargs)
 
 
 def register_with_gym():
-    """Register the four ids with gym / gymnasium when one is importable (never required)."""
+    """Register the ids with gym and / or gymnasium when importable (never required): the old `gym` gets the
+    reference's 4-tuple classes (gym_fishing/envs/__init__.py:17-35), gymnasium -- whose checker and wrappers reject a
+    4-tuple step() -- the 5-tuple GymnasiumFishingEnv around them."""
     done = []
     for mod in ("gymnasium", "gym"):
         try:
@@ -59,7 +70,11 @@ def register_with_gym():
             continue
         for env_id, cls in ENTRY_POINTS.items():
             try:
-                reg.register(id=env_id, entry_point="gym_fishing_amd.envs:" + cls)
+                if mod == "gymnasium":
+                    reg.register(id=env_id, entry_point="gym_fishing_amd.gymnasium_api:GymnasiumFishingEnv",
+                                 kwargs={"env_id": env_id})
+                else:
+                    reg.register(id=env_id, entry_point="gym_fishing_amd.envs:" + cls)
                 done.append((mod, env_id))
             except Exception:  # noqa: BLE001 - already registered
                 pass

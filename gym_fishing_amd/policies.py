@@ -28,19 +28,26 @@ def _growth_args(env):
     return kw
 
 
+def _sweep_dtype(env):
+    """The dtype BMSY / msy evaluate in: that of the observation Box's grid -- float32 by default, as the reference's
+    sweep is (a float32 grid times Python-float parameters stays float32 in NumPy); float64 for a caller who widened
+    the Box (env.observation_space.dtype = np.float64), as the reference's linspace would follow."""
+    return torch.float64 if np.dtype(env.observation_space.dtype) == np.float64 else torch.float32
+
+
 def BMSY(env, n=10001):
     """models/policies.py:51-67: sweep n states of the observation Box through one population_draw() on the
     device and return the population with the largest growth.  Like the reference, this resets the
-    environment.  The sweep is evaluated in float32 whatever the env's layout, as the reference's is (a
-    float32 grid times Python-float parameters stays float32 in NumPy): S = 0.4996 K for the flat logistic
-    maximum, not K / 2."""
+    environment.  The sweep is evaluated in the grid's dtype whatever the env's layout (_sweep_dtype): with the
+    default float32 Box S = 0.4996 K for the flat logistic maximum, not K / 2."""
     grid = np.linspace(env.observation_space.low, env.observation_space.high, num=n,
                        dtype=env.observation_space.dtype).reshape(-1)
-    state = torch.as_tensor(grid, device=env.device).to(torch.float32)
+    dt = _sweep_dtype(env)
+    state = torch.as_tensor(grid, device=env.device).to(dt)
     kw = _growth_args(env)
     K = kw.get("K", float(env.params["K"]))
     x0 = (state + 1.0) * K                                       # get_fish_population :158-160
-    growth = env.population_draw(x0, dtype=torch.float32, **kw) - x0
+    growth = env.population_draw(x0, dtype=dt, **kw) - x0
     S = float(x0[int(torch.argmax(growth))])
     env.reset()
     return S
@@ -52,8 +59,9 @@ class msy:
     def __init__(self, env, **kwargs):
         self.env = env
         self.S = BMSY(env)
-        x = torch.tensor([self.S], dtype=torch.float32, device=env.device)
-        self.msy = float(env.population_draw(x, dtype=torch.float32, **_growth_args(env))[0] - x[0])
+        dt = _sweep_dtype(env)
+        x = torch.tensor([self.S], dtype=dt, device=env.device)
+        self.msy = float(env.population_draw(x, dtype=dt, **_growth_args(env))[0] - x[0])
         env.reset()
         self.kernel_policy = (POLICY_MSY, self.msy)
 

@@ -315,8 +315,6 @@ def main():
     seeded = {}
     for env_id, kw in (("fishing-v1", {"sigma": 0.1}), ("fishing-v0", {"sigma": 0.1}), ("fishing-v2", {"sigma": 0.05}),
                        ("fishing-v5", {"sigma": 0.1}), ("fishing-v9", {"sigma": 0.1}), ("fishing-v11", {})):
-        # (fishing-v4 is left out: its BMSY sweep multiplies a float32 grid by np.float64 scalars K and r, which
-        # NumPy 2 evaluates in float64 and the reference's NumPy 1.19 in float32 -- no version-neutral fixture)
         for pname, cls in (("msy", msy), ("escapement", escapement)):
             np.random.seed(7)
             env = gym.make(env_id, **kw)
@@ -327,6 +325,22 @@ def main():
             seeded[key + "/meta"] = np.array(json.dumps({"id": env_id, "kwargs": kw, "policy": pname, "seed": 7, "reps": 2,
                                                          "S": float(model.S),
                                                          "msy": float(model.msy) if pname == "msy" else None}))
+    # fishing-v4 (round 3).  Its BMSY sweep multiplies the float32 observation grid by np.float64 scalars (the drawn K, r),
+    # which NumPy 2 evaluates in float64 and the reference's NumPy 1.19 in float32: no version-neutral table of THAT.
+    # Asked for a float64 grid -- as the policyfn fixtures below do -- every product is float64 under both, and the table
+    # pins the flow itself: the constructor's and every reset()'s K-then-r draws, BMSY's and msy's population_draw()
+    # draws, all from the one global stream, and the table's rows on the (K, r) of each episode.
+    for pname, cls in (("msy", msy), ("escapement", escapement)):
+        np.random.seed(7)
+        kw = {"sigma": 0.05, "sigma_p": 0.1}
+        env = gym.make("fishing-v4", **kw)
+        env.observation_space.dtype = np.dtype(np.float64)
+        model = cls(env)
+        df = env.simulate(RefEra(model, False), reps=2)
+        seeded["v4_%s/table" % pname] = df.to_numpy(dtype=np.float64)
+        seeded["v4_%s/meta" % pname] = np.array(json.dumps({"id": "fishing-v4", "kwargs": kw, "policy": pname, "seed": 7,
+                                                           "reps": 2, "S": float(model.S),
+                                                           "msy": float(model.msy) if pname == "msy" else None}))
     np.savez_compressed(os.path.join(OUT, "reference_seeded_sims.npz"), **seeded)
     # --- estimate_policyfn (shared_env.py:82-102): the policy's quota over a grid of 50 observations, through the
     # reference's own env.policyfn(); same action convention as the tables above (RefEra).

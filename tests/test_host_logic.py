@@ -122,6 +122,37 @@ def test_register_with_gym_is_optional():
     assert isinstance(gf.register_with_gym(), list)     # [] when neither gym nor gymnasium exists
 
 
+def test_each_registry_gets_the_api_it_speaks(monkeypatch):
+    """Stand-in `gym` and `gymnasium` registries (neither package is installed here): the old gym is handed the
+    reference's 4-tuple classes, as gym_fishing/envs/__init__.py:17-35 registers them; gymnasium -- whose checker and
+    wrappers reject a 4-tuple step() -- the 5-tuple GymnasiumFishingEnv with the id as its constructor argument."""
+    import sys
+    import types
+    seen = {"gym": [], "gymnasium": []}
+    for mod in seen:
+        top, envs, reg = types.ModuleType(mod), types.ModuleType(mod + ".envs"), types.ModuleType(mod + ".envs.registration")
+        reg.register = (lambda mod: lambda id, entry_point, kwargs=None, **kw: seen[mod].append((id, entry_point, kwargs)))(mod)
+        top.envs, envs.registration = envs, reg
+        for name, m in ((mod, top), (mod + ".envs", envs), (mod + ".envs.registration", reg)):
+            monkeypatch.setitem(sys.modules, name, m)
+    done = gf.register_with_gym()
+    assert sorted(done) == sorted((m, i) for m in seen for i in gf.ENV_IDS)
+    assert ("fishing-v1", "gym_fishing_amd.envs:FishingCtsEnv", None) in seen["gym"]
+    assert ("fishing-v4", "gym_fishing_amd.envs:FishingModelError", None) in seen["gym"]
+    assert all(ep == "gym_fishing_amd.gymnasium_api:GymnasiumFishingEnv" and kw == {"env_id": i} for i, ep, kw in seen["gymnasium"])
+    assert sorted(i for i, _, _ in seen["gymnasium"]) == sorted(gf.ENV_IDS)
+    # the entry point gymnasium.make() would import and call exists, and takes the id + the reference's kwargs
+    import importlib
+    import inspect
+    cls = getattr(importlib.import_module("gym_fishing_amd.gymnasium_api"), "GymnasiumFishingEnv")
+    assert {"env_id", "kwargs"} <= set(inspect.signature(cls.__init__).parameters)
+    assert inspect.signature(cls.reset).parameters.keys() >= {"seed", "options"}
+    with pytest.raises(ValueError):
+        gf.make("fishing-v1", api="gym5")
+    with pytest.raises(KeyError):
+        gf.make("fishing-v3", api="gymnasium")
+
+
 def test_only_tests_smoke_and_bench_touch_the_oracle():
     """The oracle is the checker, never the thing shipped: outside tests/ and oracle/ itself, only
     bench.py (cpu_baseline leg) and __graft_entry__.py (build of the C restatement, smoke check)
