@@ -52,7 +52,10 @@ BYTES_STEP = 25
 BYTES_STEP_COMPACT = 19     # --compact: years_passed as uint8 (R 1 + W 1 instead of R 4 + W 4)
 BYTES_RETURN_ACC = 8
 BYTES_SIGMA_ARRAY = 4       # fishing-v4: per-env sigma (R 4)
-BYTES_RK_ARRAYS = 8         # fishing-v4 --v4-stored: per-env r, K (R 4 + 4); their redraw writes are NOT counted
+BYTES_RK_ARRAYS = 16        # fishing-v4 --v4-stored: per-env r, K read every step (R 4 + 4) and -- on this random-policy workload, where
+                            # practically every 128-byte line holds a finished env every step (mean episode length 1.47) -- rewritten by the
+                            # redraw (W 4 + 4): rocprofv3 PMC traffic was 1.18 x the 45 B that left the writes out (profiles/r02_step_v4s_*)
+BYTES_F64 = 12              # --f64, the parity layout: obs R+W and reward W are 8 bytes wide (25 -> 37 B); the return accumulator +16
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 HBM_COPY_GBS = 6290.0       # measured float4 copy on the same table
 
@@ -86,6 +89,8 @@ def parse():
     ap.add_argument("--compact", action="store_true",
                     help="opt-in compact layout (uint8 year counter, 19 B/env-step); NOT the BASELINE layout")
     ap.add_argument("--v4-stored", action="store_true", help="config v4 with r / K arrays in HBM instead of derived (K, r)")
+    ap.add_argument("--f64", action="store_true",
+                    help="the float64 parity layout (bit-exact against the reference's arithmetic; 37 B/env-step); NOT the headline layout")
     ap.add_argument("--extra", action="store_true", help="also time the fused rollout and an N sweep")
     return ap.parse_args()
 
@@ -240,21 +245,24 @@ def make_actions(torch, cfg, n, rows, env_offset=0, pad=3072, seed=4321, device=
     return view
 
 
-def make_env(gf, torch, cfg_name, n, env_offset, with_returns, compact=False, v4_stored=False):
+def make_env(gf, torch, cfg_name, n, env_offset, with_returns, compact=False, v4_stored=False, f64=False):
     cfg = CONFIGS[cfg_name]
     kw = dict(cfg["kwargs"])
+    if f64:
+        kw["dtype"] = torch.float64
     if cfg_name == "v4":
-        kw["sigma"] = torch.full((n,), 0.05, dtype=torch.float32, device="cuda")
+        kw["sigma"] = torch.full((n,), 0.05, dtype=torch.float64 if f64 else torch.float32, device="cuda")
         kw["derived_params"] = not v4_stored
     return gf.make(cfg["env_id"], num_envs=n, env_offset=env_offset, seed=1234, track_returns=with_returns,
                    auto_reset=True, compact=compact, **kw)
 
 
-def bytes_per_env_step(cfg_name, with_returns, compact=False, v4_stored=False):
-    b = BYTES_STEP_COMPACT if compact else BYTES_STEP
+def bytes_per_env_step(cfg_name, with_returns, compact=False, v4_stored=False, f64=False):
+    w = 2 if f64 else 1         # width of the real-valued streams relative to float32
+    b = (BYTES_STEP_COMPACT if compact else BYTES_STEP) + (BYTES_F64 if f64 else 0)
     if cfg_name == "v4":
-        b += BYTES_SIGMA_ARRAY + (BYTES_RK_ARRAYS if v4_stored else 0)
-    return b + (BYTES_RETURN_ACC if with_returns else 0)
+        b += w * (BYTES_SIGMA_ARRAY + (BYTES_RK_ARRAYS if v4_stored else 0))
+    return b + (w * BYTES_RETURN_ACC if with_returns else 0)
 
 
 def spin_up(torch, env, actions, min_ms):
@@ -394,7 +402,7 @@ def main():
     cfg = CONFIGS[args.config]
     n = args.n_envs or (1 << (cfg["log2_n"] if world == 1 else cfg["log2_n_multi"]))
     with_returns = not args.no_returns
-    env = make_env(gf, torch, args.config, n, rank * n, with_returns, args.compact, args.v4_stored)
+    env = make_env(gf, torch, args.config, n, rank * n, with_returns, args.compact, args.v4_stored, args.f64)
     env.reset()
     actions = make_actions(torch, cfg, n, RING, rank * n)
 
@@ -443,13 +451,14 @@ def main():
     med_us, mean_us = per_launch_us(torch, env, actions, max(1, min(args.steps, 200)))
 
     total_env_steps = float(n) * world * args.steps
-    bytes_per = bytes_per_env_step(args.config, with_returns, args.compact, args.v4_stored)
+    bytes_per = bytes_per_env_step(args.config, with_returns, args.compact, args.v4_stored, args.f64)
     achieved = n * bytes_per / (steady_ms * 1e-3) / 1e9
     kernel = env.step_kernel_name(actions[0])
     traffic, traffic_src = pmc_traffic(kernel, n)
     esz = 1 if args.compact else 4
-    resident = n * (4 + esz + 4 + 1 + (4 if with_returns else 0) + (4 if args.config == "v4" else 0)
-                    + (8 if args.v4_stored and args.config == "v4" else 0)) + RING * (n + 3072) * 4
+    rsz = 8 if args.f64 else 4
+    resident = n * (rsz + esz + rsz + 1 + (rsz if with_returns else 0) + (rsz if args.config == "v4" else 0)
+                    + (2 * rsz if args.v4_stored and args.config == "v4" else 0)) + RING * (n + 3072) * 4
     fits = resident < 256 * 2 ** 20
     log2n = n.bit_length() - 1 if n & (n - 1) == 0 else None
     out = {
@@ -464,16 +473,16 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f64" if args.f64 else "f32",
         "data": "synthetic",
         "config": {"workload": "%s, N=%s envs per GPU, random-policy %s actions read from HBM (ring of %d batches), "
-                               "in-kernel Philox4x32-10 noise, fused auto-reset%s%s%s; one fishing_step_f32 launch per step" % (
+                               "in-kernel Philox4x32-10 noise, fused auto-reset%s%s%s; one fishing_step_%s launch per step" % (
                                    cfg["what"], ("2^%d" % log2n) if log2n is not None else str(n),
                                    "int32 [0,100)" if cfg["actions"][0] == "int" else "float32 U[%g,%g)" % cfg["actions"][1:],
                                    RING, ", per-env episodic-return accumulator + return record" if with_returns else "",
-                                   "; COMPACT layout (uint8 year counter)" if args.compact else "",
+                                   ("; COMPACT layout (uint8 year counter)" if args.compact else "") + ("; FLOAT64 parity layout" if args.f64 else ""),
                                    ("; r / K arrays in HBM" if args.v4_stored else "; (K, r) re-derived in-kernel, no r / K arrays")
-                                   if args.config == "v4" else ""),
+                                   if args.config == "v4" else "", "f64" if args.f64 else "f32"),
                    "name": args.config, "baseline_config": cfg["baseline_config"],
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-shard x%d" % world,
                    "collective": "1 all-reduce of 4 doubles per rollout (%s)" % ("RCCL" if backend == "nccl" else backend)
@@ -501,10 +510,10 @@ def main():
     }
     if stats:
         out["episode_stats"] = {k: stats[k] for k in ("n_episodes", "mean_return", "std_return", "mean_length") if k in stats}
-    if rank == 0 and world == 1 and with_returns and not args.no_subrecords and not args.compact:
+    if rank == 0 and world == 1 and with_returns and not args.no_subrecords and not args.compact and not args.f64:
         out["graph_region"] = graph_region(torch, gf, args, n, actions)
 
-    subrecords = rank == 0 and world == 1 and not args.no_subrecords and not args.compact
+    subrecords = rank == 0 and world == 1 and not args.no_subrecords and not args.compact and not args.f64
     if subrecords and with_returns:
         # for reference on the same line: the bare step (no return accumulator), i.e. exactly
         # SURVEY 8(d)'s per-unit figure, measured right after the headline region on the same device

@@ -36,8 +36,10 @@ def test_bytes_per_env_step_accounting():
     assert bench.bytes_per_env_step("v1", False, compact=True) == 19
     assert bench.bytes_per_env_step("v4", False) == 29              # derived (K, r): sigma array only
     assert bench.bytes_per_env_step("v4", True) == 37
-    assert bench.bytes_per_env_step("v4", False, v4_stored=True) == 37      # + r, K reads (SURVEY 8d's figure)
-    assert bench.bytes_per_env_step("v4", True, v4_stored=True) == 45
+    # stored r / K arrays: read every step AND rewritten by the redraw on this workload (PMC-measured, round 2): 45 / 53 B
+    assert bench.bytes_per_env_step("v4", False, v4_stored=True) == 45
+    assert bench.bytes_per_env_step("v4", True, v4_stored=True) == 53
+    assert bench.bytes_per_env_step("v1", False, f64=True) == 37 and bench.bytes_per_env_step("v1", True, f64=True) == 53
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="the failure path: only where no HIP device exists")
