@@ -15,7 +15,14 @@ kernels for gfx950 behind a C ABI (include/fishing_hip.h).
 Importing this package does not load the HIP library; constructing an env does, and
 raises FishingLibraryError if the library or a HIP device is missing.
 """
-from ._capi import FishingLibraryError
+import os as _os
+
+# dmabuf IPC: what RCCL (and any cross-process sharing of device memory) needs on this driver.  Set before anything can
+# initialise HIP, in every process that imports the package -- a rank started directly by torch.distributed.run never
+# passes through a launcher of ours.  (setdefault: an explicit choice of the caller wins.)
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from ._capi import FishingLibraryError  # noqa: E402
 
 __version__ = "0.1.0"
 

@@ -75,8 +75,9 @@ def test_bench_under_torch_distributed_run_with_one_rccl_rank():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (the rank is started by torch.distributed.run, not by bench.py's self_launch: the dmabuf-IPC setting RCCL needs on this
+    # driver must come from bench.py itself -- it is REMOVED from the environment here)
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
     proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                            "--gpus", "1", "--steps", "20", "--warmup", "5", "--spinup-ms", "5", "--n-envs", str(1 << 18),
@@ -86,3 +87,5 @@ def test_bench_under_torch_distributed_run_with_one_rccl_rank():
     assert len(lines) == 1, proc.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["episode_stats"]["n_episodes"] > 0 and out["value"] > 1e9
+    # the start-up all-reduce of ones went through RCCL and counted this one rank; a bare run carries null
+    assert out["config"]["rccl_ranks_seen"] == 1
