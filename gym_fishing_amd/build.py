@@ -34,7 +34,8 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fPIC", "-
 # and sinks them next to their first use, behind the Philox block and (the return accumulator) behind the first
 # s_waitcnt; without it the loads are issued together at the top of the tile, ahead of the scheduling fence, as the
 # kernel is written (N = 2^21 with returns: 9.8 -> 8.7 us per step; profiles/r03_small_n/).
-TU_FLAGS = {"fishing_step.hip": ["-fno-slp-vectorize"]}
+# ... and kernarg preload: the lean kernel's four leading pointer arguments arrive in SGPRs at wave launch (see the kernel).
+TU_FLAGS = {"fishing_step.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=10"]}
 
 
 def sources():
@@ -79,7 +80,10 @@ def _compile(out_path, verbose, extra_flags):
     objs = ["%s.%d.o" % (tmp, i) for i in range(len(srcs))]
     # one hipcc per translation unit, side by side (the two kernel files take about as long as each other),
     # then one link step
-    cmds = [[hipcc] + flags + TU_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj] for src, obj in zip(srcs, objs)]
+    tu_flags = dict(TU_FLAGS)
+    if os.environ.get("FISHING_STEP_TU_FLAGS") is not None:     # experiments: replace the step unit's own flags
+        tu_flags["fishing_step.hip"] = os.environ["FISHING_STEP_TU_FLAGS"].split()
+    cmds = [[hipcc] + flags + tu_flags.get(os.path.basename(src), []) + ["-c", src, "-o", obj] for src, obj in zip(srcs, objs)]
     procs = []
     for cmd in cmds:
         if verbose:

@@ -368,8 +368,17 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 // computes the quad's Philox block twice and keeps one Box-Muller pair each.
 template <typename T, int MODEL, int F, int E = 4>
 __global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
-step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_t ntiles, const uint64_t env_offset,
+step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p, T* const ep_return_p, const int64_t n_live_p,
+                 const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_t ntiles, const uint64_t env_offset,
                  const uint64_t seed, const uint64_t step_counter_arg) {
+    // The four streams every tile reads first (and the padded-tile bound the action address needs) are LEADING SCALAR
+    // arguments: this translation unit is built with -mllvm -amdgpu-kernarg-preload-count=10 (build.py), which has the
+    // command processor place the first ten kernarg dwords in SGPRs at wave launch -- a one-tile form issues its four
+    // global loads before any s_load has returned (a by-value struct is not preloaded), and fetches the rest of its
+    // arguments in one batch behind them.  Per step, back to back, against the same kernel without preload: N = 2^20
+    // 6.04 -> 5.75 us, 2^22 21.41 -> 20.87 (1.1 % above the same-shape copy), 2^19 unchanged
+    // (profiles/r03_small_n/s15_kernarg_preload_product.jsonl; harness sweep of 4 .. 14 dwords: s14_*).  Firmware
+    // without the feature runs the kernel's own s_load prologue.
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     constexpr bool kMixed = (MODEL == kModelZooMixed);    // fishing-v11: growth function per env
     constexpr bool kZoo = is_zoo_tag(MODEL) && !kMixed;   // one growth function of the zoo, compile-time kind
@@ -387,7 +396,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
     static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
     constexpr int kTileEnvs = 256 * E;
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
-    const bool RET = (F & feat::RET) && (kExact || a.ep_return != nullptr);
+    const bool RET = (F & feat::RET) && (kExact || ep_return_p != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
     const bool T8 = (F & feat::T8) && (kExact || a.t8_rt != 0);
     const bool TERM = (F & feat::TERM) && (kExact || a.terminal_obs != nullptr);
@@ -401,8 +410,9 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
     // trips in front of the first global load of every wave.  Measured (scripts/exp/ab_lean_variants.py,
     // N = 2^22): bare step 16.9 -> 16.5 us; with the return accumulator 21.67 -> 21.45 us, as long as the
     // ep_return / partials pointers stay out of the batch (21.50 with them): profiles/r01f_lean_fence_ab.txt.
+    auto batch_args = [&]() {
     if constexpr (FISHING_LEAN_BATCH_ARGS != 0 && kExact) {     // (the catch-alls are short of SGPRs as it is)
-        asm volatile("" ::"s"(a.obs), "s"(a.action), "s"(a.reward), "s"(a.done), "s"(a.t), "s"(a.counter), "s"(a.pr),
+        asm volatile("" ::"s"(obs_p), "s"(action_p), "s"(a.reward), "s"(a.done), "s"(t_p), "s"(a.counter), "s"(a.pr),
                      "s"(a.pK), "s"(a.sigma), "s"(a.C), "s"(a.x0), "s"(a.Tmax), "s"(a.n_actions), "s"(a.auto_reset),
                      "s"(ntiles), "s"(env_offset), "s"(seed), "s"(step_counter_arg));
         if constexpr (kPerEnv && !(F & feat::DERIVED)) asm volatile("" ::"s"(a.r), "s"(a.K));
@@ -417,6 +427,10 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                          "s"(a.growth.logA), "s"(a.growth.B));
         if constexpr ((F & feat::DRIFT) != 0) asm volatile("" ::"s"(a.r), "s"(a.alpha));
     }
+    };
+    // (tile-loop forms: up front.  One-tile forms: behind the tile's loads, which need only the preloaded arguments --
+    // FISHING_LEAN_BATCH_ARGS == 2 puts it up front there too, for A/B)
+    if constexpr (!kOne || FISHING_LEAN_BATCH_ARGS == 2) batch_args();
     // graph-replay mode keeps the step counter in device memory (wave-uniform: one scalar load).  With a tile loop it is
     // read here; a one-tile launch reads it AFTER issuing the tile's loads, which do not depend on it.
     auto read_counter = [&]() -> uint64_t {
@@ -449,14 +463,14 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         // redrawn), and the streams the CALLER owns -- actions, external noise -- are read at the last quad that exists
         // instead of past their end.  `live` is true everywhere otherwise.
         // (the tile's share of n_live is a scalar; per lane one 32-bit compare and one 32-bit select)
-        const int64_t tile_left = a.n_live - tile * kTileEnvs;                     // wave-uniform
+        const int64_t tile_left = n_live_p - tile * kTileEnvs;                     // wave-uniform
         const uint32_t left32 = tile_left >= kTileEnvs ? (uint32_t)kTileEnvs : (tile_left > 0 ? (uint32_t)tile_left : 0u);
         const uint32_t lane_env = threadIdx.x * (uint32_t)E;
         const bool live = lane_env < left32;
         // (E = 4: a padded tile holds at least one live quad, so the last one is tile-relative -- one 32-bit select;
         // an E = 2 half-tile may be scratch altogether)
         const int64_t cbase = (E == 4) ? tile * kTileEnvs + (int64_t)(live ? lane_env : left32 - (uint32_t)E)
-                                       : (live ? base : a.n_live - E);
+                                       : (live ? base : n_live_p - E);
         // The Philox round keys (seed + i * Weyl) are wave-uniform; hoisted out of this loop they sit in 20-30 SGPRs
         // for the whole kernel, which pushes the fishing-v4 variants (two generators) past 100 SGPRs = 7 instead of
         // 8 waves per SIMD.  Laundering the seed per tile keeps the key schedule next to its rounds (a scalar add
@@ -488,15 +502,15 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
 #pragma unroll
                 for (int j = 0; j < E; ++j) sg[j] = qs.v[j];
             }
-            const VecE<T, E> q = *reinterpret_cast<const VecE<T, E>*>(a.obs + base);
+            const VecE<T, E> q = *reinterpret_cast<const VecE<T, E>*>(obs_p + base);
             VecE<int32_t, E> qt;
             if (T8) {
                 typedef std::conditional_t<E == 4, uint32_t, uint16_t> bytesE;
-                const uint32_t w = *reinterpret_cast<const bytesE*>(reinterpret_cast<const uint8_t*>(a.t) + base);
+                const uint32_t w = *reinterpret_cast<const bytesE*>(reinterpret_cast<const uint8_t*>(t_p) + base);
 #pragma unroll
                 for (int j = 0; j < E; ++j) qt.v[j] = (int32_t)((w >> (8 * j)) & 255u);
             } else {
-                qt = *reinterpret_cast<const VecE<int32_t, E>*>(a.t + base);
+                qt = *reinterpret_cast<const VecE<int32_t, E>*>(t_p + base);
             }
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -509,11 +523,11 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 a_f[j] = 0.0f;
             }
             if (MODEL == FISHING_MODEL_V0) {
-                const VecE<int32_t, E> qa = *reinterpret_cast<const VecE<int32_t, E>*>((const int32_t*)a.action + cbase);
+                const VecE<int32_t, E> qa = *reinterpret_cast<const VecE<int32_t, E>*>((const int32_t*)action_p + cbase);
 #pragma unroll
                 for (int j = 0; j < E; ++j) a_i[j] = qa.v[j];
             } else {
-                const VecE<float, E> qa = *reinterpret_cast<const VecE<float, E>*>((const float*)a.action + cbase);
+                const VecE<float, E> qa = *reinterpret_cast<const VecE<float, E>*>((const float*)action_p + cbase);
 #pragma unroll
                 for (int j = 0; j < E; ++j) a_f[j] = qa.v[j];
             }
@@ -532,7 +546,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 for (int j = 0; j < E; ++j) rr[j] = qr.v[j];
             }
             if (RET) {
-                const VecE<T, E> qe = *reinterpret_cast<const VecE<T, E>*>(a.ep_return + base);
+                const VecE<T, E> qe = *reinterpret_cast<const VecE<T, E>*>(ep_return_p + base);
 #pragma unroll
                 for (int j = 0; j < E; ++j) er[j] = qe.v[j];
             }
@@ -545,6 +559,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
         // the loads above must be in flight BEFORE the ~100-instruction Philox block starts: without
         // this fence the scheduler hoists the (independent) generator above them in some variants
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kOne && FISHING_LEAN_BATCH_ARGS == 1) batch_args();
         if constexpr (kOne) step_counter = read_counter();
         if (noise == kNoisePhilox) {
             float zq[E];
@@ -693,7 +708,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
             VecE<T, E> qe;
 #pragma unroll
             for (int j = 0; j < E; ++j) qe.v[j] = er[j];
-            *reinterpret_cast<VecE<T, E>*>(a.ep_return + base) = qe;
+            *reinterpret_cast<VecE<T, E>*>(ep_return_p + base) = qe;
         }
         if constexpr (kMixed) {     // growth_models.py:200: a new model for the next episode
             if (auto_reset && __any(lane_done)) {
@@ -738,7 +753,7 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
                 qo.v[j] = obs_next[j];
                 qt.v[j] = t_next[j];
             }
-            *reinterpret_cast<VecE<T, E>*>(a.obs + base) = qo;
+            *reinterpret_cast<VecE<T, E>*>(obs_p + base) = qo;
             if (DRIFT) {
                 VecE<T, E> qr;
 #pragma unroll
@@ -747,9 +762,9 @@ step_kernel_lean(const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_
             }
             if (T8) {
                 typedef std::conditional_t<E == 4, uint32_t, uint16_t> bytesE;
-                *reinterpret_cast<bytesE*>(reinterpret_cast<uint8_t*>(a.t) + base) = (bytesE)pack_t4(t_next);
+                *reinterpret_cast<bytesE*>(reinterpret_cast<uint8_t*>(t_p) + base) = (bytesE)pack_t4(t_next);
             }
-            else *reinterpret_cast<VecE<int32_t, E>*>(a.t + base) = qt;
+            else *reinterpret_cast<VecE<int32_t, E>*>(t_p + base) = qt;
         }
     };
 
@@ -886,7 +901,8 @@ int lean_launch(const LeanCall<T>& c) {
     // (c.ntiles / c.blocks count 1024-env tiles; an E = 2 workgroup covers half of one)
     const int64_t nt = c.ntiles * (4 / E);
     const int64_t nb = nt < kMaxBlocks ? nt : ((int64_t)c.blocks * (4 / E) < kMaxBlocks ? (int64_t)c.blocks * (4 / E) : kMaxBlocks);
-    return launch_kernel(step_kernel_lean<T, MODEL, F, E>, (int)nb, 256, c.s, c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
+    return launch_kernel(step_kernel_lean<T, MODEL, F, E>, (int)nb, 256, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return, c.a.n_live,
+                         c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
 }
 
 // the catch-all mask of a (T, MODEL): every optional stream "may be there", noise mode at run time

@@ -189,9 +189,20 @@ __device__ __forceinline__ void wave_partials(const double (&acc)[4], double* pa
 
 // REC: 0 none; 1 the product's (LDS + barrier, 4 atomics per workgroup); 2 per wave, ds_bpermute; 3 per wave, permlane
 // swaps; +10 = the record (and its atomic) goes BEFORE the streaming stores of the tile
+#ifdef HARNESS_SCALAR_ARGS
+// the stream pointers as leading scalar arguments: what -mllvm -amdgpu-kernarg-preload-count=N can hand the wave in
+// SGPRs at launch (no s_load round trip in front of the tile's loads); a by-value struct is not preloaded
+template <int BODY, int THREADS, int E, bool RET, int REC = 0>
+__global__ void __launch_bounds__(THREADS) shape_kernel(float* obs_, const float* action_, int32_t* t_, float* ep_return_,
+                                                        float* reward_, uint8_t* done_, double* partials_, const uint64_t seed,
+                                                        const uint64_t counter, const float r, const float K, const float sigma,
+                                                        const float x0, const int32_t Tmax) {
+    const Streams s{obs_, action_, reward_, done_, t_, ep_return_, partials_};
+#else
 template <int BODY, int THREADS, int E, bool RET, int REC = 0>
 __global__ void __launch_bounds__(THREADS) shape_kernel(const Streams s, const uint64_t seed, const uint64_t counter, const float r,
                                                         const float K, const float sigma, const float x0, const int32_t Tmax) {
+#endif
     if constexpr (BODY == kEmpty) return;
     const int64_t base = ((int64_t)blockIdx.x * THREADS + threadIdx.x) * E;
     float o[E], a[E], er[E], on[E], rw[E], erf_[E];
@@ -294,8 +305,13 @@ struct Case {
 template <int BODY, int THREADS, int E, bool RET, int REC = 0>
 void launch_case(int64_t n, const Streams& s, uint64_t counter, hipStream_t st_) {
     const int64_t tile = (int64_t)THREADS * E;
+#ifdef HARNESS_SCALAR_ARGS
+    shape_kernel<BODY, THREADS, E, RET, REC><<<dim3((unsigned)(n / tile)), dim3(THREADS), 0, st_>>>(
+        s.obs, s.action, s.t, s.ep_return, s.reward, s.done, s.partials, 1234u, counter, 0.3f, 1.0f, 0.1f, 0.75f, 100);
+#else
     shape_kernel<BODY, THREADS, E, RET, REC><<<dim3((unsigned)(n / tile)), dim3(THREADS), 0, st_>>>(s, 1234u, counter, 0.3f, 1.0f, 0.1f,
                                                                                                  0.75f, 100);
+#endif
 }
 
 static FishingParams g_params;
