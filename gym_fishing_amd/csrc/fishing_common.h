@@ -322,16 +322,22 @@ inline int with_general_tag(int model, F&& f) {
 
 // Launch status of THIS launch (hipLaunchKernel's own return value), not whatever sticky error an
 // unrelated earlier call left on the thread -- and without consuming that state either.
+// `dyn_lds` bytes of (unused) dynamic LDS per workgroup cap how many workgroups a CU holds at once -- a launch-time
+// occupancy limit (launch_kernel_lds).
 template <typename... P, typename... A>
-inline int launch_kernel(void (*kernel)(P...), int blocks, int threads, hipStream_t stream, A&&... args) {
+inline int launch_kernel_lds(void (*kernel)(P...), int blocks, int threads, size_t dyn_lds, hipStream_t stream, A&&... args) {
     std::tuple<P...> packed{static_cast<P>(args)...};
     return std::apply(
         [&](auto&... a) {
             void* argv[] = {(void*)&a...};
-            return (int)hipLaunchKernel((const void*)kernel, dim3((unsigned)blocks), dim3((unsigned)threads), argv, 0,
+            return (int)hipLaunchKernel((const void*)kernel, dim3((unsigned)blocks), dim3((unsigned)threads), argv, dyn_lds,
                                         stream);
         },
         packed);
+}
+template <typename... P, typename... A>
+inline int launch_kernel(void (*kernel)(P...), int blocks, int threads, hipStream_t stream, A&&... args) {
+    return launch_kernel_lds(kernel, blocks, threads, 0, stream, std::forward<A>(args)...);
 }
 
 // ---------------------------------------------------------------- the env arithmetic

@@ -22,6 +22,7 @@
 #include "fishing_host.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 namespace fishing {
 
@@ -901,8 +902,16 @@ int lean_launch(const LeanCall<T>& c) {
     // (c.ntiles / c.blocks count 1024-env tiles; an E = 2 workgroup covers half of one)
     const int64_t nt = c.ntiles * (4 / E);
     const int64_t nb = nt < kMaxBlocks ? nt : ((int64_t)c.blocks * (4 / E) < kMaxBlocks ? (int64_t)c.blocks * (4 / E) : kMaxBlocks);
-    return launch_kernel(step_kernel_lean<T, MODEL, F, E>, (int)nb, 256, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return, c.a.n_live,
-                         c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
+    // (FISHING_X_DYN_LDS, experiments only: unused dynamic LDS per workgroup caps the workgroups a CU holds at once.  Running
+    // the one-round grids of N = 2^20 .. 2^22 in several rounds never helped -- fishing-v4 at 2^21 13.05 us with 8 workgroups
+    // per CU, 14.6 with 4, 16.5 with 2: profiles/r03_occupancy_cap.jsonl)
+#ifdef FISHING_X_DYN_LDS_KNOB
+    static const size_t x_lds = std::getenv("FISHING_X_DYN_LDS") ? (size_t)std::atol(std::getenv("FISHING_X_DYN_LDS")) : 0;
+#else
+    constexpr size_t x_lds = 0;
+#endif
+    return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)nb, 256, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
+                             c.a.n_live, c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
 }
 
 // the catch-all mask of a (T, MODEL): every optional stream "may be there", noise mode at run time
