@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,7 @@ struct Streams {
     int32_t* t;
     float* ep_return;
     double* partials;
+    unsigned long long* stamps;     // REC >= 20: 8 s_memtime stamps per workgroup (wave 0, lane 0)
 };
 
 template <int E>
@@ -196,26 +198,44 @@ template <int BODY, int THREADS, int E, bool RET, int REC = 0>
 __global__ void __launch_bounds__(THREADS) shape_kernel(float* obs_, const float* action_, int32_t* t_, float* ep_return_,
                                                         float* reward_, uint8_t* done_, double* partials_, const uint64_t seed,
                                                         const uint64_t counter, const float r, const float K, const float sigma,
-                                                        const float x0, const int32_t Tmax) {
-    const Streams s{obs_, action_, reward_, done_, t_, ep_return_, partials_};
+                                                        const float x0, const int32_t Tmax, const int stagger) {
+    const Streams s{obs_, action_, reward_, done_, t_, ep_return_, partials_, nullptr};
 #else
 template <int BODY, int THREADS, int E, bool RET, int REC = 0>
 __global__ void __launch_bounds__(THREADS) shape_kernel(const Streams s, const uint64_t seed, const uint64_t counter, const float r,
-                                                        const float K, const float sigma, const float x0, const int32_t Tmax) {
+                                                        const float K, const float sigma, const float x0, const int32_t Tmax,
+                                                        const int stagger) {
 #endif
     if constexpr (BODY == kEmpty) return;
+    constexpr bool kStamp = REC >= 20;
+    constexpr int RECV = kStamp ? REC - 10 : REC;       // the record variant proper
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (kStamp) stamp[0] = __builtin_amdgcn_s_memtime();
+    // HARNESS_STAGGER = d [, HARNESS_STAGGER_MODE]: half of the workgroups start d x 64 cycles late, so that in a one-round
+    // grid their read phase meets the other half's compute / write phase (mode 0: odd workgroups, 1: every other group of
+    // 8 = one per XCD, 2: the upper half of the grid)
+    if (stagger > 0) {
+        const int mode = stagger >> 16, d = stagger & 0xffff;
+        const bool late = mode == 0 ? (blockIdx.x & 1) : mode == 1 ? ((blockIdx.x >> 3) & 1) : (blockIdx.x >= gridDim.x / 2);
+        if (late)
+            for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const int64_t base = ((int64_t)blockIdx.x * THREADS + threadIdx.x) * E;
     float o[E], a[E], er[E], on[E], rw[E], erf_[E];
     int32_t t[E], tn[E], tl_[E];
     bool dn[E];
     double slot_old = 0.0;
-    if constexpr (REC % 10 == 4 || REC % 10 == 5) {
+    if constexpr (RECV % 10 == 4 || RECV % 10 == 5) {
         if (threadIdx.x < 4) slot_old = __builtin_nontemporal_load(&s.partials[(int64_t)blockIdx.x * 4 + threadIdx.x]);
     }
     ld<E>(s.obs + base, o);
     ldi<E>(s.t + base, t);
     ld<E>(s.action + base, a);
     if constexpr (RET) ld<E>(s.ep_return + base, er);
+    if constexpr (kStamp) {
+        __builtin_amdgcn_sched_barrier(0);
+        stamp[1] = __builtin_amdgcn_s_memtime();        // loads issued
+    }
     if constexpr (BODY == kCopy) {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -232,6 +252,12 @@ __global__ void __launch_bounds__(THREADS) shape_kernel(const Streams s, const u
         float z[E];
         noise<E>(seed, (uint64_t)base, counter, z);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kStamp) {
+            stamp[2] = __builtin_amdgcn_s_memtime();    // Philox + Box-Muller done
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp[3] = __builtin_amdgcn_s_memtime();    // loads landed
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const float ro = x0 / K - 1.0f;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -247,7 +273,7 @@ __global__ void __launch_bounds__(THREADS) shape_kernel(const Streams s, const u
         }
     }
     auto record = [&]() {
-        if constexpr (REC % 10 != 0) {
+        if constexpr (RECV % 10 != 0) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             bool any = false;
 #pragma unroll
@@ -267,8 +293,8 @@ __global__ void __launch_bounds__(THREADS) shape_kernel(const Streams s, const u
                 acc[2] = (double)cnt;
                 acc[3] = (double)tot;
             }
-            if constexpr (REC % 10 == 1) add_block_partials<THREADS / 64>(acc, s.partials);
-            else if constexpr (REC % 10 == 4 || REC % 10 == 5) {
+            if constexpr (RECV % 10 == 1) add_block_partials<THREADS / 64>(acc, s.partials);
+            else if constexpr (RECV % 10 == 4 || RECV % 10 == 5) {
                 constexpr int kRows = THREADS / 16;
                 __shared__ double red[kRows][4];
                 const int lane = threadIdx.x & 63;
@@ -279,19 +305,38 @@ __global__ void __launch_bounds__(THREADS) shape_kernel(const Streams s, const u
                     double tot = 0.0;
 #pragma unroll
                     for (int w = 0; w < kRows; ++w) tot += red[w][threadIdx.x];
-                    if (REC % 10 == 5) unsafeAtomicAdd(&s.partials[(int64_t)blockIdx.x * 4 + threadIdx.x], tot);   // (static rows, still atomic)
+                    if (RECV % 10 == 5) unsafeAtomicAdd(&s.partials[(int64_t)blockIdx.x * 4 + threadIdx.x], tot);   // (static rows, still atomic)
                     else s.partials[(int64_t)blockIdx.x * 4 + threadIdx.x] = slot_old + tot;
                 }
-            } else wave_partials<REC % 10>(acc, s.partials, (int64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6));
+            } else wave_partials<RECV % 10>(acc, s.partials, (int64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6));
         }
     };
-    if constexpr (REC >= 10) record();
+    if constexpr (kStamp) {
+        asm volatile("" ::"v"(on[0]), "v"(rw[0]), "v"(tn[0]));
+        __builtin_amdgcn_sched_barrier(0);
+        stamp[4] = __builtin_amdgcn_s_memtime();        // arithmetic done
+    }
+    if constexpr (RECV >= 10) record();
+    if constexpr (kStamp) {
+        __builtin_amdgcn_sched_barrier(0);
+        stamp[5] = __builtin_amdgcn_s_memtime();        // record (reduction + atomic issued)
+    }
     st<E, true>(s.reward + base, rw);
     std_<E>(s.done + base, dn);
     if constexpr (RET) st<E>(s.ep_return + base, er);
     st<E>(s.obs + base, on);
     sti<E>(s.t + base, tn);
-    if constexpr (REC > 0 && REC < 10) record();
+    if constexpr (RECV > 0 && RECV < 10) record();
+    if constexpr (kStamp) {
+        __builtin_amdgcn_sched_barrier(0);
+        stamp[6] = __builtin_amdgcn_s_memtime();        // stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[7] = __builtin_amdgcn_s_memtime();        // stores + atomic acknowledged
+        if (threadIdx.x == 0 && s.stamps) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s.stamps[(int64_t)blockIdx.x * 8 + k] = stamp[k];
+        }
+    }
 }
 
 struct Case {
@@ -302,21 +347,23 @@ struct Case {
     void (*launch)(int64_t n, const Streams&, uint64_t counter, hipStream_t);
 };
 
+static int g_stagger = 0;
 template <int BODY, int THREADS, int E, bool RET, int REC = 0>
 void launch_case(int64_t n, const Streams& s, uint64_t counter, hipStream_t st_) {
     const int64_t tile = (int64_t)THREADS * E;
 #ifdef HARNESS_SCALAR_ARGS
     shape_kernel<BODY, THREADS, E, RET, REC><<<dim3((unsigned)(n / tile)), dim3(THREADS), 0, st_>>>(
-        s.obs, s.action, s.t, s.ep_return, s.reward, s.done, s.partials, 1234u, counter, 0.3f, 1.0f, 0.1f, 0.75f, 100);
+        s.obs, s.action, s.t, s.ep_return, s.reward, s.done, s.partials, 1234u, counter, 0.3f, 1.0f, 0.1f, 0.75f, 100, g_stagger);
 #else
     shape_kernel<BODY, THREADS, E, RET, REC><<<dim3((unsigned)(n / tile)), dim3(THREADS), 0, st_>>>(s, 1234u, counter, 0.3f, 1.0f, 0.1f,
-                                                                                                 0.75f, 100);
+                                                                                                 0.75f, 100, g_stagger);
 #endif
 }
 
 static FishingParams g_params;
 static bool g_prod_ret = false;
 static double* g_partials = nullptr;
+static unsigned long long* g_stamps = nullptr;
 void launch_product(int64_t n, const Streams& s, uint64_t counter, hipStream_t st_) {
     FishingBuffers b;
     std::memset(&b, 0, sizeof b);
@@ -362,6 +409,8 @@ void launch_product_ret(int64_t n, const Streams& s, uint64_t c, hipStream_t st_
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? std::atoi(argv[1]) : 400;
+    if (std::getenv("HARNESS_STAGGER"))
+        g_stagger = std::atoi(std::getenv("HARNESS_STAGGER")) | ((std::getenv("HARNESS_STAGGER_MODE") ? std::atoi(std::getenv("HARNESS_STAGGER_MODE")) : 0) << 16);
     const int lo = argc > 2 ? std::atoi(argv[2]) : 17, hi = argc > 3 ? std::atoi(argv[3]) : 21;
     const char* only = argc > 4 ? argv[4] : nullptr;      // body filter
     std::vector<Case> cases = {
@@ -373,6 +422,7 @@ int main(int argc, char** argv) {
         SHAPES(kStep, "step", false),
         SHAPES(kStep, "step", true),
         RECS(256, 4), RECS(128, 4), RECS(256, 2), RECS(512, 4),
+        {"stamps", 256, 4, true, 21, launch_case<kStep, 256, 4, true, 21>},
         {"product", 256, 4, false, 0, launch_product_bare},
         {"product", 256, 4, true, 1, launch_product_ret},
     };
@@ -393,6 +443,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     CK(hipMalloc(&g_partials, 65536 * 4 * sizeof(double)));
+    CK(hipMalloc(&g_stamps, 65536 * 8 * sizeof(unsigned long long)));
     for (int ln = lo; ln <= hi; ++ln) {
         const int64_t n = 1ll << ln;
         // one arena, the product's placement: streams staggered by 12 KiB; 8 action batches
@@ -406,7 +457,7 @@ int main(int argc, char** argv) {
             CK(hipMemcpy((char*)acts + k * stride, ha.data(), (size_t)n * 4, hipMemcpyHostToDevice));
         }
         Streams s{(float*)arena, acts, (float*)(arena + stride), (uint8_t*)(arena + 4 * stride), (int32_t*)(arena + 2 * stride),
-                  (float*)(arena + 3 * stride), g_partials};
+                  (float*)(arena + 3 * stride), g_partials, g_stamps};
         // HARNESS_RR=<burst>: round-robin over the selected cases, <burst> launches of each in turn, `reps` times --
         // per-kernel durations then come from a rocprofv3 trace and see the same clock / power state on average
         const int rr = std::getenv("HARNESS_RR") ? std::atoi(std::getenv("HARNESS_RR")) : 0;
@@ -462,6 +513,28 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(hp.data(), g_partials, hp.size() * 8, hipMemcpyDeviceToHost));
             double fields[4] = {0, 0, 0, 0};
             for (size_t i = 0; i < hp.size(); ++i) fields[i & 3] += hp[i];
+            if (std::strcmp(c.body, "stamps") == 0) {       // phase durations in shader cycles: median over the workgroups of the LAST launch
+                const int64_t nwg = n / 1024;
+                std::vector<unsigned long long> hs((size_t)nwg * 8);
+                CK(hipMemcpy(hs.data(), g_stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+                const char* names[7] = {"issue_loads", "philox", "wait_loads", "arithmetic", "record", "issue_stores", "wait_acks"};
+                unsigned long long first = ~0ull, last = 0;
+                for (int64_t w = 0; w < nwg; ++w) {
+                    first = hs[w * 8] < first ? hs[w * 8] : first;
+                    last = hs[w * 8 + 7] > last ? hs[w * 8 + 7] : last;
+                }
+                std::printf("{\"log2_n\": %d, \"stamps\": true, \"first_start_to_last_end_cycles\": %llu", ln, last - first);
+                for (int k = 0; k < 7; ++k) {
+                    std::vector<long long> d((size_t)nwg);
+                    for (int64_t w = 0; w < nwg; ++w) d[w] = (long long)(hs[w * 8 + k + 1] - hs[w * 8 + k]);
+                    std::sort(d.begin(), d.end());
+                    std::printf(", \"%s\": [%lld, %lld, %lld]", names[k], d[nwg / 10], d[nwg / 2], d[nwg * 9 / 10]);
+                }
+                std::vector<long long> st0((size_t)nwg);
+                for (int64_t w = 0; w < nwg; ++w) st0[w] = (long long)(hs[w * 8] - first);
+                std::sort(st0.begin(), st0.end());
+                std::printf(", \"start_offset\": [%lld, %lld, %lld]}\n", st0[nwg / 10], st0[nwg / 2], st0[nwg * 9 / 10]);
+            }
             std::printf("{\"log2_n\": %d, \"body\": \"%s\", \"threads\": %d, \"ept\": %d, \"ret\": %s, \"grid\": %lld, "
                         "\"rec\": %d, \"record\": [%.9g, %.9g, %.0f, %.0f], \"us_back_to_back_mean\": %.3f, \"us_back_to_back_min\": %.3f}\n",
                         ln, c.body, c.threads, c.ept, c.ret ? "true" : "false", (long long)(n / ((int64_t)c.threads * c.ept)),
