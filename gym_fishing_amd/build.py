@@ -35,7 +35,11 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fPIC", "-
 # s_waitcnt; without it the loads are issued together at the top of the tile, ahead of the scheduling fence, as the
 # kernel is written (N = 2^21 with returns: 9.8 -> 8.7 us per step; profiles/r03_small_n/).
 # ... and kernarg preload: the lean kernel's four leading pointer arguments arrive in SGPRs at wave launch (see the kernel).
-TU_FLAGS = {"fishing_step.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=10"]}
+# fishing_rollout.hip: the fused kernels are VALU-bound and still run 2.5-8 % faster without the SLP vectorizer (fused
+# step 6.70 -> 6.40 us per step at N = 2^22, 1.25 -> 1.13 at 2^18; in-kernel-policy rollouts +2.5-6 %:
+# profiles/r03_rollout_no_slp.jsonl) -- its packed f32 operations save fewer issue slots than its re-ordering costs.
+TU_FLAGS = {"fishing_step.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=10"],
+            "fishing_rollout.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -81,8 +85,9 @@ def _compile(out_path, verbose, extra_flags):
     # one hipcc per translation unit, side by side (the two kernel files take about as long as each other),
     # then one link step
     tu_flags = dict(TU_FLAGS)
-    if os.environ.get("FISHING_STEP_TU_FLAGS") is not None:     # experiments: replace the step unit's own flags
-        tu_flags["fishing_step.hip"] = os.environ["FISHING_STEP_TU_FLAGS"].split()
+    for unit in ("step", "rollout", "aux"):     # experiments: FISHING_<UNIT>_TU_FLAGS replaces that unit's own flags
+        if os.environ.get("FISHING_%s_TU_FLAGS" % unit.upper()) is not None:
+            tu_flags["fishing_%s.hip" % unit] = os.environ["FISHING_%s_TU_FLAGS" % unit.upper()].split()
     cmds = [[hipcc] + flags + tu_flags.get(os.path.basename(src), []) + ["-c", src, "-o", obj] for src, obj in zip(srcs, objs)]
     procs = []
     for cmd in cmds:
