@@ -32,6 +32,9 @@ namespace fishing {
 #ifndef FISHING_NT_STORE
 #define FISHING_NT_STORE 0
 #endif
+#ifndef FISHING_NTA_MIN_BYTES
+#define FISHING_NTA_MIN_BYTES (800ll << 20)     // bytes one step streams, from which the zig-zag forms load the actions nontemporal
+#endif
 #ifndef FISHING_LEAN_FENCE
 #define FISHING_LEAN_FENCE 1     // bit 0: scheduling fence after the tile's loads, bit 1: after the Philox block.
                                  // With one Philox block per tile (quad noise) the compiler otherwise sinks
@@ -338,6 +341,7 @@ struct LeanArgs {
     int32_t noise_rt;        // feat::kNoiseRT: the noise mode of this launch
     uint32_t t8_rt, derived_rt, drift_rt;    // feat::OPT: run-time values of T8 / DERIVED / DRIFT
     uint32_t zz_rt;          // feat::OPT: zig-zag tile walk for this launch (the exact instantiations carry feat::ZZ instead)
+    uint32_t nta_rt;         // zig-zag forms: nontemporal action loads (a step streams >= FISHING_NTA_MIN_BYTES)
     int64_t n_live;          // FISHING_FLAG_PADDED_TILES: the number of envs that exist (a multiple of 4); INT64_MAX otherwise
     uint64_t origin_step, origin_counter;    // DERIVED (derive_model_error)
     GrowthT<T> growth;       // fishing-v5..v10: the growth function's parameter set (unused, hence never
@@ -405,6 +409,13 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool DERIVED = (F & feat::DERIVED) && (kExact || a.derived_rt != 0);
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
     const bool ZZ = (F & feat::ZZ) != 0 || (kOpt && a.zz_rt != 0);
+    // The caller's action stream is read once per step and never again: once a step streams ~0.8 GB (N >= 2^25, over three times the
+    // 256 MiB Infinity Cache) the zig-zag forms load it nontemporal, so that it does not evict the state lines the reversed
+    // walk is about to re-hit.  N = 2^26: 283 -> 262 us bare, 398 -> 380 with returns; 2^25: 128.5 -> 124, 181.5 -> 172.6.
+    // Not below: at 2^24 it is neutral to 3 % worse, inside the cache 6-11 % worse (the action ring itself is resident
+    // there): profiles/r03_nt_action_loads.jsonl.  (Streaming the state STORES of all but the walk's last 128-224 MB as
+    // well changed nothing beyond 1 %.)
+    const bool NTA = ZZ && a.nta_rt != 0;
     const int noise = ((F & feat::kNoiseMask) == feat::kNoiseRT) ? a.noise_rt : (F & feat::kNoiseMask);
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
@@ -524,11 +535,27 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 a_f[j] = 0.0f;
             }
             if (MODEL == FISHING_MODEL_V0) {
-                const VecE<int32_t, E> qa = *reinterpret_cast<const VecE<int32_t, E>*>((const int32_t*)action_p + cbase);
+                VecE<int32_t, E> qa;
+                if (E == 4 && NTA) {
+                    typedef int32_t i4 __attribute__((ext_vector_type(4)));
+                    const i4 w = __builtin_nontemporal_load(reinterpret_cast<const i4*>((const int32_t*)action_p + cbase));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qa.v[j] = w[j];
+                } else {
+                    qa = *reinterpret_cast<const VecE<int32_t, E>*>((const int32_t*)action_p + cbase);
+                }
 #pragma unroll
                 for (int j = 0; j < E; ++j) a_i[j] = qa.v[j];
             } else {
-                const VecE<float, E> qa = *reinterpret_cast<const VecE<float, E>*>((const float*)action_p + cbase);
+                VecE<float, E> qa;
+                if (E == 4 && NTA) {
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    const f4 w = __builtin_nontemporal_load(reinterpret_cast<const f4*>((const float*)action_p + cbase));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qa.v[j] = w[j];
+                } else {
+                    qa = *reinterpret_cast<const VecE<float, E>*>((const float*)action_p + cbase);
+                }
 #pragma unroll
                 for (int j = 0; j < E; ++j) a_f[j] = qa.v[j];
             }
@@ -1075,7 +1102,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     LeanArgs<T> a{bt.obs,   bt.action, bt.reward, bt.done,  bt.t,    bt.r,     bt.K,     bt.ep_return, bt.partials,
                   bt.counter, bt.sigma, bt.terminal_obs, bt.done_bits, bt.z_ext, pt.r, pt.K, pt.sigma, pt.C, pt.x0,
                   pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET),
-                  noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, padded ? n : INT64_MAX, pt.origin_step,
+                  noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, 0u, padded ? n : INT64_MAX, pt.origin_step,
                   pt.origin_counter, pt.growth, pt.alpha, make_divk((double)pt.K)};
     // up to 4096 workgroups = one tile each at N = 2^22: 21.39 -> 21.13 us with returns against a cap of
     // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl).  From N = 2^25 on (state streams far beyond
@@ -1103,6 +1130,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
                                                                  : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0));
     const bool zigzag = step_bytes >= FISHING_ZZ_MIN_BYTES;
     a.zz_rt = zigzag ? 1u : 0u;          // (read by the catch-alls only)
+    a.nta_rt = (zigzag && step_bytes >= FISHING_NTA_MIN_BYTES) ? 1u : 0u;
     LeanMixedArgs<T> mixed{};
     if (p->model == FISHING_MODEL_V11) {
         mixed.model_idx = bt.model_idx;
