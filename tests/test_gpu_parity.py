@@ -748,6 +748,45 @@ def test_one_tile_and_tile_loop_instantiations_agree(hh, case):
         assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True) and ra[2] > n
 
 
+@pytest.mark.parametrize("case", ["v1_K1.5", "v2_ext_noise", "v4_derived", "v9"])
+def test_float64_two_per_thread_catch_all_with_every_optional_stream(hh, case):
+    """Round 3: the float64 layout runs two envs per thread (16-byte accesses, a workgroup tile of 512 envs, the lane
+    pair sharing a quad's Philox block) -- exact instantiations for the plain requests, and from ~105 MB per step the
+    catch-all too.  That catch-all form with EVERY optional stream at once (per-env sigma, return accumulator + record,
+    terminal observations, done bytes AND ballot words: two words per wave here), N = 2^21 + a ragged tail, against the
+    general kernel over 6 auto-resetting steps: every stream bit for bit."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n = (1 << 21) + 1027
+    model = {"v1": fo.MODEL_V1, "v2": fo.MODEL_V2, "v4": fo.MODEL_V4, "v9": fo.MODEL_V9}[case.split("_")[0]]
+    derived = "derived" in case
+    kw = dict(sigma=0.1, C=0.5, Tmax=3, sigma_p=0.2, auto_reset=True, derived=derived, origin=(0, 0), K=1.5 if "K1.5" in case else 1.0)
+    pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
+    rng = np.random.default_rng(5)
+    sig = rng.uniform(0.02, 0.2, n)
+    mk = lambda: hh.State(n, np.float64, model, np.full(n, -0.25), sigma=sig, ep_return=True, terminal=True, done_bits=True)  # noqa: E731
+    A, B = mk(), mk()
+    z = torch.randn(n, dtype=torch.float64, device="cuda") if "ext_noise" in case else None
+    a0 = torch.zeros(n, device="cuda")
+    name = hh.kernel_name(pa, n, A.buffers(a0, z), np.float64)
+    assert name.startswith("fishing::step_kernel_lean<double, ") and name.endswith(", 2>") and ", 3" in name, name   # catch-all mask, E = 2
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for s in range(6):
+        a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
+        for st, p in ((A, pa), (B, pb)):
+            assert lib.fishing_step_f64(p, n, 4, st.buffers(a, z), 9, s, None) == 0
+        torch.cuda.synchronize()
+        for nm in ("obs", "reward", "done", "t", "ep_return", "terminal", "done_bits"):
+            x, y = getattr(A, nm), getattr(B, nm)
+            it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]
+            assert torch.equal(x.view(it), y.view(it)), (nm, s)
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] > n and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True)
+    del A, B
+    torch.cuda.empty_cache()
+
+
 def test_huge_batch_64bit_indexing(hh):
     """Maximum sizes: N = 2^29 + 1029 envs (2 GiB per float32 stream, byte offsets past 2^31 and
     element counts past 2^29; ragged tail behind the lean launch).  sigma = 0 and one shared
