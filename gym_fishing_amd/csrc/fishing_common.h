@@ -38,14 +38,21 @@ struct Words4 {
     uint32_t w0, w1, w2, w3;
 };
 
+// a ^ b ^ c in ONE instruction: gfx950's v_bitop3_b32 with truth table 0x96 (hipcc leaves two v_xor_b32 otherwise).  Every
+// Philox round has two (4x32) or one (2x32) such update: 20 / 10 VALU instructions less per block -- 367 -> 347 in the
+// headline step kernel, ~60 less in fishing-v4's (one noise block + four parameter blocks per thread).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
 __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                 uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int rnd = 0; rnd < 10; ++rnd) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
@@ -78,7 +85,7 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
 #pragma unroll
     for (int rnd = 0; rnd < 10; ++rnd) {
         const uint64_t p = (uint64_t)0xD256D193u * c0;
-        c0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c0 = xor3((uint32_t)(p >> 32), c1, k);
         c1 = (uint32_t)p;
         k += 0x9E3779B9u;
     }
