@@ -95,6 +95,39 @@ def fo_mask(noise=2, ret=False, sigarr=False, t8=False, term=False, bits=False, 
             | (128 if zz else 0) | (256 if derived else 0) | (512 if drift else 0) | (8192 if one else 0))
 
 
+def test_v4_derived_mode_guards_its_year_counter_and_hands_out_snapshots(hh):
+    """In the derived mode the year counter dates each env's episode and with it its (K, r).  So env.years_passed hands
+    out a COPY there (an in-place edit of it changes nothing), an ASSIGNMENT first moves the env to stored r / K arrays
+    (the parameters in force stay what they were; only the Tmax check follows the new counter), and env.K / env.r are
+    snapshots: editing one in place does not touch the env.  Outside the derived mode years_passed is the live tensor."""
+    import torch
+    import gym_fishing_amd as gf
+    n = 2048
+    env = gf.make("fishing-v4", sigma=0.05, sigma_p=0.2, num_envs=n, seed=3, Tmax=6)
+    env.reset()
+    acts = torch.rand((3, n), device="cuda") * 1.4 - 1.2
+    env.step_many(acts, 5)
+    assert env._derived
+    K0, r0 = env.K.clone(), env.r.clone()
+    yp = env.years_passed
+    assert yp.data_ptr() != env._t.data_ptr() and torch.equal(yp, env._t)
+    yp.zero_()                                   # an outside in-place edit of the copy
+    env.K.fill_(7.0)                             # ... and of a K snapshot
+    assert env._derived and torch.equal(env.K, K0) and torch.equal(env.r, r0) and int(env._t.max()) > 0
+    twin = gf.make("fishing-v4", sigma=0.05, sigma_p=0.2, num_envs=n, seed=3, Tmax=6)
+    twin.reset()
+    twin.step_many(acts, 5)
+    env.years_passed = torch.zeros(n, dtype=torch.int32, device="cuda")        # an assignment: stored arrays from here on
+    assert not env._derived and torch.equal(env.K, K0) and torch.equal(env.r, r0) and int(env._t.max()) == 0
+    assert env.years_passed.data_ptr() == env._t.data_ptr()                    # the live tensor again
+    # the parameters in force did not move: the next step's observations equal the twin's wherever the twin's env does not
+    # finish on it (there the two differ only by the year counter the caller rewrote)
+    oa, _, da, _ = env.step(acts[0])
+    ob, _, db, _ = twin.step(acts[0])
+    same = ~(da.bool() | db.bool())
+    assert int(same.sum()) > n // 4 and torch.equal(oa[same], ob[same])
+
+
 def test_v4_derived_parameters_against_the_oracle(hh):
     """The derived mode end to end against the oracle: the oracle dates every env's episode with v4_origin() and
     draws (K, r) from reset_normals() (its own Philox2x32), the device's Box-Muller being within 2e-5 of libm's;
