@@ -33,7 +33,7 @@ namespace fishing {
 #define FISHING_NT_STORE 0
 #endif
 #ifndef FISHING_NTA_MIN_BYTES
-#define FISHING_NTA_MIN_BYTES (800ll << 20)     // bytes one step streams, from which the zig-zag forms load the actions nontemporal
+#define FISHING_NTA_MIN_BYTES (200ll << 20)             // ... the zig-zag forms load the caller's actions nontemporal
 #endif
 #ifndef FISHING_LEAN_FENCE
 #define FISHING_LEAN_FENCE 1     // bit 0: scheduling fence after the tile's loads, bit 1: after the Philox block.
@@ -47,8 +47,15 @@ namespace fishing {
 #ifndef FISHING_LEAN_LOCAL_KEYS
 #define FISHING_LEAN_LOCAL_KEYS 1
 #endif
+// Bytes one step streams, from which ...
+#ifndef FISHING_XZZ_MIN_BYTES
+#define FISHING_XZZ_MIN_BYTES (100ll << 20)             // ... the one-tile forms and the catch-alls walk zig-zag (run-time flag zz_rt)
+#endif
 #ifndef FISHING_ZZ_MIN_BYTES
-#define FISHING_ZZ_MIN_BYTES (500ll << 20)  // bytes one step streams, from which the tile walk alternates direction
+#define FISHING_ZZ_MIN_BYTES (150ll << 20)              // ... the exact tile-loop forms take their zig-zag twins (N > 2^22)
+#endif
+#ifndef FISHING_ZZ_CATCHALL_MIN_BYTES
+#define FISHING_ZZ_CATCHALL_MIN_BYTES (500ll << 20)     // ... a request without a zig-zag twin prefers its catch-all's zig-zag walk
 #endif
 #ifndef FISHING_F64_E2_MAX_BYTES
 #define FISHING_F64_E2_MAX_BYTES (250ll << 20)      // float64: two envs per thread below this many bytes per step ...
@@ -396,7 +403,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     static_assert(!((F & feat::ZZ) && kOpt), "ZZ has exact instantiations only");
     static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
-    static_assert(!(F & feat::ONE) || (kExact && !(F & feat::ZZ)), "ONE: exact instantiations, no tile walk");
+    static_assert(!(F & feat::ONE) || (kExact && !(F & feat::ZZ)), "ONE: exact instantiations; their walk direction is LeanArgs::zz_rt");
     constexpr bool kOne = (F & feat::ONE) != 0;
     static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
     constexpr int kTileEnvs = 256 * E;
@@ -408,13 +415,12 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool BITS = (F & feat::BITS) && (kExact || a.done_bits != nullptr);
     const bool DERIVED = (F & feat::DERIVED) && (kExact || a.derived_rt != 0);
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
-    const bool ZZ = (F & feat::ZZ) != 0 || (kOpt && a.zz_rt != 0);
-    // The caller's action stream is read once per step and never again: once a step streams ~0.8 GB (N >= 2^25, over three times the
-    // 256 MiB Infinity Cache) the zig-zag forms load it nontemporal, so that it does not evict the state lines the reversed
-    // walk is about to re-hit.  N = 2^26: 283 -> 262 us bare, 398 -> 380 with returns; 2^25: 128.5 -> 124, 181.5 -> 172.6.
-    // Not below: at 2^24 it is neutral to 3 % worse, inside the cache 6-11 % worse (the action ring itself is resident
-    // there): profiles/r03_nt_action_loads.jsonl.  (Streaming the state STORES of all but the walk's last 128-224 MB as
-    // well changed nothing beyond 1 %.)
+    const bool ZZ = (F & feat::ZZ) != 0 || ((kOpt || (F & feat::ONE)) && a.zz_rt != 0);
+    // The caller's action stream is read once per step and never again: from ~200 MB per step (N >= 2^23) the zig-zag forms
+    // load it nontemporal, so that it does not evict the state lines the reversed walk is about to re-hit.  N = 2^26:
+    // 283 -> 262 us bare, 398 -> 380 with returns; 2^25: 128.5 -> 124, 181.5 -> 172.6; 2^23 bare 32.1 -> 31.0.  Not at 2^22:
+    // the action ring itself is cache-resident there, the hint costs 6-11 % (profiles/r03_nt_action_loads.jsonl,
+    // r03_xcd_zigzag.jsonl).  (Streaming the state STORES of all but the walk's last 128-224 MB as well: < 1 %.)
     const bool NTA = ZZ && a.nta_rt != 0;
     const int noise = ((F & feat::kNoiseMask) == feat::kNoiseRT) ? a.noise_rt : (F & feat::kNoiseMask);
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
@@ -451,7 +457,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "s"(a.counter) : "memory");
         return c + step_counter_arg;
     };
-    uint64_t step_counter = kOne ? step_counter_arg : read_counter();
+    // (a one-tile form that walks zig-zag needs the step's parity for its tile index: it reads the counter up front too)
+    uint64_t step_counter = (kOne && !ZZ) ? step_counter_arg : read_counter();
     uint64_t origin_step = a.origin_step, origin_counter = a.origin_counter;
     if (DERIVED) device_origin(a.counter, origin_step, origin_counter);
     // an exact RET instantiation is only ever launched with auto-reset on (the dispatch sends RET without it to the
@@ -462,12 +469,20 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const T robs_scalar = reset_obs<T, MODEL>(a.x0, a.pK);
 
     auto do_tile = [&](const int64_t it) {
-        // ZZ (launched for N >= 2^25, far outside the 256 MiB Infinity Cache): odd steps walk the tiles
-        // backwards, so what the previous step touched last is still cached when this one starts there
-        // (N = 2^26: 331 -> 297 us).  Inside the cache the forward walk is the faster one (2^22: 16.1 vs
-        // 16.5 us), and even a run-time switch costs the returns variant 2.5 % there: own instantiations.  The
-        // catch-alls (every fp64 request among them) take the direction as a run-time flag, zz_rt.
-        const int64_t tile = (ZZ && (step_counter & 1)) ? (ntiles - 1 - it) : it;
+        // ZZ: odd steps walk the tiles backwards, so what the previous step touched LAST is what this one reads FIRST -- while
+        // it is still cached.  Backwards IN GROUPS OF EIGHT: workgroups are dealt round-robin over the 8 XCDs, each with its
+        // own 4 MiB L2 that keeps its lines across launches; tile % 8 == workgroup % 8 in both directions keeps every tile on
+        // the XCD whose L2 may still hold it (a plain reversal moves every tile to another XCD each step: the one-tile form
+        // at N = 2^20 then takes 8.8 instead of 4.1 us).  Two caches profit: the L2s from ~100 MB per step on, where an
+        // XCD's share no longer fits its L2 (N = 2^22: 21.2 -> 18.9 us with returns, 16.0 -> 14.1 bare in the harness:
+        // profiles/r03_xcd_zigzag.jsonl) -- below that everything is L2-resident and the forward walk is as good or
+        // better --, and the 256 MiB Infinity Cache at the HBM-resident sizes (N = 2^26: 331 -> 297 us, round 1).  The exact
+        // tile-loop instantiations carry feat::ZZ, the one-tile forms and the catch-alls take the direction from zz_rt.
+        int64_t tile = it;
+        if (ZZ && (step_counter & 1)) {
+            const int64_t whole = ntiles & ~(int64_t)7;       // (a last partial group of < 8 tiles keeps its place)
+            if (it < whole) tile = (whole - 8 - (it & ~(int64_t)7)) + (it & 7);
+        }
         const int64_t base = (tile * 256 + threadIdx.x) * E;
         // FISHING_FLAG_PADDED_TILES: the state buffers have room for whole tiles, so a batch that is not a multiple of 1024
         // envs still runs in this ONE launch (no second, one-workgroup launch for the tail: 3.7-4.2 us per step).  The
@@ -588,7 +603,9 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // this fence the scheduler hoists the (independent) generator above them in some variants
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
         if constexpr (kOne && FISHING_LEAN_BATCH_ARGS == 1) batch_args();
-        if constexpr (kOne) step_counter = read_counter();
+        if constexpr (kOne) {
+            if (!ZZ) step_counter = read_counter();
+        }
         if (noise == kNoisePhilox) {
             float zq[E];
             if constexpr (E == 4) {
@@ -953,7 +970,7 @@ constexpr int catch_all_mask() {
 // `req` = the exact mask of the request.  The hot requests (what bench.py and a training loop issue) have
 // their own instantiation; everything else takes the catch-all of its (T, MODEL).
 template <typename T, int MODEL>
-int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
+int lean_dispatch(int req, bool zigzag, bool zigzag_big, const LeanCall<T>& c) {
     using namespace feat;
     constexpr int P = kNoisePhilox;
     // every forward exact instantiation has a one-tile-per-workgroup twin (feat::ONE), taken whenever the grid covers the
@@ -967,12 +984,14 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     // a zig-zag twin take it; every other request goes to its catch-all there, which walks zig-zag by a run-time flag --
     // measured better than an exact kernel walking forward (N = 2^26 zoo: 289 vs 314 us; fishing-v4 stored + sigma array
     // at 2^24: 145 vs 156-177 us: profiles/r02_zz_catch_all.jsonl).  fishing-v11 is VALU-bound and keeps its exact kernels.
-    const bool forward = !zigzag || MODEL == kModelZooMixed;
+    // (zigzag: from FISHING_ZZ_MIN_BYTES per step the requests WITH a zig-zag twin take it; zigzag_big: from
+    // FISHING_ZZ_CATCHALL_MIN_BYTES the others prefer their catch-all's zig-zag walk to an exact forward kernel)
+    const bool forward = !zigzag_big || MODEL == kModelZooMixed;
     if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
         // fishing-v0/v1/v2, float32, in-kernel noise: bare / with the return record.  K a power of two (KP2): forward and
         // zig-zag; any other K keeps the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns
         // against the catch-all at N = 2^22).
-        if (zigzag) {
+        if (zigzag && !one) {      // (a one-tile launch keeps its one-tile form, which walks zig-zag by zz_rt)
             switch (req | ZZ) {
                 FISHING_LEAN_CASE_ZZ(P | KP2 | ZZ);
                 FISHING_LEAN_CASE_ZZ(P | KP2 | RET | ZZ);
@@ -999,7 +1018,7 @@ int lean_dispatch(int req, bool zigzag, const LeanCall<T>& c) {
     if constexpr (sizeof(T) == 4 && MODEL == FISHING_MODEL_V4) {
         // fishing-v4 (per-env K: always the true division): stored or derived (K, r), sigma scalar or array (BASELINE
         // config 5), bare / with the return record; zig-zag twins for the derived ones and for stored + scalar sigma
-        if (zigzag) {
+        if (zigzag && !one) {      // (a one-tile launch keeps its one-tile form, which walks zig-zag by zz_rt)
             switch (req | ZZ) {
                 FISHING_LEAN_CASE_ZZ(P | ZZ);
                 FISHING_LEAN_CASE_ZZ(P | RET | ZZ);
@@ -1128,9 +1147,9 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     // 554 MB: 85.6 -> 82.8 us; the bare 25 B step, 420 MB, still prefers the forward walk: 62.9 vs 63.7 us).
     const int64_t step_bytes = n_full * (int64_t)(sizeof(T) == 4 ? 25 + (b->ep_return ? 8 : 0) + (b->sigma ? 4 : 0)
                                                                  : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0));
-    const bool zigzag = step_bytes >= FISHING_ZZ_MIN_BYTES;
-    a.zz_rt = zigzag ? 1u : 0u;          // (read by the catch-alls only)
-    a.nta_rt = (zigzag && step_bytes >= FISHING_NTA_MIN_BYTES) ? 1u : 0u;
+    const bool zigzag = step_bytes >= FISHING_ZZ_MIN_BYTES, zigzag_big = step_bytes >= FISHING_ZZ_CATCHALL_MIN_BYTES;
+    a.zz_rt = (step_bytes >= FISHING_XZZ_MIN_BYTES) ? 1u : 0u;          // (read by the catch-alls and the one-tile forms)
+    a.nta_rt = (a.zz_rt && step_bytes >= FISHING_NTA_MIN_BYTES) ? 1u : 0u;
     LeanMixedArgs<T> mixed{};
     if (p->model == FISHING_MODEL_V11) {
         mixed.model_idx = bt.model_idx;
@@ -1148,7 +1167,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
         if constexpr (kTag == kModelZooMixed && sizeof(T) == 8) return (int)FISHING_ERR_MODEL;     // (not reached: see `lean`)
-        else return lean_dispatch<T, kTag>(req, zigzag, call);
+        else return lean_dispatch<T, kTag>(req, zigzag, zigzag_big, call);
     });
     if (rc != 0 || n_full == n || name) return rc;
     // ragged tail (< 1024 envs): one workgroup of the general kernel

@@ -217,10 +217,16 @@ __global__ void __launch_bounds__(THREADS) shape_kernel(const Streams s, const u
     if (stagger > 0) {
         const int mode = stagger >> 16, d = stagger & 0xffff;
         const bool late = mode == 0 ? (blockIdx.x & 1) : mode == 1 ? ((blockIdx.x >> 3) & 1) : (blockIdx.x >= gridDim.x / 2);
-        if (late)
+        if (late && mode < 7)
             for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(1);
     }
-    const int64_t base = ((int64_t)blockIdx.x * THREADS + threadIdx.x) * E;
+    // HARNESS_XZZ (stagger mode 7): odd steps walk the tiles in reverse order IN GROUPS OF 8 -- tile % 8 == blockIdx % 8 stays,
+    // i.e. every tile stays on its XCD (blocks are dealt round-robin over the 8 XCDs), so what an XCD's L2 still holds from
+    // the end of the previous launch is what this launch's first workgroups read; mode 8: plain reversal (changes the XCD)
+    int64_t tile_x = blockIdx.x;
+    if ((stagger >> 16) == 7 && (counter & 1)) tile_x = (int64_t)(gridDim.x - 8 - (blockIdx.x & ~7u)) + (blockIdx.x & 7u);
+    if ((stagger >> 16) == 8 && (counter & 1)) tile_x = (int64_t)gridDim.x - 1 - blockIdx.x;
+    const int64_t base = (tile_x * THREADS + threadIdx.x) * E;
     float o[E], a[E], er[E], on[E], rw[E], erf_[E];
     int32_t t[E], tn[E], tl_[E];
     bool dn[E];
@@ -382,6 +388,37 @@ void launch_product(int64_t n, const Streams& s, uint64_t counter, hipStream_t s
         std::exit(3);
     }
 }
+// the same step as HARNESS_SPLIT launches over contiguous parts of the batch (env_offset keys the noise: same results)
+static int g_split = 1;
+void launch_product_split(int64_t n, const Streams& s, uint64_t counter, hipStream_t st_) {
+    const int64_t part = n / g_split;
+    for (int k = 0; k < g_split; ++k) {
+        FishingBuffers b;
+        std::memset(&b, 0, sizeof b);
+        b.obs = s.obs + k * part;
+        b.action = s.action + k * part;
+        b.reward = s.reward + k * part;
+        b.done = s.done + k * part;
+        b.t = s.t + k * part;
+        if (g_prod_ret) {
+            b.ep_return = s.ep_return + k * part;
+            b.return_partials = g_partials;     // (shared slots: fine for timing; a product version would give each part its own)
+        }
+        const int rc = fishing_step_f32(&g_params, part, k * part, &b, 1234u, counter, st_);
+        if (rc != 0) {
+            std::fprintf(stderr, "fishing_step_f32 rc %d\n", rc);
+            std::exit(3);
+        }
+    }
+}
+void launch_split_bare(int64_t n, const Streams& s, uint64_t c, hipStream_t st_) {
+    g_prod_ret = false;
+    launch_product_split(n, s, c, st_);
+}
+void launch_split_ret(int64_t n, const Streams& s, uint64_t c, hipStream_t st_) {
+    g_prod_ret = true;
+    launch_product_split(n, s, c, st_);
+}
 void launch_product_bare(int64_t n, const Streams& s, uint64_t c, hipStream_t st_) {
     g_prod_ret = false;
     launch_product(n, s, c, st_);
@@ -409,6 +446,7 @@ void launch_product_ret(int64_t n, const Streams& s, uint64_t c, hipStream_t st_
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? std::atoi(argv[1]) : 400;
+    if (std::getenv("HARNESS_SPLIT")) g_split = std::atoi(std::getenv("HARNESS_SPLIT"));
     if (std::getenv("HARNESS_STAGGER"))
         g_stagger = std::atoi(std::getenv("HARNESS_STAGGER")) | ((std::getenv("HARNESS_STAGGER_MODE") ? std::atoi(std::getenv("HARNESS_STAGGER_MODE")) : 0) << 16);
     const int lo = argc > 2 ? std::atoi(argv[2]) : 17, hi = argc > 3 ? std::atoi(argv[3]) : 21;
@@ -423,6 +461,8 @@ int main(int argc, char** argv) {
         SHAPES(kStep, "step", true),
         RECS(256, 4), RECS(128, 4), RECS(256, 2), RECS(512, 4),
         {"stamps", 256, 4, true, 21, launch_case<kStep, 256, 4, true, 21>},
+        {"split", 256, 4, false, 0, launch_split_bare},
+        {"split", 256, 4, true, 1, launch_split_ret},
         {"product", 256, 4, false, 0, launch_product_bare},
         {"product", 256, 4, true, 1, launch_product_ret},
     };

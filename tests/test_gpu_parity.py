@@ -787,6 +787,43 @@ def test_float64_two_per_thread_catch_all_with_every_optional_stream(hh, case):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
+@pytest.mark.parametrize("tiles", [4093, 5125], ids=["one_tile_form", "tile_loop_form"])
+def test_xcd_aware_zigzag_keeps_results_with_a_partial_last_group(hh, tiles, ret):
+    """Round 3: from ~100 MB per step odd steps walk the tiles backwards IN GROUPS OF EIGHT (tile % 8 == workgroup % 8 in
+    both directions: every tile stays on its XCD, whose L2 keeps its lines across launches).  A tile count that is not
+    a multiple of 8 leaves a last partial group in place.  The walk order must not show: 4093 tiles (the one-tile form,
+    direction from zz_rt) and 5125 tiles (the tile-loop form: its zig-zag twin with returns, 173 MB per step) + a ragged tail, four steps (even and odd counters)
+    against the general kernel, every stream bit for bit."""
+    import torch
+    n = tiles * 1024 + 517
+    kw = dict(sigma=0.1, Tmax=2, auto_reset=True)
+    pa, pb = hh.params(fo.MODEL_V1, **kw), hh.params(fo.MODEL_V1, general=True, **kw)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    name = hh.kernel_name(pa, n, hh.State(4096, np.float32, fo.MODEL_V1, np.float32(-0.25), ep_return=ret).buffers(a))
+    want = (2 | 4096 | (4 if ret else 0)) | (8192 if tiles <= 4096 else (128 if ret else 0))     # ONE, or the tile loop: its ZZ twin with returns (173 MB per step), forward bare (131 MB < 150 MB)
+    assert name.endswith(", %d>" % want), (name, want)
+    outs = []
+    for p in (pa, pb):
+        st = hh.State(n, np.float32, fo.MODEL_V1, np.float32(-0.25), ep_return=ret)
+        for s in range(4):
+            assert lib.fishing_step_f32(p, n, 0, st.buffers(a), 11, 5 + s, None) == 0
+        torch.cuda.synchronize()
+        outs.append(st)
+    A, B = outs
+    for nm in ("obs", "reward", "done", "t") + (("ep_return",) if ret else ()):
+        x, y = getattr(A, nm), getattr(B, nm)
+        it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]
+        assert torch.equal(x.view(it), y.view(it)), nm
+    if ret:
+        ra, rb = A.record(), B.record()
+        assert ra[2] == rb[2] > n and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12)
+    del A, B, outs
+    torch.cuda.empty_cache()
+
+
 def test_huge_batch_64bit_indexing(hh):
     """Maximum sizes: N = 2^29 + 1029 envs (2 GiB per float32 stream, byte offsets past 2^31 and
     element counts past 2^29; ragged tail behind the lean launch).  sigma = 0 and one shared

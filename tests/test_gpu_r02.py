@@ -324,8 +324,9 @@ def test_kernel_names_follow_the_dispatch(hh):
     assert name(p1) == "fishing::step_kernel_lean<float, 1, 12290>"                # Philox (2) | KP2 (4096): K = 1 | ONE (8192): a tile per workgroup
     assert name(p1, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 12294>"
     assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 4226>"
-    # the zig-zag walk starts where one step streams ~twice the Infinity Cache: with returns (33 B) already at N = 2^24
-    assert name(p1, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 4098>"                       # (more tiles than workgroups: the tile loop)
+    # zig-zag twins of the tile-loop forms from 150 MB per step (round 3: the walk keeps every tile on its XCD)
+    assert name(p1, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 4226>"
+    assert name(p1, n=(1 << 22) + 1024) == "fishing::step_kernel_lean<float, 1, 4098>"             # (105 MB: more tiles than workgroups, the forward tile loop)
     assert name(p1, n=1 << 20) == "fishing::step_kernel_lean<float, 1, 12290>"
     assert name(p1, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 4230>"
     assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 3199>"
