@@ -415,7 +415,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool BITS = (F & feat::BITS) && (kExact || a.done_bits != nullptr);
     const bool DERIVED = (F & feat::DERIVED) && (kExact || a.derived_rt != 0);
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
-    const bool ZZ = (F & feat::ZZ) != 0 || ((kOpt || (F & feat::ONE)) && a.zz_rt != 0);
+    const bool ZZ = (F & feat::ZZ) != 0 || ((kOpt || (F & feat::ONE) || E == 2) && a.zz_rt != 0);     // (E == 2: the float64 exact forms)
     // The caller's action stream is read once per step and never again: from ~200 MB per step (N >= 2^23) the zig-zag forms
     // load it nontemporal, so that it does not evict the state lines the reversed walk is about to re-hit.  N = 2^26:
     // 283 -> 262 us bare, 398 -> 380 with returns; 2^25: 128.5 -> 124, 181.5 -> 172.6; 2^23 bare 32.1 -> 31.0.  Not at 2^22:
@@ -1148,7 +1148,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     const int64_t step_bytes = n_full * (int64_t)(sizeof(T) == 4 ? 25 + (b->ep_return ? 8 : 0) + (b->sigma ? 4 : 0)
                                                                  : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0));
     const bool zigzag = step_bytes >= FISHING_ZZ_MIN_BYTES, zigzag_big = step_bytes >= FISHING_ZZ_CATCHALL_MIN_BYTES;
-    a.zz_rt = (step_bytes >= FISHING_XZZ_MIN_BYTES) ? 1u : 0u;          // (read by the catch-alls and the one-tile forms)
+    a.zz_rt = (step_bytes >= FISHING_XZZ_MIN_BYTES) ? 1u : 0u;          // (read by the catch-alls, the one-tile forms, the float64 exact forms)
     a.nta_rt = (a.zz_rt && step_bytes >= FISHING_NTA_MIN_BYTES) ? 1u : 0u;
     LeanMixedArgs<T> mixed{};
     if (p->model == FISHING_MODEL_V11) {
