@@ -488,6 +488,32 @@ def test_graph_replay_draws_fresh_noise_and_matches_eager(gf):
     assert torch.equal(graphed.state, eager.state)
 
 
+def test_graph_replay_at_a_zigzag_size_takes_the_walk_direction_from_the_device_counter(gf):
+    """From ~100 MB per step odd steps walk the tiles backwards (in groups of eight).  A captured launch has frozen
+    arguments, so in graph-replay mode the step's parity -- like its noise key -- comes from the device-resident counter,
+    which the one-tile forms then read BEFORE their loads.  N = 2^22 with returns (138 MB per step), three replays of a
+    3-step graph (odd length: the parity of a replay's first step alternates) against eager stepping: bit for bit."""
+    import torch
+    from gym_fishing_amd.graphs import GraphedSteps
+    n = 1 << 22
+    acts = torch.rand((3, n), device="cuda") * 1.4 - 1.2
+    mk = lambda: gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=9, Tmax=5, track_returns=True)  # noqa: E731
+    eager, graphed = mk(), mk()
+    eager.reset()
+    graphed.reset()
+    g = GraphedSteps(graphed, acts)
+    assert graphed.step_kernel_name(acts[0]) == "fishing::step_kernel_lean<float, 1, 12294, 4>"
+    for rnd in range(3):
+        g.replay()
+        eager.step_many(acts, 3)
+        assert torch.equal(graphed.state, eager.state) and torch.equal(graphed._t, eager._t), rnd
+        assert torch.equal(graphed._ep_return, eager._ep_return), rnd
+    a, b = graphed.episode_stats(), eager.episode_stats()
+    assert a["n_episodes"] == b["n_episodes"] > n and abs(a["sum_return"] - b["sum_return"]) <= 1e-9 * abs(b["sum_return"])
+    del eager, graphed, g
+    torch.cuda.empty_cache()
+
+
 def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
     """fishing-v4 re-derives (K, r) from the origin of the last reset() of all envs.  A captured launch freezes its
     arguments, so in graph-replay mode the origin lives next to the step counter in device memory (FishingBuffers.counter
