@@ -417,14 +417,33 @@ def main():
     if with_returns:
         env.episode_stats()           # warm the reduce kernel and the RCCL communicator
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def region():
+        """The timed sequence, exactly: K launches + the record's reduce kernel (+ the all-reduce) enqueued, then the
+        closing barrier + synchronize."""
+        ev0.record()
+        env.step_many(actions, args.steps)            # K launches on torch's current stream
+        ev1.record()
+        rec = env.episode_record() if with_returns else None     # reduce kernel (+ all-reduce), enqueued only
+        sync_all()
+        return rec
+
+    # One untimed dress rehearsal of that very sequence (every lazily initialised path on the host -- event timing,
+    # the reduce launch behind a burst of step launches, the barrier -- has then run once: a 20-step region is ~0.45 ms, and a
+    # first-use stall of a few hundred microseconds inside it was seen to cost a third of the figure), and no garbage
+    # collection inside the region.  Both are reported under `spinup`; neither skips or shortens the K timed steps.
+    # (the collection comes BEFORE the rehearsal: nothing but the rehearsal's own closing barrier + synchronize may lie between
+    # the last busy moment of the device and the clock's start -- a few idle milliseconds let its clocks drop, and the 20
+    # launches that follow run 2-3 us slower each)
+    import gc
+    gc.collect()
+    gc.disable()
     sync_all()
+    region()
     t0 = time.perf_counter()
-    ev0.record()
-    env.step_many(actions, args.steps)            # K launches on torch's current stream
-    ev1.record()
-    record = env.episode_record() if with_returns else None     # reduce kernel (+ all-reduce), enqueued only
-    sync_all()
+    record = region()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)     # HIP events around the K launches
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -489,8 +508,9 @@ def main():
                                  if world > 1 else "none",
                    # ranks counted by an all-reduce of ones at start-up (null: no process group, i.e. a bare 1-GPU run)
                    ("rccl_ranks_seen" if backend == "nccl" else backend + "_ranks_seen"): ranks_seen},
-        "spinup": {"ms": spin_ms, "launches": spin_launches,
-                   "note": "same launches as the timed region, ahead of --warmup; not timed"},
+        "spinup": {"ms": spin_ms, "launches": spin_launches, "rehearsal_launches": args.steps,
+                   "note": "same launches as the timed region, ahead of --warmup; then one untimed dress rehearsal of the timed "
+                           "sequence itself (K launches + record + barrier); none of it timed"},
         "roofline": {"bound": "infinity-cache/hbm" if fits else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": kernel, "bytes_per_env_step": bytes_per,
