@@ -54,29 +54,33 @@ v4_params_kernel(const ParamsT<T> p, const int64_t n, const uint64_t env_offset,
 }
 
 constexpr int kReduceThreads = 1024;
+constexpr int kReduceSlots = 4 * kReduceThreads;     // slots per pass
 __global__ void __launch_bounds__(kReduceThreads)
-reduce_returns_kernel(const double* __restrict__ partials, double* __restrict__ out4) {
-    // One workgroup of 16 waves.  Thread i owns slots i, i + 1024, i + 2048, i + 3072: four 32-byte reads (a slot's
-    // four fields are contiguous), all issued before the first add; then a fixed tree -- slot order inside the
-    // thread, a shuffle tree inside the wave, wave order across the workgroup: same bits on every run.  (Round 2's
-    // form -- 256 threads, 64 strided 8-byte reads each -- took 8 us of the bench's 20-step region; this one ~3.)
-    static_assert(kMaxBlocks % kReduceThreads == 0, "whole passes");
-    constexpr int kPerThread = kMaxBlocks / kReduceThreads;
+reduce_returns_kernel(const double* __restrict__ partials, const int passes, double* __restrict__ out4) {
+    // One workgroup of 16 waves, one pass per kReduceSlots = 4096 slots.  In a pass thread i owns slots i, i + 1024,
+    // i + 2048, i + 3072: four 32-byte reads (a slot's four fields are contiguous), all issued before the first add;
+    // then a fixed tree -- slot order inside the thread, a shuffle tree inside the wave, wave order across the
+    // workgroup: same bits on every run.  (Round 2's form -- 256 threads, 64 strided 8-byte reads each -- took 8 us
+    // of the bench's 20-step region; this one ~3 for one pass = every batch up to N = 2^22.)
+    static_assert(kPartialSlots % kReduceSlots == 0, "whole passes");
     typedef double d2 __attribute__((ext_vector_type(2)));
-    d2 lo[kPerThread], hi[kPerThread];
-#pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-        const d2* q = reinterpret_cast<const d2*>(partials + (int64_t)(threadIdx.x + k * kReduceThreads) * kPartialFields);
-        lo[k] = q[0];
-        hi[k] = q[1];
-    }
     double s[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
+    for (int pass = 0; pass < passes; ++pass) {
+        constexpr int kPerThread = 4;
+        d2 lo[kPerThread], hi[kPerThread];
 #pragma unroll
-    for (int k = 0; k < kPerThread; ++k) {
-        s[0] += lo[k][0];
-        s[1] += lo[k][1];
-        s[2] += hi[k][0];
-        s[3] += hi[k][1];
+        for (int k = 0; k < kPerThread; ++k) {
+            const d2* q = reinterpret_cast<const d2*>(partials + (int64_t)(threadIdx.x + (pass * kPerThread + k) * kReduceThreads) * kPartialFields);
+            lo[k] = q[0];
+            hi[k] = q[1];
+        }
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            s[0] += lo[k][0];
+            s[1] += lo[k][1];
+            s[2] += hi[k][0];
+            s[3] += hi[k][1];
+        }
     }
     __shared__ double red[kReduceThreads / kWave][kPartialFields];
     const int lane = threadIdx.x & (kWave - 1);
@@ -248,7 +252,7 @@ const char* fishing_error_string(int code) {
     }
 }
 
-int64_t fishing_partials_len(void) { return (int64_t)fishing::kMaxBlocks * fishing::kPartialFields; }
+int64_t fishing_partials_len(void) { return (int64_t)fishing::kPartialSlots * fishing::kPartialFields; }
 
 int fishing_reset_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                       const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream) {
@@ -285,9 +289,22 @@ int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stre
 
 int fishing_stream_synchronize(fishing_stream_t stream) { return (int)hipStreamSynchronize((hipStream_t)stream); }
 
-int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream) {
+int64_t fishing_partials_slots(int64_t n_envs) {
+    // the one-tile forms of step() give every 1024-env tile its own slot; every other kernel stays within kMaxBlocks
+    const int64_t tiles = n_envs <= 0 ? 0 : (n_envs + 256 * fishing::kEnvsPerThread - 1) / (256 * fishing::kEnvsPerThread);
+    const int64_t want = (tiles + fishing::kReduceSlots - 1) / fishing::kReduceSlots * fishing::kReduceSlots;
+    return want < fishing::kReduceSlots ? fishing::kReduceSlots : want > fishing::kPartialSlots ? fishing::kPartialSlots : want;
+}
+
+int fishing_reduce_returns_slots(const double* return_partials, int64_t slots, double* out4, fishing_stream_t stream) {
     if (!return_partials || !out4) return FISHING_ERR_NULL;
-    return fishing::launch_kernel(fishing::reduce_returns_kernel, 1, fishing::kReduceThreads, (hipStream_t)stream, return_partials, out4);
+    if (slots < fishing::kReduceSlots || slots > fishing::kPartialSlots || slots % fishing::kReduceSlots) return FISHING_ERR_SIZE;
+    return fishing::launch_kernel(fishing::reduce_returns_kernel, 1, fishing::kReduceThreads, (hipStream_t)stream, return_partials,
+                                  (int)(slots / fishing::kReduceSlots), out4);
+}
+
+int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream) {
+    return fishing_reduce_returns_slots(return_partials, fishing::kPartialSlots, out4, stream);
 }
 
 int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,

@@ -20,7 +20,12 @@ namespace fishing {
 
 constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kEnvsPerThread = 4;   // 16-byte accesses on the f32 streams
-constexpr int kMaxBlocks = 4096;    // slots of the return_partials buffer
+constexpr int kMaxBlocks = 4096;    // grid cap of every kernel that loops over tiles
+#ifndef FISHING_PARTIAL_SLOTS
+#define FISHING_PARTIAL_SLOTS 65536
+#endif
+constexpr int kPartialSlots = FISHING_PARTIAL_SLOTS;   // slots of the return_partials buffer = largest one-tile grid
+static_assert(kPartialSlots >= kMaxBlocks, "every looping grid has its slots");
 constexpr int kPartialFields = 4;   // {sum R, sum R^2, n_episodes, sum length}
 
 constexpr uint32_t kStreamNoise = 0;      // step noise

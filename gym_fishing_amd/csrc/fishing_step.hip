@@ -23,6 +23,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 
 namespace fishing {
 
@@ -931,6 +932,7 @@ struct LeanCall {
     const void* extra;       // LeanMixedArgs<T> for fishing-v11, unused otherwise
     bool two_per_thread;     // float64: E = 2 for the exact instantiations (streams cache-resident)
     bool two_per_thread_any; //          ... and for the catch-all
+    bool one_ok;             // the request's one-tile form (feat::ONE), if it has one, may cover this batch
 };
 
 template <typename T, int MODEL, int F, int E = 4>
@@ -945,7 +947,8 @@ int lean_launch(const LeanCall<T>& c) {
     if constexpr (MODEL == kModelZooMixed) ex = *static_cast<const LeanMixedArgs<T>*>(c.extra);
     // (c.ntiles / c.blocks count 1024-env tiles; an E = 2 workgroup covers half of one)
     const int64_t nt = c.ntiles * (4 / E);
-    const int64_t nb = nt < kMaxBlocks ? nt : ((int64_t)c.blocks * (4 / E) < kMaxBlocks ? (int64_t)c.blocks * (4 / E) : kMaxBlocks);
+    // one-tile forms: a workgroup per tile, up to kPartialSlots of them; tile loops: the grid step_dispatch chose
+    const int64_t nb = (F & feat::ONE) ? nt : std::min(std::min(nt, (int64_t)c.blocks * (4 / E)), (int64_t)kMaxBlocks);
     // (FISHING_X_DYN_LDS, experiments only: unused dynamic LDS per workgroup caps the workgroups a CU holds at once.  Running
     // the one-round grids of N = 2^20 .. 2^22 in several rounds never helped -- fishing-v4 at 2^21 13.05 us with 8 workgroups
     // per CU, 14.6 with 4, 16.5 with 2: profiles/r03_occupancy_cap.jsonl)
@@ -973,9 +976,11 @@ template <typename T, int MODEL>
 int lean_dispatch(int req, bool zigzag, bool zigzag_big, const LeanCall<T>& c) {
     using namespace feat;
     constexpr int P = kNoisePhilox;
-    // every forward exact instantiation has a one-tile-per-workgroup twin (feat::ONE), taken whenever the grid covers the
-    // tiles one to one -- every launch up to 4096 tiles = N = 2^22
-    const bool one = (int64_t)c.blocks == c.ntiles;
+    // every forward exact instantiation has a one-tile-per-workgroup twin (feat::ONE), taken whenever a grid of one
+    // workgroup per tile fits the return_partials slots -- every launch up to kPartialSlots tiles = N = 2^26.  (Round 3,
+    // fishing_step_f32 with returns, one-tile grid vs the capped tile loop: N = 2^23 40.0 vs 42.1 us, 2^24 80.4 vs 83,
+    // 2^25 162.4 vs 169, 2^26 338 vs 376: profiles/r03_one_tile_large_n.jsonl)
+    const bool one = c.one_ok;
 #define FISHING_LEAN_CASE_ZZ(MASK) \
     case (MASK): return lean_launch<T, MODEL, (MASK)>(c)
 #define FISHING_LEAN_CASE(MASK) \
@@ -986,7 +991,8 @@ int lean_dispatch(int req, bool zigzag, bool zigzag_big, const LeanCall<T>& c) {
     // at 2^24: 145 vs 156-177 us: profiles/r02_zz_catch_all.jsonl).  fishing-v11 is VALU-bound and keeps its exact kernels.
     // (zigzag: from FISHING_ZZ_MIN_BYTES per step the requests WITH a zig-zag twin take it; zigzag_big: from
     // FISHING_ZZ_CATCHALL_MIN_BYTES the others prefer their catch-all's zig-zag walk to an exact forward kernel)
-    const bool forward = !zigzag_big || MODEL == kModelZooMixed;
+    // (a one-tile form walks zig-zag by zz_rt, so it is never the "forward exact kernel" of that comparison)
+    const bool forward = one || !zigzag_big || MODEL == kModelZooMixed;
     if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
         // fishing-v0/v1/v2, float32, in-kernel noise: bare / with the return record.  K a power of two (KP2): forward and
         // zig-zag; any other K keeps the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns
@@ -1129,8 +1135,7 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     // N = 2^26 299 -> 287 us bare, 403 -> 391 us with returns; 2^27 666 -> 610 / 842 -> 785 us; 2^24 equal
     // (profiles/r02_caps_large_n.jsonl).  Not for fishing-v4 with derived parameters, which is as much VALU- as
     // HBM-bound and needs the occupancy: 95 -> 101 us at N = 2^24 (profiles/r02_step_v4_24_*).
-    int cap = p->launch_blocks ? p->launch_blocks : ((ntiles >= (1 << 15) && !derived) ? 768 : kMaxBlocks);
-    if (cap > kMaxBlocks) cap = kMaxBlocks;
+    const int cap = p->launch_blocks ? std::min(p->launch_blocks, kMaxBlocks) : ((ntiles >= (1 << 15) && !derived) ? 768 : kMaxBlocks);
     const int lb = (int)(ntiles < cap ? ntiles : cap);
     int req = noise;
     if (b->ep_return) req |= feat::RET;
@@ -1163,7 +1168,8 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     // (N < 2^23 for the 37-byte layout); four per thread beyond, where the access shape stops mattering
     const bool two = sizeof(T) == 8 && step_bytes < FISHING_F64_E2_MAX_BYTES && !p->launch_blocks;
     const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name, &mixed, two,
-                           two && step_bytes >= FISHING_F64_E2_MIN_BYTES};
+                           two && step_bytes >= FISHING_F64_E2_MIN_BYTES,
+                           p->launch_blocks ? lb == ntiles : ntiles <= kPartialSlots};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
         if constexpr (kTag == kModelZooMixed && sizeof(T) == 8) return (int)FISHING_ERR_MODEL;     // (not reached: see `lean`)

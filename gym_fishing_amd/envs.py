@@ -241,7 +241,9 @@ class BaseFishingEnv(_gym_env_base()):
         self._ep_return = self._partials = self._record = None
         if track_returns:
             self._ep_return = views[4]
-            self._partials = torch.zeros(int(self._lib.fishing_partials_len()), dtype=torch.float64, device=dev)
+            # one slot (4 doubles) per workgroup of the widest launch this batch can get: 4096 up to N = 2^22
+            self._partial_slots = int(self._lib.fishing_partials_slots(max(N, self._cap)))
+            self._partials = torch.zeros(4 * self._partial_slots, dtype=torch.float64, device=dev)
             self._record = torch.zeros(4, dtype=torch.float64, device=dev)
         self._action_buf = None
         self._scalar_views = None
@@ -833,8 +835,9 @@ class BaseFishingEnv(_gym_env_base()):
         if self._partials is None:
             raise RuntimeError("construct the env with track_returns=True")
         with torch.cuda.device(self.device):
-            rc = self._lib.fishing_reduce_returns(self._partials.data_ptr(), self._record.data_ptr(), self._stream())
-        _capi.check(rc, "fishing_reduce_returns")
+            rc = self._lib.fishing_reduce_returns_slots(self._partials.data_ptr(), self._partial_slots, self._record.data_ptr(),
+                                                        self._stream())
+        _capi.check(rc, "fishing_reduce_returns_slots")
         from .sharding import all_reduce_record
         rec = self._record              # scratch: rewritten from the partials by every call, so reduced in place
         if all_reduce:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FISHING_ABI_VERSION 4
+#define FISHING_ABI_VERSION 5
 
 typedef void* fishing_stream_t; /* hipStream_t */
 
@@ -144,7 +144,8 @@ typedef struct FishingBuffers {
                                           in-kernel Philox4x32-10 + Box-Muller                    */
     void* terminal_obs;  /* real  out     obs before the auto-reset (SB3 terminal_observation); nullable */
     void* ep_return;     /* real  in/out  running episodic return; nullable                       */
-    double* return_partials; /* f64[fishing_partials_len()] in/out: per-workgroup partial sums of
+    double* return_partials; /* f64[fishing_partials_len()], or f64[4 * fishing_partials_slots(n)] for batches of at
+                                most n envs; in/out: per-workgroup partial sums of
                                 {sum R, sum R^2, n_episodes, sum length} over finished episodes;
                                 needs ep_return; nullable                                         */
     int32_t* model_idx;  /* i32   in/out  fishing-v11: FISHING_KIND_* in force per env (redrawn
@@ -170,8 +171,13 @@ typedef struct FishingBuffers {
 
 int fishing_abi_version(void);
 const char* fishing_error_string(int code);
-/* number of doubles a return_partials buffer must hold (zero-initialised by the caller) */
+/* number of doubles a return_partials buffer must hold (zero-initialised by the caller): 4 per slot, one slot per
+ * workgroup of the widest launch -- 65536 slots = 2 MiB since ABI 5 (a workgroup per 1024-env tile up to N = 2^26) */
 int64_t fishing_partials_len(void);
+/* how many of those slots launches over a batch of n_envs can touch (a multiple of 4096, at most
+ * fishing_partials_len() / 4): what fishing_reduce_returns_slots needs to read, and -- for a caller that only ever
+ * passes batches of at most n_envs -- all a return_partials buffer needs to hold (4 doubles per slot) (ABI 5) */
+int64_t fishing_partials_slots(int64_t n_envs);
 
 /* BaseFishingEnv.step (envs/base_fishing_env.py:60-81) for envs [0, n) of this shard;
  * env i is global env (env_offset + i) for the noise stream.  step_counter = number of
@@ -253,6 +259,11 @@ int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stre
  * {sum R, sum R^2, n_episodes, sum length}.  out4 is then all-reduced across GPUs by
  * the host (RCCL). */
 int fishing_reduce_returns(const double* return_partials, double* out4, fishing_stream_t stream);
+/* The same over the first `slots` slots only (slots = fishing_partials_slots(n_envs) of the batch that filled them:
+ * one 4096-slot pass, ~3 us, for every batch up to N = 2^22 instead of sixteen).  FISHING_ERR_SIZE unless slots is a
+ * multiple of 4096 in [4096, fishing_partials_len() / 4].  Same bits as the full reduction while the slots beyond
+ * are zero. (ABI 5) */
+int fishing_reduce_returns_slots(const double* return_partials, int64_t slots, double* out4, fishing_stream_t stream);
 
 /* population_draw() (envs/base_fishing_env.py:121-133; v2: envs/fishing_tipping_env.py:24-35)
  * over an array of populations with the scalar r, K, sigma, C of `p`: x_out[i] = growth of

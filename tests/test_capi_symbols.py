@@ -45,7 +45,10 @@ def test_abi_version_and_struct_layout(lib):
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"(\w+)\s*;", body)
     assert tuple(fields) == _capi.BUFFER_FIELDS
-    assert lib.fishing_partials_len() == 4096 * 4
+    assert lib.fishing_partials_len() == 65536 * 4      # a workgroup per 1024-env tile up to N = 2^26 (ABI 5)
+    # slots a batch can touch: whole 4096-slot passes of the reduction, one per 2^22 envs
+    assert [lib.fishing_partials_slots(n) for n in (0, 1, 1 << 22, (1 << 22) + 1, 1 << 24, (1 << 26) - 5, 1 << 26, 1 << 30)] == \
+        [4096, 4096, 4096, 8192, 16384, 65536, 65536, 65536]
 
 
 def test_error_strings(lib):
@@ -112,6 +115,10 @@ def test_argument_errors_need_no_gpu(lib):
     assert lib.fishing_rollout_f32(p, 4, 0, b, 17, 0.0, 3, None, 0, 0, None) == -5
     assert lib.fishing_rollout_f32(p, 4, 0, b, 0, 0.0, -1, None, 0, 0, None) == -4
     assert lib.fishing_reduce_returns(None, None, None) == -1
+    assert lib.fishing_reduce_returns_slots(None, 4096, None, None) == -1
+    one = ctypes.c_double(0.0)
+    for bad in (0, 4095, 6144, 65536 + 4096):       # whole passes only, within the buffer
+        assert lib.fishing_reduce_returns_slots(ctypes.byref(one), bad, ctypes.byref(one), None) == -4
     assert lib.fishing_noise_f32(-1, 0, 0, 0, 0, None, None, None, None) == -4
     p.launch_threads = 100
     assert lib.fishing_step_f32(p, 4, 0, b, 0, 0, None) == -4             # threads not a multiple of 64

@@ -257,6 +257,32 @@ def test_helpers_match_reference_maps(gf, anchors):
     assert v.env_method("get_fish_population", np.array([-0.5]), indices=3)[0] == 1.0
 
 
+def test_episode_record_of_a_batch_beyond_4096_tiles(gf):
+    """N = 2^22 + 3 tiles: step() runs a workgroup per tile (4099 of them), the env sizes its return_partials for the
+    8192 slots such a batch can touch and reduces exactly those -- the record counts every finished episode and sums
+    every finished return, checked against the done / reward streams themselves."""
+    import torch
+    n = (1 << 22) + 3072
+    env = gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=5, Tmax=4, track_returns=True)
+    assert env._partial_slots == 8192 and env._partials.numel() == 4 * 8192
+    env.reset()
+    assert env.step_kernel_name(torch.zeros(n, device="cuda")).endswith("12294, 4>")     # KP2 | RET | ONE
+    g = torch.Generator(device="cuda").manual_seed(1)
+    running = torch.zeros(n, dtype=torch.float64, device="cuda")
+    n_done, sum_ret = 0, 0.0
+    for s in range(9):
+        a = torch.rand(n, device="cuda", generator=g) * 1.2 - 1.0
+        obs, rew, done, _ = env.step(a)
+        running += rew.double()
+        n_done += int(done.sum())
+        sum_ret += float(running[done].sum())
+        running[done] = 0.0
+    st = env.episode_stats()
+    assert st["n_episodes"] == n_done and n_done > n
+    assert st["mean_return"] * n_done == pytest.approx(sum_ret, rel=1e-6)
+    assert int(torch.count_nonzero(env._partials.view(-1, 4)[4099:])) == 0
+
+
 def test_fused_rollout_api_and_stats(gf):
     import torch
     n = 1 << 14

@@ -748,6 +748,49 @@ def test_one_tile_and_tile_loop_instantiations_agree(hh, case):
         assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True) and ra[2] > n
 
 
+@pytest.mark.parametrize("case", ["v1_ret", "v4_derived_sig_ret", "v9"])
+def test_one_tile_grid_beyond_4096_tiles(hh, case):
+    """Round 3: the one-tile forms run a workgroup per tile up to 65536 tiles (N = 2^26; return_partials grew to that
+    many slots, ABI 5) -- 4203 tiles here, one past a whole 8-tile group of the XCD-aware walk, against the tile loop on
+    a grid of 4096 (launch_blocks): same bits on every stream over 5 auto-resetting steps, same episode counts; the
+    record reduced over the 8192 slots this batch can touch equals the reduction over all 65536."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n = 1024 * 4203
+    model = {"v1": fo.MODEL_V1, "v4": fo.MODEL_V4, "v9": fo.MODEL_V9}[case.split("_")[0]]
+    ret = case.endswith("_ret")
+    derived = "derived" in case
+    kw = dict(sigma=0.1, Tmax=3, sigma_p=0.2, auto_reset=True, derived=derived, origin=(0, 0))
+    pa, pb = hh.params(model, **kw), hh.params(model, launch_blocks=4096, **kw)
+    sig = np.random.default_rng(3).uniform(0.0, 0.3, n) if "sig" in case else None
+    mk = lambda: hh.State(n, np.float32, model, np.zeros(n), sigma=sig, ep_return=ret)   # noqa: E731
+    A, B = mk(), mk()
+    a0 = torch.zeros(n, device="cuda")
+    na, nb = hh.kernel_name(pa, n, A.buffers(a0)), hh.kernel_name(pb, n, B.buffers(a0))
+    mask_a, mask_b = int(na.rstrip(">").split(",")[-1]), int(nb.rstrip(">").split(",")[-1])
+    assert mask_a & 8192 and not mask_b & 8192, (na, nb)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for s in range(5):
+        a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
+        for st, p in ((A, pa), (B, pb)):
+            assert lib.fishing_step_f32(p, n, 8, st.buffers(a), 5, s, None) == 0
+        torch.cuda.synchronize()
+        for name in ("obs", "reward", "done", "t") + (("ep_return",) if ret else ()):
+            x, y = getattr(A, name), getattr(B, name)
+            it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]
+            assert torch.equal(x.view(it), y.view(it)), (name, s)
+    if ret:
+        ra, rb = A.record(), B.record()
+        assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True) and ra[2] > n
+        assert lib.fishing_partials_slots(n) == 8192
+        assert torch.count_nonzero(A.partials.view(-1, 4)[4203:]).item() == 0
+        out = torch.zeros(4, dtype=torch.float64, device="cuda")
+        assert lib.fishing_reduce_returns_slots(A.partials.data_ptr(), 8192, out.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ra, equal_nan=True)      # (a fishing-v4 env with K = 0 returns NaN)
+
+
 @pytest.mark.parametrize("case", ["v1_K1.5", "v2_ext_noise", "v4_derived", "v9"])
 def test_float64_two_per_thread_catch_all_with_every_optional_stream(hh, case):
     """Round 3: the float64 layout runs two envs per thread (16-byte accesses, a workgroup tile of 512 envs, the lane
@@ -798,7 +841,9 @@ def test_xcd_aware_zigzag_keeps_results_with_a_partial_last_group(hh, tiles, ret
     import torch
     n = tiles * 1024 + 517
     kw = dict(sigma=0.1, Tmax=2, auto_reset=True)
-    pa, pb = hh.params(fo.MODEL_V1, **kw), hh.params(fo.MODEL_V1, general=True, **kw)
+    # (a grid capped at 4096 workgroups is what batches beyond 65536 tiles get; below, it has to be asked for)
+    pa = hh.params(fo.MODEL_V1, **kw, **({"launch_blocks": 4096} if tiles > 4096 else {}))
+    pb = hh.params(fo.MODEL_V1, general=True, **kw)
     g = torch.Generator(device="cuda").manual_seed(4)
     a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
     lib = __import__("gym_fishing_amd")._capi.lib()
@@ -1112,22 +1157,26 @@ def test_zigzag_walk_of_the_catch_all_kernels_agrees_with_general_kernel(hh, dty
 
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 @pytest.mark.parametrize("which", ["v1", "v4_derived"])
-def test_zigzag_walk_at_large_n_agrees_with_general_kernel(hh, ret, which):
-    """From N = 2^25 the float32 lean kernel walks the tiles backwards on odd steps (what the previous step touched
+@pytest.mark.parametrize("form", ["one_tile", "tile_loop"])
+def test_zigzag_walk_at_large_n_agrees_with_general_kernel(hh, ret, which, form):
+    """At N = 2^25 the float32 lean kernel walks the tiles backwards on odd steps (what the previous step touched
     last is still in the Infinity Cache) -- fishing-v0/v1/v2/v4 bare or with returns, and fishing-v4 with derived
-    parameters.  The order of the walk must not show: three steps (even, odd, even counters) at N = 2^25 + 3077
-    against the general kernel, every stream bit-for-bit."""
+    parameters; in the one-tile form (a workgroup per tile: what every batch up to 65536 tiles takes, direction from
+    zz_rt) and in the zig-zag twin of the tile loop (768 workgroups: what larger batches take).  The order of the walk
+    must not show: three steps (even, odd, even counters) at N = 2^25 + 3077 against the general kernel, every stream
+    bit-for-bit."""
     import torch
     n = (1 << 25) + 3077
     derived = which == "v4_derived"
     model = fo.MODEL_V4 if derived else fo.MODEL_V1
     kw = dict(sigma=0.1, Tmax=2, auto_reset=True, derived=derived, origin=(0, 0))
-    pa, pb = hh.params(model, **kw), hh.params(model, general=True, **kw)
+    pa = hh.params(model, **kw, **({"launch_blocks": 768} if form == "tile_loop" else {}))
+    pb = hh.params(model, general=True, **kw)
     g = torch.Generator(device="cuda").manual_seed(4)
     a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
     lib = __import__("gym_fishing_amd")._capi.lib()
     assert hh.kernel_name(pa, n, hh.State(4096, np.float32, model, np.float32(-0.25), ep_return=ret).buffers(a)).endswith(
-        ", %d>" % ((2 | 128) | (4 if ret else 0) | (256 if derived else 4096)))       # ZZ, RET, DERIVED / KP2 (K = 1)
+        ", %d>" % (2 | (128 if form == "tile_loop" else 8192) | (4 if ret else 0) | (256 if derived else 4096)))   # ZZ / ONE, RET, DERIVED / KP2 (K = 1)
     outs = []
     for p in (pa, pb):
         st = hh.State(n, np.float32, model, np.float32(-0.25), ep_return=ret)

@@ -323,12 +323,20 @@ def test_kernel_names_follow_the_dispatch(hh):
     p1 = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True)
     assert name(p1) == "fishing::step_kernel_lean<float, 1, 12290>"                # Philox (2) | KP2 (4096): K = 1 | ONE (8192): a tile per workgroup
     assert name(p1, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 12294>"
-    assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 4226>"
-    # zig-zag twins of the tile-loop forms from 150 MB per step (round 3: the walk keeps every tile on its XCD)
-    assert name(p1, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 4226>"
-    assert name(p1, n=(1 << 22) + 1024) == "fishing::step_kernel_lean<float, 1, 4098>"             # (105 MB: more tiles than workgroups, the forward tile loop)
+    # a workgroup per tile up to 65536 tiles (round 3: return_partials has that many slots); the walk direction of the
+    # one-tile forms is a run-time flag
+    assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 12290>"
+    assert name(p1, n=1 << 26) == "fishing::step_kernel_lean<float, 1, 12290>"
+    assert name(p1, n=(1 << 22) + 1024) == "fishing::step_kernel_lean<float, 1, 12290>"
+    # beyond, and on an explicitly capped grid: the tile loop -- its zig-zag twin from 150 MB per step (the walk keeps
+    # every tile on its XCD), the forward form below
+    assert name(p1, n=(1 << 26) + 1024) == "fishing::step_kernel_lean<float, 1, 4226>"
+    pc = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True, launch_blocks=4096)
+    assert name(pc, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 4226>"
+    assert name(pc, n=(1 << 22) + 1024) == "fishing::step_kernel_lean<float, 1, 4098>"             # (105 MB)
     assert name(p1, n=1 << 20) == "fishing::step_kernel_lean<float, 1, 12290>"
-    assert name(p1, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 4230>"
+    assert name(p1, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 12294>"
+    assert name(pc, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 4230>"
     assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, terminal_obs=True, done_bits=True) == "fishing::step_kernel_lean<float, 1, 3199>"
     assert name(p1, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 4098, 2>"        # float64, cache-resident: 2 envs per thread, exact
