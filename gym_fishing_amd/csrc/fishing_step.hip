@@ -948,7 +948,9 @@ int lean_launch(const LeanCall<T>& c) {
     // (c.ntiles / c.blocks count 1024-env tiles; an E = 2 workgroup covers half of one)
     const int64_t nt = c.ntiles * (4 / E);
     // one-tile forms: a workgroup per tile, up to kPartialSlots of them; tile loops: the grid step_dispatch chose
-    const int64_t nb = (F & feat::ONE) ? nt : std::min(std::min(nt, (int64_t)c.blocks * (4 / E)), (int64_t)kMaxBlocks);
+    // (two envs per thread: half-tiles, cache-resident sizes only -- within kMaxBlocks, so that a batch never touches more
+    // return_partials slots than fishing_partials_slots() promises)
+    const int64_t nb = (F & feat::ONE) ? nt : std::min(std::min(nt, (int64_t)c.blocks * (4 / E)), (int64_t)(E == 4 ? kPartialSlots : kMaxBlocks));
     // (FISHING_X_DYN_LDS, experiments only: unused dynamic LDS per workgroup caps the workgroups a CU holds at once.  Running
     // the one-round grids of N = 2^20 .. 2^22 in several rounds never helped -- fishing-v4 at 2^21 13.05 us with 8 workgroups
     // per CU, 14.6 with 4, 16.5 with 2: profiles/r03_occupancy_cap.jsonl)
@@ -1098,10 +1100,10 @@ int lean_dispatch(int req, bool zigzag, bool zigzag_big, const LeanCall<T>& c) {
 
 // Where a step() request runs.  lean: whole 1024-env tiles on step_kernel_lean (+ the ragged tail on one
 // workgroup of the general kernel); otherwise everything on the general kernel.
+// (`b`: which streams are there; `bt`: where this range of envs begins in them)
 template <typename T>
-int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64_t env_offset, const FishingBuffers* b,
-                  uint64_t seed, uint64_t step_counter, hipStream_t s, std::string* name) {
-    const BuffersT<T> bt = typed_buffers<T>(*b);
+int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                        const BuffersT<T>& bt, uint64_t seed, uint64_t step_counter, hipStream_t s, std::string* name) {
     const int noise = noise_mode(p, b);
     const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
     const bool derived = p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED);
@@ -1135,7 +1137,14 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     // N = 2^26 299 -> 287 us bare, 403 -> 391 us with returns; 2^27 666 -> 610 / 842 -> 785 us; 2^24 equal
     // (profiles/r02_caps_large_n.jsonl).  Not for fishing-v4 with derived parameters, which is as much VALU- as
     // HBM-bound and needs the occupancy: 95 -> 101 us at N = 2^24 (profiles/r02_step_v4_24_*).
-    const int cap = p->launch_blocks ? std::min(p->launch_blocks, kMaxBlocks) : ((ntiles >= (1 << 15) && !derived) ? 768 : kMaxBlocks);
+    // Round 3: a workgroup per tile while the return_partials slots last (65536 tiles = N = 2^26), for the one-tile forms
+    // and for the tile loops alike (which then run one iteration): with returns 2^24 83 -> 80 us, 2^26 376 -> 345; the
+    // float32 catch-all 101 -> 91 / 423 -> 389; float64 bare 2^24 108.6 -> 96.7, 2^25 233 -> 194
+    // (profiles/r03_one_tile_large_n.jsonl, r03_full_grid_loops.jsonl).  The caps above are what batches beyond that get.
+    // Batches beyond the slots are stepped in ranges of 2^26 envs (step_dispatch below: the tile loop on 768 workgroups
+    // took 587 / 819 us at N = 2^27, on 65536 workgroups 564 / 772, against 2 x 245 / 2 x 338: profiles/r03_one_tile_large_n.jsonl);
+    // an explicit launch_blocks keeps the single capped launch.
+    const int cap = p->launch_blocks ? std::min(p->launch_blocks, kMaxBlocks) : kPartialSlots;
     const int lb = (int)(ntiles < cap ? ntiles : cap);
     int req = noise;
     if (b->ep_return) req |= feat::RET;
@@ -1179,6 +1188,28 @@ int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64
     // ragged tail (< 1024 envs): one workgroup of the general kernel
     const BuffersT<T> tb = offset_buffers<T>(bt, n_full, t8);
     return launch_general<T>(pt, tb, noise, n - n_full, env_offset + n_full, seed, step_counter, 1, 256, s, nullptr);
+}
+
+// A launch covers at most kPartialSlots tiles = 2^26 envs (a workgroup per tile, one return_partials slot each); larger
+// batches run as consecutive ranges on the same stream -- same slots again, added in stream order, so the record keeps
+// its bits.  Odd steps take the ranges last to first, like the tiles inside them (what the previous step touched last
+// is what the Infinity Cache still holds), when the host knows the step's parity (no device-resident counter).
+template <typename T>
+int step_dispatch(const FishingParams* p, const ParamsT<T>& pt, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                  uint64_t seed, uint64_t step_counter, hipStream_t s, std::string* name) {
+    const BuffersT<T> bt = typed_buffers<T>(*b);
+    constexpr int64_t kRange = (int64_t)kPartialSlots * 256 * kEnvsPerThread;
+    if (n <= kRange || p->launch_blocks) return step_dispatch_range<T>(p, pt, n, env_offset, b, bt, seed, step_counter, s, name);
+    const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
+    const int64_t ranges = (n + kRange - 1) / kRange;
+    const bool backwards = !b->counter && (step_counter & 1);
+    for (int64_t k = 0; k < ranges; ++k) {
+        const int64_t off = (backwards ? ranges - 1 - k : k) * kRange;
+        const int64_t len = n - off < kRange ? n - off : kRange;
+        const int rc = step_dispatch_range<T>(p, pt, len, env_offset + off, b, offset_buffers<T>(bt, off, t8), seed, step_counter, s, name);
+        if (rc != 0 || name) return rc;     // (name: the kernel of the first whole range)
+    }
+    return FISHING_OK;
 }
 
 template <typename T>

@@ -869,6 +869,37 @@ def test_xcd_aware_zigzag_keeps_results_with_a_partial_last_group(hh, tiles, ret
     torch.cuda.empty_cache()
 
 
+def test_batches_beyond_65536_tiles_run_as_ranges(hh):
+    """Round 3: a launch covers at most 65536 tiles (N = 2^26: a workgroup and a return_partials slot per tile); a larger
+    batch is stepped range by range on the same stream, odd steps last range first.  N = 2^26 + 2^20 + 5 (a second,
+    short range with a ragged tail) against the general kernel over three auto-resetting steps: every stream bit for
+    bit, same episode counts, return sums equal to double rounding."""
+    import torch
+    n = (1 << 26) + (1 << 20) + 5
+    kw = dict(sigma=0.1, Tmax=2, auto_reset=True)
+    pa, pb = hh.params(fo.MODEL_V1, **kw), hh.params(fo.MODEL_V1, general=True, **kw)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
+    lib = __import__("gym_fishing_amd")._capi.lib()
+    assert hh.kernel_name(pa, n, hh.State(4096, np.float32, fo.MODEL_V1, np.float32(-0.25), ep_return=True).buffers(a)).endswith(", 12294>")
+    outs = []
+    for p in (pa, pb):
+        st = hh.State(n, np.float32, fo.MODEL_V1, np.float32(-0.25), ep_return=True)
+        for s in range(3):
+            assert lib.fishing_step_f32(p, n, 0, st.buffers(a), 11, 6 + s, None) == 0
+        torch.cuda.synchronize()
+        outs.append(st)
+    A, B = outs
+    for nm in ("obs", "reward", "done", "t", "ep_return"):
+        x, y = getattr(A, nm), getattr(B, nm)
+        it = {1: torch.uint8, 4: torch.int32}[x.element_size()]
+        assert torch.equal(x.view(it), y.view(it)), nm
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] > n // 2 and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12)
+    del A, B, outs
+    torch.cuda.empty_cache()
+
+
 def test_huge_batch_64bit_indexing(hh):
     """Maximum sizes: N = 2^29 + 1029 envs (2 GiB per float32 stream, byte offsets past 2^31 and
     element counts past 2^29; ragged tail behind the lean launch).  sigma = 0 and one shared

@@ -328,9 +328,9 @@ def test_kernel_names_follow_the_dispatch(hh):
     assert name(p1, n=1 << 25) == "fishing::step_kernel_lean<float, 1, 12290>"
     assert name(p1, n=1 << 26) == "fishing::step_kernel_lean<float, 1, 12290>"
     assert name(p1, n=(1 << 22) + 1024) == "fishing::step_kernel_lean<float, 1, 12290>"
-    # beyond, and on an explicitly capped grid: the tile loop -- its zig-zag twin from 150 MB per step (the walk keeps
-    # every tile on its XCD), the forward form below
-    assert name(p1, n=(1 << 26) + 1024) == "fishing::step_kernel_lean<float, 1, 4226>"
+    assert name(p1, n=(1 << 26) + 1024) == "fishing::step_kernel_lean<float, 1, 12290>"      # (beyond: ranges of 2^26 envs)
+    # on an explicitly capped grid: the tile loop -- its zig-zag twin from 150 MB per step (the walk keeps every tile on
+    # its XCD), the forward form below
     pc = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True, launch_blocks=4096)
     assert name(pc, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 4226>"
     assert name(pc, n=(1 << 22) + 1024) == "fishing::step_kernel_lean<float, 1, 4098>"             # (105 MB)
