@@ -50,13 +50,7 @@ namespace fishing {
 #endif
 // Bytes one step streams, from which ...
 #ifndef FISHING_XZZ_MIN_BYTES
-#define FISHING_XZZ_MIN_BYTES (100ll << 20)             // ... the one-tile forms and the catch-alls walk zig-zag (run-time flag zz_rt)
-#endif
-#ifndef FISHING_ZZ_MIN_BYTES
-#define FISHING_ZZ_MIN_BYTES (150ll << 20)              // ... the exact tile-loop forms take their zig-zag twins (N > 2^22)
-#endif
-#ifndef FISHING_ZZ_CATCHALL_MIN_BYTES
-#define FISHING_ZZ_CATCHALL_MIN_BYTES (500ll << 20)     // ... a request without a zig-zag twin prefers its catch-all's zig-zag walk
+#define FISHING_XZZ_MIN_BYTES (100ll << 20)             // ... every lean kernel walks zig-zag (run-time flag zz_rt)
 #endif
 #ifndef FISHING_F64_E2_MAX_BYTES
 #define FISHING_F64_E2_MAX_BYTES (250ll << 20)      // float64: two envs per thread below this many bytes per step ...
@@ -312,7 +306,7 @@ constexpr int SIGARR = 1 << 3;     // per-env noise scale
 constexpr int T8 = 1 << 4;         // compact layout: one-byte year counters
 constexpr int TERM = 1 << 5;       // terminal_obs: the observation before the fused auto-reset (SB3)
 constexpr int BITS = 1 << 6;       // done_bits: wave-ballot termination mask
-constexpr int ZZ = 1 << 7;         // zig-zag tile walk (N >= 2^25); never under OPT (the catch-alls read LeanArgs::zz_rt)
+// (1 << 7 was round 2's compile-time zig-zag walk: LeanArgs::zz_rt now)
 constexpr int DERIVED = 1 << 8;    // fishing-v4: (K, r) re-derived from the Philox streams, no r / K arrays
 constexpr int DRIFT = 1 << 9;      // fishing-v10: per-env r, drifting by alpha every draw
 constexpr int OPT = 1 << 10;
@@ -348,7 +342,7 @@ struct LeanArgs {
     uint32_t auto_reset;
     int32_t noise_rt;        // feat::kNoiseRT: the noise mode of this launch
     uint32_t t8_rt, derived_rt, drift_rt;    // feat::OPT: run-time values of T8 / DERIVED / DRIFT
-    uint32_t zz_rt;          // feat::OPT: zig-zag tile walk for this launch (the exact instantiations carry feat::ZZ instead)
+    uint32_t zz_rt;          // zig-zag tile walk for this launch
     uint32_t nta_rt;         // zig-zag forms: nontemporal action loads (a step streams >= FISHING_NTA_MIN_BYTES)
     int64_t n_live;          // FISHING_FLAG_PADDED_TILES: the number of envs that exist (a multiple of 4); INT64_MAX otherwise
     uint64_t origin_step, origin_counter;    // DERIVED (derive_model_error)
@@ -401,10 +395,9 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     static_assert(MODEL != kModelZooRT, "the run-time-kind tag belongs to the general kernel");
     static_assert(!(F & feat::DRIFT) || MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT, "DRIFT is fishing-v10");
     static_assert(!(F & feat::DERIVED) || kPerEnv, "DERIVED is fishing-v4");
-    static_assert(!((F & feat::ZZ) && kOpt), "ZZ has exact instantiations only");
     static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
-    static_assert(!(F & feat::ONE) || (kExact && !(F & feat::ZZ)), "ONE: exact instantiations; their walk direction is LeanArgs::zz_rt");
+    static_assert(!(F & feat::ONE) || kExact, "ONE: exact instantiations");
     constexpr bool kOne = (F & feat::ONE) != 0;
     static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
     constexpr int kTileEnvs = 256 * E;
@@ -416,7 +409,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool BITS = (F & feat::BITS) && (kExact || a.done_bits != nullptr);
     const bool DERIVED = (F & feat::DERIVED) && (kExact || a.derived_rt != 0);
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
-    const bool ZZ = (F & feat::ZZ) != 0 || ((kOpt || (F & feat::ONE) || E == 2) && a.zz_rt != 0);     // (E == 2: the float64 exact forms)
+    const bool ZZ = a.zz_rt != 0;       // (run-time in every form: round 3's exact zig-zag twins of the tile loop went when
+                                        // every batch up to 2^26 envs got a workgroup per tile)
     // The caller's action stream is read once per step and never again: from ~200 MB per step (N >= 2^23) the zig-zag forms
     // load it nontemporal, so that it does not evict the state lines the reversed walk is about to re-hit.  N = 2^26:
     // 283 -> 262 us bare, 398 -> 380 with returns; 2^25: 128.5 -> 124, 181.5 -> 172.6; 2^23 bare 32.1 -> 31.0.  Not at 2^22:
@@ -477,8 +471,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // at N = 2^20 then takes 8.8 instead of 4.1 us).  Two caches profit: the L2s from ~100 MB per step on, where an
         // XCD's share no longer fits its L2 (N = 2^22: 21.2 -> 18.9 us with returns, 16.0 -> 14.1 bare in the harness:
         // profiles/r03_xcd_zigzag.jsonl) -- below that everything is L2-resident and the forward walk is as good or
-        // better --, and the 256 MiB Infinity Cache at the HBM-resident sizes (N = 2^26: 331 -> 297 us, round 1).  The exact
-        // tile-loop instantiations carry feat::ZZ, the one-tile forms and the catch-alls take the direction from zz_rt.
+        // better --, and the 256 MiB Infinity Cache at the HBM-resident sizes (N = 2^26 with returns, a workgroup per tile:
+        // 406 us forward, 347 zig-zag: profiles/r03_zz_nta_one_tile.jsonl).
         int64_t tile = it;
         if (ZZ && (step_counter & 1)) {
             const int64_t whole = ntiles & ~(int64_t)7;       // (a last partial group of < 8 tiles keeps its place)
@@ -975,80 +969,49 @@ constexpr int catch_all_mask() {
 // `req` = the exact mask of the request.  The hot requests (what bench.py and a training loop issue) have
 // their own instantiation; everything else takes the catch-all of its (T, MODEL).
 template <typename T, int MODEL>
-int lean_dispatch(int req, bool zigzag, bool zigzag_big, const LeanCall<T>& c) {
+int lean_dispatch(int req, const LeanCall<T>& c) {
     using namespace feat;
     constexpr int P = kNoisePhilox;
-    // every forward exact instantiation has a one-tile-per-workgroup twin (feat::ONE), taken whenever a grid of one
-    // workgroup per tile fits the return_partials slots -- every launch up to kPartialSlots tiles = N = 2^26.  (Round 3,
-    // fishing_step_f32 with returns, one-tile grid vs the capped tile loop: N = 2^23 40.0 vs 42.1 us, 2^24 80.4 vs 83,
-    // 2^25 162.4 vs 169, 2^26 338 vs 376: profiles/r03_one_tile_large_n.jsonl)
+    // every exact instantiation has a one-tile-per-workgroup twin (feat::ONE), taken whenever a grid of one workgroup per
+    // tile fits the return_partials slots -- every launch up to kPartialSlots tiles = N = 2^26, and step_dispatch makes
+    // no larger ones.  (Round 3, fishing_step_f32 with returns, one-tile grid vs the capped tile loop: N = 2^23 40.0 vs
+    // 42.1 us, 2^24 80.4 vs 83, 2^25 162.4 vs 169, 2^26 338 vs 376: profiles/r03_one_tile_large_n.jsonl.)  The tile-loop
+    // forms serve explicit launch shapes (FishingParams.launch_blocks).  Every form takes its walk direction from zz_rt.
     const bool one = c.one_ok;
-#define FISHING_LEAN_CASE_ZZ(MASK) \
-    case (MASK): return lean_launch<T, MODEL, (MASK)>(c)
 #define FISHING_LEAN_CASE(MASK) \
     case (MASK): return one ? lean_launch<T, MODEL, (MASK) | ONE>(c) : lean_launch<T, MODEL, (MASK)>(c)
-    // Once a step streams ~500 MB the tiles are walked zig-zag (see the kernel).  Requests whose exact instantiation has
-    // a zig-zag twin take it; every other request goes to its catch-all there, which walks zig-zag by a run-time flag --
-    // measured better than an exact kernel walking forward (N = 2^26 zoo: 289 vs 314 us; fishing-v4 stored + sigma array
-    // at 2^24: 145 vs 156-177 us: profiles/r02_zz_catch_all.jsonl).  fishing-v11 is VALU-bound and keeps its exact kernels.
-    // (zigzag: from FISHING_ZZ_MIN_BYTES per step the requests WITH a zig-zag twin take it; zigzag_big: from
-    // FISHING_ZZ_CATCHALL_MIN_BYTES the others prefer their catch-all's zig-zag walk to an exact forward kernel)
-    // (a one-tile form walks zig-zag by zz_rt, so it is never the "forward exact kernel" of that comparison)
-    const bool forward = one || !zigzag_big || MODEL == kModelZooMixed;
     if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
-        // fishing-v0/v1/v2, float32, in-kernel noise: bare / with the return record.  K a power of two (KP2): forward and
-        // zig-zag; any other K keeps the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns
+        // fishing-v0/v1/v2, float32, in-kernel noise: bare / with the return record.  K a power of two (KP2) skips the division;
+        // any other K keeps the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns
         // against the catch-all at N = 2^22).
-        if (zigzag && !one) {      // (a one-tile launch keeps its one-tile form, which walks zig-zag by zz_rt)
-            switch (req | ZZ) {
-                FISHING_LEAN_CASE_ZZ(P | KP2 | ZZ);
-                FISHING_LEAN_CASE_ZZ(P | KP2 | RET | ZZ);
-                default: break;
-            }
+        switch (req) {
+            FISHING_LEAN_CASE(P | KP2);
+            FISHING_LEAN_CASE(P | KP2 | RET);
+            FISHING_LEAN_CASE(P);
+            FISHING_LEAN_CASE(P | RET);
+            default: break;
         }
-        if (forward) {
-            switch (req) {
-                FISHING_LEAN_CASE(P | KP2);
-                FISHING_LEAN_CASE(P | KP2 | RET);
-                FISHING_LEAN_CASE(P);
-                FISHING_LEAN_CASE(P | RET);
+        if constexpr (MODEL == FISHING_MODEL_V1) {
+            switch (req) {      // the compact layout bench.py --compact measures
+                FISHING_LEAN_CASE(P | KP2 | T8);
+                FISHING_LEAN_CASE(P | KP2 | T8 | RET);
                 default: break;
-            }
-            if constexpr (MODEL == FISHING_MODEL_V1) {
-                switch (req) {      // the compact layout bench.py --compact measures
-                    FISHING_LEAN_CASE(P | KP2 | T8);
-                    FISHING_LEAN_CASE(P | KP2 | T8 | RET);
-                    default: break;
-                }
             }
         }
     }
     if constexpr (sizeof(T) == 4 && MODEL == FISHING_MODEL_V4) {
         // fishing-v4 (per-env K: always the true division): stored or derived (K, r), sigma scalar or array (BASELINE
-        // config 5), bare / with the return record; zig-zag twins for the derived ones and for stored + scalar sigma
-        if (zigzag && !one) {      // (a one-tile launch keeps its one-tile form, which walks zig-zag by zz_rt)
-            switch (req | ZZ) {
-                FISHING_LEAN_CASE_ZZ(P | ZZ);
-                FISHING_LEAN_CASE_ZZ(P | RET | ZZ);
-                FISHING_LEAN_CASE_ZZ(P | DERIVED | ZZ);
-                FISHING_LEAN_CASE_ZZ(P | DERIVED | RET | ZZ);
-                FISHING_LEAN_CASE_ZZ(P | DERIVED | SIGARR | ZZ);
-                FISHING_LEAN_CASE_ZZ(P | DERIVED | SIGARR | RET | ZZ);
-                default: break;
-            }
-        }
-        if (forward) {
-            switch (req) {
-                FISHING_LEAN_CASE(P);
-                FISHING_LEAN_CASE(P | RET);
-                FISHING_LEAN_CASE(P | SIGARR);
-                FISHING_LEAN_CASE(P | SIGARR | RET);
-                FISHING_LEAN_CASE(P | DERIVED);
-                FISHING_LEAN_CASE(P | DERIVED | RET);
-                FISHING_LEAN_CASE(P | DERIVED | SIGARR);
-                FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET);
-                default: break;
-            }
+        // config 5), bare / with the return record
+        switch (req) {
+            FISHING_LEAN_CASE(P);
+            FISHING_LEAN_CASE(P | RET);
+            FISHING_LEAN_CASE(P | SIGARR);
+            FISHING_LEAN_CASE(P | SIGARR | RET);
+            FISHING_LEAN_CASE(P | DERIVED);
+            FISHING_LEAN_CASE(P | DERIVED | RET);
+            FISHING_LEAN_CASE(P | DERIVED | SIGARR);
+            FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET);
+            default: break;
         }
     }
 #ifndef FISHING_NO_ZOO_HOT
@@ -1057,27 +1020,22 @@ int lean_dispatch(int req, bool zigzag, bool zigzag_big, const LeanCall<T>& c) {
     // float64 parity layout gains under 1 % from exact instantiations -- 26.65 vs 26.87 us, it is bound by its
     // 32-byte-per-lane access shape -- and runs on its catch-alls: profiles/r02_ab_variants.jsonl.)
     if constexpr (sizeof(T) == 4 && is_zoo_tag(MODEL)) {
-        if (forward) {
-            switch (req) {
-                FISHING_LEAN_CASE(P);
-                FISHING_LEAN_CASE(P | RET);
-                default: break;
-            }
+        switch (req) {
+            FISHING_LEAN_CASE(P);
+            FISHING_LEAN_CASE(P | RET);
+            default: break;
         }
     }
     // fishing-v10 = Beverton-Holt with the per-env drifting r stream
     if constexpr (sizeof(T) == 4 && MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT) {
-        if (forward) {
-            switch (req) {
-                FISHING_LEAN_CASE(P | DRIFT);
-                FISHING_LEAN_CASE(P | DRIFT | RET);
-                default: break;
-            }
+        switch (req) {
+            FISHING_LEAN_CASE(P | DRIFT);
+            FISHING_LEAN_CASE(P | DRIFT | RET);
+            default: break;
         }
     }
 #endif
 #undef FISHING_LEAN_CASE
-#undef FISHING_LEAN_CASE_ZZ
     // float64: two envs per thread while a step's streams sit in the Infinity Cache (see the kernel).  Relieved of the
     // 32-byte access shape the layout feels its arithmetic -- two IEEE float64 divisions per env, ~25 instructions each --
     // so fishing-v0/v1/v2 with K a power of two have exact instantiations there (no division, no option tests)
@@ -1156,13 +1114,10 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     if (derived) req |= feat::DERIVED;
     if (drift) req |= feat::DRIFT;
     if (a.dk.pow2 && is_core_model(p->model) && p->model != FISHING_MODEL_V4) req |= feat::KP2;
-    // The zig-zag walk once a step's streams are about twice the 256 MiB Infinity Cache (for the requests that have such
-    // an instantiation): every size from N = 2^25 on, at 2^24 the variants with the return accumulator (33 B x 2^24 =
-    // 554 MB: 85.6 -> 82.8 us; the bare 25 B step, 420 MB, still prefers the forward walk: 62.9 vs 63.7 us).
+    // The zig-zag walk (see the kernel) from ~100 MB per step, nontemporal action loads from ~200 MB
     const int64_t step_bytes = n_full * (int64_t)(sizeof(T) == 4 ? 25 + (b->ep_return ? 8 : 0) + (b->sigma ? 4 : 0)
                                                                  : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0));
-    const bool zigzag = step_bytes >= FISHING_ZZ_MIN_BYTES, zigzag_big = step_bytes >= FISHING_ZZ_CATCHALL_MIN_BYTES;
-    a.zz_rt = (step_bytes >= FISHING_XZZ_MIN_BYTES) ? 1u : 0u;          // (read by the catch-alls, the one-tile forms, the float64 exact forms)
+    a.zz_rt = (step_bytes >= FISHING_XZZ_MIN_BYTES) ? 1u : 0u;
     a.nta_rt = (a.zz_rt && step_bytes >= FISHING_NTA_MIN_BYTES) ? 1u : 0u;
     LeanMixedArgs<T> mixed{};
     if (p->model == FISHING_MODEL_V11) {
@@ -1182,7 +1137,7 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
         if constexpr (kTag == kModelZooMixed && sizeof(T) == 8) return (int)FISHING_ERR_MODEL;     // (not reached: see `lean`)
-        else return lean_dispatch<T, kTag>(req, zigzag, zigzag_big, call);
+        else return lean_dispatch<T, kTag>(req, call);
     });
     if (rc != 0 || n_full == n || name) return rc;
     // ragged tail (< 1024 envs): one workgroup of the general kernel

@@ -836,7 +836,7 @@ def test_xcd_aware_zigzag_keeps_results_with_a_partial_last_group(hh, tiles, ret
     """Round 3: from ~100 MB per step odd steps walk the tiles backwards IN GROUPS OF EIGHT (tile % 8 == workgroup % 8 in
     both directions: every tile stays on its XCD, whose L2 keeps its lines across launches).  A tile count that is not
     a multiple of 8 leaves a last partial group in place.  The walk order must not show: 4093 tiles (the one-tile form,
-    direction from zz_rt) and 5125 tiles (the tile-loop form: its zig-zag twin with returns, 173 MB per step) + a ragged tail, four steps (even and odd counters)
+    direction from zz_rt) and 5125 tiles on an explicit grid of 4096 (the tile-loop form) + a ragged tail, four steps (even and odd counters)
     against the general kernel, every stream bit for bit."""
     import torch
     n = tiles * 1024 + 517
@@ -848,7 +848,7 @@ def test_xcd_aware_zigzag_keeps_results_with_a_partial_last_group(hh, tiles, ret
     a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
     lib = __import__("gym_fishing_amd")._capi.lib()
     name = hh.kernel_name(pa, n, hh.State(4096, np.float32, fo.MODEL_V1, np.float32(-0.25), ep_return=ret).buffers(a))
-    want = (2 | 4096 | (4 if ret else 0)) | (8192 if tiles <= 4096 else (128 if ret else 0))     # ONE, or the tile loop: its ZZ twin with returns (173 MB per step), forward bare (131 MB < 150 MB)
+    want = (2 | 4096 | (4 if ret else 0)) | (8192 if tiles <= 4096 else 0)     # ONE, or the tile loop
     assert name.endswith(", %d>" % want), (name, want)
     outs = []
     for p in (pa, pb):
@@ -1193,7 +1193,7 @@ def test_zigzag_walk_at_large_n_agrees_with_general_kernel(hh, ret, which, form)
     """At N = 2^25 the float32 lean kernel walks the tiles backwards on odd steps (what the previous step touched
     last is still in the Infinity Cache) -- fishing-v0/v1/v2/v4 bare or with returns, and fishing-v4 with derived
     parameters; in the one-tile form (a workgroup per tile: what every batch up to 65536 tiles takes, direction from
-    zz_rt) and in the zig-zag twin of the tile loop (768 workgroups: what larger batches take).  The order of the walk
+    zz_rt) and in the tile loop (768 workgroups: an explicit launch shape).  The order of the walk
     must not show: three steps (even, odd, even counters) at N = 2^25 + 3077 against the general kernel, every stream
     bit-for-bit."""
     import torch
@@ -1207,7 +1207,7 @@ def test_zigzag_walk_at_large_n_agrees_with_general_kernel(hh, ret, which, form)
     a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
     lib = __import__("gym_fishing_amd")._capi.lib()
     assert hh.kernel_name(pa, n, hh.State(4096, np.float32, model, np.float32(-0.25), ep_return=ret).buffers(a)).endswith(
-        ", %d>" % (2 | (128 if form == "tile_loop" else 8192) | (4 if ret else 0) | (256 if derived else 4096)))   # ZZ / ONE, RET, DERIVED / KP2 (K = 1)
+        ", %d>" % (2 | (0 if form == "tile_loop" else 8192) | (4 if ret else 0) | (256 if derived else 4096)))   # ONE, RET, DERIVED / KP2 (K = 1)
     outs = []
     for p in (pa, pb):
         st = hh.State(n, np.float32, model, np.float32(-0.25), ep_return=ret)
