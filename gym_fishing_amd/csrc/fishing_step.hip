@@ -972,14 +972,17 @@ template <typename T, int MODEL>
 int lean_dispatch(int req, const LeanCall<T>& c) {
     using namespace feat;
     constexpr int P = kNoisePhilox;
-    // every exact instantiation has a one-tile-per-workgroup twin (feat::ONE), taken whenever a grid of one workgroup per
-    // tile fits the return_partials slots -- every launch up to kPartialSlots tiles = N = 2^26, and step_dispatch makes
+    // The exact float32 instantiations are one-tile-per-workgroup forms (feat::ONE), taken whenever a grid of one workgroup
+    // per tile fits the return_partials slots -- every launch up to kPartialSlots tiles = N = 2^26, and step_dispatch makes
     // no larger ones.  (Round 3, fishing_step_f32 with returns, one-tile grid vs the capped tile loop: N = 2^23 40.0 vs
-    // 42.1 us, 2^24 80.4 vs 83, 2^25 162.4 vs 169, 2^26 338 vs 376: profiles/r03_one_tile_large_n.jsonl.)  The tile-loop
-    // forms serve explicit launch shapes (FishingParams.launch_blocks).  Every form takes its walk direction from zz_rt.
+    // 42.1 us, 2^24 80.4 vs 83, 2^25 162.4 vs 169, 2^26 338 vs 376: profiles/r03_one_tile_large_n.jsonl.)  An explicit
+    // launch shape that does not cover the tiles one to one (FishingParams.launch_blocks: experiments, tests) runs the
+    // catch-all's tile loop; the exact tile-loop twins went with their last product use.
     const bool one = c.one_ok;
-#define FISHING_LEAN_CASE(MASK) \
-    case (MASK): return one ? lean_launch<T, MODEL, (MASK) | ONE>(c) : lean_launch<T, MODEL, (MASK)>(c)
+#define FISHING_LEAN_CASE(MASK)                                          \
+    case (MASK):                                                         \
+        if (one) return lean_launch<T, MODEL, (MASK) | ONE>(c);          \
+        break
     if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
         // fishing-v0/v1/v2, float32, in-kernel noise: bare / with the return record.  K a power of two (KP2) skips the division;
         // any other K keeps the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns
