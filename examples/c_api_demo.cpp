@@ -44,9 +44,10 @@ int main() {
     hipMalloc(&ep_return, n * 4);
     hipMalloc(&done, n);
     hipMalloc(&t, n * 4);
-    hipMalloc(&partials, fishing_partials_len() * sizeof(double));
+    const int64_t slots = fishing_partials_slots(n);      // what a batch of n envs can touch (4 doubles per slot)
+    hipMalloc(&partials, slots * 4 * sizeof(double));
     hipMalloc(&record, 4 * sizeof(double));
-    hipMemset(partials, 0, fishing_partials_len() * sizeof(double));
+    hipMemset(partials, 0, slots * 4 * sizeof(double));
     std::vector<float> a(n, -0.9375f);
     hipMemcpy(action, a.data(), n * 4, hipMemcpyHostToDevice);
 
@@ -64,7 +65,7 @@ int main() {
     hipStreamCreate(&stream);
     CHECK(fishing_reset_f32(&p, n, 0, &b, nullptr, /*seed*/ 0, /*reset_counter*/ 0, stream));
     for (uint64_t s = 0; s < 101; ++s) CHECK(fishing_step_f32(&p, n, 0, &b, 0, s, stream));
-    CHECK(fishing_reduce_returns(partials, record, stream));
+    CHECK(fishing_reduce_returns_slots(partials, slots, record, stream));
     hipStreamSynchronize(stream);
     double rec[4];
     hipMemcpy(rec, record, sizeof rec, hipMemcpyDeviceToHost);

@@ -397,7 +397,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     static_assert(!(F & feat::DERIVED) || kPerEnv, "DERIVED is fishing-v4");
     static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
-    static_assert(!(F & feat::ONE) || kExact, "ONE: exact instantiations");
+    static_assert(!(F & feat::ONE) || E == 4, "ONE: whole 1024-env tiles");
     constexpr bool kOne = (F & feat::ONE) != 0;
     static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
     constexpr int kTileEnvs = 256 * E;
@@ -1056,6 +1056,7 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
             if (c.two_per_thread_any) return lean_launch<T, MODEL, catch_all_mask<MODEL>(), 2>(c);
         }
     }
+    if (one) return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE>(c);
     return lean_launch<T, MODEL, catch_all_mask<MODEL>()>(c);
 }
 
