@@ -920,13 +920,11 @@ struct LeanCall {
     const LeanArgs<T>& a;
     int64_t ntiles;
     uint64_t env_offset, seed, step_counter;
-    int blocks;
     hipStream_t s;
     std::string* name;
     const void* extra;       // LeanMixedArgs<T> for fishing-v11, unused otherwise
     bool two_per_thread;     // float64: E = 2 for the exact instantiations (streams cache-resident)
     bool two_per_thread_any; //          ... and for the catch-all
-    bool one_ok;             // the request's one-tile form (feat::ONE), if it has one, may cover this batch
 };
 
 template <typename T, int MODEL, int F, int E = 4>
@@ -939,12 +937,13 @@ int lean_launch(const LeanCall<T>& c) {
     }
     LeanExtra<T, MODEL> ex{};
     if constexpr (MODEL == kModelZooMixed) ex = *static_cast<const LeanMixedArgs<T>*>(c.extra);
-    // (c.ntiles / c.blocks count 1024-env tiles; an E = 2 workgroup covers half of one)
+    // (c.ntiles counts 1024-env tiles; an E = 2 workgroup covers half of one)
     const int64_t nt = c.ntiles * (4 / E);
     // one-tile forms: a workgroup per tile, up to kPartialSlots of them; tile loops: the grid step_dispatch chose
-    // (two envs per thread: half-tiles, cache-resident sizes only -- within kMaxBlocks, so that a batch never touches more
-    // return_partials slots than fishing_partials_slots() promises)
-    const int64_t nb = (F & feat::ONE) ? nt : std::min(std::min(nt, (int64_t)c.blocks * (4 / E)), (int64_t)(E == 4 ? kPartialSlots : kMaxBlocks));
+    // E = 4: a workgroup per tile (feat::ONE).  E = 2 (float64, cache-resident sizes only): half-tiles in a loop, on at
+    // most kMaxBlocks workgroups -- a batch never touches more return_partials slots than fishing_partials_slots() promises
+    static_assert((E == 4) == ((F & feat::ONE) != 0), "four envs per thread <=> one tile per workgroup");
+    const int64_t nb = E == 4 ? nt : std::min(nt, (int64_t)kMaxBlocks);
     // (FISHING_X_DYN_LDS, experiments only: unused dynamic LDS per workgroup caps the workgroups a CU holds at once.  Running
     // the one-round grids of N = 2^20 .. 2^22 in several rounds never helped -- fishing-v4 at 2^21 13.05 us with 8 workgroups
     // per CU, 14.6 with 4, 16.5 with 2: profiles/r03_occupancy_cap.jsonl)
@@ -972,17 +971,12 @@ template <typename T, int MODEL>
 int lean_dispatch(int req, const LeanCall<T>& c) {
     using namespace feat;
     constexpr int P = kNoisePhilox;
-    // The exact float32 instantiations are one-tile-per-workgroup forms (feat::ONE), taken whenever a grid of one workgroup
-    // per tile fits the return_partials slots -- every launch up to kPartialSlots tiles = N = 2^26, and step_dispatch makes
-    // no larger ones.  (Round 3, fishing_step_f32 with returns, one-tile grid vs the capped tile loop: N = 2^23 40.0 vs
-    // 42.1 us, 2^24 80.4 vs 83, 2^25 162.4 vs 169, 2^26 338 vs 376: profiles/r03_one_tile_large_n.jsonl.)  An explicit
-    // launch shape that does not cover the tiles one to one (FishingParams.launch_blocks: experiments, tests) runs the
-    // catch-all's tile loop; the exact tile-loop twins went with their last product use.
-    const bool one = c.one_ok;
-#define FISHING_LEAN_CASE(MASK)                                          \
-    case (MASK):                                                         \
-        if (one) return lean_launch<T, MODEL, (MASK) | ONE>(c);          \
-        break
+    // Every four-envs-per-thread instantiation -- exact or catch-all -- is a one-tile-per-workgroup form (feat::ONE): a
+    // lean launch always covers its tiles one to one (step_dispatch_range).  Only the float64 two-envs-per-thread forms
+    // keep the tile loop.  (Catch-all as a one-tile form, float32 with terminal observations + returns: N = 2^21 12.8 ->
+    // 10.35 us, 2^22 23.6 -> 21.35; 62 instead of 106 SGPRs, 52 instead of 67 VGPRs: profiles/r03_catch_all_one_tile.jsonl.)
+#define FISHING_LEAN_CASE(MASK) \
+    case (MASK): return lean_launch<T, MODEL, (MASK) | ONE>(c)
     if constexpr (sizeof(T) == 4 && !is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
         // fishing-v0/v1/v2, float32, in-kernel noise: bare / with the return record.  K a power of two (KP2) skips the division;
         // any other K keeps the correctly rounded division (17.5 -> 16.2 us bare, 22.6 -> 21.5 us with returns
@@ -1056,8 +1050,7 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
             if (c.two_per_thread_any) return lean_launch<T, MODEL, catch_all_mask<MODEL>(), 2>(c);
         }
     }
-    if (one) return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE>(c);
-    return lean_launch<T, MODEL, catch_all_mask<MODEL>()>(c);
+    return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE>(c);
 }
 
 // Where a step() request runs.  lean: whole 1024-env tiles on step_kernel_lean (+ the ragged tail on one
@@ -1070,12 +1063,16 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
     const bool derived = p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED);
     const int64_t tile = 256 * kEnvsPerThread;
-    // (fishing-v11 in float64 stays on the general kernel: its lean catch-all would spill to scratch memory)
     // (under FISHING_FLAG_PADDED_TILES also batches below one tile: 3.1 instead of 5.3 us per step at N = 1000)
     const bool pad_ok = (p->flags & FISHING_FLAG_PADDED_TILES) != 0 && (n % kEnvsPerThread) == 0;
+    // The lean kernel runs a workgroup per tile (step_dispatch hands it at most kPartialSlots tiles); an explicit launch
+    // shape that does not cover the tiles one to one (experiments, tests) gets the general kernel in that shape.
+    const int64_t tiles_up = (n + tile - 1) / tile;
+    const bool covers = tiles_up <= kPartialSlots && (!p->launch_blocks || p->launch_blocks >= tiles_up);
     const bool lean = !(p->flags & FISHING_FLAG_DIAG_GENERAL_KERNEL) && b->reward && b->done &&
-                      (p->launch_threads == 0 || p->launch_threads == 256) && (n >= tile || pad_ok) &&
-                      !(p->model == FISHING_MODEL_V11 && sizeof(T) == 8);
+                      (p->launch_threads == 0 || p->launch_threads == 256) && (n >= tile || pad_ok) && covers;
+    // (fishing-v11 in float64 too: as a one-tile form its catch-all needs 105 VGPRs and spills 16 SGPRs -- 58 us per step
+    // at N = 2^22 against 81 on the general kernel, where rounds 1-2 kept it)
     if (!lean) {
         int blocks, threads;
         launch_shape(p, n, blocks, threads);
@@ -1093,21 +1090,12 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
                   pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET),
                   noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, 0u, padded ? n : INT64_MAX, pt.origin_step,
                   pt.origin_counter, pt.growth, pt.alpha, make_divk((double)pt.K)};
-    // up to 4096 workgroups = one tile each at N = 2^22: 21.39 -> 21.13 us with returns against a cap of
-    // 2048, equal for the bare step (profiles/r01j_lean_block_cap.jsonl).  From N = 2^25 on (state streams far beyond
-    // the Infinity Cache) FEWER workgroups looping over more tiles stream better from HBM -- 768 = 3 per CU:
-    // N = 2^26 299 -> 287 us bare, 403 -> 391 us with returns; 2^27 666 -> 610 / 842 -> 785 us; 2^24 equal
-    // (profiles/r02_caps_large_n.jsonl).  Not for fishing-v4 with derived parameters, which is as much VALU- as
-    // HBM-bound and needs the occupancy: 95 -> 101 us at N = 2^24 (profiles/r02_step_v4_24_*).
-    // Round 3: a workgroup per tile while the return_partials slots last (65536 tiles = N = 2^26), for the one-tile forms
-    // and for the tile loops alike (which then run one iteration): with returns 2^24 83 -> 80 us, 2^26 376 -> 345; the
-    // float32 catch-all 101 -> 91 / 423 -> 389; float64 bare 2^24 108.6 -> 96.7, 2^25 233 -> 194
-    // (profiles/r03_one_tile_large_n.jsonl, r03_full_grid_loops.jsonl).  The caps above are what batches beyond that get.
-    // Batches beyond the slots are stepped in ranges of 2^26 envs (step_dispatch below: the tile loop on 768 workgroups
-    // took 587 / 819 us at N = 2^27, on 65536 workgroups 564 / 772, against 2 x 245 / 2 x 338: profiles/r03_one_tile_large_n.jsonl);
-    // an explicit launch_blocks keeps the single capped launch.
-    const int cap = p->launch_blocks ? std::min(p->launch_blocks, kMaxBlocks) : kPartialSlots;
-    const int lb = (int)(ntiles < cap ? ntiles : cap);
+    // Launch geometry.  Rounds 1-2 capped the grid (4096 workgroups, 768 from N = 2^25: of two LOOPING grids the smaller
+    // streamed better from HBM: profiles/r02_caps_large_n.jsonl).  Round 3: a workgroup per tile at every size -- with
+    // returns 2^24 83 -> 80 us, 2^26 376 -> 345; the float32 catch-all 101 -> 91 / 423 -> 389; float64 bare 2^24
+    // 108.6 -> 96.7, 2^25 233 -> 194 (profiles/r03_one_tile_large_n.jsonl, r03_full_grid_loops.jsonl).  Batches beyond
+    // the 65536 slots are stepped in ranges of 2^26 envs (step_dispatch below: the tile loop took 587 / 819 us at
+    // N = 2^27 on 768 workgroups, 564 / 772 on 65536; two ranges take 528 / 742).
     int req = noise;
     if (b->ep_return) req |= feat::RET;
     if (b->ep_return && !(p->flags & FISHING_FLAG_AUTO_RESET)) req |= feat::LATCH;
@@ -1135,13 +1123,11 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     // float64 with two envs per thread while one step's streams fit the 256 MiB Infinity Cache with room to spare
     // (N < 2^23 for the 37-byte layout); four per thread beyond, where the access shape stops mattering
     const bool two = sizeof(T) == 8 && step_bytes < FISHING_F64_E2_MAX_BYTES && !p->launch_blocks;
-    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, lb, s, name, &mixed, two,
-                           two && step_bytes >= FISHING_F64_E2_MIN_BYTES,
-                           p->launch_blocks ? lb == ntiles : ntiles <= kPartialSlots};
+    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, s, name, &mixed, two,
+                           two && step_bytes >= FISHING_F64_E2_MIN_BYTES};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
-        if constexpr (kTag == kModelZooMixed && sizeof(T) == 8) return (int)FISHING_ERR_MODEL;     // (not reached: see `lean`)
-        else return lean_dispatch<T, kTag>(req, call);
+        return lean_dispatch<T, kTag>(req, call);
     });
     if (rc != 0 || n_full == n || name) return rc;
     // ragged tail (< 1024 envs): one workgroup of the general kernel

@@ -9,16 +9,18 @@ CASES = (("f64_v1", "fishing-v1", dict(sigma=0.1, dtype=torch.float64), (22, 23,
          ("f32_v1_term_ret", "fishing-v1", dict(sigma=0.1, track_returns=True, record_terminal_obs=True), (22, 23, 24, 25, 26)),
          ("f32_v1_K1.5_ret", "fishing-v1", dict(sigma=0.1, K=1.5, track_returns=True), (23, 24, 26)),
          ("f32_v4_stored_sig_ret", "fishing-v4", dict(sigma=0.05, derived_params=False, track_returns=True), (23, 24)))
-only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
+only = sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] else None
+sizes_arg = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else None
 for name, env_id, kw, sizes in CASES:
     if only and name not in only:
         continue
+    sizes = sizes_arg or sizes
     for ln in sizes:
         n = 1 << ln
         ring = torch.empty((4, n + 3072), device="cuda"); acts = ring[:, :n]; acts.copy_(torch.rand((4, n), device="cuda") * 2 - 1)
         e = gf.make(env_id, num_envs=n, seed=1, **kw)
         e.reset()
-        K = 100 if ln <= 23 else 40
+        K = 400 if ln <= 21 else 100 if ln <= 23 else 40
         v = []
         for rnd in range(3):
             e.step_many(acts, 20)

@@ -97,11 +97,11 @@ def test_argument_errors_need_no_gpu(lib):
     p.K = 1.0
     bo = _capi.make_buffers(obs=4096, t=8192, action=12288, reward=16384, done=20480)
     assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
-    assert name.value == b"fishing::step_kernel_lean<float, 1, 3199, 4>"     # sigma = 0 (no generator): the catch-all
+    assert name.value == b"fishing::step_kernel_lean<float, 1, 11391, 4>"     # sigma = 0 (no generator): the catch-all
     p.sigma = 0.1
     bo.ep_return = 24576
     assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
-    assert name.value == b"fishing::step_kernel_lean<float, 1, 3199, 4>"     # a record without auto-reset: the catch-all's latch
+    assert name.value == b"fishing::step_kernel_lean<float, 1, 11391, 4>"     # a record without auto-reset: the catch-all's latch
     p.flags = _capi.FLAG_AUTO_RESET
     assert lib.fishing_step_kernel_name_f32(p, 1 << 22, bo, name, 128) == 0
     assert name.value == b"fishing::step_kernel_lean<float, 1, 12294, 4>"    # (last argument: envs per thread) Philox (2) | RET (4) | KP2 (4096) | ONE (8192: a tile per workgroup): K = 1

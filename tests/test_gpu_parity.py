@@ -697,11 +697,11 @@ def test_lean_and_general_kernels_agree(hh, model, ret, n, dtype):
 @pytest.mark.parametrize("case", ["v1", "v1_ret", "v0_ret", "v2_ret", "v1_K1.5_ret", "v4_derived_sig_ret", "v4_stored_ret", "v9_ret",
                                   "v1_padded_ret", "v1_counter_ret"])
 def test_one_tile_and_tile_loop_instantiations_agree(hh, case):
-    """Round 3: the exact float32 instantiations are one-tile forms (feat::ONE: a tile per workgroup, no loop, the return
+    """Round 3: the float32 instantiations are one-tile forms (feat::ONE: a tile per workgroup, no loop, the return
     record's atomic ahead of the tile's stores; what every launch takes); a grid capped below the tile count
-    (launch_blocks = 3) runs the same request on its catch-all's tile loop.  Same bits on every stream over 10
-    auto-resetting steps, same episode counts, return sums equal to double rounding (the partial sums land in different
-    slots).  Also with a padded last tile and with the device-resident step counter."""
+    (launch_blocks = 3) runs the same request on the general kernel's grid-stride loop.  Same bits on every stream
+    over 10 auto-resetting steps, same episode counts, return sums equal to double rounding (the partial sums land in
+    different slots).  Also with a padded last tile and with the device-resident step counter."""
     import torch
     from gym_fishing_amd import _capi
     lib = _capi.lib()
@@ -724,8 +724,8 @@ def test_one_tile_and_tile_loop_instantiations_agree(hh, case):
     a0 = torch.zeros(n, device="cuda")
     na = hh.kernel_name(pa, n, A.buffers(a0))
     nb = hh.kernel_name(pb, n, B.buffers(a0))
-    mask_a, mask_b = int(na.rstrip(">").split(",")[-1]), int(nb.rstrip(">").split(",")[-1])
-    assert mask_a & 8192 and not mask_a & 1024 and mask_b & 1024 and not mask_b & 8192, (na, nb)      # ONE exact / OPT catch-all
+    mask_a = int(na.rstrip(">").split(",")[-1])
+    assert mask_a & 8192 and not mask_a & 1024 and nb.startswith("fishing::step_kernel<"), (na, nb)      # ONE exact / the general kernel
     counter = torch.zeros(1, dtype=torch.int64, device="cuda") if "counter" in case else None
     g = torch.Generator(device="cuda").manual_seed(n)
     for s in range(10):
@@ -768,8 +768,7 @@ def test_one_tile_grid_beyond_4096_tiles(hh, case):
     A, B = mk(), mk()
     a0 = torch.zeros(n, device="cuda")
     na, nb = hh.kernel_name(pa, n, A.buffers(a0)), hh.kernel_name(pb, n, B.buffers(a0))
-    mask_a, mask_b = int(na.rstrip(">").split(",")[-1]), int(nb.rstrip(">").split(",")[-1])
-    assert mask_a & 8192 and not mask_b & 8192, (na, nb)
+    assert int(na.rstrip(">").split(",")[-1]) & 8192 and nb.startswith("fishing::step_kernel<"), (na, nb)
     g = torch.Generator(device="cuda").manual_seed(n)
     for s in range(5):
         a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
@@ -848,8 +847,8 @@ def test_xcd_aware_zigzag_keeps_results_with_a_partial_last_group(hh, tiles, ret
     a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
     lib = __import__("gym_fishing_amd")._capi.lib()
     name = hh.kernel_name(pa, n, hh.State(4096, np.float32, fo.MODEL_V1, np.float32(-0.25), ep_return=ret).buffers(a))
-    want = (2 | 4096 | 8192 | (4 if ret else 0)) if tiles <= 4096 else 3199     # ONE, or the catch-all's tile loop
-    assert name.endswith(", %d>" % want), (name, want)
+    want = ", %d>" % (2 | 4096 | 8192 | (4 if ret else 0)) if tiles <= 4096 else "step_kernel<float, 1>"     # ONE, or the general kernel's loop
+    assert name.endswith(want), (name, want)
     outs = []
     for p in (pa, pb):
         st = hh.State(n, np.float32, fo.MODEL_V1, np.float32(-0.25), ep_return=ret)
@@ -1167,7 +1166,7 @@ def test_zigzag_walk_of_the_catch_all_kernels_agrees_with_general_kernel(hh, dty
     lib = __import__("gym_fishing_amd")._capi.lib()
     fn = lib.fishing_step_f32 if dtype == np.float32 else lib.fishing_step_f64
     assert hh.kernel_name(pa, n, hh.State(4096, dtype, fo.MODEL_V1, dtype(-0.25), ep_return=True, terminal=True).buffers(a),
-                          dtype=dtype).endswith(", 3199>")
+                          dtype=dtype).endswith(", 11391>")
     outs = []
     for p in (pa, pb):
         st = hh.State(n, dtype, fo.MODEL_V1, dtype(-0.25), ep_return=True, terminal=True)
@@ -1207,8 +1206,8 @@ def test_zigzag_walk_at_large_n_agrees_with_general_kernel(hh, ret, which, form)
     a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
     lib = __import__("gym_fishing_amd")._capi.lib()
     assert hh.kernel_name(pa, n, hh.State(4096, np.float32, model, np.float32(-0.25), ep_return=ret).buffers(a)).endswith(
-        ", %d>" % ((3455 if derived else 3199) if form == "tile_loop"        # (the catch-all's tile loop)
-                   else 2 | 8192 | (4 if ret else 0) | (256 if derived else 4096)))   # ONE, RET, DERIVED / KP2 (K = 1)
+        "step_kernel<float, %d>" % (4 if derived else 1) if form == "tile_loop"        # (the general kernel's loop)
+        else ", %d>" % (2 | 8192 | (4 if ret else 0) | (256 if derived else 4096)))   # ONE, RET, DERIVED / KP2 (K = 1)
     outs = []
     for p in (pa, pb):
         st = hh.State(n, np.float32, model, np.float32(-0.25), ep_return=ret)

@@ -332,16 +332,16 @@ def test_kernel_names_follow_the_dispatch(hh):
     # on an explicitly capped grid: the tile loop (round 3's compile-time zig-zag twins, mask bit 128, are gone: every form
     # takes its walk direction from a run-time flag)
     pc = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True, launch_blocks=4096)
-    assert name(pc, n=1 << 24) == "fishing::step_kernel_lean<float, 1, 3199>"       # ... the catch-all's
+    assert name(pc, n=1 << 24) == "fishing::step_kernel<float, 1>"                  # ... the general kernel's
     assert name(pc, n=1 << 22) == "fishing::step_kernel_lean<float, 1, 12290>"      # (4096 workgroups cover 4096 tiles one to one)
     assert name(p1, n=1 << 20) == "fishing::step_kernel_lean<float, 1, 12290>"
     assert name(p1, n=1 << 24, ep_return=True, return_partials=True) == "fishing::step_kernel_lean<float, 1, 12294>"
-    assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 3199>"
-    assert name(p1, terminal_obs=True, done_bits=True) == "fishing::step_kernel_lean<float, 1, 3199>"
+    assert name(p1, terminal_obs=True) == "fishing::step_kernel_lean<float, 1, 11391>"
+    assert name(p1, terminal_obs=True, done_bits=True) == "fishing::step_kernel_lean<float, 1, 11391>"
     assert name(p1, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 4098, 2>"        # float64, cache-resident: 2 envs per thread, exact
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5, auto_reset=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 3199, 2>"
-    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5, auto_reset=True), n=1 << 20, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 3199>"
-    assert name(p1, n=1 << 24, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 3199>"
+    assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5, auto_reset=True), n=1 << 20, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 11391>"
+    assert name(p1, n=1 << 24, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 11391>"
     assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 4, 3455, 2>"
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 12306>"
     assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 12290>"
@@ -352,15 +352,15 @@ def test_kernel_names_follow_the_dispatch(hh):
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, general=True)) == "fishing::step_kernel<float, 1>"
     # the return record without auto-reset needs the latch, which only the catch-all carries
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=False), ep_return=True, return_partials=True) == \
-        "fishing::step_kernel_lean<float, 1, 3199>"
+        "fishing::step_kernel_lean<float, 1, 11391>"
     assert name(p1, n=1000) == "fishing::step_kernel<float, 1>"
     assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True)) == "fishing::step_kernel_lean<float, 4, 8450>"
-    # fishing-v11 (growth function per env): float32 on the lean kernel, float64 on the general one
+    # fishing-v11 (growth function per env): the lean kernel in both layouts (float64 on its catch-all, round 3)
     p11 = hh.params(fo.MODEL_V11, sigma=0.1, models=[0, 1, 2, 3, 4], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE], auto_reset=True)
     b11 = hh.State(4096, np.float32, fo.MODEL_V11, np.zeros(4096), model_idx=np.zeros(4096, np.int32), ep_return=True)
     full11 = b11.buffers(b11.action_tensor(np.zeros(4096, np.float32)))
     assert hh.kernel_name(p11, n, full11) == "fishing::step_kernel_lean<float, 105, 8198>"
-    assert hh.kernel_name(p11, n, full11, np.float64) == "fishing::step_kernel<double, 105>"
+    assert hh.kernel_name(p11, n, full11, np.float64) == "fishing::step_kernel_lean<double, 105, 11391>"
 
 
 # ------------------------------------------------------------------ the host mirror in the derived mode
