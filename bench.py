@@ -560,8 +560,8 @@ def main():
         ab = make_actions(torch, cfg, big, rows)
         eb.step_many(ab, 24)
         us, _ = timed_steps(torch, eb, ab, 100)
-        # the same env once more in a second allocation (made while the first is alive): at this size the launch time
-        # follows the allocation the arena landed in; reported beside the first, never instead
+        # the same env once more in a second allocation (made while the first is alive): round 2 saw +-7 % between
+        # allocations at this size, round 3 could not reproduce it; reported beside the first
         eb2 = make_env(gf, torch, args.config, big, 0, with_returns, False, args.v4_stored)
         eb2.reset()
         eb2.step_many(ab, 24)
@@ -575,6 +575,20 @@ def main():
                                "note": "same workload, N = 2^%d: far outside the Infinity Cache" % (big.bit_length() - 1)}
         del eb, ab
         torch.cuda.empty_cache()
+        if args.config != "v4":
+            # ... and at N = 2^24 (SURVEY.md section 8d names both sizes): 554 MB of streams, twice the Infinity Cache
+            mid = 1 << 24
+            em = make_env(gf, torch, args.config, mid, 0, with_returns, False, args.v4_stored)
+            em.reset()
+            am = make_actions(torch, cfg, mid, rows)
+            em.step_many(am, 24)
+            usm, _ = timed_steps(torch, em, am, 200)
+            out["hbm_resident"]["n_2p24"] = {"n_envs": mid, "steps": 200, "avg_launch_us": usm,
+                                             "achieved_GBps": mid * bytes_per / usm / 1e3,
+                                             "frac": mid * bytes_per / usm / 1e3 / HBM_PEAK_GBS,
+                                             "kernel": em.step_kernel_name(am[0])}
+            del em, am
+            torch.cuda.empty_cache()
         # launch-bound sizes: the fused multi-step kernel (K steps per launch, state in registers) next to
         # the launch-per-step path; env-steps/s only -- its HBM traffic is 9 B/env-step, not the headline's
         fused = {}
