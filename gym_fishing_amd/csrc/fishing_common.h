@@ -124,7 +124,7 @@ __device__ __forceinline__ void param_block(uint64_t seed, uint64_t env, uint64_
 // Hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_cos_f32 / v_sin_f32 (argument
 // in revolutions, so no 2*pi multiply).  |z| <= sqrt(66 ln 2) = 6.76.
 __device__ __forceinline__ void box_muller(uint32_t w0, uint32_t w1, float& zc, float& zs) {
-    const float u1 = (float)w0 * 0x1p-32f + 0x1p-33f;
+    const float u1 = __builtin_fmaf((float)w0, 0x1p-32f, 0x1p-33f);      // (the product is exact: same bits as mul + add, one instruction)
     const float u2 = (float)w1 * 0x1p-32f;
     const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
     zc = rad * __builtin_amdgcn_cosf(u2);

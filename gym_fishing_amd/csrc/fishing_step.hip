@@ -350,6 +350,9 @@ struct LeanArgs {
                              // loaded, by the v0/v1/v2/v4 instantiations)
     T alpha;                 // DRIFT
     DivK dk;                 // KP2: the scalar K's exact reciprocal
+    T robs;                  // the reset observation x0 / K - 1 of the scalar-K models, divided on the host (IEEE, same bits):
+                             // wave-uniform, but the device has no scalar float division -- 13 VALU instructions per
+                             // thread, ahead of the tile's stores
 };
 
 // fishing-v11 only (MODEL == kModelZooMixed): the growth kind in force per env, the model list it is redrawn from and
@@ -461,7 +464,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool auto_reset = (kExact && (F & feat::RET)) ? true : a.auto_reset != 0;
     const bool LATCH = (F & feat::LATCH) && !auto_reset;
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
-    const T robs_scalar = reset_obs<T, MODEL>(a.x0, a.pK);
+    const T robs_scalar = (MODEL == FISHING_MODEL_V4) ? a.x0 : a.robs;       // (reset_obs<T, MODEL>(a.x0, a.pK))
 
     auto do_tile = [&](const int64_t it) {
         // ZZ: odd steps walk the tiles backwards, so what the previous step touched LAST is what this one reads FIRST -- while
@@ -1089,7 +1092,7 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
                   bt.counter, bt.sigma, bt.terminal_obs, bt.done_bits, bt.z_ext, pt.r, pt.K, pt.sigma, pt.C, pt.x0,
                   pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET),
                   noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, 0u, padded ? n : INT64_MAX, pt.origin_step,
-                  pt.origin_counter, pt.growth, pt.alpha, make_divk((double)pt.K)};
+                  pt.origin_counter, pt.growth, pt.alpha, make_divk((double)pt.K), (T)(pt.x0 / pt.K - (T)1)};
     // Launch geometry.  Rounds 1-2 capped the grid (4096 workgroups, 768 from N = 2^25: of two LOOPING grids the smaller
     // streamed better from HBM: profiles/r02_caps_large_n.jsonl).  Round 3: a workgroup per tile at every size -- with
     // returns 2^24 83 -> 80 us, 2^26 376 -> 345; the float32 catch-all 101 -> 91 / 423 -> 389; float64 bare 2^24
