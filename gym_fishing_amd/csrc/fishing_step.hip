@@ -312,9 +312,9 @@ constexpr int DRIFT = 1 << 9;      // fishing-v10: per-env r, drifting by alpha 
 constexpr int OPT = 1 << 10;
 constexpr int LATCH = 1 << 11;     // RET without auto-reset: a finished env that is stepped on must not enter the record
                                    // again.  Catch-all only -- the exact RET instantiations are the auto-reset ones.
-constexpr int ONE = 1 << 13;       // one tile per workgroup (grid == ntiles; every launch up to N = 2^22): no tile loop, and with RET the
+constexpr int ONE = 1 << 13;       // one tile per workgroup (grid == ntiles; every four-envs-per-thread launch): no tile loop, and with RET the
                                    // return record -- workgroup reduction + its atomic -- is issued BEFORE the tile's stores, so the
-                                   // atomic's round trip runs under theirs.  Exact instantiations only.  Per step at N = 2^19 / 2^20 /
+                                   // atomic's round trip runs under theirs.  Exact instantiations and catch-alls alike.  Per step at N = 2^19 / 2^20 /
                                    // 2^21, back to back: 4.75 -> 4.09, 6.15 -> 5.71, 9.78 -> 8.15 us (profiles/r03_small_n/).
 constexpr int KP2 = 1 << 12;       // the scalar K is a power of two (K = 1 included): x / K is the exact multiply x * (1 / K),
                                    // same bits, a third of the instructions.  Exact instantiations of fishing-v0/v1/v2 only;
@@ -942,7 +942,6 @@ int lean_launch(const LeanCall<T>& c) {
     if constexpr (MODEL == kModelZooMixed) ex = *static_cast<const LeanMixedArgs<T>*>(c.extra);
     // (c.ntiles counts 1024-env tiles; an E = 2 workgroup covers half of one)
     const int64_t nt = c.ntiles * (4 / E);
-    // one-tile forms: a workgroup per tile, up to kPartialSlots of them; tile loops: the grid step_dispatch chose
     // E = 4: a workgroup per tile (feat::ONE).  E = 2 (float64, cache-resident sizes only): half-tiles in a loop, on at
     // most kMaxBlocks workgroups -- a batch never touches more return_partials slots than fishing_partials_slots() promises
     static_assert((E == 4) == ((F & feat::ONE) != 0), "four envs per thread <=> one tile per workgroup");
