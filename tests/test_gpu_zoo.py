@@ -354,20 +354,25 @@ def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
             assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12) and ra[2] > 0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
-def test_v11_lean_and_general_kernels_agree(hh, ret):
-    """fishing-v11 in float32 takes the lean step kernel too (growth function per env: the wave regroups its envs by
-    kind through LDS; the kinds are redrawn at every auto-reset): same bits as the general kernel on every stream and on
-    the kind array over 14 auto-resetting steps, three-model list in a non-default order, ragged tail included."""
+def test_v11_lean_and_general_kernels_agree(hh, ret, dtype):
+    """fishing-v11 takes the lean step kernel too (growth function per env: the wave regroups its envs by kind through
+    LDS; the kinds are redrawn at every auto-reset) -- exact instantiations in float32, the catch-all's one-tile form in
+    float64 (round 3; the general kernel before): same bits as the general kernel on every stream and on the kind array
+    over 14 auto-resetting steps, three-model list in a non-default order, ragged tail included."""
     import torch
     n = 1024 * 6 + 13
     lib = __import__("gym_fishing_amd")._capi.lib()
     table = [dict(d, sigma=0.1) for d in fo.V11_TABLE]
     kw = dict(sigma=0.1, Tmax=4, auto_reset=True, models=[4, 0, 3], zoo_table=table)
     pa, pb = hh.params(fo.MODEL_V11, **kw), hh.params(fo.MODEL_V11, general=True, **kw)
-    A, B = (hh.State(n, np.float32, fo.MODEL_V11, np.zeros(n), ep_return=ret, model_idx=np.zeros(n, np.int32)) for _ in range(2))
-    assert hh.kernel_name(pa, n, A.buffers(A.obs)) == "fishing::step_kernel_lean<float, 105, %d>" % (8198 if ret else 8194)
-    assert hh.kernel_name(pb, n, B.buffers(B.obs)) == "fishing::step_kernel<float, 105>"
+    A, B = (hh.State(n, dtype, fo.MODEL_V11, np.zeros(n), ep_return=ret, model_idx=np.zeros(n, np.int32)) for _ in range(2))
+    f32 = dtype == np.float32
+    assert hh.kernel_name(pa, n, A.buffers(A.obs), dtype) == ("fishing::step_kernel_lean<float, 105, %d>" % (8198 if ret else 8194) if f32
+                                                               else "fishing::step_kernel_lean<double, 105, 11391>")
+    assert hh.kernel_name(pb, n, B.buffers(B.obs), dtype) == "fishing::step_kernel<%s, 105>" % ("float" if f32 else "double")
+    step = lib.fishing_step_f32 if f32 else lib.fishing_step_f64
     A.reset(pa, seed=5, env_offset=12)
     B.reset(pb, seed=5, env_offset=12)
     assert len(set(A.model_idx.cpu().tolist())) == 3
@@ -375,11 +380,11 @@ def test_v11_lean_and_general_kernels_agree(hh, ret):
     for s in range(14):
         a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
         for st, p in ((A, pa), (B, pb)):
-            assert lib.fishing_step_f32(p, n, 12, st.buffers(a), 5, s, None) == 0
+            assert step(p, n, 12, st.buffers(a), 5, s, None) == 0
         torch.cuda.synchronize()
         for name in ("obs", "reward", "done", "t", "model_idx") + (("ep_return",) if ret else ()):
             x, y = getattr(A, name), getattr(B, name)
-            it = {1: torch.uint8, 4: torch.int32}[x.element_size()]
+            it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]
             assert torch.equal(x.view(it), y.view(it)), (name, s)
     if ret:
         ra, rb = A.record(), B.record()
