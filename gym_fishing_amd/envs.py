@@ -547,6 +547,13 @@ class BaseFishingEnv(_gym_env_base()):
         for k in self._STATE_TENSORS:
             if k in sd and getattr(self, k) is None and k != "_counter" and not (k in ("_r_arr", "_K_arr") and v4_arrays):
                 raise ValueError("state has %s but this env was built without it" % k)
+            # sizes too: a state of another batch size must not get as far as the first copy_.  (return_partials grew with
+            # ABI 5 for batches beyond 2^22 envs: an older, shorter buffer loads into the first slots -- the record is
+            # the sum over slots -- a longer one cannot.)
+            if k in sd and getattr(self, k) is not None and k != "_counter":
+                have, got = getattr(self, k).numel(), sd[k].numel()
+                if got != have and not (k == "_partials" and got < have):
+                    raise ValueError("state's %s has %d elements, this env's %d" % (k, got, have))
         if self._host_mapped:
             torch.cuda.current_stream(self.device).synchronize()
         if self._per_env:                       # fishing-v4: same parameter mode as the saved env
@@ -564,6 +571,9 @@ class BaseFishingEnv(_gym_env_base()):
                     self.enable_graph_replay()
                 if k == "_counter":         # (format 1 kept the step counter alone; the origin words follow _origin below)
                     self._counter[:sd[k].numel()].copy_(sd[k])
+                elif k == "_partials" and sd[k].numel() < self._partials.numel():
+                    self._partials.zero_()
+                    self._partials[:sd[k].numel()].copy_(sd[k])
                 else:
                     getattr(self, k).copy_(sd[k])
         self._seed, self._step_count, self._reset_count = sd["seed"], sd["step_count"], sd["reset_count"]

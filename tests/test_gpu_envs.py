@@ -726,6 +726,30 @@ def test_state_dict_resume_is_bit_exact(gf):
     assert want == got
 
 
+def test_load_state_dict_checks_sizes_before_it_changes_anything(gf):
+    """A state of another batch size is refused before the first field changes (the env keeps running as it was); a
+    return_partials buffer shorter than the env's -- written before the buffer grew with the batch (ABI 5) -- loads
+    into the first slots, the rest zero: the record is the sum over slots."""
+    import torch
+    a = gf.make("fishing-v1", sigma=0.1, num_envs=4096, seed=8, Tmax=5, track_returns=True)
+    a.reset()
+    acts = torch.rand((4, 4096), device="cuda") * 2 - 1
+    a.step_many(acts, 12)
+    sd = a.state_dict()
+    b = gf.make("fishing-v1", sigma=0.1, num_envs=2048, seed=8, Tmax=5, track_returns=True)
+    b.reset()
+    before = (b.state.clone(), b._step_count, b._seed)
+    with pytest.raises(ValueError, match="elements"):
+        b.load_state_dict(sd)
+    assert torch.equal(b.state, before[0]) and (b._step_count, b._seed) == before[1:]
+    short = dict(sd)
+    short["_partials"] = sd["_partials"][:4 * 1024].clone()       # (only the first four slots of a 4096-env batch are ever written)
+    c = gf.make("fishing-v1", sigma=0.1, num_envs=4096, seed=1, Tmax=5, track_returns=True)
+    c._partials.fill_(7.0)
+    c.load_state_dict(short)
+    assert c.episode_stats() == a.episode_stats()
+
+
 def test_bench_contract_json_line(gf):
     """bench.py prints exactly ONE JSON line with the contract's keys (small run, no CPU baseline)."""
     import json
