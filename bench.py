@@ -406,11 +406,18 @@ def main():
     env.reset()
     actions = make_actions(torch, cfg, n, RING, rank * n)
 
+    barrier_first = use_dist and backend == "nccl" and os.environ.get("FISHING_BENCH_BARRIER_FIRST", "1") == "1"
+
     def sync_all():
-        torch.cuda.synchronize()
+        # barrier + synchronize.  RCCL's barrier is a collective on the device, ordered behind everything this rank has
+        # enqueued, and torch blocks the host until it has run: enqueued straight behind the launches its launch latency
+        # hides under them (one host <-> device round trip per bracket instead of two).  A host-side barrier (gloo
+        # rehearsal) says nothing about the device, so there the device is drained first.
+        if use_dist and not barrier_first:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
 
     spin_ms, spin_launches = spin_up(torch, env, actions, args.spinup_ms)
     env.step_many(actions, args.warmup)
