@@ -746,6 +746,63 @@ def test_randomised_requests_agree_across_dispatch_general_and_fused(hh, trial):
             assert ra[2] == rc[2] and ra[3] == rc[3] and np.allclose(ra[:2], rc[:2], rtol=1e-12, equal_nan=True), what
 
 
+@pytest.mark.parametrize("trial", range(10))
+def test_randomised_requests_beyond_4096_tiles(hh, trial):
+    """Round 3: a workgroup per tile at every size.  Ten random requests at N in (2^22, 1.5 * 2^23] -- 4097 .. 12288 tiles
+    + a ragged tail: the exact one-tile forms, the catch-alls' (terminal observations, ballot words, sigma array),
+    float64 on two envs per thread (up to ~6600 tiles) and on four -- three steps each (the XCD-aware zig-zag walks an
+    odd and an even one) against the general kernel: every stream bit for bit, the return records to double rounding."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    rng = np.random.default_rng(7700 + trial)
+    kind = ["v1", "v0", "v2", "v4d", "v9", "v1", "v4s", "v1", "v2", "v10"][trial]
+    model = {"v0": fo.MODEL_V0, "v1": fo.MODEL_V1, "v2": fo.MODEL_V2, "v4s": fo.MODEL_V4, "v4d": fo.MODEL_V4, "v9": fo.MODEL_V9,
+             "v10": fo.MODEL_V10}[kind]
+    dtype = np.float64 if trial in (5, 7, 8) else np.float32
+    n = int(rng.integers((1 << 22) + 1, 3 << 22))
+    ret, sigarr = bool(rng.random() < 0.7), bool(rng.random() < 0.3)
+    term, bits = bool(rng.random() < 0.4), bool(rng.random() < 0.3)
+    derived = kind == "v4d"
+    T, off, seed, c0 = 3, 4 * int(rng.integers(0, 50)), int(rng.integers(1, 1 << 40)), int(rng.integers(0, 300))
+    kw = dict(sigma=0.12, C=0.5, Tmax=2, sigma_p=0.15, auto_reset=True)
+    if kind in ("v0", "v1", "v2"):
+        kw["K"] = float(rng.choice([1.0, 2.0, 1.5]))
+        kw["x0"] = 0.75 * kw["K"]
+    if kind == "v10":
+        kw.update(r=0.8, alpha=-0.01)
+    per_env, drift = model == fo.MODEL_V4, model == fo.MODEL_V10
+    sig = rng.uniform(0.02, 0.2, n) if sigarr else None
+    g = torch.Generator(device="cuda").manual_seed(trial)
+    row = -(-n // 4) * 4            # (every action batch 16-byte aligned)
+    ring = (torch.randint(0, 100, (T, row), device="cuda", generator=g, dtype=torch.int32) if model == fo.MODEL_V0
+            else (torch.rand((T, row), device="cuda", generator=g) * 1.45 - 1.15).float())[:, :n]
+    fn = lib.fishing_step_f32 if dtype == np.float32 else lib.fishing_step_f64
+    outs, names_seen = [], []
+    for general in (False, True):
+        p = hh.params(model, general=general, derived=derived, origin=(c0, 0), **kw)
+        st = hh.State(n, dtype, model, np.zeros(n), r=(np.full(n, kw.get("r", 0.3)) if (per_env and not derived) or drift else None),
+                      K=np.full(n, 1.0) if per_env and not derived else None, sigma=sig, ep_return=ret, terminal=term, done_bits=bits)
+        st.reset(p, seed=seed, counter=0, env_offset=off)
+        names_seen.append(hh.kernel_name(p, n, st.buffers(ring[0]), dtype))
+        for s in range(T):
+            assert fn(p, n, off, st.buffers(ring[s]), seed, c0 + s, None) == 0
+        torch.cuda.synchronize()
+        outs.append(st)
+    A, B = outs
+    what = (kind, np.dtype(dtype).name, n, ret, sigarr, term, bits, names_seen)
+    assert "step_kernel_lean" in names_seen[0] and "step_kernel<" in names_seen[1], what
+    names = (["obs", "t", "reward", "done"] + (["ep_return"] if ret else []) + (["K", "r"] if per_env and not derived else [])
+             + (["r"] if drift else []) + (["terminal"] if term else []) + (["done_bits"] if bits else []))
+    for name in names:
+        assert _bits_equal(getattr(A, name), getattr(B, name)), (name,) + what
+    if ret:
+        ra, rb = A.record(), B.record()
+        assert ra[2] == rb[2] > 0 and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12, equal_nan=True), what
+    del A, B, outs
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("where", ["step_counter_crosses_2^32", "env_index_crosses_2^32", "both_far_beyond_2^32"])
 def test_v4_derived_parameters_across_the_32_bit_boundaries(hh, where):
     """The derivation does its integer work in 32 bits while every counter and env index of a tile fits, in 64 bits
