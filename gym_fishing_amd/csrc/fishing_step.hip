@@ -312,7 +312,7 @@ constexpr int DRIFT = 1 << 9;      // fishing-v10: per-env r, drifting by alpha 
 constexpr int OPT = 1 << 10;
 constexpr int LATCH = 1 << 11;     // RET without auto-reset: a finished env that is stepped on must not enter the record
                                    // again.  Catch-all only -- the exact RET instantiations are the auto-reset ones.
-constexpr int ONE = 1 << 13;       // one tile per workgroup (grid == ntiles; every four-envs-per-thread launch): no tile loop, and with RET the
+constexpr int ONE = 1 << 13;       // one tile per workgroup (grid == ntiles; every lean launch since round 3): no tile loop, and with RET the
                                    // return record -- workgroup reduction + its atomic -- is issued BEFORE the tile's stores, so the
                                    // atomic's round trip runs under theirs.  Exact instantiations and catch-alls alike.  Per step at N = 2^19 / 2^20 /
                                    // 2^21, back to back: 4.75 -> 4.09, 6.15 -> 5.71, 9.78 -> 8.15 us (profiles/r03_small_n/).
@@ -374,10 +374,10 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 // E = envs per thread: 4 everywhere (16-byte accesses on the 4-byte streams) except the float64 parity layout at
 // cache-resident sizes, which runs E = 2 -- 16 bytes per lane on ITS streams instead of 32 (two 16-byte accesses, half
 // of each 64-byte line per instruction): a copy over the same streams takes 23.5 instead of 27.2 us at N = 2^22
-// (profiles/r02_f64_access_shape.jsonl).  A workgroup's tile is 256 * E envs; the lane pair that shares an env quad
-// computes the quad's Philox block twice and keeps one Box-Muller pair each.
+// (profiles/r02_f64_access_shape.jsonl).  A workgroup is 1024 / E threads on one 1024-env tile; the lane pair that shares
+// an env quad computes the quad's Philox block twice and keeps one Box-Muller pair each.
 template <typename T, int MODEL, int F, int E = 4>
-__global__ void __launch_bounds__(256) FISHING_LEAN_ATTRS
+__global__ void __launch_bounds__(1024 / E) FISHING_LEAN_ATTRS
 step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p, T* const ep_return_p, const int64_t n_live_p,
                  const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_t ntiles, const uint64_t env_offset,
                  const uint64_t seed, const uint64_t step_counter_arg) {
@@ -400,10 +400,10 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     static_assert(!(F & feat::DERIVED) || kPerEnv, "DERIVED is fishing-v4");
     static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
-    static_assert(!(F & feat::ONE) || E == 4, "ONE: whole 1024-env tiles");
-    constexpr bool kOne = (F & feat::ONE) != 0;
+    static_assert((F & feat::ONE) != 0, "every lean form is a one-tile form: a workgroup of 1024 / E threads per 1024-env tile");
     static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
-    constexpr int kTileEnvs = 256 * E;
+    constexpr int kThreads = 1024 / E;
+    constexpr int kTileEnvs = 1024;
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || ep_return_p != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -444,19 +444,18 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         if constexpr ((F & feat::DRIFT) != 0) asm volatile("" ::"s"(a.r), "s"(a.alpha));
     }
     };
-    // (tile-loop forms: up front.  One-tile forms: behind the tile's loads, which need only the preloaded arguments --
-    // FISHING_LEAN_BATCH_ARGS == 2 puts it up front there too, for A/B)
-    if constexpr (!kOne || FISHING_LEAN_BATCH_ARGS == 2) batch_args();
-    // graph-replay mode keeps the step counter in device memory (wave-uniform: one scalar load).  With a tile loop it is
-    // read here; a one-tile launch reads it AFTER issuing the tile's loads, which do not depend on it.
+    // (behind the tile's loads, which need only the preloaded arguments -- FISHING_LEAN_BATCH_ARGS == 2 puts it up front, for A/B)
+    if constexpr (FISHING_LEAN_BATCH_ARGS == 2) batch_args();
+    // graph-replay mode keeps the step counter in device memory (wave-uniform: one scalar load), read AFTER the tile's
+    // loads are issued, which do not depend on it
     auto read_counter = [&]() -> uint64_t {
         if (!a.counter) return step_counter_arg;
         uint64_t c;
         asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c) : "s"(a.counter) : "memory");
         return c + step_counter_arg;
     };
-    // (a one-tile form that walks zig-zag needs the step's parity for its tile index: it reads the counter up front too)
-    uint64_t step_counter = (kOne && !ZZ) ? step_counter_arg : read_counter();
+    // (... unless the launch walks zig-zag: the tile index needs the step's parity)
+    uint64_t step_counter = !ZZ ? step_counter_arg : read_counter();
     uint64_t origin_step = a.origin_step, origin_counter = a.origin_counter;
     if (DERIVED) device_origin(a.counter, origin_step, origin_counter);
     // an exact RET instantiation is only ever launched with auto-reset on (the dispatch sends RET without it to the
@@ -481,7 +480,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             const int64_t whole = ntiles & ~(int64_t)7;       // (a last partial group of < 8 tiles keeps its place)
             if (it < whole) tile = (whole - 8 - (it & ~(int64_t)7)) + (it & 7);
         }
-        const int64_t base = (tile * 256 + threadIdx.x) * E;
+        const int64_t base = (tile * kThreads + threadIdx.x) * E;
         // FISHING_FLAG_PADDED_TILES: the state buffers have room for whole tiles, so a batch that is not a multiple of 1024
         // envs still runs in this ONE launch (no second, one-workgroup launch for the tail: 3.7-4.2 us per step).  The
         // envs behind the last one are scratch: stepped like any other, but they never finish (neither recorded nor
@@ -492,10 +491,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         const uint32_t left32 = tile_left >= kTileEnvs ? (uint32_t)kTileEnvs : (tile_left > 0 ? (uint32_t)tile_left : 0u);
         const uint32_t lane_env = threadIdx.x * (uint32_t)E;
         const bool live = lane_env < left32;
-        // (E = 4: a padded tile holds at least one live quad, so the last one is tile-relative -- one 32-bit select;
-        // an E = 2 half-tile may be scratch altogether)
-        const int64_t cbase = (E == 4) ? tile * kTileEnvs + (int64_t)(live ? lane_env : left32 - (uint32_t)E)
-                                       : (live ? base : n_live_p - E);
+        // (a padded tile holds at least one live quad, so the last live thread's envs are tile-relative -- one 32-bit select)
+        const int64_t cbase = tile * kTileEnvs + (int64_t)(live ? lane_env : left32 - (uint32_t)E);
         // The Philox round keys (seed + i * Weyl) are wave-uniform; hoisted out of this loop they sit in 20-30 SGPRs
         // for the whole kernel, which pushes the fishing-v4 variants (two generators) past 100 SGPRs = 7 instead of
         // 8 waves per SIMD.  Laundering the seed per tile keeps the key schedule next to its rounds (a scalar add
@@ -600,10 +597,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // the loads above must be in flight BEFORE the ~100-instruction Philox block starts: without
         // this fence the scheduler hoists the (independent) generator above them in some variants
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kOne && FISHING_LEAN_BATCH_ARGS == 1) batch_args();
-        if constexpr (kOne) {
-            if (!ZZ) step_counter = read_counter();
-        }
+        if constexpr (FISHING_LEAN_BATCH_ARGS == 1) batch_args();
+        if (!ZZ) step_counter = read_counter();
         if (noise == kNoisePhilox) {
             float zq[E];
             if constexpr (E == 4) {
@@ -725,11 +720,11 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             if (BITS) {         // the wave's 64 * E flags as E 64-bit words (ballots, no LDS)
                 const int lane = threadIdx.x & (kWave - 1);
                 const uint64_t word = ballot_tile_words<E>(nibble, lane);
-                const int64_t wave_env0 = (tile * 256 + (threadIdx.x & ~(kWave - 1))) * E;
+                const int64_t wave_env0 = (tile * kThreads + (threadIdx.x & ~(kWave - 1))) * E;
                 if (lane < E) a.done_bits[(wave_env0 >> 6) + lane] = word;
             }
         };
-        if (!(kOne && RET)) store_outputs();
+        if (!RET) store_outputs();
         bool lane_done = false;
 #pragma unroll
         for (int j = 0; j < E; ++j) lane_done |= dn[j];
@@ -744,10 +739,9 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #pragma unroll
                 for (int j = 0; j < E; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
             }
-            if constexpr (kOne) {       // the record's atomic first, the tile's stores behind it
-                if (a.partials) add_block_partials<4, 4>(acc, a.partials);
-                store_outputs();
-            }
+            // the record's atomic first, the tile's stores behind it
+            if (a.partials) add_block_partials<kThreads / kWave, kThreads / kWave>(acc, a.partials);
+            store_outputs();
             VecE<T, E> qe;
 #pragma unroll
             for (int j = 0; j < E; ++j) qe.v[j] = er[j];
@@ -811,14 +805,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         }
     };
 
-    if constexpr (kOne) {
-        do_tile(blockIdx.x);
-    } else {
-        for (int64_t it = blockIdx.x; it < ntiles; it += gridDim.x) do_tile(it);
-        if (RET) {
-            if (a.partials) add_block_partials<4, 4>(acc, a.partials);
-        }
-    }
+    do_tile(blockIdx.x);
 }
 
 // ---------------------------------------------------------------- host side
@@ -940,12 +927,10 @@ int lean_launch(const LeanCall<T>& c) {
     }
     LeanExtra<T, MODEL> ex{};
     if constexpr (MODEL == kModelZooMixed) ex = *static_cast<const LeanMixedArgs<T>*>(c.extra);
-    // (c.ntiles counts 1024-env tiles; an E = 2 workgroup covers half of one)
-    const int64_t nt = c.ntiles * (4 / E);
-    // E = 4: a workgroup per tile (feat::ONE).  E = 2 (float64, cache-resident sizes only): half-tiles in a loop, on at
-    // most kMaxBlocks workgroups -- a batch never touches more return_partials slots than fishing_partials_slots() promises
-    static_assert((E == 4) == ((F & feat::ONE) != 0), "four envs per thread <=> one tile per workgroup");
-    const int64_t nb = E == 4 ? nt : std::min(nt, (int64_t)kMaxBlocks);
+    // a workgroup of 1024 / E threads per 1024-env tile (feat::ONE): 256 x 4 envs, or 512 x 2 for the float64 layout at
+    // cache-resident sizes; one return_partials slot per tile either way
+    static_assert((F & feat::ONE) != 0, "every lean form is a one-tile form");
+    const int64_t nt = c.ntiles, nb = c.ntiles;
     // (FISHING_X_DYN_LDS, experiments only: unused dynamic LDS per workgroup caps the workgroups a CU holds at once.  Running
     // the one-round grids of N = 2^20 .. 2^22 in several rounds never helped -- fishing-v4 at 2^21 13.05 us with 8 workgroups
     // per CU, 14.6 with 4, 16.5 with 2: profiles/r03_occupancy_cap.jsonl)
@@ -954,7 +939,7 @@ int lean_launch(const LeanCall<T>& c) {
 #else
     constexpr size_t x_lds = 0;
 #endif
-    return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)nb, 256, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
+    return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)nb, 1024 / E, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
                              c.a.n_live, c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
 }
 
@@ -1042,14 +1027,14 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
         if (c.two_per_thread) {
             if constexpr (!is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
                 switch (req) {
-                    case (P | KP2): return lean_launch<T, MODEL, (P | KP2), 2>(c);
-                    case (P | KP2 | RET): return lean_launch<T, MODEL, (P | KP2 | RET), 2>(c);
+                    case (P | KP2): return lean_launch<T, MODEL, (P | KP2 | ONE), 2>(c);
+                    case (P | KP2 | RET): return lean_launch<T, MODEL, (P | KP2 | RET | ONE), 2>(c);
                     default: break;
                 }
             }
             // (the catch-all pays for E = 2 with a third more instructions per env -- the lane pair's second Philox
             // block, its option tests twice: worth it only from ~110 MB per step on, N = 2^22 and 2^21 with returns)
-            if (c.two_per_thread_any) return lean_launch<T, MODEL, catch_all_mask<MODEL>(), 2>(c);
+            if (c.two_per_thread_any) return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE, 2>(c);
         }
     }
     return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE>(c);
