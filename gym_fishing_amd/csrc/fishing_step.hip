@@ -53,8 +53,7 @@ namespace fishing {
 #define FISHING_XZZ_MIN_BYTES (100ll << 20)             // ... every lean kernel walks zig-zag (run-time flag zz_rt)
 #endif
 #ifndef FISHING_F64_E2_MAX_BYTES
-#define FISHING_F64_E2_MAX_BYTES (250ll << 20)      // float64: two envs per thread below this many bytes per step ...
-#define FISHING_F64_E2_MIN_BYTES (105ll << 20)      // ... the catch-alls only above this many (profiles/r03_f64_two_per_thread.jsonl)
+#define FISHING_F64_E2_MAX_BYTES (512ll << 20)      // float64: two envs per thread below this many bytes per step
 #endif
 #ifndef FISHING_STEP_MAXTHREADS
 #define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
@@ -913,8 +912,7 @@ struct LeanCall {
     hipStream_t s;
     std::string* name;
     const void* extra;       // LeanMixedArgs<T> for fishing-v11, unused otherwise
-    bool two_per_thread;     // float64: E = 2 for the exact instantiations (streams cache-resident)
-    bool two_per_thread_any; //          ... and for the catch-all
+    bool two_per_thread;     // float64: E = 2 (512-thread workgroups)
 };
 
 template <typename T, int MODEL, int F, int E = 4>
@@ -1020,7 +1018,7 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
     }
 #endif
 #undef FISHING_LEAN_CASE
-    // float64: two envs per thread while a step's streams sit in the Infinity Cache (see the kernel).  Relieved of the
+    // float64: two envs per thread up to ~512 MB per step (see the kernel and step_dispatch_range).  Relieved of the
     // 32-byte access shape the layout feels its arithmetic -- two IEEE float64 divisions per env, ~25 instructions each --
     // so fishing-v0/v1/v2 with K a power of two have exact instantiations there (no division, no option tests)
     if constexpr (sizeof(T) == 8 && MODEL != kModelZooMixed) {
@@ -1032,9 +1030,7 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
                     default: break;
                 }
             }
-            // (the catch-all pays for E = 2 with a third more instructions per env -- the lane pair's second Philox
-            // block, its option tests twice: worth it only from ~110 MB per step on, N = 2^22 and 2^21 with returns)
-            if (c.two_per_thread_any) return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE, 2>(c);
+            return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE, 2>(c);
         }
     }
     return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE>(c);
@@ -1107,11 +1103,12 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
             mixed.zoo[k] = pt.zoo[k];
         }
     }
-    // float64 with two envs per thread while one step's streams fit the 256 MiB Infinity Cache with room to spare
-    // (N < 2^23 for the 37-byte layout); four per thread beyond, where the access shape stops mattering
+    // float64 with two envs per thread up to ~512 MB per step (N <= 2^23); four per thread beyond, where the access shape
+    // stops mattering.  As 512-thread one-tile workgroups the two-per-thread forms win from the smallest batch on -- exact
+    // and catch-all alike (the tile-loop form's catch-all only paid from ~105 MB per step) -- and at 2^23 too: bare 47-50 ->
+    // 42.6 us, with returns 67-69 -> 66.3; 2^24 equal, 2^25 with returns 4 % behind (profiles/r03_f64_one_tile_512_threads.jsonl)
     const bool two = sizeof(T) == 8 && step_bytes < FISHING_F64_E2_MAX_BYTES && !p->launch_blocks;
-    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, s, name, &mixed, two,
-                           two && step_bytes >= FISHING_F64_E2_MIN_BYTES};
+    const LeanCall<T> call{a, ntiles, (uint64_t)env_offset, seed, step_counter, s, name, &mixed, two};
     const int rc = with_model_tag(p->model, [&](auto tag) {
         constexpr int kTag = decltype(tag)::value;
         return lean_dispatch<T, kTag>(req, call);

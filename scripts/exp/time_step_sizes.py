@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import gym_fishing_amd as gf
 CASES = (("f64_v1", "fishing-v1", dict(sigma=0.1, dtype=torch.float64), (22, 23, 24, 25)),
          ("f64_v1_ret", "fishing-v1", dict(sigma=0.1, dtype=torch.float64, track_returns=True), (22, 23, 24, 25)),
+         ("f64_v1_K1.5_ret", "fishing-v1", dict(sigma=0.1, K=1.5, dtype=torch.float64, track_returns=True), (20, 22, 24)),
          ("f32_v1_term_ret", "fishing-v1", dict(sigma=0.1, track_returns=True, record_terminal_obs=True), (22, 23, 24, 25, 26)),
          ("f32_v1_K1.5_ret", "fishing-v1", dict(sigma=0.1, K=1.5, track_returns=True), (23, 24, 26)),
          ("f32_v4_stored_sig_ret", "fishing-v4", dict(sigma=0.05, derived_params=False, track_returns=True), (23, 24)))
