@@ -113,6 +113,28 @@ population_draw_kernel(const ParamsT<T> p, const int kind, const int64_t n, cons
     }
 }
 
+// ... and under fishing-v11 (ModelUncertainty.population_draw, growth_models.py:190-194): element i grows under the growth
+// function model_idx[i] with THAT function's parameter set.  Five wave-uniform passes, each over the lanes of its kind
+// (the parameter sets stay scalar operands); a kind outside [0, 5) counts as Beverton-Holt, as in the step kernels.
+template <typename T>
+__global__ void __launch_bounds__(256)
+population_draw_mixed_kernel(const ParamsT<T> p, const int64_t n, const T* __restrict__ x_in, const T* __restrict__ z,
+                             const int32_t* __restrict__ model_idx, T* __restrict__ x_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int kind = model_idx[i];
+        kind = (kind >= 0 && kind < FISHING_N_KINDS) ? kind : FISHING_KIND_BEVERTON_HOLT;
+        const T x = x_in[i], zi = z ? z[i] : (T)0;
+        T out = (T)0;
+        if (kind == FISHING_KIND_ALLEN) out = zoo_population_draw<T, FISHING_KIND_ALLEN>(kind, x, zi, p.zoo[FISHING_KIND_ALLEN]);
+        if (kind == FISHING_KIND_BEVERTON_HOLT) out = zoo_population_draw<T, FISHING_KIND_BEVERTON_HOLT>(kind, x, zi, p.zoo[FISHING_KIND_BEVERTON_HOLT]);
+        if (kind == FISHING_KIND_MYERS) out = zoo_population_draw<T, FISHING_KIND_MYERS>(kind, x, zi, p.zoo[FISHING_KIND_MYERS]);
+        if (kind == FISHING_KIND_MAY) out = zoo_population_draw<T, FISHING_KIND_MAY>(kind, x, zi, p.zoo[FISHING_KIND_MAY]);
+        if (kind == FISHING_KIND_RICKER) out = zoo_population_draw<T, FISHING_KIND_RICKER>(kind, x, zi, p.zoo[FISHING_KIND_RICKER]);
+        x_out[i] = out;
+    }
+}
+
 __global__ void counter_add_kernel(uint64_t* counter, uint64_t delta) { *counter += delta; }
 
 __global__ void __launch_bounds__(256)
@@ -165,6 +187,24 @@ reset_normals_kernel(const int64_t n, const uint64_t env_offset, const uint64_t 
     }
 }
 
+// test hook: the library's own float64 / float32 elementary functions, one value per thread
+__global__ void __launch_bounds__(256)
+math_kernel(const int64_t n, const int fn, const double* __restrict__ in, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = in[i];
+        double r;
+        switch (fn) {          // wave-uniform
+            case FISHING_MATH_LOG_F64: r = log_f64(v); break;
+            case FISHING_MATH_EXP_F64: r = exp_f64(v); break;
+            case FISHING_MATH_LOG_MID: r = log_mid(v); break;
+            case FISHING_MATH_EXP_MID: r = exp_mid(v); break;
+            default: r = (double)expm1_f32((float)v); break;
+        }
+        out[i] = r;
+    }
+}
+
 static inline int grid_for(int64_t n, int cap) {
     const int64_t nb = (n + 255) / 256;
     return (int)std::max<int64_t>(1, std::min<int64_t>(nb, cap));
@@ -211,14 +251,21 @@ int v4_params_impl(const FishingParams* p, int64_t n, int64_t env_offset, const 
 }
 
 template <typename T>
-int population_draw_impl(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
-                         fishing_stream_t stream) {
+int population_draw_impl(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
+                         void* x_out, fishing_stream_t stream) {
     if (!p || !x_in || !x_out) return FISHING_ERR_NULL;
     if (n < 0) return FISHING_ERR_SIZE;
+    if (!is_core_model(p->model) && !is_zoo_model(p->model)) return FISHING_ERR_MODEL;
+    // the growth function per element is fishing-v11's: there it is required, anywhere else there is nothing to select
+    if (p->model == FISHING_MODEL_V11 && !model_idx) return FISHING_ERR_NULL;
+    if (p->model != FISHING_MODEL_V11 && model_idx) return FISHING_ERR_UNSUPPORTED;
     if (n == 0) return FISHING_OK;
     const ParamsT<T> pt = narrow_params<T>(*p);
     const int blocks = grid_for(n, 2048);
     hipStream_t s = (hipStream_t)stream;
+    if (p->model == FISHING_MODEL_V11)
+        return launch_kernel(population_draw_mixed_kernel<T>, blocks, 256, s, pt, n, (const T*)x_in, (const T*)z, model_idx,
+                             (T*)x_out);
     if (is_zoo_model(p->model) && p->model != FISHING_MODEL_V11)
         return launch_kernel(population_draw_kernel<T, kModelZoo>, blocks, 256, s, pt, kind_of_model(p->model), n,
                              (const T*)x_in, (const T*)z, (T*)x_out);
@@ -272,13 +319,13 @@ int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset,
     return fishing::v4_params_impl<double>(p, n, env_offset, t, K_out, r_out, seed, step_counter, stream);
 }
 
-int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
-                                fishing_stream_t stream) {
-    return fishing::population_draw_impl<float>(p, n, x_in, z, x_out, stream);
+int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
+                                void* x_out, fishing_stream_t stream) {
+    return fishing::population_draw_impl<float>(p, n, x_in, z, model_idx, x_out, stream);
 }
-int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
-                                fishing_stream_t stream) {
-    return fishing::population_draw_impl<double>(p, n, x_in, z, x_out, stream);
+int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
+                                void* x_out, fishing_stream_t stream) {
+    return fishing::population_draw_impl<double>(p, n, x_in, z, model_idx, x_out, stream);
 }
 
 int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stream) {
@@ -322,6 +369,13 @@ int fishing_step_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint6
     if (n == 0) return FISHING_OK;
     return fishing::launch_kernel(fishing::step_normals_kernel, fishing::grid_for(n, fishing::kMaxBlocks), 256,
                                   (hipStream_t)stream, n, (uint64_t)env_offset, seed, counter, z);
+}
+
+int fishing_math_f64(int64_t n, int32_t fn, const double* in, double* out, fishing_stream_t stream) {
+    if (n < 0 || fn < FISHING_MATH_LOG_F64 || fn > FISHING_MATH_EXPM1_F32) return FISHING_ERR_SIZE;
+    if (!in || !out) return FISHING_ERR_NULL;
+    if (n == 0) return FISHING_OK;
+    return fishing::launch_kernel(fishing::math_kernel, fishing::grid_for(n, 2048), 256, (hipStream_t)stream, n, (int)fn, in, out);
 }
 
 int fishing_reset_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,

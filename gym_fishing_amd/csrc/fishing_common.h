@@ -155,28 +155,46 @@ constexpr int kModelZooMixed = kModelZoo + FISHING_N_KINDS;
 constexpr int kModelZooRT = kModelZooMixed + 1;    // general kernel: one growth function, kind decided at run time
 constexpr bool is_zoo_tag(int model_tag) { return model_tag >= kModelZoo && model_tag <= kModelZooRT; }
 
+// One growth function's parameter set (FishingGrowthParams) plus per-launch constants evaluated once on the host in
+// double (libm).  Every field is a double whatever the layout T: the float32 kernels evaluate the growth function in float64
+// (zoo_population_draw below), and a float32-rounded r or log(A) alone would cost 3e-8 of the 1e-6 the layout is held to;
+// wave-uniform, so they live in SGPR pairs and only the fields a kernel's growth function reads are ever loaded.
 template <typename T>
-struct GrowthT {                 // FishingGrowthParams narrowed to T
-    T r, K, sigma, C, M, theta, q, b, a;
-    // per-launch constants of the growth functions, evaluated once on the host in double
-    // (libm) instead of once per env on the device:
-    T bq;      // May:            b ** q                       (growth_models.py:238)
-    T logA;    // B-H / Myers:    log(clip(r, 0, inf) + 1) / log(r + 1)   (:222,:225 / :248,:251)
-    T B;       // Beverton-Holt:  clip(K, 0, inf) / clip(r, 0, inf)       (:224)
+struct GrowthT {
+    double r, K, sigma, C, M, theta, q, b, a;
+    double bq;      // May:            b ** q                       (growth_models.py:238)
+    double logA;    // B-H / Myers:    log(clip(r, 0, inf) + 1) / log(r + 1)   (:222,:225 / :248,:251)
+    double B;       // Beverton-Holt:  clip(K, 0, inf) / clip(r, 0, inf)       (:224)
+    // the algebraic form of the float32 layout (FISHING_ZOO_F32_MATH 2):
+    double A;       // B-H: clip(r, 0, inf) + 1;  Myers: r + 1
+    double invK;    // 1 / K        (Allen, Ricker;  B-H under drift: 1 / clip(K, 0, inf))
+    double invM;    // 1 / M        (May, Myers)
+    double invB;    // B-H: clip(r, 0, inf) / clip(K, 0, inf) = 1 / B
+    double gc;      // Allen: r (1 - C) / K, the coefficient of (1 - x / K) in mu - log x
+    int32_t ipow;   // May's q / Myers' theta when it is one of 1, 2, 3, 4 (x ** e by multiplication), else 0
 };
 
 template <typename T>
 inline GrowthT<T> make_growth(double r, double K, double sigma, double C, double M, double theta, double q,
-                              double b, double a, bool beverton_holt) {
-    GrowthT<T> g{(T)r, (T)K, (T)sigma, (T)C, (T)M, (T)theta, (T)q, (T)b, (T)a, (T)0, (T)0, (T)0};
-    g.bq = (T)std::pow(b, q);
-    if (beverton_holt) {
+                              double b, double a, int kind) {
+    GrowthT<T> g{r, K, sigma, C, M, theta, q, b, a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
+    g.gc = r * (1.0 - C) / K;
+    g.bq = std::pow(b, q);
+    g.invK = 1.0 / K;
+    g.invM = 1.0 / M;
+    if (kind == FISHING_KIND_BEVERTON_HOLT) {
         const double rc = r < 0 ? 0 : r, Kc = K < 0 ? 0 : K;
-        g.logA = (T)std::log(rc + 1.0);
-        g.B = (T)(Kc / rc);
+        g.logA = std::log(rc + 1.0);
+        g.A = rc + 1.0;
+        g.B = Kc / rc;
+        g.invB = rc / Kc;
+        g.invK = 1.0 / Kc;
     } else {
-        g.logA = (T)std::log(r + 1.0);
+        g.logA = std::log(r + 1.0);
+        g.A = r + 1.0;
     }
+    const double e = kind == FISHING_KIND_MAY ? q : theta;
+    g.ipow = (e == 1.0 || e == 2.0 || e == 3.0 || e == 4.0) ? (int32_t)e : 0;
     return g;
 }
 
@@ -238,14 +256,13 @@ inline ParamsT<T> narrow_params(const FishingParams& p) {
     // the host-side constants (pow / log) only where a growth function of the zoo will read them
     q.growth = GrowthT<T>{};
     if (is_zoo_model(p.model) && p.model != FISHING_MODEL_V11)
-        q.growth = make_growth<T>(p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a,
-                                  p.model == FISHING_MODEL_V6 || p.model == FISHING_MODEL_V10);
+        q.growth = make_growth<T>(p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a, kind_of_model(p.model));
     for (int k = 0; k < FISHING_N_KINDS; ++k) {
         q.kinds[k] = p.kinds[k];
         q.zoo[k] = GrowthT<T>{};
         if (p.model == FISHING_MODEL_V11) {
             const FishingGrowthParams& g = p.zoo[k];
-            q.zoo[k] = make_growth<T>(g.r, g.K, g.sigma, g.C, g.M, g.theta, g.q, g.b, g.a, k == FISHING_KIND_BEVERTON_HOLT);
+            q.zoo[k] = make_growth<T>(g.r, g.K, g.sigma, g.C, g.M, g.theta, g.q, g.b, g.a, k);
         }
     }
     return q;
@@ -426,63 +443,439 @@ __device__ __forceinline__ float pow_t<float>(float v, float e) {
     return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(v));    // v_exp_f32 is 2**x
 }
 
+// ---------------------------------------------------------------- the zoo's float32 layout: how the growth function is evaluated
+// The growth functions of fishing-v5..v11 are exp(mu(x) + sigma z) with mu = log(x) + ... : a round trip through log and
+// exp whose O(1) intermediate terms each carry a float32 rounding of 6e-8 when evaluated in float32.  Against the
+// reference's float64 numbers that form lands up to 4.5e-7 off on the reference-held fixtures and 1.06e-6 off (Myers) on a
+// dense sweep of the state space (profiles/r04_zoo_f32_error.json) -- at the edge of the north star's "obs within 1e-6".
+// The float32 kernels therefore evaluate the algebraically equal form WITHOUT the round trip,
+//     x' = pre(x) * exp(g(x, z)):   pre = x,                             g = r (1 - x/K) (1 - C)/K + sigma z    Allen
+//                                   pre = x,                             g = r (1 - x/K) + sigma z              Ricker
+//                                   pre = A x / (1 + x/B),               g = sigma z                            Beverton-Holt
+//                                   pre = A x^theta / (1 + x^theta/M),   g = sigma z                            Myers
+//                                   pre = exp_mu(x)  (NaN when < 0),     g = sigma z                            May
+// whose special values agree with the reference's (x = 0 -> 0, x = inf -> NaN, exp_mu < 0 -> NaN, NaN -> NaN; K, M, B of
+// 0 or inf as IEEE division has them).
+//   FISHING_ZOO_F32_MATH 4 (default): all of it in float32 -- g by fma chains, pre with one <= 1-ulp division (div_f32),
+//       exp on the hardware (v_exp_f32 behind one scaling multiply), one multiply.  No logarithm at all, so faster than
+//       the round trip of rounds 1-3 AND closer to the reference: <= 3.2e-7 on the fixtures, <= 4.7e-7 on the sweep
+//       (the round trip: 4.5e-7 / 1.06e-6); fishing-v5 14.8 us per step at N = 2^22 against 15.3.
+//   3 ("hybrid"): g and expm1(g) in float32 (expm1 by argument reduction + a degree-7 polynomial), pre in float64 (a
+//       handful of multiply-adds and one div_mid), x' = fma(pre, expm1(g), pre) in float64, rounded to float32 ONCE:
+//       <= 2.3e-7 / 2.2e-7; +0-8 % step time, the VALU-bound fishing-v11 rollouts -40 %.
+//   2: everything in float64 (exp_mid, a ~1e-11 polynomial exp): <= 2.3e-7 / 1.4e-7 -- the fixtures' figure is the
+//       float32 rounding of the INPUTS, which no evaluation can remove; +3-10 % step time, fused rollouts at half speed.
+//   1: the round trip in float32 arithmetic with the library's ~1-ulp logf / expf (4.5e-7 / 9.3e-7).
+//   0: the round trip in float32 arithmetic on the hardware transcendentals (rounds 1-3).
+// (every figure: profiles/r04_zoo_f32_error.json, measured by tests/measure_zoo_f32_error.py on builds with
+// -DFISHING_ZOO_F32_MATH=n)
+// The float64 parity layout keeps the reference's round trip (log_f64 / exp_f64 below; 2e-14 against the reference).
+#ifndef FISHING_ZOO_F32_MATH
+#define FISHING_ZOO_F32_MATH 4
+#endif
+
+// a / b to ~1e-14 relative: v_rcp_f32 seed + one Newton step in float64 (5 instructions; the IEEE float64 division is
+// ~25).  Denominators outside float32's comfortable range (zeros, infinities, NaN included) take the IEEE division.
+__device__ __forceinline__ double div_mid(double a, double b) {
+    const double ab = __builtin_fabs(b);
+    if (!(ab > 0x1p-100 && ab < 0x1p100)) return a / b;
+    const double r0 = (double)__builtin_amdgcn_rcpf((float)b);
+    return a * __builtin_fma(__builtin_fma(-b, r0, 1.0), r0, r0);
+}
+// log(v) to ~2e-12 relative for finite v > 0 (0 -> -inf; negatives, inf, NaN, extremes: the library).
+// v = m 2^e with m in [sqrt(1/2), sqrt(2)): log v = e ln2 + 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716,
+// atanh(s) = s (1 + s^2/3 + ... + s^12/13) -- the first omitted term is s^14/15 <= 1.3e-12.
+__device__ __forceinline__ double log_mid(double v) {
+    if (!(v > 0x1p-1000 && v < 0x1p1000) && v != 0.0) return log(v);
+    double m = __builtin_amdgcn_frexp_mant(v);                 // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(v);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double s = div_mid(m - 1.0, m + 1.0);
+    const double s2 = s * s;
+    double q = 1.0 / 13.0;
+    q = __builtin_fma(q, s2, 1.0 / 11.0);
+    q = __builtin_fma(q, s2, 1.0 / 9.0);
+    q = __builtin_fma(q, s2, 1.0 / 7.0);
+    q = __builtin_fma(q, s2, 1.0 / 5.0);
+    q = __builtin_fma(q, s2, 1.0 / 3.0);
+    q = __builtin_fma(q, s2, 1.0);
+    const double r = __builtin_fma((double)e, 0.69314718055994530942, (s + s) * q);
+    return (v == 0.0) ? -__builtin_huge_val() : r;
+}
+// exp(y) to ~1e-11 relative: y = n ln2 + r, |r| <= 0.3466, Taylor to r^9/9! (remainder 7e-12), v_ldexp_f64 (which
+// saturates to inf / flushes to 0 by itself).  -inf -> 0, +inf -> inf, NaN -> NaN.
+__device__ __forceinline__ double exp_mid(double y) {
+    const double yc = __builtin_fmin(__builtin_fmax(y, -746.0), 710.0);
+    const double n = __builtin_rint(yc * 1.4426950408889634074);
+    double r = __builtin_fma(-n, 0x1.62e42fefa39efp-1, yc);
+    r = __builtin_fma(-n, 0x1.abc9e3b39803fp-56, r);
+    double p = 1.0 / 362880.0;
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double res = __builtin_amdgcn_ldexp(p, (int)n);
+    return (y != y) ? y : res;
+}
+// x ** e for x >= 0: by multiplication when e is one of 1 .. 4 (make_growth: ipow; the defaults q = theta = 3), else
+// exp(e log x).  pow(0, e > 0) = 0 and NaN propagates either way.
+__device__ __forceinline__ double pow_mid(double x, double e, int ipow) {
+    if (ipow == 0) return exp_mid(e * log_mid(x));      // wave-uniform
+    const double x2 = x * x;
+    return ipow == 1 ? x : ipow == 2 ? x2 : ipow == 3 ? x2 * x : x2 * x2;
+}
+
+// ---------------------------------------------------------------- float64 log / exp of the parity layout's zoo
+// The float64 zoo kernels are VALU-bound on their transcendentals: the device library's log is 98 VALU instructions (a
+// double-double evaluation), its exp 42; fishing-v11 inlines eight logs and seven exps.  These are the classic < 1 ulp
+// forms of FreeBSD msun / fdlibm (e_log.c, e_exp.c: the published argument reductions and minimax coefficients, restated
+// here) with the two divisions done as a v_rcp_f64 seed + Newton steps on a denominator that is known to sit in
+// [1.6, 2.5] -- no scaling, no fix-up: 38 and 33 instructions.  Same special values as the library (log: 0 -> -inf,
+// negative -> NaN, inf -> inf; exp: -inf -> 0, overflow -> inf; NaN -> NaN; subnormal arguments and results handled by
+// v_frexp / v_ldexp).  Held to the zoo's float64 tolerance (2e-14 of the population against the reference's numbers;
+// the two routines themselves measure <= 1 ulp against libm: tests/test_gpu_zoo.py::test_zoo_f64_log_exp_are_within_one_ulp).
+// -DFISHING_ZOO_F64_LIBM=1 builds the library calls back in (rounds 1-3).
+#ifndef FISHING_ZOO_F64_LIBM
+#define FISHING_ZOO_F64_LIBM 0
+#endif
+// n / d for d in [1.5, 2.6]: rcp seed (~2^-26), two Newton steps on the reciprocal, one correction of the quotient
+__device__ __forceinline__ double div_safe_range(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ double log_f64(double v) {
+    // v = 2^k (1 + f), sqrt(2)/2 <= 1 + f < sqrt(2);  s = f / (2 + f);  log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
+    double m = __builtin_amdgcn_frexp_mant(v);                 // [0.5, 1) (v itself for 0, inf, NaN)
+    int k = __builtin_amdgcn_frexp_exp(v);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    k = low ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = div_safe_range(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                                         2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    const double r = __builtin_fma(dk, 6.93147180369123816490e-01,
+                                   f - (hfsq - __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10)));
+    const double inf = __builtin_huge_val();
+    // (v == inf: frexp hands inf back, f = inf, the quotient NaN)
+    return (v > 0.0) ? ((v == inf) ? inf : r) : ((v == 0.0) ? -inf : __builtin_nan(""));
+}
+__device__ __forceinline__ double exp_f64(double y) {
+    // y = k ln2 + r, |r| <= ln2 / 2;  exp(r) = 1 + 2 r / (R(r) - r),  R(r) = 2 - c + ...:  1 - ((lo - r c / (2 - c)) - hi)
+    const double yc = __builtin_fmin(__builtin_fmax(y, -746.0), 710.0);
+    const double kf = __builtin_rint(yc * 1.44269504088896338700e+00);
+    const double hi = __builtin_fma(-kf, 6.93147180369123816490e-01, yc);
+    const double lo = kf * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, 4.13813679705723846039e-08,
+                                           -1.65339022054652515390e-06), 6.61375632143793436117e-05), -2.77777777770155933842e-03),
+                                           1.66666666666666019037e-01);
+    const double e = 1.0 - ((lo - div_safe_range(r * c, 2.0 - c)) - hi);
+    const double res = __builtin_amdgcn_ldexp(e, (int)kf);
+    return (y != y) ? y : res;
+}
+
+// Math policies of the round-trip form: W = the type mu is evaluated in
+struct MathLibF64 {          // the float64 parity layout
+    typedef double W;
+#if FISHING_ZOO_F64_LIBM
+    static __device__ __forceinline__ double log(double v) { return ::log(v); }
+    static __device__ __forceinline__ double exp(double v) { return ::exp(v); }
+#else
+    static __device__ __forceinline__ double log(double v) { return log_f64(v); }
+    static __device__ __forceinline__ double exp(double v) { return exp_f64(v); }
+#endif
+    static __device__ __forceinline__ double pow(double v, double e) { return exp(e * log(v)); }
+};
+struct MathHwF32 {           // FISHING_ZOO_F32_MATH 0
+    typedef float W;
+    static __device__ __forceinline__ float log(float v) { return log_t<float>(v); }
+    static __device__ __forceinline__ float exp(float v) { return __expf(v); }
+    static __device__ __forceinline__ float pow(float v, float e) { return pow_t<float>(v, e); }
+};
+struct MathLibF32 {          // FISHING_ZOO_F32_MATH 1
+    typedef float W;
+    static __device__ __forceinline__ float log(float v) { return ::logf(v); }
+    static __device__ __forceinline__ float exp(float v) { return ::expf(v); }
+    static __device__ __forceinline__ float pow(float v, float e) { return ::expf(e * ::logf(v)); }
+};
+template <typename T>
+using ZooRoundTripMath = std::conditional_t<sizeof(T) == 8, MathLibF64,
+                                            std::conditional_t<FISHING_ZOO_F32_MATH == 1, MathLibF32, MathHwF32>>;
+
 // The five growth functions of growth_models.py:208-261; each ends in
 // np.maximum(0, np.random.lognormal(mu, sigma)) = max(0, exp(mu + sigma z)).  The reference
-// really does round-trip through log and exp (also at sigma = 0); so does this.
+// really does round-trip through log and exp (also at sigma = 0); so does this form -- the float64 parity layout's.
 // RECOMPUTE: P.r changed on the device (fishing-v10 drift) -> logA / B are evaluated here
-template <typename T, int KIND = -1, bool RECOMPUTE = false>
-__device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const GrowthT<T>& P) {
-    const T inf = (T)__builtin_huge_val();
+template <typename T, typename M, int KIND, bool RECOMPUTE>
+__device__ __forceinline__ T zoo_draw_round_trip(int kind_rt, T x_in, T z_in, const GrowthT<T>& P) {
+    typedef typename M::W W;
+    const W inf = (W)__builtin_huge_val();
+    const W x = (W)x_in, z = (W)z_in;
     const int kind = (KIND >= 0) ? KIND : kind_rt;      // compile-time kind folds the switch away
-    T mu;
+    W mu;
     switch (kind) {
         case FISHING_KIND_ALLEN:          // :208-217
-            mu = log_t<T>(x) + P.r * ((T)1 - x / P.K) * ((T)1 - P.C) / P.K;
+            mu = M::log(x) + (W)P.r * ((W)1 - x / (W)P.K) * ((W)1 - (W)P.C) / (W)P.K;
             break;
         case FISHING_KIND_MYERS: {        // :247-255   (log(A), A = r + 1, comes from the host)
-            const T lx = log_t<T>(x);
-            mu = P.logA + P.theta * lx - log_t<T>((T)1 + exp_t<T>(P.theta * lx) / P.M);   // x**theta
+            const W lx = M::log(x);
+            mu = (W)P.logA + (W)P.theta * lx - M::log((W)1 + M::exp((W)P.theta * lx) / (W)P.M);   // x**theta
             break;
         }
         case FISHING_KIND_MAY: {          // :229-242   (b**q comes from the host)
-            const T xq = pow_t<T>(x, P.q);
-            const T exp_mu = x + x * P.r * ((T)1 - x / P.M) - P.a * xq / (xq + P.bq);
-            mu = log_t<T>(exp_mu);
+            const W xq = M::pow(x, (W)P.q);
+            const W exp_mu = x + x * (W)P.r * ((W)1 - x / (W)P.M) - (W)P.a * xq / (xq + (W)P.bq);
+            mu = M::log(exp_mu);
             break;
         }
         case FISHING_KIND_RICKER:         // :258-261
-            mu = log_t<T>(x) + P.r * ((T)1 - x / P.K);
+            mu = M::log(x) + (W)P.r * ((W)1 - x / (W)P.K);
             break;
         default: {                        // Beverton-Holt :220-226 (np.clip(., 0, inf): NaN passes)
-            const T xc = (x < (T)0) ? (T)0 : ((x > inf) ? inf : x);
-            T logA = P.logA, B = P.B;
+            const W xc = (x < (W)0) ? (W)0 : ((x > inf) ? inf : x);
+            W logA = (W)P.logA, B = (W)P.B;
             if (RECOMPUTE) {
-                const T rc = (P.r < (T)0) ? (T)0 : P.r;
-                const T Kc = (P.K < (T)0) ? (T)0 : P.K;
-                logA = log_t<T>(rc + (T)1);
+                const W rc = ((W)P.r < (W)0) ? (W)0 : (W)P.r;
+                const W Kc = ((W)P.K < (W)0) ? (W)0 : (W)P.K;
+                logA = M::log(rc + (W)1);
                 B = Kc / rc;
             }
-            mu = logA + log_t<T>(xc) - log_t<T>((T)1 + xc / B);
+            mu = logA + M::log(xc) - M::log((W)1 + xc / B);
             break;
         }
     }
-    const T g = exp_t<T>(mu + P.sigma * z);
-    return (g > (T)0) ? g : ((g != g) ? g : (T)0);    // np.maximum(0, g)
+    const W g = M::exp(mu + (W)P.sigma * z);
+    return (T)((g > (W)0) ? g : ((g != g) ? g : (W)0));    // np.maximum(0, g)
+}
+
+// The same five functions without the round trip, in float64, for the float32 layout (see FISHING_ZOO_F32_MATH above):
+// exp(log(x) + g + sigma z) = x exp(g + sigma z), and so on.
+template <int KIND, bool RECOMPUTE, typename T>
+__device__ __forceinline__ double zoo_draw_algebraic(int kind_rt, double x, double z, const GrowthT<T>& P) {
+    const int kind = (KIND >= 0) ? KIND : kind_rt;
+    const double sz = P.sigma * z;
+    double res;
+    switch (kind) {
+        case FISHING_KIND_ALLEN:          // :208-217
+            res = x * exp_mid(P.r * (1.0 - x * P.invK) * (1.0 - P.C) * P.invK + sz);
+            break;
+        case FISHING_KIND_MYERS: {        // :247-255: exp(log A + theta log x - log(1 + x^theta / M)) = A x^theta / (1 + x^theta / M)
+            const double xt = pow_mid(x, P.theta, P.ipow);
+            res = div_mid(P.A * xt, 1.0 + xt * P.invM) * exp_mid(sz);
+            break;
+        }
+        case FISHING_KIND_MAY: {          // :229-242: exp(log(exp_mu)) = exp_mu; log of a negative number is NaN there
+            const double xq = pow_mid(x, P.q, P.ipow);
+            const double exp_mu = x + x * P.r * (1.0 - x * P.invM) - div_mid(P.a * xq, xq + P.bq);
+            res = (exp_mu < 0.0) ? __builtin_nan("") : exp_mu * exp_mid(sz);
+            break;
+        }
+        case FISHING_KIND_RICKER:         // :258-261
+            res = x * exp_mid(P.r * (1.0 - x * P.invK) + sz);
+            break;
+        default: {                        // Beverton-Holt :220-226: A x / (1 + x / B)
+            const double xc = (x < 0.0) ? 0.0 : x;
+            double A = P.A, invB = P.invB;
+            if (RECOMPUTE) {              // fishing-v10: r drifts per env; invK = 1 / clip(K, 0, inf) from the host
+                const double rc = (P.r < 0.0) ? 0.0 : P.r;
+                A = rc + 1.0;
+                invB = rc * P.invK;
+            }
+            res = div_mid(A * xc, 1.0 + xc * invB) * exp_mid(sz);
+            break;
+        }
+    }
+    return (res > 0.0) ? res : ((res != res) ? res : 0.0);    // np.maximum(0, .)
+}
+
+// expm1(g) in float32: g = n ln2 + r (ln2 split hi / lo, |r| <= 0.3466), expm1(r) = r + r^2 (1/2 + r/6 + ... + r^5/5040)
+// (first omitted term r^8/8! <= 5e-9), expm1(g) = 2^n expm1(r) + (2^n - 1).  Absolute error <= ~5e-8 max(1, exp(g)).
+// -inf -> -1, +inf -> inf, NaN -> NaN.
+__device__ __forceinline__ float expm1_f32(float g) {
+    const float gc = __builtin_fminf(__builtin_fmaxf(g, -104.0f), 89.0f);
+    const float n = __builtin_rintf(gc * 1.44269504088896341f);
+    float r = __builtin_fmaf(-n, 0.693145751953125f, gc);
+    r = __builtin_fmaf(-n, 1.428606765330187e-06f, r);
+    float q = 1.0f / 5040.0f;
+    q = __builtin_fmaf(q, r, 1.0f / 720.0f);
+    q = __builtin_fmaf(q, r, 1.0f / 120.0f);
+    q = __builtin_fmaf(q, r, 1.0f / 24.0f);
+    q = __builtin_fmaf(q, r, 1.0f / 6.0f);
+    q = __builtin_fmaf(q, r, 0.5f);
+    const float p = __builtin_fmaf(r, q * r, r);
+    const float s = __builtin_amdgcn_ldexpf(1.0f, (int)n);
+    const float e = __builtin_fmaf(s, p, s - 1.0f);
+    return (g != g) ? g : e;
+}
+
+// (pre, g) of one growth function, the hybrid form: pre in float64, g in float32 (see FISHING_ZOO_F32_MATH above).
+// `sz` = sigma * z, already formed in float32.
+template <int KIND, bool RECOMPUTE, typename T>
+__device__ __forceinline__ void zoo_pre_g(float x, float sz, const GrowthT<T>& P, double& pre, float& g) {
+    static_assert(KIND >= 0 && KIND < FISHING_N_KINDS, "a compile-time kind");
+    const double xd = (double)x;
+    if constexpr (KIND == FISHING_KIND_ALLEN) {                 // :208-217
+        pre = xd;
+        g = __builtin_fmaf((float)P.gc, __builtin_fmaf(-x, (float)P.invK, 1.0f), sz);
+    } else if constexpr (KIND == FISHING_KIND_RICKER) {         // :258-261
+        pre = xd;
+        g = __builtin_fmaf((float)P.r, __builtin_fmaf(-x, (float)P.invK, 1.0f), sz);
+    } else if constexpr (KIND == FISHING_KIND_MYERS) {          // :247-255
+        const double xt = pow_mid(xd, P.theta, P.ipow);
+        pre = div_mid(P.A * xt, __builtin_fma(xt, P.invM, 1.0));
+        g = sz;
+    } else if constexpr (KIND == FISHING_KIND_MAY) {            // :229-242
+        const double xq = pow_mid(xd, P.q, P.ipow);
+        const double exp_mu = xd + xd * P.r * (1.0 - xd * P.invM) - div_mid(P.a * xq, xq + P.bq);
+        pre = (exp_mu < 0.0) ? __builtin_nan("") : exp_mu;
+        g = sz;
+    } else {                                                    // Beverton-Holt :220-226
+        const double xc = (xd < 0.0) ? 0.0 : xd;
+        double A = P.A, invB = P.invB;
+        if (RECOMPUTE) {              // fishing-v10: r drifts per env; invK = 1 / clip(K, 0, inf) from the host
+            const double rc = (P.r < 0.0) ? 0.0 : P.r;
+            A = rc + 1.0;
+            invB = rc * P.invK;
+        }
+        pre = div_mid(A * xc, __builtin_fma(xc, invB, 1.0));
+        g = sz;
+    }
+}
+// x' = max(0, pre + pre expm1(g)), one rounding to float32
+__device__ __forceinline__ float zoo_finish_hybrid(double pre, float g) {
+    const double res = __builtin_fma(pre, (double)expm1_f32(g), pre);
+    return (float)((res > 0.0) ? res : ((res != res) ? res : 0.0));     // np.maximum(0, .)
+}
+template <int KIND, bool RECOMPUTE, typename T>
+__device__ __forceinline__ float zoo_draw_hybrid(int kind_rt, float x, float z, const GrowthT<T>& P) {
+    const float sz = (float)P.sigma * z;
+    double pre = 0.0;
+    float g = 0.0f;
+    if constexpr (KIND >= 0) {
+        zoo_pre_g<KIND, RECOMPUTE, T>(x, sz, P, pre, g);
+    } else {            // run-time kind (the general kernel's single-kind zoo, population_draw sweeps): wave-uniform switch
+        switch (kind_rt) {
+            case FISHING_KIND_ALLEN: zoo_pre_g<FISHING_KIND_ALLEN, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_MYERS: zoo_pre_g<FISHING_KIND_MYERS, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_MAY: zoo_pre_g<FISHING_KIND_MAY, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_RICKER: zoo_pre_g<FISHING_KIND_RICKER, false, T>(x, sz, P, pre, g); break;
+            default: zoo_pre_g<FISHING_KIND_BEVERTON_HOLT, RECOMPUTE, T>(x, sz, P, pre, g); break;
+        }
+    }
+    return zoo_finish_hybrid(pre, g);
+}
+
+// ---- FISHING_ZOO_F32_MATH 4: the same algebraic form entirely in float32 on the hardware exp (v_exp_f32)
+// n / d to <= 1 ulp: v_rcp_f32 + one correction of the quotient (4 instructions; the IEEE float32 division is ~10).
+// Denominators outside the comfortable range (zeros, infinities, NaN included) take the IEEE division.
+__device__ __forceinline__ float div_f32(float n, float d) {
+    const float ad = __builtin_fabsf(d);
+    if (!(ad > 0x1p-60f && ad < 0x1p60f)) return n / d;
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = n * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+__device__ __forceinline__ float pow_f32(float x, float e, int ipow) {
+    if (ipow == 0) return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));      // wave-uniform
+    const float x2 = x * x;
+    return ipow == 1 ? x : ipow == 2 ? x2 : ipow == 3 ? x2 * x : x2 * x2;
+}
+template <int KIND, bool RECOMPUTE, typename T>
+__device__ __forceinline__ void zoo_pre_g_f32(float x, float sz, const GrowthT<T>& P, float& pre, float& g) {
+    static_assert(KIND >= 0 && KIND < FISHING_N_KINDS, "a compile-time kind");
+    if constexpr (KIND == FISHING_KIND_ALLEN) {
+        pre = x;
+        g = __builtin_fmaf((float)P.gc, __builtin_fmaf(-x, (float)P.invK, 1.0f), sz);
+    } else if constexpr (KIND == FISHING_KIND_RICKER) {
+        pre = x;
+        g = __builtin_fmaf((float)P.r, __builtin_fmaf(-x, (float)P.invK, 1.0f), sz);
+    } else if constexpr (KIND == FISHING_KIND_MYERS) {
+        const float xt = pow_f32(x, (float)P.theta, P.ipow);
+        pre = div_f32((float)P.A * xt, __builtin_fmaf(xt, (float)P.invM, 1.0f));
+        g = sz;
+    } else if constexpr (KIND == FISHING_KIND_MAY) {
+        const float xq = pow_f32(x, (float)P.q, P.ipow);
+        const float exp_mu = __builtin_fmaf(x * (float)P.r, __builtin_fmaf(-x, (float)P.invM, 1.0f), x) -
+                             div_f32((float)P.a * xq, xq + (float)P.bq);
+        pre = (exp_mu < 0.0f) ? __builtin_nanf("") : exp_mu;
+        g = sz;
+    } else {
+        const float xc = (x < 0.0f) ? 0.0f : x;
+        float A = (float)P.A, invB = (float)P.invB;
+        if (RECOMPUTE) {
+            const float rc = ((float)P.r < 0.0f) ? 0.0f : (float)P.r;
+            A = rc + 1.0f;
+            invB = rc * (float)P.invK;
+        }
+        pre = div_f32(A * xc, __builtin_fmaf(xc, invB, 1.0f));
+        g = sz;
+    }
+}
+__device__ __forceinline__ float zoo_finish_f32(float pre, float g) {
+    const float res = pre * __builtin_amdgcn_exp2f(g * 1.44269504088896341f);
+    return (res > 0.0f) ? res : ((res != res) ? res : 0.0f);
+}
+template <int KIND, bool RECOMPUTE, typename T>
+__device__ __forceinline__ float zoo_draw_f32(int kind_rt, float x, float z, const GrowthT<T>& P) {
+    const float sz = (float)P.sigma * z;
+    float pre = 0.0f, g = 0.0f;
+    if constexpr (KIND >= 0) {
+        zoo_pre_g_f32<KIND, RECOMPUTE, T>(x, sz, P, pre, g);
+    } else {
+        switch (kind_rt) {
+            case FISHING_KIND_ALLEN: zoo_pre_g_f32<FISHING_KIND_ALLEN, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_MYERS: zoo_pre_g_f32<FISHING_KIND_MYERS, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_MAY: zoo_pre_g_f32<FISHING_KIND_MAY, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_RICKER: zoo_pre_g_f32<FISHING_KIND_RICKER, false, T>(x, sz, P, pre, g); break;
+            default: zoo_pre_g_f32<FISHING_KIND_BEVERTON_HOLT, RECOMPUTE, T>(x, sz, P, pre, g); break;
+        }
+    }
+    return zoo_finish_f32(pre, g);
+}
+
+template <typename T, int KIND = -1, bool RECOMPUTE = false>
+__device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const GrowthT<T>& P) {
+    if constexpr (sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4)
+        return (T)zoo_draw_f32<KIND, RECOMPUTE, T>(kind_rt, (float)x, (float)z, P);
+    else if constexpr (sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 3)
+        return (T)zoo_draw_hybrid<KIND, RECOMPUTE, T>(kind_rt, (float)x, (float)z, P);
+    else if constexpr (sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 2)
+        return (T)zoo_draw_algebraic<KIND, RECOMPUTE, T>(kind_rt, (double)x, (double)z, P);
+    else
+        return zoo_draw_round_trip<T, ZooRoundTripMath<T>, KIND, RECOMPUTE>(kind_rt, x, z, P);
 }
 
 // fishing-v11: the growth function differs per env, so a straight per-lane switch runs all five
 // functions for every one of a thread's four envs (20 masked passes per wave, most lanes idle in
 // each).  Instead each wave regroups its 256 envs BY KIND through a wave-private LDS window, ONCE for
 // all kinds: every env gets a slot = start of its kind's segment + its rank inside the kind (ballot +
-// mbcnt; segments are padded to whole 64-slot chunks, so a chunk never mixes kinds), (x, z) pairs go
-// to their slots in one write phase, the wave evaluates growth function k on the chunks of segment k
-// with wave-uniform parameters (ceil(n_k / 64) passes per kind, 5-7 in total), and every env reads
-// its result back from its slot: three LDS phases per tile whatever the number of kinds.  Same
-// function on the same inputs as zoo_population_draw<T, k>: identical bits.
+// mbcnt), (x, z) pairs go to their slots in one write phase, the wave evaluates growth function k on
+// segment k in chunks of 64 slots with wave-uniform parameters (ceil(n_k / 64) passes per kind, 5-7 in
+// total), and every env reads its result back from its slot: three LDS phases per tile whatever the
+// number of kinds.  Same function on the same inputs as zoo_population_draw<T, k>: identical bits.
 // Must be called by all 64 lanes of the wave (envs that do not take part pass kind < 0).
-// `win` is this wave's window: kZooWindowSlots pairs.  256 envs in 5 padded segments fill at most
-// 512 slots (the padded total is a multiple of 64 below 256 + 5 * 63).
-constexpr int kZooWindowSlots = 512;
+// `win` is this wave's window: kZooWindowSlots pairs, one per env of the wave -- the segments follow each other
+// without padding (a chunk is read by `count - c` lanes of ONE kind's pass, so a chunk never mixes kinds whatever
+// its start; rounds 1-3 padded every segment to whole chunks and needed twice the LDS: 33 KB per workgroup in
+// float64 = four workgroups per CU).
+constexpr int kZooWindowSlots = 256;
 template <typename T>
 struct alignas(2 * sizeof(T)) ZooSlot {
     T x, z;
@@ -502,7 +895,7 @@ __device__ __forceinline__ void zoo_rank_kind(const int (&kind)[4], int (&slot)[
     }
     begin = next;
     count = total;
-    next += (total + kWave - 1) & ~(kWave - 1);
+    next += total;
 }
 
 template <typename T, int K>
@@ -516,6 +909,10 @@ __device__ __forceinline__ void zoo_eval_kind(ZooSlot<T>* __restrict__ win, int 
     }
 }
 
+// (Round 4 also measured a branch-free "select" form for the float32 layout -- every lane evaluates the (pre, g) of all
+// kinds present in its wave for its own four envs and selects, no LDS: the same 24.2 us per step at N = 2^22 as this
+// regroup, 13 % slower in the VALU-bound random-policy rollout, since it evaluates five functions per env instead of
+// one: profiles/r04_v11_forms.jsonl.  Not kept.)
 template <typename T>
 __device__ __forceinline__ void zoo_draw_regrouped(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
                                                    const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[4],
@@ -537,10 +934,16 @@ __device__ __forceinline__ void zoo_draw_regrouped(const int (&kind)[4], const T
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (scheduling fences: each pass fetches ITS parameter set -- wave-uniform kernel arguments -- when it starts; left alone the
+    // scheduler hoists all five sets' scalar loads to the top, 100+ SGPRs live across the whole regroup)
     zoo_eval_kind<T, FISHING_KIND_ALLEN>(win, begin[0], count[0], zoo[FISHING_KIND_ALLEN], lane);
+    __builtin_amdgcn_sched_barrier(0);
     zoo_eval_kind<T, FISHING_KIND_BEVERTON_HOLT>(win, begin[1], count[1], zoo[FISHING_KIND_BEVERTON_HOLT], lane);
+    __builtin_amdgcn_sched_barrier(0);
     zoo_eval_kind<T, FISHING_KIND_MYERS>(win, begin[2], count[2], zoo[FISHING_KIND_MYERS], lane);
+    __builtin_amdgcn_sched_barrier(0);
     zoo_eval_kind<T, FISHING_KIND_MAY>(win, begin[3], count[3], zoo[FISHING_KIND_MAY], lane);
+    __builtin_amdgcn_sched_barrier(0);
     zoo_eval_kind<T, FISHING_KIND_RICKER>(win, begin[4], count[4], zoo[FISHING_KIND_RICKER], lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -549,23 +952,6 @@ __device__ __forceinline__ void zoo_draw_regrouped(const int (&kind)[4], const T
     for (int j = 0; j < 4; ++j) out[j] = (slot[j] >= 0) ? win[slot[j]].x : out[j];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();              // the next tile reuses the window
-}
-
-// step() with a zoo growth function: quota / obs maps use the env's K (K_obs), the growth its
-// own parameter set (self.params in the reference).
-template <typename T, int KIND = -1, bool RECOMPUTE = false>
-__device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int kind, const GrowthT<T>& P,
-                                             T K_obs, int32_t Tmax, T& obs_next, T& reward, bool& done,
-                                             int32_t& t_next) {
-    T x = (obs + (T)1) * K_obs;
-    const T h = (quota < x) ? quota : x;
-    const T d = x - h;
-    x = ((T)0 > d) ? (T)0 : d;
-    x = zoo_population_draw<T, KIND, RECOMPUTE>(kind, x, z, P);
-    obs_next = x / K_obs - (T)1;
-    reward = ((T)0 > h) ? (T)0 : h;
-    t_next = t + 1;
-    done = (t_next > Tmax) || (x <= (T)0);
 }
 
 // x / K.  When K is a power of two (the default K = 1 included) the quotient is exact up to the
@@ -584,13 +970,36 @@ inline DivK make_divk(double K) {
 }
 template <typename T>
 __device__ __forceinline__ T div_K(T x, T K, const DivK& d);
+// (a run-time `pow2` is wave-uniform: a real branch -- the empty asm keeps the compiler from evaluating the 10 / 25-instruction
+// division speculatively and selecting afterwards; a compile-time `pow2` folds the branch away)
 template <>
 __device__ __forceinline__ float div_K<float>(float x, float K, const DivK& d) {
-    return d.pow2 ? x * d.inv_f : x / K;
+    if (d.pow2) return x * d.inv_f;
+    asm volatile("");
+    return x / K;
 }
 template <>
 __device__ __forceinline__ double div_K<double>(double x, double K, const DivK& d) {
-    return d.pow2 ? x * d.inv_d : x / K;
+    if (d.pow2) return x * d.inv_d;
+    asm volatile("");
+    return x / K;
+}
+
+// step() with a zoo growth function: quota / obs maps use the env's K (K_obs), the growth its
+// own parameter set (self.params in the reference).  `dk`: K_obs is a power of two (div_K below).
+template <typename T, int KIND = -1, bool RECOMPUTE = false>
+__device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int kind, const GrowthT<T>& P,
+                                             T K_obs, int32_t Tmax, T& obs_next, T& reward, bool& done,
+                                             int32_t& t_next, const DivK& dk = DivK{false, 0.0f, 0.0}) {
+    T x = (obs + (T)1) * K_obs;
+    const T h = (quota < x) ? quota : x;
+    const T d = x - h;
+    x = ((T)0 > d) ? (T)0 : d;
+    x = zoo_population_draw<T, KIND, RECOMPUTE>(kind, x, z, P);
+    obs_next = div_K<T>(x, K_obs, dk) - (T)1;
+    reward = ((T)0 > h) ? (T)0 : h;
+    t_next = t + 1;
+    done = (t_next > Tmax) || (x <= (T)0);
 }
 
 // population_draw(): base_fishing_env.py:121-133 (logistic), fishing_tipping_env.py:24-35

@@ -656,7 +656,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                                       (int)(threadIdx.x & (kWave - 1)));
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
-                    obs_next[j] = xn[j] / KK[j] - (T)1;
+                    obs_next[j] = div_K<T>(xn[j], KK[j], a.dk) - (T)1;       // (the env's scalar K: a multiply when it is a power of two)
                     rew[j] = ((T)0 > hv[j]) ? (T)0 : hv[j];
                     t_next[j] = t[j] + 1;
                     dn[j] = (t_next[j] > a.Tmax) || (xn[j] <= (T)0);
@@ -675,7 +675,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 GrowthT<T> P = ex.zoo[kk];
                 P.sigma = sg[j];
                 env_step_zoo<T, -1, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], a.Tmax, obs_next[j], rew[j], dn[j],
-                                           t_next[j]);
+                                           t_next[j], a.dk);
             } else if constexpr (kZoo) {
                 GrowthT<T> P = a.growth;
                 if (SIGARR) P.sigma = sg[j];
@@ -683,10 +683,10 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                     rr[j] = rr[j] + a.alpha;
                     P.r = rr[j];
                     env_step_zoo<T, kZooKind, true>(obs[j], t[j], quota, z[j], kZooKind, P, KK[j], a.Tmax, obs_next[j],
-                                                    rew[j], dn[j], t_next[j]);
+                                                    rew[j], dn[j], t_next[j], a.dk);
                 } else {
                     env_step_zoo<T, kZooKind, false>(obs[j], t[j], quota, z[j], kZooKind, P, KK[j], a.Tmax, obs_next[j],
-                                                     rew[j], dn[j], t_next[j]);
+                                                     rew[j], dn[j], t_next[j], a.dk);
                 }
             } else {
                 env_step<T, MODEL>(obs[j], t[j], quota, z[j], rr[j], KK[j], sg[j], a.C, a.Tmax, obs_next[j], rew[j],
@@ -1021,6 +1021,16 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
     // float64: two envs per thread up to ~512 MB per step (see the kernel and step_dispatch_range).  Relieved of the
     // 32-byte access shape the layout feels its arithmetic -- two IEEE float64 divisions per env, ~25 instructions each --
     // so fishing-v0/v1/v2 with K a power of two have exact instantiations there (no division, no option tests)
+    // fishing-v11 in float64: the growth functions' log / exp make it VALU-bound, and its catch-all -- every option a
+    // run-time test, plus the straight per-lane switch of the per-env-sigma path: five inlined growth functions for each of
+    // a thread's four envs -- spilled (36 B of scratch per lane, 16 SGPRs) at 105 VGPRs; the two hot requests get exact forms
+    if constexpr (sizeof(T) == 8 && MODEL == kModelZooMixed) {
+        switch (req) {
+            case (P): return lean_launch<T, MODEL, (P | ONE)>(c);
+            case (P | RET): return lean_launch<T, MODEL, (P | RET | ONE)>(c);
+            default: break;
+        }
+    }
     if constexpr (sizeof(T) == 8 && MODEL != kModelZooMixed) {
         if (c.two_per_thread) {
             if constexpr (!is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {

@@ -918,12 +918,16 @@ class BaseFishingEnv(_gym_env_base()):
             return (fish_population / K - 1.0).reshape(-1, 1)
         return np.array([fish_population / K - 1])
 
-    def population_draw(self, x=None, noise=None, sigma=None, dtype=None, r=None, K=None):
+    def population_draw(self, x=None, noise=None, sigma=None, dtype=None, r=None, K=None, model_idx=None):
         """base_fishing_env.py:121-133 (v2: fishing_tipping_env.py:24-35) over an array of
         populations -- the call BMSY() makes (models/policies.py:59-63).  `x` None uses
         self.fish_population like the reference's zero-argument form (scalar protocol).
         `dtype` picks the arithmetic (default: the env's layout); `sigma`, `r`, `K` override the
-        scalar parameters for this call only."""
+        scalar parameters for this call only.
+        fishing-v11 (growth_models.py:190-194: the growth function in force, with ITS parameter set).  One env: its
+        model.  N envs: `x` holds one population per env and env i grows under model_idx[i], the function in force
+        there -- or pass `model_idx` (int32, one FISHING_KIND per element of `x`) to choose per element, e.g. one sweep
+        per growth function in a single launch (policies.BMSY does)."""
         use_attr = x is None
         if use_attr:
             x = self.fish_population
@@ -954,21 +958,27 @@ class BaseFishingEnv(_gym_env_base()):
                 cp.r = float(r)
             if K is not None:
                 cp.K = float(K)
+        kinds = None
+        if model_idx is not None and self.MODEL != MODEL_V11:
+            raise ValueError("model_idx selects fishing-v11's growth function per element; %s has one" % type(self).__name__)
         if self.MODEL == MODEL_V11:
             # growth_models.py:190-194: the growth function currently in force, with ITS parameter set
-            if not self._scalar:
-                raise NotImplementedError("population_draw() over an array is defined for one growth function: "
-                                          "use the scalar protocol (one env, one model in force) for fishing-v11")
-            name = self.model
-            cp = _capi.FishingParams.from_buffer_copy(cp)
-            cp.model = {"allen": MODEL_V5, "beverton_holt": MODEL_V6, "may": MODEL_V7, "myers": MODEL_V8,
-                        "ricker": MODEL_V9}[name]
-            for k in ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a"):
-                setattr(cp, k, float(self.model_params[name].get(k, 0.0) or 0.0))
+            if model_idx is not None:
+                kinds = torch.as_tensor(model_idx).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+                if kinds.numel() != xt.numel():
+                    raise ValueError("model_idx needs one entry per population (%d), got %d" % (xt.numel(), kinds.numel()))
+            elif self._scalar:
+                kinds = self._model_idx[:1].expand(xt.numel()).contiguous()      # one env, one model in force
+            elif xt.numel() == self.num_envs:
+                kinds = self._model_idx                                          # env i under the model in force there
+            else:
+                raise ValueError("fishing-v11 with num_envs=%d: pass one population per env (each grows under its env's "
+                                 "model in force) or model_idx= with one growth-function kind per population"
+                                 % self.num_envs)
         fn = getattr(self._lib, "fishing_population_draw_" + ("f32" if dtype == torch.float32 else "f64"))
         with torch.cuda.device(self.device):
-            rc = fn(cp, xt.numel(), xt.data_ptr(), zt.data_ptr() if zt is not None else None, out.data_ptr(),
-                    self._stream())
+            rc = fn(cp, xt.numel(), xt.data_ptr(), zt.data_ptr() if zt is not None else None,
+                    kinds.data_ptr() if kinds is not None else None, out.data_ptr(), self._stream())
         _capi.check(rc, "fishing_population_draw")
         if isinstance(x, torch.Tensor):
             return out.reshape(x.shape)

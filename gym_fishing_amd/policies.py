@@ -35,11 +35,21 @@ def _sweep_dtype(env):
     return torch.float64 if np.dtype(env.observation_space.dtype) == np.float64 else torch.float32
 
 
+def _per_env_models(env):
+    """fishing-v11 with N envs: every env runs its own growth function, so BMSY / msy are per-env quantities."""
+    return env.MODEL == 11 and not env._scalar
+
+
 def BMSY(env, n=10001):
     """models/policies.py:51-67: sweep n states of the observation Box through one population_draw() on the
     device and return the population with the largest growth.  Like the reference, this resets the
     environment.  The sweep is evaluated in the grid's dtype whatever the env's layout (_sweep_dtype): with the
-    default float32 Box S = 0.4996 K for the flat logistic maximum, not K / 2."""
+    default float32 Box S = 0.4996 K for the flat logistic maximum, not K / 2.
+    fishing-v11 with N envs: what N reference envs would return, one S per env -- that of the growth function in force in
+    that env when BMSY is called (growth_models.py:190-194) -- as a [N] tensor; one sweep per growth function of the
+    model list, all in one launch.
+    fishing-v4 with N envs evaluates the growth curve at the parameter MEANS (one S for the batch), where N reference
+    envs would each sweep with their own drawn (K, r); the scalar protocol uses the pair drawn."""
     grid = np.linspace(env.observation_space.low, env.observation_space.high, num=n,
                        dtype=env.observation_space.dtype).reshape(-1)
     dt = _sweep_dtype(env)
@@ -47,6 +57,16 @@ def BMSY(env, n=10001):
     kw = _growth_args(env)
     K = kw.get("K", float(env.params["K"]))
     x0 = (state + 1.0) * K                                       # get_fish_population :158-160
+    if _per_env_models(env):
+        kinds = sorted({int(k) for k in env._c_params().kinds[:len(env.models)]})
+        X = x0.repeat(len(kinds))
+        idx = torch.tensor(kinds, dtype=torch.int32, device=env.device).repeat_interleave(n)
+        growth = (env.population_draw(X, dtype=dt, model_idx=idx) - X).reshape(len(kinds), n)
+        S_kind = torch.zeros(5, dtype=dt, device=env.device)
+        S_kind[torch.tensor(kinds, device=env.device)] = x0[torch.argmax(growth, dim=1)]
+        S = S_kind[env.model_idx.long()]                         # the model in force per env, BEFORE the reset below redraws it
+        env.reset()
+        return S
     growth = env.population_draw(x0, dtype=dt, **kw) - x0
     S = float(x0[int(torch.argmax(growth))])
     env.reset()
@@ -60,6 +80,13 @@ class msy:
         self.env = env
         self.S = BMSY(env)
         dt = _sweep_dtype(env)
+        if _per_env_models(env):
+            # one quota per env: f(S_i) - S_i under the growth function in force in env i NOW -- BMSY's reset has redrawn
+            # it, exactly as the reference's msy evaluates population_draw() after BMSY's env.reset() (:7-13)
+            self.msy = env.population_draw(self.S, dtype=dt) - self.S
+            env.reset()
+            self.kernel_policy = None                            # (the fused kernel takes one scalar parameter)
+            return
         x = torch.tensor([self.S], dtype=dt, device=env.device)
         self.msy = float(env.population_draw(x, dtype=dt, **_growth_args(env))[0] - x[0])
         env.reset()
@@ -79,7 +106,7 @@ class escapement:
     def __init__(self, env, **kwargs):
         self.env = env
         self.S = BMSY(env)
-        self.kernel_policy = (POLICY_ESCAPEMENT, self.S)
+        self.kernel_policy = None if isinstance(self.S, torch.Tensor) else (POLICY_ESCAPEMENT, self.S)
 
     def predict(self, obs, **kwargs):
         pop = self.env.get_fish_population(obs)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FISHING_ABI_VERSION 5
+#define FISHING_ABI_VERSION 6
 
 typedef void* fishing_stream_t; /* hipStream_t */
 
@@ -265,14 +265,18 @@ int fishing_reduce_returns(const double* return_partials, double* out4, fishing_
  * are zero. (ABI 5) */
 int fishing_reduce_returns_slots(const double* return_partials, int64_t slots, double* out4, fishing_stream_t stream);
 
-/* population_draw() (envs/base_fishing_env.py:121-133; v2: envs/fishing_tipping_env.py:24-35)
- * over an array of populations with the scalar r, K, sigma, C of `p`: x_out[i] = growth of
- * x_in[i] under noise z[i] (z nullable => 0).  This is how the reference's BMSY() sweeps the
- * growth curve (models/policies.py:59-63). */
-int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
-                                fishing_stream_t stream);
-int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, void* x_out,
-                                fishing_stream_t stream);
+/* population_draw() (envs/base_fishing_env.py:121-133; v2: envs/fishing_tipping_env.py:24-35; the zoo's:
+ * envs/growth_models.py:208-261) over an array of populations with the scalar r, K, sigma, C, ... of `p`:
+ * x_out[i] = growth of x_in[i] under noise z[i] (z nullable => 0).  This is how the reference's BMSY() sweeps the
+ * growth curve (models/policies.py:59-63).
+ * model_idx (ABI 6): i32[n], fishing-v11 only and required there (FISHING_ERR_NULL without, FISHING_ERR_UNSUPPORTED
+ * with any other model): element i grows under growth function model_idx[i] (FISHING_KIND_*) with that function's
+ * parameter set p->zoo[model_idx[i]] -- ModelUncertainty.population_draw (envs/growth_models.py:190-194: "the model
+ * in force, with ITS params") for N envs, or for one sweep per growth function in a single launch. */
+int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
+                                void* x_out, fishing_stream_t stream);
+int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
+                                void* x_out, fishing_stream_t stream);
 
 /* hipStreamSynchronize(stream): lets a host binding without a HIP runtime binding of its own (ctypes)
  * wait for the launches it enqueued -- the scalar gym.Env protocol reads its one env's results from
@@ -303,6 +307,17 @@ int fishing_step_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint6
  * Box-Muller of (w0, w1) -> (zK, zr). */
 int fishing_reset_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
                               float* zK, float* zr, fishing_stream_t stream);
+
+/* Test/diagnostic (ABI 6): the elementary functions the zoo's growth functions are built on, applied elementwise --
+ * out[i] = fn(in[i]).  The float64 parity layout's log / exp (FISHING_MATH_LOG_F64 / _EXP_F64: the < 1-ulp msun forms
+ * of csrc/fishing_common.h, held to <= 1 ulp of libm by tests/test_gpu_zoo.py), the ~1e-11 polynomial forms of the
+ * float64-internal builds (_LOG_MID / _EXP_MID) and the hybrid build's float32 expm1 (input and output widened). */
+#define FISHING_MATH_LOG_F64 0
+#define FISHING_MATH_EXP_F64 1
+#define FISHING_MATH_LOG_MID 2
+#define FISHING_MATH_EXP_MID 3
+#define FISHING_MATH_EXPM1_F32 4
+int fishing_math_f64(int64_t n, int32_t fn, const double* in, double* out, fishing_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -7,13 +7,15 @@ Counts VALU / SALU / VMEM / LDS instructions of each kernel whose demangled name
 frequent VALU opcodes.  Straight-line kernels (one tile per workgroup), so static counts ~ executed counts."""
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gym_fishing_amd.build import TU_FLAGS  # noqa: E402  (the per-unit flags of the product build: -fno-slp-vectorize, kernarg preload)
 
 
 def mixes(tu, extra=()):
     src = os.path.join(ROOT, "gym_fishing_amd", "csrc", tu + ".hip")
     asm = "/tmp/%s.%d.s" % (tu, os.getpid())
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fno-gpu-rdc",
-                    "-S", "--cuda-device-only", src, "-o", asm] + list(extra), check=True, stderr=subprocess.DEVNULL)
+                    "-S", "--cuda-device-only", src, "-o", asm] + TU_FLAGS.get(tu + ".hip", []) + list(extra), check=True, stderr=subprocess.DEVNULL)
     txt = open(asm).read()
     os.remove(asm)
     out = {}

@@ -355,12 +355,12 @@ def test_kernel_names_follow_the_dispatch(hh):
         "fishing::step_kernel_lean<float, 1, 11391>"
     assert name(p1, n=1000) == "fishing::step_kernel<float, 1>"
     assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True)) == "fishing::step_kernel_lean<float, 4, 8450>"
-    # fishing-v11 (growth function per env): the lean kernel in both layouts (float64 on its catch-all, round 3)
+    # fishing-v11 (growth function per env): the lean kernel in both layouts, exact instantiations (float64: round 4)
     p11 = hh.params(fo.MODEL_V11, sigma=0.1, models=[0, 1, 2, 3, 4], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE], auto_reset=True)
     b11 = hh.State(4096, np.float32, fo.MODEL_V11, np.zeros(4096), model_idx=np.zeros(4096, np.int32), ep_return=True)
     full11 = b11.buffers(b11.action_tensor(np.zeros(4096, np.float32)))
     assert hh.kernel_name(p11, n, full11) == "fishing::step_kernel_lean<float, 105, 8198>"
-    assert hh.kernel_name(p11, n, full11, np.float64) == "fishing::step_kernel_lean<double, 105, 11391>"
+    assert hh.kernel_name(p11, n, full11, np.float64) == "fishing::step_kernel_lean<double, 105, 8198>"
 
 
 # ------------------------------------------------------------------ the host mirror in the derived mode

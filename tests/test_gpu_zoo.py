@@ -1,11 +1,13 @@
 """GPU parity of the growth-model zoo fishing-v5..v11 (growth_models.py).
 
 These models go through log / exp / pow, which are not bit-reproducible between NumPy/libm
-and the device math library, so parity is tolerance-based, on the POPULATION x = (obs+1) K:
-  * fp64 layout: |dx| <= 2e-14 * x per step against the golden vectors captured from the
-    reference (a few ulp of exp(mu), mu = O(1));
-  * fp32 layout (hardware v_log/v_exp): |dx| <= 2e-5 * x per step against the float64 oracle.
-reward (= harvest, no transcendental) and done / t stay exact.
+and the device math library, so parity is tolerance-based:
+  * fp64 layout: on the POPULATION x = (obs+1) K, |dx| <= 2e-14 * x per step against the golden vectors
+    captured from the reference (a few ulp of exp(mu), mu = O(1)); reward, done, t exact;
+  * fp32 layout: the north star's bar -- |obs - ref| <= 1e-6 and |reward - ref| <= 1e-6 per step, absolute,
+    against the reference's float64 numbers (round 4: the float32 kernels evaluate the growth function in
+    float64 and round once, fishing_common.h: FISHING_ZOO_F32_MATH; measured maxima per growth function in
+    profiles/r04_zoo_f32_error.json.  Rounds 1-3 held the population to 2e-5 relative on the hardware transcendentals).
 """
 import numpy as np
 import pytest
@@ -16,7 +18,8 @@ from test_oracle_golden import ZOO_DEFAULTS
 
 pytestmark = pytest.mark.gpu
 ZOO = load_zoo_cases()
-F64_RTOL, F32_RTOL = 2e-14, 2e-5
+F64_RTOL = 2e-14
+F32_ATOL = 1e-6         # on obs and on reward, absolute (BASELINE.json north_star)
 
 
 @pytest.fixture(scope="module")
@@ -47,7 +50,16 @@ def hip_params(hh, c, **over):
     return hh.params(model, **kw)
 
 
+def obs_close_f32(obs_dev, obs_ref):
+    a, b = np.asarray(obs_dev, dtype=np.float64), np.asarray(obs_ref, dtype=np.float64)
+    assert np.asarray(obs_dev).dtype == np.float32
+    bad = ~((np.abs(a - b) <= F32_ATOL) | (np.isnan(a) & np.isnan(b)))
+    assert not bad.any(), "max |obs - ref| %.3e at %s" % (np.nanmax(np.abs(a - b)), np.argwhere(bad)[0])
+
+
 def pop_close(obs_dev, obs_ref, K, rtol):
+    if np.asarray(obs_dev).dtype == np.float32:
+        return obs_close_f32(obs_dev, obs_ref)
     a = (np.asarray(obs_dev, dtype=np.float64) + 1.0) * K
     b = (np.asarray(obs_ref, dtype=np.float64) + 1.0) * K
     # the state that is carried is obs = x/K - 1: near extinction (obs -> -1) its spacing, not the
@@ -76,13 +88,13 @@ def test_zoo_golden_single_steps(hh, c, dtype):
                   r=c.params_r.reshape(-1) if model == fo.MODEL_V10 else None,
                   model_idx=c.model_idx.reshape(-1) if model == fo.MODEL_V11 else None)
     obs, rew, done, t = st.step(hip_params(hh, c), c.action.reshape(-1), z=c.z.reshape(-1))
-    pop_close(obs, c.obs.reshape(-1), K, F64_RTOL if dtype == np.float64 else F32_RTOL)
+    pop_close(obs, c.obs.reshape(-1), K, F64_RTOL)
     if dtype == np.float64:
         assert np.array_equal(rew, c.reward.reshape(-1))
         assert (done == c.done.reshape(-1)).all()
     else:
-        assert np.abs(rew - c.reward.reshape(-1)).max() <= 1e-6
-        # an f32 population within 1e-5 of zero may flip the extinction flag: none in the fixtures
+        assert np.abs(rew - c.reward.reshape(-1)).max() <= F32_ATOL
+        # an f32 population within 1e-6 of zero may flip the extinction flag: none in the fixtures
         assert (done == c.done.reshape(-1)).all()
     assert (t == c.t.reshape(-1)).all()
     if model == fo.MODEL_V10:     # r drifted by alpha and was written back
@@ -155,7 +167,7 @@ def test_zoo_philox_auto_reset_vs_oracle(hh, model, dtype):
         w = hh.device_noise(n // 4, seed, 0, fo.STREAM_RESET, off // 4)[0]          # the device's own words, by quad
         assert np.array_equal(np.array([4, 0, 3])[((w.reshape(-1)[:n].astype(np.uint64) * np.uint64(3))
                                                     >> np.uint64(32)).astype(int)], want[:4 * (n // 4)])
-    rtol = F64_RTOL if dtype == np.float64 else F32_RTOL
+    rtol = F64_RTOL
     for s in range(T):
         a = rng.uniform(-1, -0.6, n).astype(np.float32)
         o, rew, done, t2 = st.step(p, a, seed=seed, step_counter=s, env_offset=off)
@@ -170,7 +182,7 @@ def test_zoo_philox_auto_reset_vs_oracle(hh, model, dtype):
                                          K, Tmax=Tmax, kind=kind)
         term = st.terminal.cpu().numpy()
         pop_close(term, eo, K, rtol)
-        assert np.abs(rew.astype(np.float64) - er).max() <= (0 if dtype == np.float64 else 1e-6)
+        assert np.abs(rew.astype(np.float64) - er).max() <= (0 if dtype == np.float64 else F32_ATOL)
         # extinction flag: x <= 0 is decided on the population before it is folded into obs; only a
         # population within rounding distance of zero may be classified differently
         differ = done != ed
@@ -358,8 +370,8 @@ def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 def test_v11_lean_and_general_kernels_agree(hh, ret, dtype):
     """fishing-v11 takes the lean step kernel too (growth function per env: the wave regroups its envs by kind through
-    LDS; the kinds are redrawn at every auto-reset) -- exact instantiations in float32, the catch-all's one-tile form in
-    float64 (round 3; the general kernel before): same bits as the general kernel on every stream and on the kind array
+    LDS; the kinds are redrawn at every auto-reset) -- exact instantiations in both layouts (float64: round 4; the catch-all's
+    one-tile form in round 3, the general kernel before): same bits as the general kernel on every stream and on the kind array
     over 14 auto-resetting steps, three-model list in a non-default order, ragged tail included."""
     import torch
     n = 1024 * 6 + 13
@@ -369,8 +381,8 @@ def test_v11_lean_and_general_kernels_agree(hh, ret, dtype):
     pa, pb = hh.params(fo.MODEL_V11, **kw), hh.params(fo.MODEL_V11, general=True, **kw)
     A, B = (hh.State(n, dtype, fo.MODEL_V11, np.zeros(n), ep_return=ret, model_idx=np.zeros(n, np.int32)) for _ in range(2))
     f32 = dtype == np.float32
-    assert hh.kernel_name(pa, n, A.buffers(A.obs), dtype) == ("fishing::step_kernel_lean<float, 105, %d>" % (8198 if ret else 8194) if f32
-                                                               else "fishing::step_kernel_lean<double, 105, 11391>")
+    assert hh.kernel_name(pa, n, A.buffers(A.obs), dtype) == "fishing::step_kernel_lean<%s, 105, %d>" % (
+        "float" if f32 else "double", 8198 if ret else 8194)
     assert hh.kernel_name(pb, n, B.buffers(B.obs), dtype) == "fishing::step_kernel<%s, 105>" % ("float" if f32 else "double")
     step = lib.fishing_step_f32 if f32 else lib.fishing_step_f64
     A.reset(pa, seed=5, env_offset=12)
@@ -423,3 +435,130 @@ def test_zoo_scalar_protocol_seeded_like_the_reference(name):
                 obs = env.reset()
                 assert obs[0] == c.reset_obs[e, s + 1]
         env.close()
+
+
+# ------------------------------------------------------------------ fishing-v11: population_draw / BMSY with N envs (ABI 6)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_v11_population_draw_selects_the_growth_function_per_element(hh, dtype):
+    """fishing_population_draw_* with model_idx (ABI 6; ModelUncertainty.population_draw, growth_models.py:190-194): element i
+    grows under growth function model_idx[i] with THAT function's parameter set -- against the oracle's
+    zoo_population_draw per kind over one mixed array; extinct stocks and an out-of-range kind (-> Beverton-Holt, as in
+    the step kernels) included."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n = 5 * 4001 + 3
+    rng = np.random.default_rng(11)
+    kinds = rng.integers(0, 5, n).astype(np.int32)
+    kinds[-3:] = [7, -1, 99]
+    table = [dict(d, sigma=0.1) for d in fo.V11_TABLE]
+    x = (rng.uniform(0.0, 2.0, n)).astype(dtype)
+    x[::501] = 0.0
+    z = rng.standard_normal(n).astype(dtype)
+    p = hh.params(fo.MODEL_V11, models=[0, 1, 2, 3, 4], zoo_table=table)
+    xt, zt, kt = hh.dev(x), hh.dev(z), hh.dev(kinds)
+    out = torch.empty_like(xt)
+    fn = lib.fishing_population_draw_f32 if dtype == np.float32 else lib.fishing_population_draw_f64
+    assert fn(p, n, xt.data_ptr(), zt.data_ptr(), kt.data_ptr(), out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float64)
+    eff = np.where((kinds >= 0) & (kinds < 5), kinds, fo.KIND_BH)
+    want = np.zeros(n)
+    for k in range(5):
+        m = eff == k
+        want[m] = fo.zoo_population_draw(k, x[m].astype(np.float64), z[m].astype(np.float64), table[k])
+    assert (np.isnan(got) == np.isnan(want)).all()
+    ok = ~np.isnan(want)
+    if dtype == np.float64:
+        assert (np.abs(got - want)[ok] <= F64_RTOL * np.abs(want[ok])).all()
+    else:
+        assert np.abs(got - want)[ok].max() <= F32_ATOL * 1.5           # (populations, in units of the largest K = 1.5)
+    assert (got[x == 0] == 0).all()
+    # without the selector fishing-v11 has no growth function to apply; with any other model there is nothing to select
+    assert fn(p, n, xt.data_ptr(), zt.data_ptr(), None, out.data_ptr(), None) == -1        # FISHING_ERR_NULL
+    p9 = hh.params(fo.MODEL_V9, sigma=0.1)
+    assert fn(p9, n, xt.data_ptr(), zt.data_ptr(), kt.data_ptr(), out.data_ptr(), None) == -7      # FISHING_ERR_UNSUPPORTED
+
+
+def test_v11_num_envs_population_draw_and_bmsy_follow_each_envs_model(hh):
+    """An N-env fishing-v11 batch: population_draw(x) grows env i's stock under env i's model in force (round 3 raised
+    NotImplementedError here), BMSY(env) returns one S per env -- that of its growth function, equal to what the scalar
+    protocol's BMSY returns with that model in force (models/policies.py:51-67) -- and msy / escapement built on it
+    drive the batch through simulate()."""
+    import torch
+    import gym_fishing_amd as gf
+    from gym_fishing_amd import policies
+    n = 64
+    env = gf.make("fishing-v11", num_envs=n, seed=3)
+    env.reset()
+    idx = env.model_idx.clone()
+    assert len(set(idx.cpu().tolist())) == 5
+    x = torch.linspace(0.1, 1.4, n, device="cuda", dtype=torch.float64)
+    got = env.population_draw(x, dtype=torch.float64).cpu().numpy()
+    want = np.zeros(n)
+    for k in range(5):
+        m = idx.cpu().numpy() == k
+        want[m] = fo.zoo_population_draw(k, x.cpu().numpy()[m], np.zeros(m.sum()), fo.V11_TABLE[k])
+    assert np.allclose(got, want, rtol=F64_RTOL, atol=0)
+    with pytest.raises(ValueError):
+        env.population_draw(x[:5])                       # neither one per env nor a model_idx
+    S = policies.BMSY(env)
+    assert isinstance(S, torch.Tensor) and S.shape == (n,)
+    names = ["allen", "beverton_holt", "myers", "may", "ricker"]
+    per_kind = {}
+    for k, name in enumerate(names):
+        one = gf.make("fishing-v11", models=[name])      # scalar protocol, this growth function in force
+        per_kind[k] = policies.BMSY(one)
+    want_S = np.array([per_kind[int(k)] for k in idx.cpu().tolist()], dtype=np.float32)
+    assert np.array_equal(S.cpu().numpy(), want_S)
+    esc = policies.escapement(env)
+    assert esc.kernel_policy is None and esc.S.shape == (n,)
+    a, _ = esc.predict(env.state)
+    assert a.shape == (n, 1) and a.dtype == torch.float32
+    df = env.simulate(esc)
+    assert len(df) > n and df["reward"].sum() > 0
+    m = policies.msy(env)
+    # (f(S_i) - S_i under the model drawn by BMSY's reset -- the reference's order of events -- may well be negative)
+    assert m.msy.shape == (n,) and bool(torch.isfinite(m.msy).all())
+    a, _ = m.predict(env.state)
+    assert a.shape == (n, 1)
+
+
+def test_zoo_f64_log_exp_are_within_one_ulp(hh):
+    """The float64 parity layout's own log / exp (csrc/fishing_common.h: log_f64 / exp_f64, the msun argument reductions
+    and coefficients with the divisions done by Newton steps) against libm, element by element: <= 1 ulp over the
+    populations and exponents the growth functions see and far beyond, special values exact.  The polynomial forms of
+    the float64-internal builds (log_mid / exp_mid) to 1e-10, the hybrid build's float32 expm1 to 2.5e-7 of max(1, e^g)
+    (two float32 roundings of the result's leading term and the polynomial's 1.5e-8)."""
+    import math
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+
+    def run(fn, v):
+        t = hh.dev(np.asarray(v, dtype=np.float64))
+        o = torch.empty_like(t)
+        assert lib.fishing_math_f64(t.numel(), fn, t.data_ptr(), o.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        return o.cpu().numpy()
+    rng = np.random.default_rng(8)
+    v = np.concatenate([np.exp(rng.uniform(-40, 40, 200000)), 1.0 + rng.uniform(-0.3, 0.45, 100000), rng.uniform(0, 3, 100000),
+                        [5e-324, 2.2250738585072014e-308, 1.0, 0.5, 2.0, 1e308]])
+    got = run(0, v)
+    want = np.array([math.log(x) for x in v])
+    assert hh.ulp_diff(got, want).max() <= 1
+    special = run(0, [0.0, -0.0, -1.0, np.inf, np.nan])
+    assert special[0] == -np.inf and special[1] == -np.inf and np.isnan(special[2]) and special[3] == np.inf and np.isnan(special[4])
+    y = np.concatenate([rng.uniform(-745, 709, 200000), rng.uniform(-3, 3, 200000), [0.0, -0.0, 1.0, -1.0, 709.78, -745.13]])
+    got = run(1, y)
+    want = np.array([math.exp(x) for x in y])
+    assert hh.ulp_diff(got, want).max() <= 1
+    special = run(1, [-np.inf, np.inf, np.nan, 710.0, -746.0])
+    assert special[0] == 0.0 and special[1] == np.inf and np.isnan(special[2]) and special[3] == np.inf and special[4] == 0.0
+    assert np.abs(run(2, v[:300000]) - np.log(v[:300000])).max() <= 1e-10 * 100            # |log| up to ~92
+    assert np.abs(run(3, y[200000:400000]) / np.exp(y[200000:400000]) - 1.0).max() <= 1e-10
+    g = rng.uniform(-20, 20, 200000).astype(np.float32).astype(np.float64)
+    e = run(4, g)
+    assert (np.abs(e - np.expm1(g)) <= 2.5e-7 * np.maximum(1.0, np.exp(g))).all()
+    se = run(4, [-np.inf, np.inf, np.nan, 0.0])
+    assert se[0] == -1.0 and se[1] == np.inf and np.isnan(se[2]) and se[3] == 0.0
