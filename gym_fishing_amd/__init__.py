@@ -17,12 +17,28 @@ raises FishingLibraryError if the library or a HIP device is missing.
 """
 import os as _os
 
-# dmabuf IPC: what RCCL (and any cross-process sharing of device memory) needs on this driver.  Set before anything can
-# initialise HIP, in every process that imports the package -- a rank started directly by torch.distributed.run never
-# passes through a launcher of ours.  (setdefault: an explicit choice of the caller wins.)
-_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-from ._capi import FishingLibraryError  # noqa: E402
+def ensure_dmabuf_ipc():
+    """RCCL (and any cross-process sharing of device memory) needs dmabuf IPC on this driver: HSA_ENABLE_IPC_MODE_LEGACY=0,
+    read when HIP initialises.  Called by the multi-rank entry points (sharding.make_sharded, bench.py) -- importing the
+    package does not touch the process environment.  An explicit choice of the caller wins; returns False, with a warning,
+    when the variable had to be set but HIP is already up (too late for this process: export it before starting)."""
+    if "HSA_ENABLE_IPC_MODE_LEGACY" in _os.environ:
+        return True
+    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    try:
+        import torch
+        late = torch.cuda.is_initialized()
+    except Exception:  # noqa: BLE001
+        late = False
+    if late:
+        import warnings
+        warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY=0 set after HIP was initialised: it does not take effect in this process; "
+                      "export it before launching multi-GPU ranks")
+    return not late
+
+
+from ._capi import FishingLibraryError  # noqa: E402, F401
 
 __version__ = "0.1.0"
 

@@ -52,7 +52,8 @@ def _deps():
 
 
 def is_stale():
-    if not os.path.exists(LIB_PATH) or not os.path.exists(RESOURCES_PATH):
+    # (a missing kernel_resources.json next to a valid prebuilt library only means "no PMC quote" to bench.py: not stale)
+    if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
     return any(os.path.getmtime(s) > t for s in _deps() if os.path.exists(s))

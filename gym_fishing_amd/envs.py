@@ -226,9 +226,11 @@ class BaseFishingEnv(_gym_env_base()):
             raise ValueError("derived_params=True needs fishing-v4 with num_envs, rng='philox' and the int32 year counter")
         self._derived = self._derived_capable
         self._origin = (0, 0)            # (step count, reset counter) of the last reset() of all envs
+        self._K_store = self._r_store = None      # (see _param_store)
         if self._per_env and not self._derived:
-            self._r_arr = self._per_env_buffer(dtype, float(params["r"]))
-            self._K_arr = self._per_env_buffer(dtype, float(params["K"]))
+            self._K_arr, self._r_arr = self._param_store()
+            self._r_arr.fill_(float(params["r"]))
+            self._K_arr.fill_(float(params["K"]))
         if self.MODEL == MODEL_V10:      # the drifting growth rate is per-env state (growth_models.py:151)
             self._r_arr = self._per_env_buffer(dtype, float(params["r"]))
         self._model_idx = self._per_env_buffer(torch.int32) if self.MODEL == MODEL_V11 else None
@@ -351,14 +353,43 @@ class BaseFishingEnv(_gym_env_base()):
         return K, r
 
     def _current_step_count(self):
-        return self._step_count             # (kept in step with the device-resident counter of the graph-replay mode)
+        """How many step() calls this env has made.  In graph-replay mode the device-resident counter is the truth -- a
+        replayed hipGraph (GraphedSteps, or a caller's own torch.cuda.CUDAGraph) advances only that -- so the host's
+        copy is refreshed from it here (one 8-byte read that waits for the stream: reset(), env.K / env.r, state_dict()
+        and leaving the derived mode ask, step() never does)."""
+        if self._counter is not None:
+            self._step_count = int(self._counter[0].item())
+        return self._step_count
+
+    def _param_store(self):
+        """The (K, r) arrays of a fishing-v4 env, allocated once and kept for the env's lifetime: a launch captured in a
+        hipGraph while the env ran on stored arrays keeps reading -- and, on every auto-reset, WRITING -- these addresses,
+        so they must never go back to the allocator while the env lives, whatever mode it is in by then."""
+        if self._K_store is None:
+            self._K_store, self._r_store = self._per_env_buffer(self.dtype), self._per_env_buffer(self.dtype)
+        return self._K_store, self._r_store
 
     def _leave_derived_mode(self):
         """Store the parameters in force and continue with r / K arrays (until the next full reset())."""
         if self._derived:
-            self._K_arr, self._r_arr = self._derive_params()
+            self._K_arr, self._r_arr = self._derive_params(self._param_store())
             self._derived = False
             self._cbuf = None
+
+    def launch_signature(self):
+        """Everything a captured launch has frozen: the parameter struct's source values, fishing-v4's parameter mode and
+        the address of every stream.  A hipGraph captured from this env replays correctly only while this value is what it
+        was at capture time (GraphedSteps checks it on every replay and re-captures; a caller's own torch.cuda.CUDAGraph
+        must do the same): env.Tmax = ..., env.sigma = ..., env.K = ..., seed(), a masked reset() of fishing-v4 and
+        load_state_dict() can all change it."""
+        ptr = lambda t: (t.data_ptr() if t is not None else 0)  # noqa: E731
+        key = list(self._param_key())
+        if self._counter is not None:
+            key[4] = None       # (fishing-v4's episode origin travels in the device-resident counter words in this mode)
+        return (tuple(key), self._seed, self._derived,
+                tuple(ptr(t) for t in (self._obs, self._t, self._reward, self._done, self._done_bits, self._r_arr, self._K_arr,
+                                       self._sigma_arr, self._terminal_obs, self._ep_return, self._partials, self._model_idx,
+                                       self._counter)))
 
     def _K_view(self, out=None):
         if self._derived:
@@ -523,7 +554,7 @@ class BaseFishingEnv(_gym_env_base()):
             torch.cuda.current_stream(self.device).synchronize()
         sd = {k: getattr(self, k).clone() for k in self._STATE_TENSORS if getattr(self, k) is not None}
         sd.update(format=STATE_FORMAT, v4_param_stream=V4_PARAM_STREAM,
-                  seed=self._seed, step_count=self._step_count, reset_count=self._reset_count,
+                  seed=self._seed, step_count=self._current_step_count(), reset_count=self._reset_count,
                   params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state,
                   v4_derived=self._derived, v4_origin=tuple(self._origin), auto_reset=self.auto_reset,
                   attrs={k: getattr(self, k) for k in self._STATE_ATTRS if hasattr(self, k)})
@@ -533,14 +564,22 @@ class BaseFishingEnv(_gym_env_base()):
             sd["numpy_rng_state"] = np.random.get_state()
         return sd
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, strict=True):
+        """Resume from state_dict().  fishing-v4 on the Philox streams redraws (K, r) at every reset from a generator that
+        is part of the state's meaning (`v4_param_stream`): a state written under another scheme (round 1: one Philox4x32
+        block per env PAIR; no tag at all before format 2) is refused in the derived mode, where the parameters in force
+        themselves would come out different.  A stored-array state carries its (K, r) in force, so `strict=False` loads it
+        with a warning -- the run continues exactly until the first redraw, which then follows this library's stream.  Envs
+        that never use that stream (rng="numpy": the scalar protocol's default) load any fishing-v4 state."""
         # everything that can refuse the state is checked BEFORE the first field changes: a failed load leaves the env as it was
-        if self._per_env and sd.get("v4_param_stream") != V4_PARAM_STREAM:
-            # fishing-v4 redraws (K, r) at every reset from a generator that is part of the state's meaning: a checkpoint
-            # written under another scheme (round 1: one Philox4x32 block per env PAIR; no tag at all before format 2)
-            # would load and then continue on different parameters
-            raise ValueError("fishing-v4 state was written with parameter stream %r, this library draws %r: it cannot "
-                             "resume bit-for-bit" % (sd.get("v4_param_stream"), V4_PARAM_STREAM))
+        if self._per_env and not self._np_rng and sd.get("v4_param_stream") != V4_PARAM_STREAM:
+            if strict or sd.get("v4_derived", False):
+                raise ValueError("fishing-v4 state was written with parameter stream %r, this library draws %r: it cannot "
+                                 "resume bit-for-bit%s" % (sd.get("v4_param_stream"), V4_PARAM_STREAM,
+                                                           "" if sd.get("v4_derived", False) else " (strict=False loads the stored (K, r))"))
+            import warnings
+            warnings.warn("fishing-v4 state written with parameter stream %r: the (K, r) in force are loaded, redraws will "
+                          "follow %r" % (sd.get("v4_param_stream"), V4_PARAM_STREAM))
         if self._per_env and sd.get("v4_derived", False) and not self._derived_capable:
             raise ValueError("state was saved in the derived-parameter mode, which this env cannot run")
         v4_arrays = self._per_env and not sd.get("v4_derived", False)
@@ -561,8 +600,7 @@ class BaseFishingEnv(_gym_env_base()):
                 self._derived, self._K_arr, self._r_arr = True, None, None
             elif self._derived:
                 self._derived = False
-                self._K_arr = self._per_env_buffer(self.dtype)
-                self._r_arr = self._per_env_buffer(self.dtype)
+                self._K_arr, self._r_arr = self._param_store()
             self._origin = tuple(sd.get("v4_origin", (0, 0)))
             self._cbuf = None
         for k in self._STATE_TENSORS:
@@ -594,8 +632,12 @@ class BaseFishingEnv(_gym_env_base()):
     def enable_graph_replay(self):
         """Keep the step counter in device memory from now on.  step() / step_many() / rollout()
         then launch with frozen arguments plus a one-thread counter bump, so a hipGraph that
-        captured them (torch.cuda.CUDAGraph, or gym_fishing_amd.graphs.GraphedSteps) draws
-        fresh noise on every replay.  Same noise stream as the host-counter mode."""
+        captured them (gym_fishing_amd.graphs.GraphedSteps, or a caller's own torch.cuda.CUDAGraph) draws
+        fresh noise on every replay.  Same noise stream as the host-counter mode.
+        What a capture freezes besides the counter: every scalar of the parameter struct, fishing-v4's parameter mode
+        (derived / stored arrays) and every stream's address -- launch_signature().  GraphedSteps re-captures when that
+        changes; a caller replaying a torch.cuda.CUDAGraph of its own must compare launch_signature() itself.  The env
+        never frees a stream a capture may still reference (fishing-v4's r / K arrays live as long as the env)."""
         if self._counter is None:
             # {step counter, v4 origin step, v4 origin counter}: a captured launch freezes FishingParams, and with them the
             # origin that the derived fishing-v4 parameters date episodes from -- so in this mode the kernels read the

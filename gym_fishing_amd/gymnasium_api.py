@@ -41,14 +41,30 @@ class GymnasiumFishingEnv(_base()):
         self.observation_space = env.observation_space
         self.action_space = env.action_space
 
-    # everything else (Tmax, K, r, state, simulate, state_dict, ...) is the wrapped env's
+    # Everything else (Tmax, K, r, sigma, init_state, state, simulate, state_dict, ...) is the wrapped env's -- reads AND
+    # writes: `env.unwrapped.Tmax = 50`, `.sigma = ...`, `.K = ...` are legal in the reference (its helpers and SB3
+    # callbacks do exactly that) and must reach the object whose attributes feed the kernels' parameter struct, not
+    # shadow it on this wrapper.
+    _OWN = frozenset(("env", "render_mode", "observation_space", "action_space", "spec", "metadata", "np_random",
+                      "_np_random", "_np_random_seed"))
+
     def __getattr__(self, name):
         if name == "env":
             raise AttributeError(name)
         return getattr(self.env, name)
 
+    def __setattr__(self, name, value):
+        if name in self._OWN or "env" not in self.__dict__:
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self.env, name, value)
+        if name in ("observation_space", "action_space") and "env" in self.__dict__:
+            setattr(self.env, name, value)        # (BMSY's sweep follows the env's observation Box dtype)
+
     @property
     def unwrapped(self):
+        """gymnasium's contract: the innermost gymnasium.Env -- this object (the 4-tuple env underneath is not one).
+        Attribute writes on it are forwarded (see __setattr__), so `env.unwrapped.Tmax = 50` still reaches the kernels."""
         return self
 
     def reset(self, *, seed=None, options=None):

@@ -70,8 +70,10 @@ def all_reduce_record(rec, group=None):
 def make_sharded(env_id, total_envs, rank=None, world_size=None, **kwargs):
     """This rank's shard of a `total_envs`-wide vec-env: make(id, num_envs=count,
     env_offset=offset, ...).  Every rank passes the same seed."""
-    from . import make
+    from . import ensure_dmabuf_ipc, make
     r, w, _ = dist_info()
+    if (w if world_size is None else world_size) > 1:
+        ensure_dmabuf_ipc()
     rank = r if rank is None else rank
     world_size = w if world_size is None else world_size
     offset, count = shard_range(total_envs, rank, world_size)

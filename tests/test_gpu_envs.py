@@ -585,6 +585,136 @@ def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
     assert torch.equal(fresh.state, before) and fresh._derived
 
 
+def test_graph_replay_follows_a_parameter_mode_switch_after_the_capture(gf):
+    """A captured launch has frozen fishing-v4's parameter mode and the addresses of its r / K streams.  GraphedSteps
+    re-captures when the env's launch signature moved, and the env never frees the arrays a capture may still write:
+    (1) capture in the derived mode, then a masked reset() (per-env episode origins from there on) -> replays equal an
+    eager env that did the same; (2) seed() first (stored arrays), capture, then a full reset() (back to derived) ->
+    replays equal eager, and the arrays the first graph wrote through are still the env's own."""
+    import torch
+    from gym_fishing_amd.graphs import GraphedSteps
+    n = 3072
+    acts = torch.rand((3, n), device="cuda") * 1.4 - 1.2
+    mask = torch.rand(n, device="cuda") < 0.3
+    mk = lambda: gf.make("fishing-v4", sigma=0.05, sigma_p=0.2, num_envs=n, seed=5, Tmax=6)  # noqa: E731
+    # (1)
+    eager, graphed = mk(), mk()
+    eager.reset()
+    graphed.reset()
+    g = GraphedSteps(graphed, acts)
+    for _ in range(2):
+        g.replay()
+        eager.step_many(acts, 3)
+    assert g.recaptures == 0 and torch.equal(graphed.state, eager.state)
+    graphed.reset(mask)
+    eager.reset(mask)
+    sig = graphed.launch_signature()
+    for _ in range(3):
+        g.replay()
+        eager.step_many(acts, 3)
+        assert torch.equal(graphed.state, eager.state) and torch.equal(graphed.K, eager.K) and torch.equal(graphed.r, eager.r)
+    assert g.recaptures == 1 and graphed.launch_signature() == sig
+    # a scalar of the parameter struct changed behind the capture's back: honoured by the next replay
+    graphed.Tmax = eager.Tmax = 3
+    g.replay()
+    eager.step_many(acts, 3)
+    assert g.recaptures == 2 and torch.equal(graphed.state, eager.state) and torch.equal(graphed._t, eager._t)
+    # (2)
+    eager, graphed = mk(), mk()
+    for e in (eager, graphed):
+        e.reset()
+        e.seed(77)                          # the parameters in force were drawn under the old seed: stored arrays
+        assert not e._derived
+    g = GraphedSteps(graphed, acts)
+    K_ptr = graphed._K_arr.data_ptr()
+    g.replay()
+    eager.step_many(acts, 3)
+    assert torch.equal(graphed.state, eager.state) and torch.equal(graphed.K, eager.K)
+    graphed.reset()
+    eager.reset()
+    assert graphed._derived and graphed._K_arr is None and graphed._K_store.data_ptr() == K_ptr      # kept, not freed
+    junk = [torch.full((n,), 7.0, device="cuda") for _ in range(8)]          # whatever would have reused a freed block
+    for _ in range(3):
+        g.replay()
+        eager.step_many(acts, 3)
+        assert torch.equal(graphed.state, eager.state) and torch.equal(graphed.K, eager.K)
+    assert g.recaptures == 1 and all(bool((j == 7.0).all()) for j in junk)
+
+
+def test_raw_graph_replays_keep_the_step_count_the_env_acts_on(gf):
+    """A caller's own torch.cuda.CUDAGraph of env.step() advances only the device-resident counter.  Everything that
+    needs the step count afterwards -- reset()'s episode origin, env.K / env.r of the derived mode, state_dict() -- reads
+    it from the device: the run equals eager stepping bit for bit, the checkpoint resumes."""
+    import torch
+    n = 2048
+    a = torch.rand(n, device="cuda") * 1.4 - 1.2
+    mk = lambda: gf.make("fishing-v4", sigma=0.05, sigma_p=0.2, num_envs=n, seed=9, Tmax=5)  # noqa: E731
+    eager, graphed = mk(), mk()
+    eager.reset()
+    graphed.reset()
+    graphed.enable_graph_replay()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step(a)                     # warm-up outside the capture (torch's rule); eager takes the same step
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step(a)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        graphed.step(a)
+    host_before = graphed._step_count
+    for _ in range(9):
+        graph.replay()
+        eager.step(a)
+    assert graphed._step_count == host_before            # the host never saw the replays ...
+    assert torch.equal(graphed.K, eager.K) and torch.equal(graphed.r, eager.r)      # ... env.K asks the device
+    assert graphed._step_count == eager._step_count == 10
+    sd = graphed.state_dict()
+    assert sd["step_count"] == 10
+    graph.replay()
+    eager.step(a)
+    graphed.reset()
+    eager.reset()
+    assert graphed._origin == eager._origin == (11, 2)
+    for _ in range(4):
+        graph.replay()
+        eager.step(a)
+    assert torch.equal(graphed.state, eager.state) and torch.equal(graphed.K, eager.K)
+    fresh = mk()
+    fresh.load_state_dict(sd)
+    again = mk()
+    again.reset()
+    for _ in range(10):
+        again.step(a)
+    assert torch.equal(fresh.state, again.state) and torch.equal(fresh.K, again.K)
+
+
+def test_v4_state_without_the_stream_tag_loads_where_it_can(gf):
+    """load_state_dict refuses a fishing-v4 state written under another parameter stream only where the stream decides
+    what the state means: the derived mode always; stored arrays unless strict=False (the (K, r) in force are in the
+    state; a warning says redraws will differ); never for rng='numpy' envs, which do not use that stream."""
+    import torch
+    import warnings
+    n = 1024
+    env = gf.make("fishing-v4", num_envs=n, seed=1, derived_params=False)
+    env.reset()
+    env.step(torch.zeros(n, device="cuda") - 0.9)
+    sd = {k: v for k, v in env.state_dict().items() if k not in ("format", "v4_param_stream")}
+    other = gf.make("fishing-v4", num_envs=n, seed=1, derived_params=False)
+    with pytest.raises(ValueError, match="strict=False"):
+        other.load_state_dict(sd)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        other.load_state_dict(sd, strict=False)
+    assert len(w) == 1 and torch.equal(other.K, env.K) and torch.equal(other.state, env.state)
+    one = gf.make("fishing-v4")                         # scalar protocol, rng="numpy"
+    one.reset()
+    sd1 = {k: v for k, v in one.state_dict().items() if k not in ("format", "v4_param_stream")}
+    two = gf.make("fishing-v4")
+    two.load_state_dict(sd1)
+    assert two.K == one.K and two.r == one.r
+
+
 @pytest.mark.parametrize("env_id", ["fishing-v1", "fishing-v0", "fishing-v4"])
 def test_gymnasium_api_splits_done_into_terminated_and_truncated(gf, env_id):
     """make(id, api="gymnasium"): reset() -> (obs, info), step() -> 5-tuple with truncated = years_passed > Tmax and
@@ -605,6 +735,14 @@ def test_gymnasium_api_splits_done_into_terminated_and_truncated(gf, env_id):
     flags = [e5.step(leave)[2:4] for _ in range(6)]
     assert flags[:5] == [(False, False)] * 5 and flags[5] == (False, True)
     assert e5.Tmax == 5 and e5.unwrapped is e5 and e5.action_space is e5.env.action_space
+    # attribute WRITES reach the wrapped env (the reference's callers set env.unwrapped.Tmax / .sigma / .K), not a shadow
+    e5.unwrapped.Tmax = 2
+    e5.sigma = 0.25
+    assert e5.env.Tmax == 2 and e5.env.sigma == 0.25 and "Tmax" not in e5.__dict__ and "sigma" not in e5.__dict__
+    e5.reset()
+    assert [e5.step(leave)[3] for _ in range(3)] == [False, False, True]          # truncated by the NEW horizon
+    e5.render_mode = "human"
+    assert e5.__dict__["render_mode"] == "human" and not hasattr(e5.env, "render_mode")
     # N envs with fused auto-reset: both kinds of ending in one batch, and the 4-tuple env's done is their union
     n = 512
     kw = dict(num_envs=n, seed=11, sigma=0.05, Tmax=4)
