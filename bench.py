@@ -216,6 +216,54 @@ def pmc_traffic(kernel, n_envs, built=None):
     return None, None
 
 
+# --------------------------------------------------------------------------------------- the device seam
+class HipRuntime:
+    """Where a rank's envs live and how it waits for them: the HIP device, one per rank.  (FISHING_BENCH_RUNTIME =
+    "module:attr" swaps this object for a stand-in -- tests/bench_rehearsal.py puts the CPU oracle behind the same
+    interface so that THIS file's multi-rank control flow -- self-launch, process group, ranks_seen, shard offsets, action
+    slices, record all-reduce, barriers, the MAX over ranks, the JSON relay -- runs at world = 8 on a box without eight
+    GPUs.  A rehearsal line says so in config.rehearsal and carries no roofline; the driver never sets the variable.)"""
+    name = None              # a stand-in names itself here
+    cuda = True
+    backend = "nccl"
+    device = "cuda"
+
+    def claim_device(self, torch, rank, local_rank):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device")
+        single_device = os.environ.get("FISHING_BENCH_SINGLE_DEVICE") == "1"
+        # (device_count() does not initialise the GPU on this image; no re-exec and no retry from here on, whatever fails)
+        if not single_device and torch.cuda.device_count() < local_rank + 1:
+            raise SystemExit("bench.py rank %d: LOCAL_RANK=%d but only %d HIP device(s) visible (HIP_VISIBLE_DEVICES=%r, "
+                             "ROCR_VISIBLE_DEVICES=%r): one rank per GPU needs --gpus <= the devices of this node" % (
+                                 rank, local_rank, torch.cuda.device_count(), os.environ.get("HIP_VISIBLE_DEVICES"),
+                                 os.environ.get("ROCR_VISIBLE_DEVICES")))
+        # rehearsal knob (not used by the driver): several ranks on ONE device over gloo, to run the
+        # multi-rank control flow on a single-GPU box
+        if single_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        return local_rank
+
+    def synchronize(self, torch):
+        torch.cuda.synchronize()
+
+    def event(self, torch):
+        return torch.cuda.Event(enable_timing=True)
+
+    def make_env(self, gf, torch, cfg_name, n, env_offset, with_returns, compact=False, v4_stored=False, f64=False):
+        return make_env(gf, torch, cfg_name, n, env_offset, with_returns, compact, v4_stored, f64)
+
+
+def load_runtime():
+    spec = os.environ.get("FISHING_BENCH_RUNTIME")
+    if not spec:
+        return HipRuntime()
+    import importlib
+    mod, _, attr = spec.partition(":")
+    return getattr(importlib.import_module(mod), attr or "Runtime")()
+
+
 # --------------------------------------------------------------------------------------- one rank
 ACTION_CHUNK = 1 << 16
 
@@ -265,15 +313,16 @@ def bytes_per_env_step(cfg_name, with_returns, compact=False, v4_stored=False, f
     return b + (w * BYTES_RETURN_ACC if with_returns else 0)
 
 
-def spin_up(torch, env, actions, min_ms):
+def spin_up(torch, env, actions, min_ms, rt=None):
     """Run the benchmark's own launches until `min_ms` of wall time has passed (device clocks ramp under load;
     the first launches of a cold device run 10-40 % slow).  Returns (ms, launches)."""
     t0 = time.perf_counter()
     launches = 0
+    burst = 256 if rt is None or rt.cuda else 1
     while (time.perf_counter() - t0) * 1e3 < min_ms:
-        env.step_many(actions, 256)
-        torch.cuda.synchronize()
-        launches += 256
+        env.step_many(actions, burst)
+        (rt.synchronize(torch) if rt is not None else torch.cuda.synchronize())
+        launches += burst
     return (time.perf_counter() - t0) * 1e3, launches
 
 
@@ -346,26 +395,15 @@ def main():
     import torch
     import torch.distributed as dist
 
+    rt = load_runtime()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d under torch.distributed.run needs %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device")
-    single_device = os.environ.get("FISHING_BENCH_SINGLE_DEVICE") == "1"
-    # (device_count() does not initialise the GPU on this image; no re-exec and no retry from here on, whatever fails)
-    if not single_device and torch.cuda.device_count() < local_rank + 1:
-        raise SystemExit("bench.py rank %d: LOCAL_RANK=%d but only %d HIP device(s) visible (HIP_VISIBLE_DEVICES=%r, "
-                         "ROCR_VISIBLE_DEVICES=%r): one rank per GPU needs --gpus <= the devices of this node" % (
-                             rank, local_rank, torch.cuda.device_count(), os.environ.get("HIP_VISIBLE_DEVICES"),
-                             os.environ.get("ROCR_VISIBLE_DEVICES")))
-    # rehearsal knobs (not used by the driver): several ranks on ONE device over gloo, to run the
-    # multi-rank control flow on a single-GPU box
-    backend = os.environ.get("FISHING_BENCH_BACKEND", "nccl")
-    if single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
+    # a rank that cannot get its device exits non-zero here, with a one-line diagnosis: no re-exec, no retry
+    local_rank = rt.claim_device(torch, rank, local_rank)
+    backend = os.environ.get("FISHING_BENCH_BACKEND", rt.backend)
     # under torch.distributed.run (RANK set) the process group is created for any world size, so
     # the single-rank launch exercises the same RCCL init / all-reduce / barrier code as N > 1
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
@@ -384,7 +422,7 @@ def main():
             # every rank contributes a one: the sum is the number of ranks the collective library actually joined
             ones = torch.ones(1, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(ones)
-            torch.cuda.synchronize()
+            rt.synchronize(torch)
             ranks_seen = int(round(float(ones.item())))
         finally:
             sys.stdout.flush()
@@ -402,9 +440,9 @@ def main():
     cfg = CONFIGS[args.config]
     n = args.n_envs or (1 << (cfg["log2_n"] if world == 1 else cfg["log2_n_multi"]))
     with_returns = not args.no_returns
-    env = make_env(gf, torch, args.config, n, rank * n, with_returns, args.compact, args.v4_stored, args.f64)
+    env = rt.make_env(gf, torch, args.config, n, rank * n, with_returns, args.compact, args.v4_stored, args.f64)
     env.reset()
-    actions = make_actions(torch, cfg, n, RING, rank * n)
+    actions = make_actions(torch, cfg, n, RING, rank * n, device=rt.device)
 
     barrier_first = use_dist and backend == "nccl" and os.environ.get("FISHING_BENCH_BARRIER_FIRST", "1") == "1"
 
@@ -414,16 +452,16 @@ def main():
         # hides under them (one host <-> device round trip per bracket instead of two).  A host-side barrier (gloo
         # rehearsal) says nothing about the device, so there the device is drained first.
         if use_dist and not barrier_first:
-            torch.cuda.synchronize()
+            rt.synchronize(torch)
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        rt.synchronize(torch)
 
-    spin_ms, spin_launches = spin_up(torch, env, actions, args.spinup_ms)
+    spin_ms, spin_launches = spin_up(torch, env, actions, args.spinup_ms, rt)
     env.step_many(actions, args.warmup)
     if with_returns:
         env.episode_stats()           # warm the reduce kernel and the RCCL communicator
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0, ev1 = rt.event(torch), rt.event(torch)
 
     def region():
         """The timed sequence, exactly: K launches + the record's reduce kernel (+ the all-reduce) enqueued, then the
@@ -464,23 +502,26 @@ def main():
     # lead-in so that the device is already busy when the first event fires -- HIP events around the K launches then
     # hold K kernel durations and nothing else.  (The bracket over the timed region above also contains the idle
     # device's pick-up of the first launch, ~10-25 us once: 0.5 us per step at K = 20, invisible at K = 5050.)
-    lead = 16
-    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    k_steady = max(args.steps, 256)          # (at the driver's K = 20 the events' own few us would be 1-2 % of the bracket)
-    env.step_many(actions, lead)
-    s0.record()
-    env.step_many(actions, k_steady)
-    s1.record()
-    torch.cuda.synchronize()
-    steady_ms = s0.elapsed_time(s1) / k_steady
-    med_us, mean_us = per_launch_us(torch, env, actions, max(1, min(args.steps, 200)))
+    if rt.cuda:
+        lead = 16
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        k_steady = max(args.steps, 256)          # (at the driver's K = 20 the events' own few us would be 1-2 % of the bracket)
+        env.step_many(actions, lead)
+        s0.record()
+        env.step_many(actions, k_steady)
+        s1.record()
+        torch.cuda.synchronize()
+        steady_ms = s0.elapsed_time(s1) / k_steady
+        med_us, mean_us = per_launch_us(torch, env, actions, max(1, min(args.steps, 200)))
+    else:               # a rehearsal measures nothing about a kernel
+        k_steady, steady_ms, med_us, mean_us = args.steps, kernel_ms, None, None
 
     total_env_steps = float(n) * world * args.steps
     bytes_per = bytes_per_env_step(args.config, with_returns, args.compact, args.v4_stored, args.f64)
     achieved = n * bytes_per / (steady_ms * 1e-3) / 1e9
     kernel = env.step_kernel_name(actions[0])
-    traffic, traffic_src = pmc_traffic(kernel, n)
+    traffic, traffic_src = pmc_traffic(kernel, n) if rt.cuda else (None, None)
     esz = 1 if args.compact else 4
     rsz = 8 if args.f64 else 4
     resident = n * (rsz + esz + rsz + 1 + (rsz if with_returns else 0) + (rsz if args.config == "v4" else 0)
@@ -514,7 +555,8 @@ def main():
                    "collective": "1 all-reduce of 4 doubles per rollout (%s)" % ("RCCL" if backend == "nccl" else backend)
                                  if world > 1 else "none",
                    # ranks counted by an all-reduce of ones at start-up (null: no process group, i.e. a bare 1-GPU run)
-                   ("rccl_ranks_seen" if backend == "nccl" else backend + "_ranks_seen"): ranks_seen},
+                   ("rccl_ranks_seen" if backend == "nccl" else backend + "_ranks_seen"): ranks_seen,
+                   "rehearsal": rt.name},
         "spinup": {"ms": spin_ms, "launches": spin_launches, "rehearsal_launches": args.steps,
                    "note": "same launches as the timed region, ahead of --warmup; then one untimed dress rehearsal of the timed "
                            "sequence itself (K launches + record + barrier); none of it timed"},
@@ -537,6 +579,10 @@ def main():
     }
     if stats:
         out["episode_stats"] = {k: stats[k] for k in ("n_episodes", "mean_return", "std_return", "mean_length") if k in stats}
+    if not rt.cuda:
+        out["roofline"] = None
+        args.no_subrecords = args.no_cpu_baseline = True
+        args.extra = False
     if rank == 0 and world == 1 and with_returns and not args.no_subrecords and not args.compact and not args.f64:
         out["graph_region"] = graph_region(torch, gf, args, n, actions)
 

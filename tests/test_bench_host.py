@@ -54,3 +54,68 @@ def test_gpus_n_self_launch_relays_child_failure():
     assert proc.returncode != 0
     assert proc.stdout.strip() == ""
     assert "needs a HIP device" in proc.stderr
+
+
+# ------------------------------------------------------------------ world = 8, rehearsed on the CPU
+def _rehearse(gpus, config, n_envs, steps=3, warmup=1, extra_env=None, timeout=600):
+    """`python bench.py --gpus N ...` through its own self-launch, with the CPU oracle behind the device seam."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(FISHING_BENCH_RUNTIME="tests.bench_rehearsal:Runtime", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", str(steps), "--warmup", str(warmup),
+           "--spinup-ms", "0", "--config", config, "--n-envs", str(n_envs)]
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("config", ["v2", "v4"])
+def test_eight_rank_rehearsal_of_the_bench_rank_path(config):
+    """The first 8-GPU run will be unattended.  This is that run's control flow, at world = 8, on the CPU: `bench.py
+    --gpus 8` starts eight child ranks (torch.distributed.run, 127.0.0.1), each claims its device, joins the process group
+    (gloo here), counts the ranks with an all-reduce of ones, builds its envs at offset rank * n and its slice of the
+    global action ring, runs spin-up / warm-up / dress rehearsal / the timed region with the record's all-reduce and the
+    closing barrier inside it, the elapsed time is MAX-reduced, rank 0 prints ONE JSON line and the parent relays it.  The
+    ORACLE advances the envs (tests/bench_rehearsal.py), so the merged record is checkable: it equals the record of ONE
+    rank stepping all 8 n envs -- BASELINE configs 4 (fishing-v2) and 5 (fishing-v4, (K, r) redrawn per episode from the
+    global env index)."""
+    n, steps, warmup = 2048, 3, 1
+    proc = _rehearse(8, config, n, steps, warmup)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["gloo_ranks_seen"] == 8 and out["scaling"] == "weak"
+    assert out["config"]["global_envs"] == 8 * n and out["config"]["envs_per_gpu"] == n
+    assert "rehearsal" in out["config"] and out["roofline"] is None and out["cpu_baseline"] is None
+    assert out["config"]["collective"].startswith("1 all-reduce of 4 doubles")
+    assert out["value"] == pytest.approx(8 * n * steps / (out["ms_per_step"] * steps * 1e-3), rel=1e-9)
+    one = _rehearse(1, config, 8 * n, steps, warmup)
+    assert one.returncode == 0, one.stderr[-3000:]
+    ref = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][0])
+    assert ref["n_gpus"] == 1 and ref["config"]["gloo_ranks_seen"] is None
+    a, b = out["episode_stats"], ref["episode_stats"]
+    assert a["n_episodes"] == b["n_episodes"] > 0
+    for k in ("mean_return", "std_return", "mean_length"):
+        assert a[k] == pytest.approx(b[k], rel=1e-9), k
+
+
+@pytest.mark.timeout(600)
+def test_rehearsed_rank_without_a_device_fails_loudly():
+    """`--gpus 8` on a node that shows six devices: ranks 6 and 7 exit non-zero with a one-line diagnosis, no re-exec, no
+    retry; torch.distributed.run tears the others down and the parent relays the failure -- no JSON line."""
+    proc = _rehearse(8, "v1", 1024, extra_env={"FISHING_REHEARSAL_DEVICES": "6"}, timeout=500)
+    assert proc.returncode != 0 and proc.stdout.strip() == ""
+    assert "only 6 rehearsal device(s)" in proc.stderr
+
+
+def test_config_shards_of_eight_ranks_are_quad_aligned_and_tile():
+    """The per-rank blocks the 8-GPU run will own: BASELINE config 4 (2^19 per rank) and config 5 (2^21 per rank) --
+    offsets are multiples of 4 (noise quads, 16-byte rows) and of the 2^16-env action chunks, the blocks tile
+    [0, 8 n) exactly, and sharding.shard_range gives the same blocks for the global batch."""
+    from gym_fishing_amd import sharding
+    for name in ("v2", "v4"):
+        n = 1 << bench.CONFIGS[name]["log2_n_multi"]
+        assert n == (1 << 19 if name == "v2" else 1 << 21)
+        blocks = [sharding.shard_range(8 * n, r, 8) for r in range(8)]
+        assert blocks == [(r * n, n) for r in range(8)]
+        assert all(off % 4 == 0 and off % bench.ACTION_CHUNK == 0 for off, _ in blocks)
