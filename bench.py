@@ -52,6 +52,7 @@ BYTES_STEP = 25
 BYTES_STEP_COMPACT = 19     # --compact: years_passed as uint8 (R 1 + W 1 instead of R 4 + W 4)
 BYTES_RETURN_ACC = 8
 BYTES_SIGMA_ARRAY = 4       # fishing-v4: per-env sigma (R 4)
+BYTES_V4_STAMP = 8          # fishing-v4 --v4-stamped: per-env origin stamps after a masked reset (R 4 + W 4; int32 in every layout)
 BYTES_RK_ARRAYS = 16        # fishing-v4 --v4-stored: per-env r, K read every step (R 4 + 4) and -- on this random-policy workload, where
                             # practically every 128-byte line holds a finished env every step (mean episode length 1.47) -- rewritten by the
                             # redraw (W 4 + 4): rocprofv3 PMC traffic was 1.18 x the 45 B that left the writes out (profiles/r02_step_v4s_*)
@@ -89,6 +90,8 @@ def parse():
     ap.add_argument("--compact", action="store_true",
                     help="opt-in compact layout (uint8 year counter, 19 B/env-step); NOT the BASELINE layout")
     ap.add_argument("--v4-stored", action="store_true", help="config v4 with r / K arrays in HBM instead of derived (K, r)")
+    ap.add_argument("--v4-stamped", action="store_true",
+                    help="config v4 after a masked reset(): derived (K, r) with per-env origin stamps (45 B/env-step)")
     ap.add_argument("--f64", action="store_true",
                     help="the float64 parity layout (bit-exact against the reference's arithmetic; 37 B/env-step); NOT the headline layout")
     ap.add_argument("--extra", action="store_true", help="also time the fused rollout and an N sweep")
@@ -305,11 +308,11 @@ def make_env(gf, torch, cfg_name, n, env_offset, with_returns, compact=False, v4
                    auto_reset=True, compact=compact, **kw)
 
 
-def bytes_per_env_step(cfg_name, with_returns, compact=False, v4_stored=False, f64=False):
+def bytes_per_env_step(cfg_name, with_returns, compact=False, v4_stored=False, f64=False, v4_stamped=False):
     w = 2 if f64 else 1         # width of the real-valued streams relative to float32
     b = (BYTES_STEP_COMPACT if compact else BYTES_STEP) + (BYTES_F64 if f64 else 0)
     if cfg_name == "v4":
-        b += w * (BYTES_SIGMA_ARRAY + (BYTES_RK_ARRAYS if v4_stored else 0))
+        b += w * (BYTES_SIGMA_ARRAY + (BYTES_RK_ARRAYS if v4_stored else 0)) + (BYTES_V4_STAMP if v4_stamped and not v4_stored else 0)
     return b + (w * BYTES_RETURN_ACC if with_returns else 0)
 
 
@@ -442,6 +445,9 @@ def main():
     with_returns = not args.no_returns
     env = rt.make_env(gf, torch, args.config, n, rank * n, with_returns, args.compact, args.v4_stored, args.f64)
     env.reset()
+    stamped = args.v4_stamped and args.config == "v4" and not args.v4_stored and rt.cuda
+    if stamped:         # one env in eight reset on its own: the batch stays in the derived mode, on per-env origin stamps
+        env.reset(torch.arange(n, device="cuda") % 8 == 0)
     actions = make_actions(torch, cfg, n, RING, rank * n, device=rt.device)
 
     barrier_first = use_dist and backend == "nccl" and os.environ.get("FISHING_BENCH_BARRIER_FIRST", "1") == "1"
@@ -518,7 +524,7 @@ def main():
         k_steady, steady_ms, med_us, mean_us = args.steps, kernel_ms, None, None
 
     total_env_steps = float(n) * world * args.steps
-    bytes_per = bytes_per_env_step(args.config, with_returns, args.compact, args.v4_stored, args.f64)
+    bytes_per = bytes_per_env_step(args.config, with_returns, args.compact, args.v4_stored, args.f64, stamped)
     achieved = n * bytes_per / (steady_ms * 1e-3) / 1e9
     kernel = env.step_kernel_name(actions[0])
     traffic, traffic_src = pmc_traffic(kernel, n) if rt.cuda else (None, None)
@@ -548,7 +554,8 @@ def main():
                                    "int32 [0,100)" if cfg["actions"][0] == "int" else "float32 U[%g,%g)" % cfg["actions"][1:],
                                    RING, ", per-env episodic-return accumulator + return record" if with_returns else "",
                                    ("; COMPACT layout (uint8 year counter)" if args.compact else "") + ("; FLOAT64 parity layout" if args.f64 else ""),
-                                   ("; r / K arrays in HBM" if args.v4_stored else "; (K, r) re-derived in-kernel, no r / K arrays")
+                                   ("; r / K arrays in HBM" if args.v4_stored else "; (K, r) re-derived in-kernel, no r / K arrays"
+                                    + (", per-env origin stamps after a masked reset of one env in eight" if stamped else ""))
                                    if args.config == "v4" else "", "f64" if args.f64 else "f32"),
                    "name": args.config, "baseline_config": cfg["baseline_config"],
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-shard x%d" % world,
@@ -583,6 +590,8 @@ def main():
         out["roofline"] = None
         args.no_subrecords = args.no_cpu_baseline = True
         args.extra = False
+    if stamped:
+        args.no_subrecords = True
     if rank == 0 and world == 1 and with_returns and not args.no_subrecords and not args.compact and not args.f64:
         out["graph_region"] = graph_region(torch, gf, args, n, actions)
 

@@ -46,7 +46,7 @@ class FishingParams(ctypes.Structure):
 
 
 BUFFER_FIELDS = ("obs", "action", "reward", "done", "done_bits", "t", "r", "K", "sigma", "z_ext",
-                 "terminal_obs", "ep_return", "return_partials", "model_idx", "counter")
+                 "terminal_obs", "ep_return", "return_partials", "model_idx", "counter", "v4_stamp")
 
 
 class FishingBuffers(ctypes.Structure):
@@ -69,8 +69,8 @@ SIGNATURES = {
     "fishing_reset_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_vp, c_u64, c_u64, c_vp]),
     "fishing_step_fused_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_u64, c_u64, c_vp]),
     "fishing_step_fused_f64": (c_i32, [_PP, c_i64, c_i64, _BP, c_i64, c_i32, c_i32, c_vp, c_vp, c_i64, c_u64, c_u64, c_vp]),
-    "fishing_v4_params_f32": (c_i32, [_PP, c_i64, c_i64, c_vp, c_vp, c_vp, c_u64, c_u64, c_vp]),
-    "fishing_v4_params_f64": (c_i32, [_PP, c_i64, c_i64, c_vp, c_vp, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_v4_params_f32": (c_i32, [_PP, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_u64, c_u64, c_vp]),
+    "fishing_v4_params_f64": (c_i32, [_PP, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_u64, c_u64, c_vp]),
     "fishing_step_kernel_name_f32": (c_i32, [_PP, c_i64, _BP, ctypes.c_char_p, c_i64]),
     "fishing_step_kernel_name_f64": (c_i32, [_PP, c_i64, _BP, ctypes.c_char_p, c_i64]),
     "fishing_rollout_f32": (c_i32, [_PP, c_i64, c_i64, _BP, c_i32, c_dbl, c_i32, c_vp, c_u64, c_u64, c_vp]),

@@ -31,6 +31,9 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
             b.K[i] = K;
             b.r[i] = r;
         }
+        // ... but an env reset on its own is stamped with this reset's counter (its episode's origin); a reset of every
+        // env clears the stamps: the origin words date every episode again
+        if (MODEL == FISHING_MODEL_V4 && b.stamp) b.stamp[i] = mask ? (int32_t)(uint32_t)(reset_counter + 1) : 0;
         b.obs[i] = reset_obs<T, MODEL>(p.x0, K);
         if (p.flags & FISHING_FLAG_T_U8) reinterpret_cast<uint8_t*>(b.t)[i] = 0;
         else b.t[i] = 0;
@@ -42,12 +45,13 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
 template <typename T>
 __global__ void __launch_bounds__(256)
 v4_params_kernel(const ParamsT<T> p, const int64_t n, const uint64_t env_offset, const int32_t* __restrict__ t,
-                 T* __restrict__ K_out, T* __restrict__ r_out, const uint64_t seed, const uint64_t step_counter) {
+                 const int32_t* __restrict__ stamp, T* __restrict__ K_out, T* __restrict__ r_out, const uint64_t seed,
+                 const uint64_t step_counter) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         T K, r;
         derive_model_error<T>(seed, env_offset + (uint64_t)i, step_counter, t[i], p.origin_step, p.origin_counter,
-                              p.K_mean, p.r_mean, p.sigma_p, K, r);
+                              p.K_mean, p.r_mean, p.sigma_p, K, r, stamp ? stamp[i] : 0);
         if (K_out) K_out[i] = K;
         if (r_out) r_out[i] = r;
     }
@@ -219,9 +223,11 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
     const ParamsT<T> pt = narrow_params<T>(*p);
     BuffersT<T> bt = typed_buffers<T>(*b);
     if (p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED)) {
-        // envs reset one by one no longer share the origin the derivation dates episodes from: the caller
-        // materialises the parameters (fishing_v4_params_*) and continues with arrays
-        if (mask) return FISHING_ERR_UNSUPPORTED;
+        // envs reset one by one no longer share the origin the derivation dates episodes from: each gets its own, in
+        // FishingBuffers.v4_stamp (a caller without that buffer materialises the parameters -- fishing_v4_params_* -- and
+        // continues with arrays)
+        if (mask && !b->v4_stamp) return FISHING_ERR_UNSUPPORTED;
+        if (mask && reset_counter >= 0x7FFFFFFFull) return FISHING_ERR_SIZE;       // (the stamp is 31 bits of reset counter + 1)
         bt.K = bt.r = nullptr;
     }
     const int blocks = grid_for(n, 2048);
@@ -238,8 +244,8 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
 }
 
 template <typename T>
-int v4_params_impl(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out, void* r_out,
-                   uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+int v4_params_impl(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, const int32_t* stamp, void* K_out,
+                   void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
     if (!p || !t) return FISHING_ERR_NULL;
     if (p->model != FISHING_MODEL_V4) return FISHING_ERR_MODEL;
     if (n < 0 || env_offset < 0) return FISHING_ERR_SIZE;
@@ -247,7 +253,7 @@ int v4_params_impl(const FishingParams* p, int64_t n, int64_t env_offset, const 
     if (n == 0) return FISHING_OK;
     const ParamsT<T> pt = narrow_params<T>(*p);
     return launch_kernel(v4_params_kernel<T>, grid_for(n, 2048), 256, (hipStream_t)stream, pt, n, (uint64_t)env_offset, t,
-                         (T*)K_out, (T*)r_out, seed, step_counter);
+                         stamp, (T*)K_out, (T*)r_out, seed, step_counter);
 }
 
 template <typename T>
@@ -310,13 +316,13 @@ int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, con
     return fishing::reset_impl<double>(p, n, env_offset, b, mask, seed, reset_counter, stream);
 }
 
-int fishing_v4_params_f32(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out,
-                          void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
-    return fishing::v4_params_impl<float>(p, n, env_offset, t, K_out, r_out, seed, step_counter, stream);
+int fishing_v4_params_f32(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, const int32_t* stamp,
+                          void* K_out, void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::v4_params_impl<float>(p, n, env_offset, t, stamp, K_out, r_out, seed, step_counter, stream);
 }
-int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out,
-                          void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
-    return fishing::v4_params_impl<double>(p, n, env_offset, t, K_out, r_out, seed, step_counter, stream);
+int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, const int32_t* stamp,
+                          void* K_out, void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::v4_params_impl<double>(p, n, env_offset, t, stamp, K_out, r_out, seed, step_counter, stream);
 }
 
 int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,

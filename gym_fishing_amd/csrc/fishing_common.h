@@ -285,6 +285,7 @@ struct BuffersT {
     double* partials;
     int32_t* model_idx;
     const uint64_t* counter;
+    int32_t* stamp;
 };
 
 template <typename T>
@@ -305,6 +306,7 @@ inline BuffersT<T> typed_buffers(const FishingBuffers& b) {
     q.partials = b.return_partials;
     q.model_idx = b.model_idx;
     q.counter = b.counter;
+    q.stamp = b.v4_stamp;
     return q;
 }
 
@@ -1096,25 +1098,30 @@ __device__ __forceinline__ void draw_model_error(uint64_t seed, uint64_t env, ui
 // (FISHING_FLAG_V4_DERIVED; 8 B/env-step of reads and, on the random-policy workload where nearly every
 // 128-byte line holds a finished env, 8 B/env-step of redraw writes saved).  Same values bit for bit
 // as the stored-array path, which draws from the same blocks at the moment of the reset.
+// `stamp` (FishingBuffers.v4_stamp; 0 = none): the env was reset on its own by the masked reset() with reset counter
+// stamp - 1 and has not finished since -- its episode runs on THAT reset's draw, whatever its year counter says.
 template <typename T, bool NARROW = false>
 __device__ __forceinline__ void derive_model_error(uint64_t seed, uint64_t env, uint64_t step_counter, int32_t t,
                                                    uint64_t origin_step, uint64_t origin_counter, T K_mean,
-                                                   T r_mean, T sigma_p, T& K, T& r) {
+                                                   T r_mean, T sigma_p, T& K, T& r, int32_t stamp = 0) {
     if constexpr (NARROW) {
         // every env index of the wave fits 32 bits and every counter 31 (derive_fits_32): the same block with half the
         // integer work -- param_block's key terms of the high parts are zero, the key is wave-uniform
         const uint32_t since = (uint32_t)step_counter - (uint32_t)t;
         const bool from_reset = since == (uint32_t)origin_step;
+        uint32_t c1 = from_reset ? ((uint32_t)origin_counter | kParamResetBit) : since - 1u;
+        c1 = stamp ? (((uint32_t)stamp - 1u) | kParamResetBit) : c1;
         uint32_t w0, w1;
-        philox2x32_10((uint32_t)env, from_reset ? ((uint32_t)origin_counter | kParamResetBit) : since - 1u, param_key(seed), w0, w1);
+        philox2x32_10((uint32_t)env, c1, param_key(seed), w0, w1);
         float zK, zr;
         box_muller(w0, w1, zK, zr);
         K = clip_param<T>(K_mean + sigma_p * (T)zK);
         r = clip_param<T>(r_mean + sigma_p * (T)zr);
     } else {
         const uint64_t since = step_counter - (uint64_t)(int64_t)t;
-        const bool from_reset = since == origin_step;
-        draw_model_error_block<T>(seed, env, from_reset ? origin_counter : since - 1, from_reset, K_mean, r_mean, sigma_p, K, r);
+        const bool from_reset = (since == origin_step) || stamp != 0;
+        const uint64_t counter = stamp ? (uint64_t)(uint32_t)(stamp - 1) : (from_reset ? origin_counter : since - 1);
+        draw_model_error_block<T>(seed, env, counter, from_reset, K_mean, r_mean, sigma_p, K, r);
     }
 }
 // FishingBuffers.counter under FISHING_FLAG_V4_DERIVED: {step counter, origin step, origin counter} in device memory, so

@@ -57,6 +57,9 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         int32_t t[4];
         bool dn[4], live[4];    // live: a real env whose episode is still running
         int32_t kind[4];
+        int32_t st[4] = {0, 0, 0, 0};       // fishing-v4 derived: per-env origin stamps (FishingBuffers.v4_stamp)
+        const bool stamped = derived && b.stamp != nullptr;
+        bool stamp_dirty = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             kind[j] = (kZooKind >= 0) ? kZooKind : FISHING_KIND_BEVERTON_HOLT;
@@ -81,12 +84,13 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             if (zoo_mixed) load4<int32_t>(b.model_idx, base, n, full, kind, FISHING_KIND_BEVERTON_HOLT);
             if (b.sigma) load4<T>(b.sigma, base, n, full, sg, p.sigma);
             if (b.ep_return) load4<T>(b.ep_return, base, n, full, er, (T)0);
+            if (stamped) load4<int32_t>(b.stamp, base, n, full, st, 0);
         }
         if (derived) {      // once per launch; the redraws below keep (K, r) current from then on
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 derive_model_error<T>(seed_arg, env_offset + (uint64_t)base + j, step_counter0, t[j], origin_step,
-                                      origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
+                                      origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j], st[j]);
         }
         bool kind_dirty = false;
         const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
@@ -242,6 +246,13 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     if (redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
                                               p.K_mean, p.r_mean, p.sigma_p, p.x0, fin, KK, rr, obs, t))
                         kr_dirty = true;
+                    if (stamped) {          // an auto-reset env is dated by its year counter again
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            stamp_dirty |= fin[j] && st[j] != 0;
+                            st[j] = fin[j] ? 0 : st[j];
+                        }
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -269,6 +280,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                 store4<T>(b.K, base, n, full, KK);
                 store4<T>(b.r, base, n, full, rr);
             }
+            if (stamp_dirty) store4<int32_t>(b.stamp, base, n, full, st);
             if (zoo_drift) store4<T>(b.r, base, n, full, rr);
             if (zoo_mixed && kind_dirty) store4<int32_t>(b.model_idx, base, n, full, kind);
             if (b.done) {
@@ -374,6 +386,7 @@ struct FusedArgs {
     const T* sigma_arr;
     T* reward_steps;         // [n_steps][out_stride], nullable
     uint8_t* done_steps;     // [n_steps][out_stride], nullable
+    int32_t* stamp;          // fishing-v4 derived: per-env origin stamps (FishingBuffers.v4_stamp), nullable
     int64_t action_stride, out_stride;
     int32_t ring_len, n_steps;
     T pr, pK, sigma, C, x0, r_mean, K_mean, sigma_p;
@@ -444,6 +457,9 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
         int32_t t[4];
         int32_t kind[4];
         bool dn[4];
+        int32_t st[4] = {0, 0, 0, 0};       // fishing-v4 derived: per-env origin stamps (FishingBuffers.v4_stamp)
+        const bool stamped = derived && a.stamp != nullptr;
+        bool stamp_dirty = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             obs[j] = (T)0;
@@ -467,6 +483,7 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
             if constexpr (zoo_mixed) load4<int32_t>(ex.model_idx, base, n, full, kind, FISHING_KIND_BEVERTON_HOLT);
             if (a.sigma_arr) load4<T>(a.sigma_arr, base, n, full, sg, a.sigma);
             if (a.ep_return) load4<T>(a.ep_return, base, n, full, er, (T)0);
+            if (stamped) load4<int32_t>(a.stamp, base, n, full, st, 0);
         }
         // the action rows: kPrefetch steps in flight
         float pf_f[kPrefetch][4];
@@ -489,7 +506,7 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter0, t[j], origin_step,
-                                      origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+                                      origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j], st[j]);
         }
         const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
         bool kr_dirty = false;
@@ -624,6 +641,13 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                             if (redraw_tile<T, MODEL>(seed_s, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
                                                       a.K_mean, a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs, t))
                                 kr_dirty = true;
+                            if (stamped) {          // an auto-reset env is dated by its year counter again
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    stamp_dirty |= dn[j] && st[j] != 0;
+                                    st[j] = dn[j] ? 0 : st[j];
+                                }
+                            }
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -645,6 +669,7 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                 store4<T>(a.K, base, n, full, KK);
                 store4<T>(a.r, base, n, full, rr);
             }
+            if (stamp_dirty) store4<int32_t>(a.stamp, base, n, full, st);
             if (drift) store4<T>(a.r, base, n, full, rr);
             if constexpr (zoo_mixed) {
                 if (kind_dirty) store4<int32_t>(ex.model_idx, base, n, full, kind);
@@ -680,7 +705,7 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
     const int noise = noise_mode(p, b);
     const bool per_env = p->model == FISHING_MODEL_V4;
     const FusedArgs<T> a{bt.obs, bt.action, bt.reward, bt.done, bt.t, bt.r, bt.K, bt.ep_return, bt.partials, bt.counter,
-                         bt.sigma, (T*)reward_steps, done_steps, action_stride, out_stride, ring_len, n_steps, pt.r, pt.K,
+                         bt.sigma, (T*)reward_steps, done_steps, bt.stamp, action_stride, out_stride, ring_len, n_steps, pt.r, pt.K,
                          pt.sigma, pt.C, pt.x0, pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions,
                          (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET), (uint32_t)((p->flags & FISHING_FLAG_T_U8) != 0),
                          (uint32_t)(per_env && (p->flags & FISHING_FLAG_V4_DERIVED)), (uint32_t)(p->model == FISHING_MODEL_V10),
@@ -737,6 +762,7 @@ int step_fused_impl(const FishingParams* p, int64_t n, int64_t env_offset, const
             tl.sigma_arr = a.sigma_arr ? a.sigma_arr + o : nullptr;
             tl.reward_steps = a.reward_steps ? a.reward_steps + o : nullptr;
             tl.done_steps = a.done_steps ? a.done_steps + o : nullptr;
+            tl.stamp = a.stamp ? a.stamp + o : nullptr;
             if constexpr (kTag == kModelZooMixed) ex.model_idx = ex.model_idx + o;
             // (the tail adds its record to workgroup slot 0, as the per-step path.s tail launch does)
             return launch_kernel(step_fused_kernel<T, kTag, true>, 1, 256, (hipStream_t)stream, tl, ex, n - n_full,

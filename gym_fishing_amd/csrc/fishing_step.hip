@@ -105,6 +105,8 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         float a_f[4];
         int32_t a_i[4];
         int32_t kind[4];
+        int32_t st[4] = {0, 0, 0, 0};       // fishing-v4 derived: per-env origin stamps (FishingBuffers.v4_stamp)
+        const bool stamped = derived && b.stamp != nullptr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             kind[j] = zoo_kind;
@@ -132,6 +134,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
             if (zoo_mixed) load4<int32_t>(b.model_idx, base, n, full, kind, FISHING_KIND_BEVERTON_HOLT);
             if (b.sigma) load4<T>(b.sigma, base, n, full, sg, p.sigma);
             if (noise == kNoiseExt) load4<T>(b.z_ext, base, n, full, z, (T)0);
+            if (stamped) load4<int32_t>(b.stamp, base, n, full, st, 0);
         }
         if (noise == kNoisePhilox) {
             float zq[4];
@@ -143,7 +146,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 derive_model_error<T>(seed, env_offset + (uint64_t)base + j, step_counter, t[j], origin_step,
-                                      origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j]);
+                                      origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j], st[j]);
         }
 
         T obs_next[4], rew[4];
@@ -268,8 +271,10 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                     if (dn[j]) {
                         obs_next[j] = reset_obs<T, MODEL>(p.x0, KK[j]);    // fishing-v4: x0, whatever the new K
                         t_next[j] = 0;
+                        st[j] = 0;          // ... and from here on the year counter dates the episode again
                     }
                 }
+                if (stamped && active) store4<int32_t>(b.stamp, base, n, full, st);
             }
             if (kPerEnv && redrawn) {
                 store4<T>(b.K, base, n, full, KK);
@@ -315,6 +320,8 @@ constexpr int ONE = 1 << 13;       // one tile per workgroup (grid == ntiles; ev
                                    // return record -- workgroup reduction + its atomic -- is issued BEFORE the tile's stores, so the
                                    // atomic's round trip runs under theirs.  Exact instantiations and catch-alls alike.  Per step at N = 2^19 / 2^20 /
                                    // 2^21, back to back: 4.75 -> 4.09, 6.15 -> 5.71, 9.78 -> 8.15 us (profiles/r03_small_n/).
+constexpr int STAMP = 1 << 14;     // fishing-v4 derived: per-env origin stamps (FishingBuffers.v4_stamp: R 4 + W 4).  Catch-all only --
+                                   // masked resets are the rare path; the exact DERIVED instantiations stay stamp-free.
 constexpr int KP2 = 1 << 12;       // the scalar K is a power of two (K = 1 included): x / K is the exact multiply x * (1 / K),
                                    // same bits, a third of the instructions.  Exact instantiations of fishing-v0/v1/v2 only;
                                    // any other K takes the catch-all's correctly rounded division.
@@ -336,6 +343,7 @@ struct LeanArgs {
     T* terminal_obs;         // TERM
     uint64_t* done_bits;     // BITS: bit i % 64 of word i / 64 = done[i]
     const T* z_ext;          // kNoiseExt
+    int32_t* stamp;          // STAMP
     T pr, pK, sigma, C, x0, r_mean, K_mean, sigma_p;
     int32_t Tmax, n_actions;
     uint32_t auto_reset;
@@ -398,6 +406,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     static_assert(!(F & feat::DRIFT) || MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT, "DRIFT is fishing-v10");
     static_assert(!(F & feat::DERIVED) || kPerEnv, "DERIVED is fishing-v4");
     static_assert(!(F & feat::LATCH) || kOpt, "LATCH lives in the catch-alls");
+    static_assert(!(F & feat::STAMP) || (kOpt && kPerEnv && (F & feat::DERIVED)), "STAMP: fishing-v4's derived catch-all");
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
     static_assert((F & feat::ONE) != 0, "every lean form is a one-tile form: a workgroup of 1024 / E threads per 1024-env tile");
     static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
@@ -410,6 +419,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool TERM = (F & feat::TERM) && (kExact || a.terminal_obs != nullptr);
     const bool BITS = (F & feat::BITS) && (kExact || a.done_bits != nullptr);
     const bool DERIVED = (F & feat::DERIVED) && (kExact || a.derived_rt != 0);
+    const bool STAMP = (F & feat::STAMP) && DERIVED && a.stamp != nullptr;
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
     const bool ZZ = a.zz_rt != 0;       // (run-time in every form: round 3's exact zig-zag twins of the tile loop went when
                                         // every batch up to 2^26 envs got a workgroup per tile)
@@ -503,11 +513,19 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         if constexpr (FISHING_LEAN_LOCAL_KEYS != 0 && (kPerEnv || (kOpt && sizeof(T) == 4))) asm volatile("" : "+s"(seed_it));
         T obs[E], rr[E], KK[E], z[E], er[E], sg[E];
         int32_t t[E], a_i[E];
-        int32_t kind[E];
+        int32_t kind[E], st[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) kind[j] = FISHING_KIND_BEVERTON_HOLT;
+        for (int j = 0; j < E; ++j) {
+            kind[j] = FISHING_KIND_BEVERTON_HOLT;
+            st[j] = 0;
+        }
         float a_f[E];
         {
+            if (STAMP) {
+                const VecE<int32_t, E> qs = *reinterpret_cast<const VecE<int32_t, E>*>(a.stamp + base);
+#pragma unroll
+                for (int j = 0; j < E; ++j) st[j] = qs.v[j];
+            }
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 sg[j] = a.sigma;
@@ -619,12 +637,12 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #pragma unroll
                 for (int j = 0; j < E; ++j)
                     derive_model_error<T, true>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], origin_step,
-                                                origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+                                                origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j], st[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < E; ++j)
                     derive_model_error<T>(seed_it, env_offset + (uint64_t)base + j, step_counter, t[j], origin_step,
-                                          origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j]);
+                                          origin_counter, a.K_mean, a.r_mean, a.sigma_p, KK[j], rr[j], st[j]);
             }
         }
         // LATCH: envs that were finished before this step (only possible without auto-reset) must not be recorded
@@ -779,6 +797,13 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 const bool rs = dn[j] && auto_reset;
                 obs_next[j] = rs ? robs_scalar : obs_next[j];
                 t_next[j] = rs ? 0 : t_next[j];
+                st[j] = rs ? 0 : st[j];         // (from here on the year counter dates the episode again)
+            }
+            if (STAMP && auto_reset && __any(lane_done)) {
+                VecE<int32_t, E> qs;
+#pragma unroll
+                for (int j = 0; j < E; ++j) qs.v[j] = st[j];
+                *reinterpret_cast<VecE<int32_t, E>*>(a.stamp + base) = qs;
             }
         }
         {
@@ -828,6 +853,7 @@ int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     if (!b->obs || !b->t) return FISHING_ERR_NULL;
     const bool derived = p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED);
     if (derived && (p->flags & FISHING_FLAG_T_U8)) return FISHING_ERR_UNSUPPORTED;     // a saturating counter cannot date an episode
+    if (b->v4_stamp && !derived) return FISHING_ERR_UNSUPPORTED;                          // origin stamps belong to the derived mode
     if (p->model == FISHING_MODEL_V4 && !derived && (!b->r || !b->K)) return FISHING_ERR_NULL;
     // (clip_param relies on it; the reference turns a non-finite mean into NaN populations)
     if (p->model == FISHING_MODEL_V4 && !(std::isfinite(p->K_mean) && std::isfinite(p->r_mean) && std::isfinite(p->sigma_p)))
@@ -836,7 +862,7 @@ int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     if (b->counter && (((uintptr_t)b->counter) & 7u)) return FISHING_ERR_ALIGN;
     const void* ptrs[] = {b->obs,  b->action, b->reward, b->done,         b->done_bits, b->t,           b->r,
                           b->K,    b->sigma,  b->z_ext,  b->terminal_obs, b->ep_return, b->return_partials,
-                          b->model_idx};
+                          b->model_idx, b->v4_stamp};
     for (const void* q : ptrs)
         if (misaligned(q)) return FISHING_ERR_ALIGN;
     return FISHING_OK;
@@ -883,6 +909,7 @@ BuffersT<T> offset_buffers(const BuffersT<T>& b, int64_t off, bool t_u8) {
     q.terminal_obs = b.terminal_obs ? b.terminal_obs + off : nullptr;
     q.ep_return = b.ep_return ? b.ep_return + off : nullptr;
     q.model_idx = b.model_idx ? b.model_idx + off : nullptr;
+    q.stamp = b.stamp ? b.stamp + off : nullptr;
     return q;
 }
 
@@ -945,7 +972,7 @@ int lean_launch(const LeanCall<T>& c) {
 template <int MODEL>
 constexpr int catch_all_mask() {
     int f = feat::kNoiseRT | feat::RET | feat::SIGARR | feat::T8 | feat::TERM | feat::BITS | feat::OPT | feat::LATCH;
-    if (MODEL == FISHING_MODEL_V4) f |= feat::DERIVED;
+    if (MODEL == FISHING_MODEL_V4) f |= feat::DERIVED | feat::STAMP;
     if (MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT) f |= feat::DRIFT;
     return f;
 }
@@ -1079,7 +1106,7 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     const int64_t n_full = padded ? n : ntiles * tile;
     const bool drift = p->model == FISHING_MODEL_V10;
     LeanArgs<T> a{bt.obs,   bt.action, bt.reward, bt.done,  bt.t,    bt.r,     bt.K,     bt.ep_return, bt.partials,
-                  bt.counter, bt.sigma, bt.terminal_obs, bt.done_bits, bt.z_ext, pt.r, pt.K, pt.sigma, pt.C, pt.x0,
+                  bt.counter, bt.sigma, bt.terminal_obs, bt.done_bits, bt.z_ext, bt.stamp, pt.r, pt.K, pt.sigma, pt.C, pt.x0,
                   pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET),
                   noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, 0u, padded ? n : INT64_MAX, pt.origin_step,
                   pt.origin_counter, pt.growth, pt.alpha, make_divk((double)pt.K), (T)(pt.x0 / pt.K - (T)1)};
@@ -1097,11 +1124,12 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     if (b->terminal_obs) req |= feat::TERM;
     if (b->done_bits) req |= feat::BITS;
     if (derived) req |= feat::DERIVED;
+    if (derived && b->v4_stamp) req |= feat::STAMP;
     if (drift) req |= feat::DRIFT;
     if (a.dk.pow2 && is_core_model(p->model) && p->model != FISHING_MODEL_V4) req |= feat::KP2;
     // The zig-zag walk (see the kernel) from ~100 MB per step, nontemporal action loads from ~200 MB
-    const int64_t step_bytes = n_full * (int64_t)(sizeof(T) == 4 ? 25 + (b->ep_return ? 8 : 0) + (b->sigma ? 4 : 0)
-                                                                 : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0));
+    const int64_t step_bytes = n_full * (int64_t)((sizeof(T) == 4 ? 25 + (b->ep_return ? 8 : 0) + (b->sigma ? 4 : 0)
+                                                                  : 37 + (b->ep_return ? 16 : 0) + (b->sigma ? 8 : 0)) + (b->v4_stamp ? 8 : 0));
     a.zz_rt = (step_bytes >= FISHING_XZZ_MIN_BYTES) ? 1u : 0u;
     a.nta_rt = (a.zz_rt && step_bytes >= FISHING_NTA_MIN_BYTES) ? 1u : 0u;
     LeanMixedArgs<T> mixed{};

@@ -217,9 +217,10 @@ class BaseFishingEnv(_gym_env_base()):
             self._sigma_scalar = float(sigma)
         # fishing-v4 on the Philox streams keeps NO r / K arrays: every kernel re-derives an env's (K, r) from the
         # block that drew them, which the env's year counter identifies (fishing_common.h: derive_model_error) --
-        # 8 B/env-step of reads and about as much of redraw writes less.  Arrays come back (once, through
-        # fishing_v4_params_*) when something makes the parameters underivable: a masked reset(), env.K = ... /
-        # env.r = ..., seed(); the next full reset() returns to the derived mode.
+        # 8 B/env-step of reads and about as much of redraw writes less.  A masked reset() keeps the mode: the envs it
+        # resets get a per-env origin stamp (4 B read + 4 B written per env-step until the next reset of all envs).  Arrays
+        # come back (once, through fishing_v4_params_*) when something makes the parameters underivable: env.K = ... /
+        # env.r = ..., seed(), an outside write to years_passed; the next full reset() returns to the derived mode.
         self._derived_capable = (self._per_env and not self._np_rng and not self._scalar and not self.compact
                                  and (derived_params is None or bool(derived_params)))
         if derived_params and not self._derived_capable:
@@ -227,6 +228,9 @@ class BaseFishingEnv(_gym_env_base()):
         self._derived = self._derived_capable
         self._origin = (0, 0)            # (step count, reset counter) of the last reset() of all envs
         self._K_store = self._r_store = None      # (see _param_store)
+        # fishing-v4 derived: per-env episode origins of envs reset one by one (FishingBuffers.v4_stamp; allocated by the
+        # first masked reset(), dropped from the launches again by the next reset of every env, never freed)
+        self._stamp = self._stamp_store = None
         if self._per_env and not self._derived:
             self._K_arr, self._r_arr = self._param_store()
             self._r_arr.fill_(float(params["r"]))
@@ -347,7 +351,8 @@ class BaseFishingEnv(_gym_env_base()):
         K, r = out if out is not None else (self._per_env_buffer(self.dtype), self._per_env_buffer(self.dtype))
         with torch.cuda.device(self.device):
             rc = getattr(self._lib, "fishing_v4_params_" + self._suffix)(
-                self._c_params(), self.num_envs, self.env_offset, self._t.data_ptr(), K.data_ptr(), r.data_ptr(),
+                self._c_params(), self.num_envs, self.env_offset, self._t.data_ptr(),
+                self._stamp.data_ptr() if self._stamp is not None else None, K.data_ptr(), r.data_ptr(),
                 self._seed, self._current_step_count(), self._stream())
         _capi.check(rc, "fishing_v4_params")
         return K, r
@@ -369,11 +374,20 @@ class BaseFishingEnv(_gym_env_base()):
             self._K_store, self._r_store = self._per_env_buffer(self.dtype), self._per_env_buffer(self.dtype)
         return self._K_store, self._r_store
 
+    def _stamp_buffer(self):
+        """fishing-v4's origin stamps (int32, zeroed): one allocation for the env's lifetime, like _param_store."""
+        if self._stamp_store is None:
+            self._stamp_store = self._per_env_buffer(torch.int32)
+        else:
+            self._stamp_store.zero_()
+        return self._stamp_store
+
     def _leave_derived_mode(self):
         """Store the parameters in force and continue with r / K arrays (until the next full reset())."""
         if self._derived:
             self._K_arr, self._r_arr = self._derive_params(self._param_store())
             self._derived = False
+            self._stamp = None              # (origin stamps belong to the derived mode)
             self._cbuf = None
 
     def launch_signature(self):
@@ -389,7 +403,7 @@ class BaseFishingEnv(_gym_env_base()):
         return (tuple(key), self._seed, self._derived,
                 tuple(ptr(t) for t in (self._obs, self._t, self._reward, self._done, self._done_bits, self._r_arr, self._K_arr,
                                        self._sigma_arr, self._terminal_obs, self._ep_return, self._partials, self._model_idx,
-                                       self._counter)))
+                                       self._counter, self._stamp)))
 
     def _K_view(self, out=None):
         if self._derived:
@@ -465,7 +479,8 @@ class BaseFishingEnv(_gym_env_base()):
             done=ptr(self._done) if with_outputs else None, done_bits=ptr(self._done_bits), t=ptr(self._t),
             r=ptr(self._r_arr), K=ptr(self._K_arr), sigma=ptr(self._sigma_arr), z_ext=ptr(z_ext),
             terminal_obs=ptr(self._terminal_obs), ep_return=ptr(self._ep_return),
-            return_partials=ptr(self._partials), model_idx=ptr(self._model_idx), counter=ptr(self._counter))
+            return_partials=ptr(self._partials), model_idx=ptr(self._model_idx), counter=ptr(self._counter),
+            v4_stamp=ptr(self._stamp))
 
     def _step_buffers(self, action_ptr, z_ptr):
         """The step() FishingBuffers: built once (the env's tensors never move), only the
@@ -544,7 +559,7 @@ class BaseFishingEnv(_gym_env_base()):
 
     # ------------------------------------------------------------------ checkpoint / resume
     _STATE_TENSORS = ("_obs", "_t", "_reward", "_done", "_r_arr", "_K_arr", "_sigma_arr", "_ep_return", "_partials",
-                      "_model_idx", "_counter")
+                      "_model_idx", "_counter", "_stamp")
     _STATE_ATTRS = ("_sigma_scalar", "n_actions", "C", "K_mean", "r_mean", "sigma_p")
 
     def state_dict(self):
@@ -584,7 +599,7 @@ class BaseFishingEnv(_gym_env_base()):
             raise ValueError("state was saved in the derived-parameter mode, which this env cannot run")
         v4_arrays = self._per_env and not sd.get("v4_derived", False)
         for k in self._STATE_TENSORS:
-            if k in sd and getattr(self, k) is None and k != "_counter" and not (k in ("_r_arr", "_K_arr") and v4_arrays):
+            if k in sd and getattr(self, k) is None and k not in ("_counter", "_stamp") and not (k in ("_r_arr", "_K_arr") and v4_arrays):
                 raise ValueError("state has %s but this env was built without it" % k)
             # sizes too: a state of another batch size must not get as far as the first copy_.  (return_partials grew with
             # ABI 5 for batches beyond 2^22 envs: an older, shorter buffer loads into the first slots -- the record is
@@ -598,9 +613,12 @@ class BaseFishingEnv(_gym_env_base()):
         if self._per_env:                       # fishing-v4: same parameter mode as the saved env
             if sd.get("v4_derived", False):
                 self._derived, self._K_arr, self._r_arr = True, None, None
+                self._stamp = self._stamp_buffer() if "_stamp" in sd else None
             elif self._derived:
                 self._derived = False
                 self._K_arr, self._r_arr = self._param_store()
+            if not self._derived:
+                self._stamp = None
             self._origin = tuple(sd.get("v4_origin", (0, 0)))
             self._cbuf = None
         for k in self._STATE_TENSORS:
@@ -665,7 +683,10 @@ class BaseFishingEnv(_gym_env_base()):
             self.seed(seed)
         m = None
         if mask is not None:
-            self._leave_derived_mode()      # envs reset at different times: their parameters go to arrays
+            # envs reset at different times: in the derived mode each masked env's episode origin goes into its stamp
+            # (R 4 + W 4 per env-step from here on, until the next reset of every env) -- no r / K arrays
+            if self._derived and self._stamp is None:
+                self._stamp, self._cbuf = self._stamp_buffer(), None
             m = torch.as_tensor(mask).to(device=self.device).reshape(self.num_envs).to(torch.uint8).contiguous()
         elif self._derived_capable:         # a reset of ALL envs: its counters date every episode from here on
             self._derived, self._K_arr, self._r_arr, self._cbuf = True, None, None, None
@@ -676,6 +697,8 @@ class BaseFishingEnv(_gym_env_base()):
                                 self._seed, self._reset_count, self._stream())
         _capi.check(rc, "fishing_reset")
         self._reset_count += 1
+        if mask is None and self._stamp is not None:        # (cleared by the kernel: the launches go back to the stamp-free forms)
+            self._stamp, self._cbuf = None, None
         self._numpy_redraw()
         if self._host_mapped and not self._scalar:
             self._host_sync()

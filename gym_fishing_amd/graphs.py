@@ -49,7 +49,7 @@ class GraphedSteps:
         side.wait_stream(torch.cuda.current_stream(env.device))
         with torch.cuda.stream(side):
             snap = (env._obs.clone(), env._t.clone())
-            state = (env._ep_return, env._partials, env._r_arr, env._K_arr, env._model_idx)
+            state = (env._ep_return, env._partials, env._r_arr, env._K_arr, env._model_idx, env._stamp)
             extra = [t.clone() if t is not None else None for t in state]
             for _ in range(self._warmup):
                 self._run()

@@ -66,11 +66,11 @@ typedef void* fishing_stream_t; /* hipStream_t */
 #define FISHING_FLAG_V4_DERIVED 8u /* fishing-v4 on the in-kernel streams: FishingBuffers.r / .K are not
                                 read or written (may be NULL); every kernel re-derives an env's (K, r)
                                 from (seed, env index, the step or reset() that began its episode), which
-                                it reads off years_passed -- see v4_origin_step below.  Same values as the
+                                it reads off years_passed -- see v4_origin_step below -- or, for envs reset
+                                one by one, off FishingBuffers.v4_stamp.  Same values as the
                                 stored-array mode bit for bit.  Not with FISHING_FLAG_T_U8 (a saturating
-                                counter cannot date an episode), user-supplied parameters, or after a
-                                masked reset (the host then calls fishing_v4_params_* once and continues
-                                with arrays).                                                        */
+                                counter cannot date an episode) or user-supplied parameters (the host then
+                                calls fishing_v4_params_* once and continues with arrays).              */
 #define FISHING_FLAG_PADDED_TILES 16u /* every in/out STATE buffer of FishingBuffers (obs, t, reward, done, done_bits,
                                 r, K, sigma, terminal_obs, ep_return, model_idx -- not action, not z_ext) has room for
                                 ceil(n / 1024) * 1024 elements; the elements behind the n-th are scratch the library may
@@ -160,6 +160,15 @@ typedef struct FishingBuffers {
                                 from counter[1..2] and ignore FishingParams.v4_origin_* -- a captured
                                 launch (frozen arguments) keeps deriving the right (K, r) after a
                                 reset() of all envs, which only rewrites those two words (ABI 4).  */
+    int32_t* v4_stamp;   /* i32   in/out  FISHING_FLAG_V4_DERIVED only, nullable (ABI 6).  Per-env episode origin for envs
+                                that were reset ONE BY ONE: stamp[i] != 0 says the episode running in env i began with the
+                                masked fishing_reset_* whose reset_counter was stamp[i] - 1, and its (K, r) are that
+                                reset's draw for env i (fishing_model_error.py:41-43); stamp[i] == 0: the episode is dated by
+                                years_passed as described at v4_origin_step.  fishing_reset_* with a mask writes the
+                                stamps of the masked envs (and needs the buffer: FISHING_ERR_UNSUPPORTED without), a
+                                reset of every env clears them all; step() / rollout() clear an env's stamp when they
+                                auto-reset it.  R 4 + W 4 bytes per env-step on top of the derived mode's 37 -- 45 against
+                                the 53 of stored r / K arrays.  Any other model or mode: must be NULL.  */
 } FishingBuffers;
 
 /* In-kernel policies for the fused rollout (callers of step(): shared_env.py:29-54,
@@ -198,8 +207,8 @@ int fishing_step_many_f64(const FishingParams* p, int64_t n, int64_t env_offset,
 
 /* BaseFishingEnv.reset (envs/base_fishing_env.py:83-91) / FishingModelError.reset
  * (envs/fishing_model_error.py:41-48).  mask: u8[n], nullable => reset every env.
- * Writes obs, t = 0, ep_return = 0 (and K, r for v4; under FISHING_FLAG_V4_DERIVED nothing more -- and only a
- * reset of every env is served: a mask returns FISHING_ERR_UNSUPPORTED). */
+ * Writes obs, t = 0, ep_return = 0 (and K, r for v4; under FISHING_FLAG_V4_DERIVED nothing more -- a mask then stamps
+ * the masked envs' episode origin into FishingBuffers.v4_stamp and needs that buffer: FISHING_ERR_UNSUPPORTED without). */
 int fishing_reset_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                       const uint8_t* mask, uint64_t seed, uint64_t reset_counter, fishing_stream_t stream);
 int fishing_reset_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
@@ -238,12 +247,13 @@ int fishing_step_fused_f64(const FishingParams* p, int64_t n, int64_t env_offset
                            fishing_stream_t stream);
 
 /* fishing-v4 under FISHING_FLAG_V4_DERIVED: materialise the (K, r) in force for envs [0, n) given their
- * years_passed `t` at step count `step_counter` (what env.K / env.r show, and what the host stores when it
+ * years_passed `t` (and, where masked resets happened, their origin stamps `stamp`: i32[n], nullable -- see
+ * FishingBuffers.v4_stamp; ABI 6) at step count `step_counter` (what env.K / env.r show, and what the host stores when it
  * leaves the derived mode).  K_out / r_out: real[n], either may be NULL. */
-int fishing_v4_params_f32(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out,
-                          void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream);
-int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, void* K_out,
-                          void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream);
+int fishing_v4_params_f32(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, const int32_t* stamp,
+                          void* K_out, void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream);
+int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset, const int32_t* t, const int32_t* stamp,
+                          void* K_out, void* r_out, uint64_t seed, uint64_t step_counter, fishing_stream_t stream);
 
 /* Diagnostic: the demangled name (as rocprofv3 prints it, without the argument list) of the kernel that
  * fishing_step_f32/_f64 would launch for the whole tiles of this request -- the same dispatch code decides,

@@ -45,7 +45,7 @@ class State:
     """Device buffers of one shard, created from host arrays."""
 
     def __init__(self, n, dtype, model, obs, t=None, r=None, K=None, sigma=None, ep_return=False,
-                 terminal=False, done_bits=False, model_idx=None, t_u8=False):
+                 terminal=False, done_bits=False, model_idx=None, t_u8=False, stamp=None):
         self.n, self.np_dtype, self.model = n, np.dtype(dtype), model
         td = TORCH_OF[self.np_dtype]
         self.obs = dev(np.broadcast_to(np.asarray(obs, dtype=dtype), (n,)))
@@ -62,6 +62,7 @@ class State:
         self.done_bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda") if done_bits else None
         self.model_idx = (dev(np.broadcast_to(np.asarray(model_idx, dtype=np.int32), (n,)))
                           if model_idx is not None else None)
+        self.stamp = dev(np.broadcast_to(np.asarray(stamp, dtype=np.int32), (n,))) if stamp is not None else None
 
     def buffers(self, action=None, z_ext=None):
         p = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
@@ -69,7 +70,7 @@ class State:
                                   done_bits=p(self.done_bits), t=p(self.t), r=p(self.r), K=p(self.K),
                                   sigma=p(self.sigma), z_ext=p(z_ext), terminal_obs=p(self.terminal),
                                   ep_return=p(self.ep_return), return_partials=p(self.partials),
-                                  model_idx=p(self.model_idx))
+                                  model_idx=p(self.model_idx), v4_stamp=p(self.stamp))
 
     @property
     def suffix(self):
@@ -87,11 +88,11 @@ class State:
         torch.cuda.synchronize()
         return self.host()
 
-    def reset(self, p, mask=None, seed=0, counter=0, env_offset=0):
+    def reset(self, p, mask=None, seed=0, counter=0, env_offset=0, expect=0):
         m = dev(np.asarray(mask, dtype=np.uint8)) if mask is not None else None
         fn = getattr(_capi.lib(), "fishing_reset_" + self.suffix)
         rc = fn(p, self.n, env_offset, self.buffers(), m.data_ptr() if m is not None else None, seed, counter, None)
-        assert rc == 0, rc
+        assert rc == expect, rc
         torch.cuda.synchronize()
 
     def rollout(self, p, policy, param, T, seed=0, step_counter=0, env_offset=0, record=False):
@@ -139,7 +140,8 @@ class State:
         K = torch.zeros(self.n, dtype=td, device="cuda")
         r = torch.zeros(self.n, dtype=td, device="cuda")
         fn = getattr(_capi.lib(), "fishing_v4_params_" + self.suffix)
-        rc = fn(p, self.n, env_offset, self.t.data_ptr(), K.data_ptr(), r.data_ptr(), seed, step_counter, None)
+        rc = fn(p, self.n, env_offset, self.t.data_ptr(), self.stamp.data_ptr() if self.stamp is not None else None,
+                K.data_ptr(), r.data_ptr(), seed, step_counter, None)
         assert rc == 0, rc
         torch.cuda.synchronize()
         return K.cpu().numpy(), r.cpu().numpy()

@@ -40,6 +40,8 @@ def test_bytes_per_env_step_accounting():
     assert bench.bytes_per_env_step("v4", False, v4_stored=True) == 45
     assert bench.bytes_per_env_step("v4", True, v4_stored=True) == 53
     assert bench.bytes_per_env_step("v1", False, f64=True) == 37 and bench.bytes_per_env_step("v1", True, f64=True) == 53
+    # fishing-v4 derived with per-env origin stamps (after a masked reset): R 4 + W 4 on top of 37
+    assert bench.bytes_per_env_step("v4", True, v4_stamped=True) == 45 and bench.bytes_per_env_step("v4", False, v4_stamped=True) == 37
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="the failure path: only where no HIP device exists")

@@ -39,7 +39,7 @@ def test_abi_version_and_struct_layout(lib):
     assert lib.fishing_abi_version() == _capi.ABI_VERSION
     # FishingParams: 4 x i32, 8 x f64, 2 x i32 (88) + 6 x f64 + 6 x i32 (160) + 5 x 9 x f64 (520) + 2 x u64 -> 536 bytes
     assert ctypes.sizeof(_capi.FishingParams) == 536
-    assert ctypes.sizeof(_capi.FishingBuffers) == 15 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(_capi.FishingBuffers) == 16 * ctypes.sizeof(ctypes.c_void_p)       # (v4_stamp: ABI 6)
     hdr = open(HEADER).read()
     body = hdr[hdr.index("typedef struct FishingBuffers {"):hdr.index("} FishingBuffers;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
@@ -84,11 +84,15 @@ def test_argument_errors_need_no_gpu(lib):
     p.flags = _capi.FLAG_V4_DERIVED | _capi.FLAG_T_U8
     assert lib.fishing_reset_f32(p, 4, 0, b, None, 0, 0, None) == -7      # derived parameters need the int32 year counter
     p.flags = _capi.FLAG_V4_DERIVED
-    assert lib.fishing_reset_f32(p, 4, 0, b, 24576, 0, 0, None) == -7     # ... and a reset of ALL envs (no mask)
+    assert lib.fishing_reset_f32(p, 4, 0, b, 24576, 0, 0, None) == -7     # ... and, for a masked reset, the origin stamps (v4_stamp)
+    bs = _capi.make_buffers(obs=4096, t=8192, action=12288, v4_stamp=28672)
+    assert lib.fishing_reset_f32(p, 4, 0, bs, 24576, 0, 0x7FFFFFFF, None) == -4      # a stamp holds 31 bits of reset counter + 1
     p.flags = 0
-    assert lib.fishing_v4_params_f32(p, 4, 0, None, None, None, 0, 0, None) == -1
+    bs = _capi.make_buffers(obs=4096, t=8192, action=12288, r=16384, K=20480, v4_stamp=28672)
+    assert lib.fishing_step_f32(p, 4, 0, bs, 0, 0, None) == -7            # stamps belong to the derived mode
+    assert lib.fishing_v4_params_f32(p, 4, 0, None, None, None, None, 0, 0, None) == -1
     p.model = _capi.MODEL_V1
-    assert lib.fishing_v4_params_f32(p, 4, 0, 4096, None, None, 0, 0, None) == -2     # fishing-v4 only
+    assert lib.fishing_v4_params_f32(p, 4, 0, 4096, None, None, None, 0, 0, None) == -2     # fishing-v4 only
     assert lib.fishing_step_fused_f32(p, 4, 0, b, 4, 0, 3, None, None, 0, 0, 0, None) == -4   # ring_len <= 0
     assert lib.fishing_step_fused_f32(p, 4, 0, b, 4, 2, 3, 4096, None, 2, 0, 0, None) == -3   # out_stride < n
     bz = _capi.make_buffers(obs=4096, t=8192, action=12288, z_ext=16384)

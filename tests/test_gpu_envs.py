@@ -226,6 +226,16 @@ def test_masked_reset_and_seed(gf):
     assert bool((st[1::2] == before.reshape(-1)[1::2]).all())
     assert bool((env.K[1::2] == K0[1::2]).all()) and bool((env.K[::2] != K0[::2]).any())
     assert bool((env.years_passed[::2] == 0).all()) and bool((env.years_passed[1::2] == 1).all())
+    # the masked reset kept fishing-v4 in the derived mode (per-env origin stamps, no r / K arrays): a DERIVED kernel steps it
+    assert env._derived and env._K_arr is None and "28031" in env.step_kernel_name()
+    stored = gf.make("fishing-v4", sigma=0.05, num_envs=n, seed=9, auto_reset=False, derived_params=False)
+    stored.reset()
+    stored.step(a)
+    stored.reset(mask=mask)
+    for _ in range(3):
+        env.step(a)
+        stored.step(a)
+    assert torch.equal(env.state, stored.state) and torch.equal(env.K, stored.K) and torch.equal(env.r, stored.r)
     # same seed -> same parameter draws
     env2 = gf.make("fishing-v4", sigma=0.05, num_envs=n, seed=9, auto_reset=False)
     env2.reset()

@@ -342,7 +342,7 @@ def test_kernel_names_follow_the_dispatch(hh):
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5, auto_reset=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 11391, 2>"
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, K=1.5, auto_reset=True), n=1 << 20, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 11391, 2>"
     assert name(p1, n=1 << 24, dtype=np.float64) == "fishing::step_kernel_lean<double, 1, 11391>"
-    assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 4, 11647, 2>"
+    assert name(hh.params(fo.MODEL_V4, sigma=0.1, derived=True), dtype=np.float64) == "fishing::step_kernel_lean<double, 4, 28031, 2>"     # (its catch-all: DERIVED | STAMP "may be there")
     assert name(hh.params(fo.MODEL_V1, sigma=0.1, t_u8=True)) == "fishing::step_kernel_lean<float, 1, 12306>"
     assert name(hh.params(fo.MODEL_V0, sigma=0.1)) == "fishing::step_kernel_lean<float, 0, 12290>"
     # a K that is not a power of two keeps the correctly rounded division
@@ -367,8 +367,8 @@ def test_kernel_names_follow_the_dispatch(hh):
 def test_env_v4_derived_mode_equals_the_stored_mode_and_survives_its_exits(hh):
     """make("fishing-v4", num_envs=N) keeps no r / K arrays (derived_params defaults to on for the Philox streams);
     derived_params=False keeps them.  Same seed => same trajectories and the same env.K / env.r, through step(),
-    step_many(), the fused rollout, a mid-run full reset(), and the three exits from the derived mode: a masked
-    reset(), env.K = ..., seed()."""
+    step_many(), the fused rollout, a mid-run full reset(), masked resets (per-env origin stamps: the derived mode
+    stays), and the exits from the derived mode: env.K = ..., seed()."""
     import torch
     import gym_fishing_amd as gf
     n = 4096 + 8
@@ -412,14 +412,41 @@ def test_env_v4_derived_mode_equals_the_stored_mode_and_survives_its_exits(hh):
     mask = torch.zeros(n, dtype=torch.bool, device="cuda")
     mask[::5] = True
     for e in (D, S):
-        e.reset(mask)                                            # envs restart at different times -> arrays
-    assert not D._derived and D._K_arr is not None
+        e.reset(mask)                                            # envs restart at different times -> per-env origin stamps
+    # (round 4: the masked reset keeps the derived mode -- no r / K arrays -- on the catch-all's stamped form, 45 B per env-step)
+    assert D._derived and D._K_arr is None and D._stamp is not None
+    assert D.step_kernel_name(ring[0]) == "fishing::step_kernel_lean<float, 4, 28031, 4>"
+    assert int((D._stamp != 0).sum()) == int(mask.sum()) and int(D._stamp.max()) == D._reset_count
+    check("right after a masked reset")
+    for s in range(9):
+        for e in (D, S):
+            e.step(ring[s % 4])
+        check("step %d after a masked reset" % s)
     for e in (D, S):
         e.step_many(ring, 8)
-    check("after a masked reset")
+    check("step_many after a masked reset")
+    for e in (D, S):
+        e.step_many(ring, 7, fused=True)
+    check("fused step_many after a masked reset")
+    mask2 = torch.zeros(n, dtype=torch.bool, device="cuda")
+    mask2[3::7] = True
+    for e in (D, S):
+        e.reset(mask2)                                           # a second masked reset: later stamps over earlier ones
+        e.rollout(9, policy="random")
+    check("fused rollout after a second masked reset")
+    sd_stamped = D.state_dict()
+    assert "_stamp" in sd_stamped and sd_stamped["v4_derived"]
+    R2 = mk(None)
+    R2.load_state_dict(sd_stamped)                               # a checkpoint taken in the stamped mode resumes in it
+    assert R2._derived and R2._stamp is not None and torch.equal(R2._stamp, D._stamp) and torch.equal(R2.K, D.K)
+    for e in (D, S, R2):
+        e.step_many(ring, 6)
+    check("after the stamped checkpoint")
+    assert torch.equal(R2._obs, D._obs) and torch.equal(R2._t, D._t)
     for e in (D, S):
         e.reset()
-    assert D._derived and D._K_arr is None                       # a full reset returns to the derived mode
+    assert D._derived and D._K_arr is None and D._stamp is None  # a full reset clears the stamps: the stamp-free kernels again
+    assert D.step_kernel_name(ring[0]) == "fishing::step_kernel_lean<float, 4, 8454, 4>"
     for e in (D, S):
         e.step_many(ring, 5)
         e.K = 1.25                                               # user-supplied parameters -> arrays
@@ -891,3 +918,77 @@ def test_policyfn_reproduces_the_reference_table(hh, key, table):
     df = env.policyfn(model, reps=2)
     got = df.to_numpy(dtype=np.float64) if hasattr(df, "to_numpy") else np.stack([df[c] for c in ("state", "action", "rep")], 1)
     same(got, table, key)
+
+
+def test_v4_origin_stamps_through_the_c_abi(hh):
+    """FishingBuffers.v4_stamp (ABI 6): a masked fishing_reset_* under FISHING_FLAG_V4_DERIVED stamps the masked envs with
+    its reset counter + 1; from there the derived batch -- general kernel (ragged size), lean catch-all, fused kernel --
+    equals a stored-array batch reset with the same mask bit for bit, fishing_v4_params_* shows the stored (K, r), an
+    auto-reset clears an env's stamp, and a reset of every env clears them all.  Without the buffer the masked reset is
+    refused (FISHING_ERR_UNSUPPORTED), as before."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n, off, seed = 5 * 1024 + 12, 8, 41
+    kw = dict(sigma=0.05, sigma_p=0.2, Tmax=5, auto_reset=True)
+    pS = hh.params(fo.MODEL_V4, **kw)
+    S = hh.State(n, np.float32, fo.MODEL_V4, np.zeros(n), r=np.zeros(n), K=np.ones(n), ep_return=True)
+    D = hh.State(n, np.float32, fo.MODEL_V4, np.zeros(n), ep_return=True, stamp=np.zeros(n, np.int32))
+    bare = hh.State(n, np.float32, fo.MODEL_V4, np.zeros(n))
+    rng = np.random.default_rng(2)
+    step_count, reset_count = 0, 3
+    pD = hh.params(fo.MODEL_V4, derived=True, origin=(step_count, reset_count), **kw)
+    S.reset(pS, seed=seed, counter=reset_count, env_offset=off)
+    D.reset(pD, seed=seed, counter=reset_count, env_offset=off)
+    reset_count += 1
+
+    def same(tag):
+        for name in ("obs", "t", "reward", "done", "ep_return"):
+            a, b = getattr(S, name), getattr(D, name)
+            assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b), (tag, name)
+        K, r = D.v4_params(pD, seed=seed, step_counter=step_count, env_offset=off)
+        assert np.array_equal(K, S.K.cpu().numpy()) and np.array_equal(r, S.r.cpu().numpy()), tag
+
+    def steps(k, fused=False):
+        nonlocal step_count
+        acts = rng.uniform(-1.1, 0.2, (k, n)).astype(np.float32)
+        if fused:
+            S.step_fused(pS, acts, k, seed=seed, step_counter=step_count, env_offset=off, per_step=False)
+            D.step_fused(pD, acts, k, seed=seed, step_counter=step_count, env_offset=off, per_step=False)
+            step_count += k
+        else:
+            for i in range(k):
+                S.step(pS, acts[i], seed=seed, step_counter=step_count, env_offset=off)
+                D.step(pD, acts[i], seed=seed, step_counter=step_count, env_offset=off)
+                step_count += 1
+    steps(4)
+    same("before the masked reset")
+    mask = (rng.random(n) < 0.3).astype(np.uint8)
+    bare.reset(pD, mask=mask, seed=seed, counter=reset_count, env_offset=off, expect=-7)     # no stamps to write
+    S.reset(pS, mask=mask, seed=seed, counter=reset_count, env_offset=off)
+    D.reset(pD, mask=mask, seed=seed, counter=reset_count, env_offset=off)
+    assert np.array_equal(D.stamp.cpu().numpy(), np.where(mask, reset_count + 1, 0))
+    reset_count += 1
+    same("after the masked reset")
+    steps(1)
+    same("one step on")
+    st = D.stamp.cpu().numpy()
+    done = D.done.cpu().numpy().astype(bool)
+    assert (st[done] == 0).all() and (st[~done & mask.astype(bool)] == reset_count).all()    # cleared exactly where auto-reset
+    steps(5)
+    same("per-step launches")
+    mask2 = (rng.random(n) < 0.2).astype(np.uint8)
+    S.reset(pS, mask=mask2, seed=seed, counter=reset_count, env_offset=off)
+    D.reset(pD, mask=mask2, seed=seed, counter=reset_count, env_offset=off)
+    reset_count += 1
+    steps(6, fused=True)
+    same("fused launch after a second masked reset")
+    ra, rb = S.record(), D.record()
+    assert ra[2] == rb[2] > 0 and ra[3] == rb[3]
+    # a reset of every env: all stamps cleared, the origin words date the episodes again
+    pD = hh.params(fo.MODEL_V4, derived=True, origin=(step_count, reset_count), **kw)
+    S.reset(pS, seed=seed, counter=reset_count, env_offset=off)
+    D.reset(pD, seed=seed, counter=reset_count, env_offset=off)
+    assert int(D.stamp.abs().sum()) == 0
+    steps(3)
+    same("after the reset of every env")
