@@ -65,7 +65,7 @@ def main():
         with open(a.out + "_kernel_stats.csv", "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-            for r in rows[:12]:
+            for r in rows[:40]:
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                             r["MinNs"], r["MaxNs"], r["StdDev"]])
         for r in rows:

@@ -120,7 +120,7 @@ def timing(tag, n=1 << 22):
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 5)
             w = 4 if f32 else 8
-            byt = (13 + 3 * w) + (2 * w if returns else 0) + (2 * w if idn == "fishing-v10" else 0) + (4 if idn == "fishing-v11" else 0)
+            byt = (13 + 3 * w) + (2 * w if returns else 0) + (2 * w if idn == "fishing-v10" else 0) + (8 if idn == "fishing-v11" else 0)
             us = statistics.median(ts)
             print(json.dumps(dict(tag=tag, kind="time", id=idn, dtype="float32" if f32 else "float64", n=n, returns=returns,
                                   kernel=env.step_kernel_name(), us_per_step=round(us, 2), bytes_per_env_step=byt,
