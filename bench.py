@@ -469,12 +469,16 @@ def main():
         env.episode_stats()           # warm the reduce kernel and the RCCL communicator
     ev0, ev1 = rt.event(torch), rt.event(torch)
 
-    def region():
+    def region(with_events=False):
         """The timed sequence, exactly: K launches + the record's reduce kernel (+ the all-reduce) enqueued, then the
-        closing barrier + synchronize."""
-        ev0.record()
+        closing barrier + synchronize.  (`with_events`: the untimed rehearsal brackets its K launches with HIP events --
+        roofline.avg_launch_us_timed_region; two event packets cost the 20-step region 9 of its 417 us, so the timed
+        pass carries none: profiles/r04_region_variants.jsonl.)"""
+        if with_events:
+            ev0.record()
         env.step_many(actions, args.steps)            # K launches on torch's current stream
-        ev1.record()
+        if with_events:
+            ev1.record()
         rec = env.episode_record() if with_returns else None     # reduce kernel (+ all-reduce), enqueued only
         sync_all()
         return rec
@@ -490,12 +494,12 @@ def main():
     gc.collect()
     gc.disable()
     sync_all()
-    region()
+    region(with_events=True)
+    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)     # HIP events around the rehearsal's K launches
     t0 = time.perf_counter()
     record = region()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)     # HIP events around the K launches
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -576,8 +580,9 @@ def main():
                      "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                      "cache_resident": fits,
                      "note": "avg_launch_us = HIP events around max(K, 256) launches enqueued behind a 16-launch lead-in (device "
-                             "busy when the first event fires), per launch; avg_launch_us_timed_region = the same bracket over the timed "
-                             "region itself (includes the idle device's pick-up of the first launch); "
+                             "busy when the first event fires), per launch; avg_launch_us_timed_region = the same bracket over the K "
+                             "launches of the untimed dress rehearsal of the timed region (includes the idle device's pick-up of the "
+                             "first launch; the timed pass itself carries no event packets); "
                              "launch_us_median_event_pairs = median event-to-event time of single launches (each pair adds "
                              "its own ~2.5 us of packet gaps).  Resident arrays %.0f MB "
                              "(state streams + %d action batches): %s the 256 MiB Infinity Cache%s" % (
