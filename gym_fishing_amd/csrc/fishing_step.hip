@@ -829,6 +829,9 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         }
     };
 
+    // (Round 4 tried starting a CU's eight workgroups of fishing-v4's one-round grid at N = 2^21 in two phases -- s_sleep of
+    // 0.2 .. 14 us in every other workgroup of a CU -- so that one half computes while the other half's loads fly: 13.0-13.5 us
+    // against 13.2 at the short sleeps, worse beyond: profiles/r04_v4_stagger.jsonl.  Not kept.)
     do_tile(blockIdx.x);
 }
 
