@@ -56,22 +56,26 @@ def main():
         print(json.dumps(dict(row="f4 zoo step", id=idn, dtype=str(dtype)[6:], kernel=env.step_kernel_name(), n_envs=n, env_steps_per_launch=n,
                               bytes_per_env_step=byt, us_per_launch=round(us, 2), frac_of_8TBps=round(n * byt / us / 8e6, 3))), flush=True)
         del env
-    # fused K-step kernel (caller's actions): the launch-bound regime's tool, N = 2^20, 101 steps per launch, reward / done rows out
-    nn = 1 << 20
-    a2 = torch.empty((8, nn + 3072), device="cuda")[:, :nn]
-    a2.copy_(torch.rand((8, nn), device="cuda") * 2 - 1)
-    rows_r = torch.empty((101, nn), dtype=torch.float32, device="cuda")
-    rows_d = torch.empty((101, nn), dtype=torch.uint8, device="cuda")
-    for idn in ("fishing-v1", "fishing-v4"):
-        env = make(idn, nn)
-        f = lambda: env.step_many(a2, 101, fused=True, rewards_out=rows_r, dones_out=rows_d)  # noqa: E731
-        f()
-        torch.cuda.synchronize()
-        us = events(f, 6 if QUICK else 40)
-        print(json.dumps(dict(row="f1 fused step", id=idn, kernel="fishing::step_fused_kernel<float, %d" % (1 if idn == "fishing-v1" else 4), n_envs=nn,
-                              env_steps_per_launch=nn * 101, bytes_per_env_step=9, us_per_launch=round(us, 1),
-                              env_steps_per_s="%.3e" % (nn * 101 / us * 1e6))), flush=True)
-        del env
+    # fused K-step kernel (caller's actions): the launch-bound regime's tool (N = 2^20) and at the metric's size (2^22); 101 steps per
+    # launch, reward / done rows out
+    for ln in (20, 22):
+        nn = 1 << ln
+        a2 = torch.empty((8, nn + 3072), device="cuda")[:, :nn]
+        a2.copy_(torch.rand((8, nn), device="cuda") * 2 - 1)
+        rows_r = torch.empty((101, nn), dtype=torch.float32, device="cuda")
+        rows_d = torch.empty((101, nn), dtype=torch.uint8, device="cuda")
+        for idn in ("fishing-v1", "fishing-v4"):
+            env = make(idn, nn)
+            f = lambda: env.step_many(a2, 101, fused=True, rewards_out=rows_r, dones_out=rows_d)  # noqa: E731
+            f()
+            torch.cuda.synchronize()
+            us = events(f, (6 if QUICK else 40) if ln == 20 else (3 if QUICK else 12))
+            print(json.dumps(dict(row="f1 fused step", id=idn, log2_n=ln, kernel="fishing::step_fused_kernel<float, %d" % (1 if idn == "fishing-v1" else 4),
+                                  n_envs=nn, env_steps_per_launch=nn * 101, bytes_per_env_step=9, us_per_launch=round(us, 1),
+                                  env_steps_per_s="%.3e" % (nn * 101 / us * 1e6))), flush=True)
+            del env
+        del a2, rows_r, rows_d
+        torch.cuda.empty_cache()
     # in-kernel-policy rollouts: no action traffic at all; VALU-bound
     for idn, pol, param, tag in (("fishing-v1", "random", 0.0, "1, 0, true"), ("fishing-v1", "escapement", 0.5, "1, 2, true"),
                                  ("fishing-v4", "random", 0.0, "4, 0, true"), ("fishing-v11", "random", 0.0, "105, -1, true")):

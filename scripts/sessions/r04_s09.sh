@@ -9,7 +9,7 @@ mkdir -p "$O/summ"
 python3 scripts/summarize_f_rows.py "$O/f_rows" "$O/summ/r04" > "$O/summ.log" 2>&1 || { echo "summary failed"; tail -20 "$O/summ.log"; exit 3; }
 cp "$O/f_rows/rows.jsonl" "$O/summ/r04_f_rows_events.jsonl"
 rm -rf "$O/f_rows/trace" "$O/f_rows/pmc_fetch" "$O/f_rows/pmc_write" "$O/f_rows/pmc_sq"
-bash scripts/profile_bench.sh "r04_s09/prof_v4_stamped" --config v4 --v4-stamped > /dev/null || { echo "profile v4 stamped failed"; exit 4; }
-python3 scripts/summarize_profile.py "$O/prof_v4_stamped" "$O/summ/r04_step_v4_stamped_21" > /dev/null || { echo "summary v4 stamped failed"; exit 5; }
-rm -rf "$O/prof_v4_stamped"
+
+
+
 echo done

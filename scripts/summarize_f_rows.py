@@ -25,12 +25,14 @@ def main():
         if r["row"] == "f4 zoo step":
             name = "zoo_%s_%s" % (r["id"].replace("fishing-", ""), "f64" if r["dtype"] == "float64" else "f32")
         elif r["row"] == "f1 fused step":
-            name = "fused_step_%s_2p20" % r["id"].replace("fishing-", "")
+            name = "fused_step_%s_2p%d" % (r["id"].replace("fishing-", ""), r.get("log2_n", 20))
         else:
             name = "rollout_%s_%s" % (r["id"].replace("fishing-", ""), r["policy"])
         out = "%s_%s" % (prefix, name)
+        # (a thread steps four envs: Grid_Size_X = n / 4 work-items; the fused kernel runs at two sizes in this trace)
         subprocess.run([sys.executable, os.path.join(HERE, "summarize_profile.py"), raw, out, "--kernel", r["kernel"],
-                        "--n-envs", str(r["env_steps_per_launch"]), "--bytes", str(max(r["bytes_per_env_step"], 1))],
+                        "--n-envs", str(r["env_steps_per_launch"]), "--bytes", str(max(r["bytes_per_env_step"], 1))]
+                       + (["--grid", str(r["n_envs"] // 4)] if r["row"] == "f1 fused step" else []),
                        check=True, stdout=subprocess.DEVNULL)
         s = json.load(open(out + "_summary.json"))
         shared = prefix + "_f_rows_kernel_stats.csv"    # (one shared rocprofv3 --stats table instead of a copy per kernel)
@@ -47,7 +49,7 @@ def main():
         if "avg_ns" in s:
             s["env_steps_per_s_rocprofv3"] = r["env_steps_per_launch"] / s["avg_ns"] * 1e9
         for k, v in sq.items():
-            if s.get("kernel") and k.startswith(s["kernel"][:100]):
+            if s.get("kernel") and k.startswith(s["kernel"][:100]) and r["row"] != "f1 fused step":     # (per-kernel medians: sizes mixed)
                 s["sq"] = {a: b for a, b in v.items() if a.startswith("share") or a in ("launches", "valu_issue_utilisation", "median_duration_ns")}
         json.dump(s, open(out + "_summary.json", "w"), indent=1)
         index.append({"file": os.path.basename(out) + "_summary.json", "kernel": s.get("kernel"), "avg_us": round(s.get("avg_ns", 0) / 1e3, 2),

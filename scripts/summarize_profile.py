@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--kernel", default=None, help="substring of the kernel name (default: roofline.kernel of the bench line)")
     ap.add_argument("--n-envs", type=int, default=None)
     ap.add_argument("--bytes", type=int, default=None, help="algorithmic bytes per env-step")
+    ap.add_argument("--grid", type=int, default=None,
+                    help="only launches with this Grid_Size_X (work-items): for a kernel that the traced program runs at several "
+                         "sizes; durations then come from the kernel trace, not from the --stats table")
     ap.add_argument("--latest", action="store_true")
     a = ap.parse_args()
     full = None
@@ -83,10 +86,12 @@ def main():
 
     trace = find(os.path.join(a.raw, "trace"), "*kernel_trace.csv")
     if trace:
-        rows = [r for r in csv.DictReader(open(trace)) if same(r["Kernel_Name"])]
+        rows = [r for r in csv.DictReader(open(trace)) if same(r["Kernel_Name"]) and (a.grid is None or int(r["Grid_Size_X"]) == a.grid)]
         if rows:
             d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
             summ["trace_median_ns"] = statistics.median(d)
+            if a.grid is not None:      # the --stats table mixes this kernel's sizes: take the figures from the trace
+                summ.update(calls=len(d), avg_ns=statistics.fmean(d), min_ns=float(min(d)), max_ns=float(max(d)), grid_filter=a.grid)
             summ["grid"] = int(rows[0]["Grid_Size_X"])
             summ["workgroup"] = int(rows[0]["Workgroup_Size_X"])
             summ["vgpr"] = int(rows[0]["VGPR_Count"])
@@ -97,7 +102,7 @@ def main():
         if not f:
             continue
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-                if same(r["Kernel_Name"]) and r["Counter_Name"] == counter]
+                if same(r["Kernel_Name"]) and r["Counter_Name"] == counter and (a.grid is None or int(r["Grid_Size"]) == a.grid)]
         if vals:
             summ[counter + "_KiB_median"] = statistics.median(vals)
             summ[counter + "_launches"] = len(vals)

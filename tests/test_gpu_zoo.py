@@ -562,3 +562,50 @@ def test_zoo_f64_log_exp_are_within_one_ulp(hh):
     assert (np.abs(e - np.expm1(g)) <= 2.5e-7 * np.maximum(1.0, np.exp(g))).all()
     se = run(4, [-np.inf, np.inf, np.nan, 0.0])
     assert se[0] == -1.0 and se[1] == np.inf and np.isnan(se[2]) and se[3] == 0.0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_zoo_special_values_follow_the_reference(hh, dtype):
+    """The growth functions at the edges of their domain, through fishing_population_draw_*, against the oracle's float64
+    evaluation of the reference's log / exp round trip on the same inputs: extinct, tiny, huge, infinite and NaN stocks
+    under zero, large, infinite and NaN noise.  The float32 layout evaluates an algebraically equal form WITHOUT the round
+    trip (fishing_common.h: FISHING_ZOO_F32_MATH) -- this is where "equal" is checked value by value: the same NaNs, the
+    same zeros, the same infinities, finite values within the layout's tolerance (x' up to 1e6 here: relative)."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    tiny = 1e-30
+    xs = np.array([0.0, tiny, 1e-12, 1e-3, 0.4, 1.0, 2.5, 1e3, 1e6, np.inf, np.nan])
+    zs = np.array([0.0, 1.0, -1.0, 6.5, -6.5, np.inf, -np.inf, np.nan])
+    X, Z = (a.reshape(-1) for a in np.meshgrid(xs, zs, indexing="ij"))
+    n = X.size
+    fn = lib.fishing_population_draw_f32 if dtype == np.float32 else lib.fishing_population_draw_f64
+    for env_id in ("fishing-v5", "fishing-v6", "fishing-v7", "fishing-v8", "fishing-v9"):
+        model = fo.MODEL_OF_ID[env_id]
+        P = dict(ZOO_DEFAULTS[env_id], sigma=0.2)
+        p = hh.params(model, r=float(P.get("r", 0.3)), K=float(P["K"]), sigma=0.2, C=float(P.get("C", 0.5)), M=float(P.get("M", 0.0)),
+                      theta=float(P.get("theta", 0.0)), q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)))
+        xt, zt = hh.dev(X.astype(dtype)), hh.dev(Z.astype(dtype))
+        out = torch.empty_like(xt)
+        assert fn(p, n, xt.data_ptr(), zt.data_ptr(), None, out.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().astype(np.float64)
+        with np.errstate(all="ignore"):
+            want = fo.zoo_population_draw(fo.KIND_OF_MODEL[model], X.astype(dtype).astype(np.float64), Z.astype(dtype).astype(np.float64), P)
+            want = want.astype(dtype).astype(np.float64)          # (what the layout can hold: float32 overflows to inf, underflows to 0)
+        bad = []
+        for i in range(n):
+            if dtype == np.float32 and np.isinf(Z[i]) and 0.0 < X[i] < 1e-10:
+                # x ** 3 underflows float32 (1e-90): the algebraic form sees an extinct stock (0 * inf = NaN), the round
+                # trip's log does not.  Infinite noise never comes out of the generator (|z| <= 6.76).
+                continue
+            if np.isnan(want[i]) or np.isnan(got[i]):
+                ok = np.isnan(want[i]) and np.isnan(got[i])
+            elif np.isinf(want[i]) or want[i] == 0.0:
+                # (a float32 result within a rounding of the range's end may land on either side of it)
+                ok = got[i] == want[i] or (dtype == np.float32 and (got[i] > 1e38 or got[i] < 1e-37))
+            else:
+                ok = abs(got[i] - want[i]) <= (2e-14 if dtype == np.float64 else 2e-6) * abs(want[i]) + 1e-300
+            if not ok:
+                bad.append((env_id, float(X[i]), float(Z[i]), float(got[i]), float(want[i])))
+        assert not bad, bad
