@@ -78,8 +78,10 @@ SIGNATURES = {
     "fishing_reduce_returns": (c_i32, [c_vp, c_vp, c_vp]),
     "fishing_reduce_returns_slots": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     "fishing_counter_add": (c_i32, [c_vp, c_u64, c_vp]),
-    "fishing_population_draw_f32": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "fishing_population_draw_f64": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "fishing_population_draw_f32": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "fishing_population_draw_f64": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "fishing_bmsy_sweep_f32": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "fishing_bmsy_sweep_f64": (c_i32, [_PP, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "fishing_stream_synchronize": (c_i32, [c_vp]),
     "fishing_noise_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "fishing_step_normals_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_vp, c_vp]),

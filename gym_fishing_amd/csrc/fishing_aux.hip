@@ -106,14 +106,42 @@ reduce_returns_kernel(const double* __restrict__ partials, const int passes, dou
 template <typename T, int MODEL>
 __global__ void __launch_bounds__(256)
 population_draw_kernel(const ParamsT<T> p, const int kind, const int64_t n, const T* __restrict__ x_in,
-                       const T* __restrict__ z, T* __restrict__ x_out) {
+                       const T* __restrict__ z, const T* __restrict__ r_arr, const T* __restrict__ K_arr, T* __restrict__ x_out) {
     const GrowthT<T> P = p.growth;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         if constexpr (is_zoo_tag(MODEL))
             x_out[i] = zoo_population_draw<T>(kind, x_in[i], z ? z[i] : (T)0, P);
-        else
-            x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, p.r, p.K, p.sigma, p.C);
+        else        // (r_arr / K_arr: element i under ITS parameters -- N fishing-v4 envs, each with the pair it drew)
+            x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, r_arr ? r_arr[i] : p.r, K_arr ? K_arr[i] : p.K, p.sigma, p.C);
+    }
+}
+
+// BMSY() for N envs that each carry their own (K, r) (fishing-v4; models/policies.py:51-67 run once per env): env i sweeps the
+// observation grid `states` through one noise-free population_draw under ITS parameters and keeps the population with the
+// largest growth -- x0 = (state + 1) * K_i (get_fish_population :158-160), growth = population_draw(x0) - x0, S_i = x0 at
+// np.argmax (the first maximum; a NaN counts as the maximum, as in NumPy).  One env per thread, the grid point is
+// wave-uniform: n_envs * n_states growth evaluations, ~10 ms for 2^21 envs x 10001 states.
+template <typename T, int MODEL>
+__global__ void __launch_bounds__(256)
+bmsy_sweep_kernel(const ParamsT<T> p, const int64_t n_envs, const T* __restrict__ K_arr, const T* __restrict__ r_arr,
+                  const T* __restrict__ states, const int64_t n_states, T* __restrict__ S_out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_envs;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T K = K_arr ? K_arr[i] : p.K, r = r_arr ? r_arr[i] : p.r;
+        T best = (T)0, S = (T)0;
+        bool have = false, best_nan = false;
+        for (int64_t j = 0; j < n_states; ++j) {
+            const T x0 = (states[j] + (T)1) * K;
+            const T g = population_draw<T, MODEL>(x0, (T)0, r, K, (T)0, p.C) - x0;
+            const bool g_nan = g != g;
+            const bool take = !have || (!best_nan && (g_nan || g > best));
+            best = take ? g : best;
+            S = take ? x0 : S;
+            best_nan = take ? g_nan : best_nan;
+            have = true;
+        }
+        S_out[i] = S;
     }
 }
 
@@ -258,10 +286,12 @@ int v4_params_impl(const FishingParams* p, int64_t n, int64_t env_offset, const 
 
 template <typename T>
 int population_draw_impl(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
-                         void* x_out, fishing_stream_t stream) {
+                         const void* r_arr, const void* K_arr, void* x_out, fishing_stream_t stream) {
     if (!p || !x_in || !x_out) return FISHING_ERR_NULL;
     if (n < 0) return FISHING_ERR_SIZE;
     if (!is_core_model(p->model) && !is_zoo_model(p->model)) return FISHING_ERR_MODEL;
+    // per-element (r, K) are the logistic / tipping models' (the zoo's functions read their own parameter sets)
+    if ((r_arr || K_arr) && !is_core_model(p->model)) return FISHING_ERR_UNSUPPORTED;
     // the growth function per element is fishing-v11's: there it is required, anywhere else there is nothing to select
     if (p->model == FISHING_MODEL_V11 && !model_idx) return FISHING_ERR_NULL;
     if (p->model != FISHING_MODEL_V11 && model_idx) return FISHING_ERR_UNSUPPORTED;
@@ -274,14 +304,31 @@ int population_draw_impl(const FishingParams* p, int64_t n, const void* x_in, co
                              (T*)x_out);
     if (is_zoo_model(p->model) && p->model != FISHING_MODEL_V11)
         return launch_kernel(population_draw_kernel<T, kModelZoo>, blocks, 256, s, pt, kind_of_model(p->model), n,
-                             (const T*)x_in, (const T*)z, (T*)x_out);
+                             (const T*)x_in, (const T*)z, (const T*)nullptr, (const T*)nullptr, (T*)x_out);
     if (p->model == FISHING_MODEL_V2)
         return launch_kernel(population_draw_kernel<T, FISHING_MODEL_V2>, blocks, 256, s, pt, 0, n, (const T*)x_in,
-                             (const T*)z, (T*)x_out);
+                             (const T*)z, (const T*)r_arr, (const T*)K_arr, (T*)x_out);
     if (p->model == FISHING_MODEL_V0 || p->model == FISHING_MODEL_V1 || p->model == FISHING_MODEL_V4)
         return launch_kernel(population_draw_kernel<T, FISHING_MODEL_V1>, blocks, 256, s, pt, 0, n, (const T*)x_in,
-                             (const T*)z, (T*)x_out);
+                             (const T*)z, (const T*)r_arr, (const T*)K_arr, (T*)x_out);
     return FISHING_ERR_MODEL;
+}
+
+template <typename T>
+int bmsy_sweep_impl(const FishingParams* p, int64_t n_envs, const void* K_arr, const void* r_arr, const void* states,
+                    int64_t n_states, void* S_out, fishing_stream_t stream) {
+    if (!p || !states || !S_out) return FISHING_ERR_NULL;
+    if (n_envs < 0 || n_states < 1) return FISHING_ERR_SIZE;
+    if (!is_core_model(p->model)) return FISHING_ERR_MODEL;
+    if (n_envs == 0) return FISHING_OK;
+    const ParamsT<T> pt = narrow_params<T>(*p);
+    const int blocks = grid_for(n_envs, 1 << 20);
+    hipStream_t s = (hipStream_t)stream;
+    if (p->model == FISHING_MODEL_V2)
+        return launch_kernel(bmsy_sweep_kernel<T, FISHING_MODEL_V2>, blocks, 256, s, pt, n_envs, (const T*)K_arr, (const T*)r_arr,
+                             (const T*)states, n_states, (T*)S_out);
+    return launch_kernel(bmsy_sweep_kernel<T, FISHING_MODEL_V1>, blocks, 256, s, pt, n_envs, (const T*)K_arr, (const T*)r_arr,
+                         (const T*)states, n_states, (T*)S_out);
 }
 
 }  // namespace fishing
@@ -326,12 +373,20 @@ int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset,
 }
 
 int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
-                                void* x_out, fishing_stream_t stream) {
-    return fishing::population_draw_impl<float>(p, n, x_in, z, model_idx, x_out, stream);
+                                const void* r, const void* K, void* x_out, fishing_stream_t stream) {
+    return fishing::population_draw_impl<float>(p, n, x_in, z, model_idx, r, K, x_out, stream);
 }
 int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
-                                void* x_out, fishing_stream_t stream) {
-    return fishing::population_draw_impl<double>(p, n, x_in, z, model_idx, x_out, stream);
+                                const void* r, const void* K, void* x_out, fishing_stream_t stream) {
+    return fishing::population_draw_impl<double>(p, n, x_in, z, model_idx, r, K, x_out, stream);
+}
+int fishing_bmsy_sweep_f32(const FishingParams* p, int64_t n_envs, const void* K, const void* r, const void* states,
+                           int64_t n_states, void* S_out, fishing_stream_t stream) {
+    return fishing::bmsy_sweep_impl<float>(p, n_envs, K, r, states, n_states, S_out, stream);
+}
+int fishing_bmsy_sweep_f64(const FishingParams* p, int64_t n_envs, const void* K, const void* r, const void* states,
+                           int64_t n_states, void* S_out, fishing_stream_t stream) {
+    return fishing::bmsy_sweep_impl<double>(p, n_envs, K, r, states, n_states, S_out, stream);
 }
 
 int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stream) {

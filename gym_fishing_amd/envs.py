@@ -988,7 +988,7 @@ class BaseFishingEnv(_gym_env_base()):
         populations -- the call BMSY() makes (models/policies.py:59-63).  `x` None uses
         self.fish_population like the reference's zero-argument form (scalar protocol).
         `dtype` picks the arithmetic (default: the env's layout); `sigma`, `r`, `K` override the
-        scalar parameters for this call only.
+        scalar parameters for this call only (`r` / `K` as tensors: one value per population).
         fishing-v11 (growth_models.py:190-194: the growth function in force, with ITS parameter set).  One env: its
         model.  N envs: `x` holds one population per env and env i grows under model_idx[i], the function in force
         there -- or pass `model_idx` (int32, one FISHING_KIND per element of `x`) to choose per element, e.g. one sweep
@@ -1015,6 +1015,18 @@ class BaseFishingEnv(_gym_env_base()):
             # moves r by alpha, and keeps the moved value
             r = float(self._r_arr[0]) + float(self.params.get("alpha", 0.0))
             self._r_arr.fill_(r)
+        # `r` / `K` as tensors (one value per population): element i under ITS parameters -- N fishing-v4 envs, each with the
+        # pair it drew (policies.msy); scalars override the struct's for this call
+        r_arr = K_arr = None
+        if isinstance(r, torch.Tensor) or isinstance(K, torch.Tensor):
+            if self.MODEL not in (MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4):
+                raise ValueError("per-population r / K are the logistic / tipping models'")
+            if isinstance(r, torch.Tensor):
+                r_arr, r = r.to(device=self.device, dtype=dtype).reshape(-1).contiguous(), None
+            if isinstance(K, torch.Tensor):
+                K_arr, K = K.to(device=self.device, dtype=dtype).reshape(-1).contiguous(), None
+            if any(a is not None and a.numel() != xt.numel() for a in (r_arr, K_arr)):
+                raise ValueError("r / K tensors need one value per population (%d)" % xt.numel())
         if sigma is not None or r is not None or K is not None:     # never edit the cached struct step() uses
             cp = _capi.FishingParams.from_buffer_copy(cp)
             if sigma is not None:
@@ -1043,7 +1055,8 @@ class BaseFishingEnv(_gym_env_base()):
         fn = getattr(self._lib, "fishing_population_draw_" + ("f32" if dtype == torch.float32 else "f64"))
         with torch.cuda.device(self.device):
             rc = fn(cp, xt.numel(), xt.data_ptr(), zt.data_ptr() if zt is not None else None,
-                    kinds.data_ptr() if kinds is not None else None, out.data_ptr(), self._stream())
+                    kinds.data_ptr() if kinds is not None else None, r_arr.data_ptr() if r_arr is not None else None,
+                    K_arr.data_ptr() if K_arr is not None else None, out.data_ptr(), self._stream())
         _capi.check(rc, "fishing_population_draw")
         if isinstance(x, torch.Tensor):
             return out.reshape(x.shape)
@@ -1052,6 +1065,21 @@ class BaseFishingEnv(_gym_env_base()):
         if use_attr:
             self.fish_population = res
         return res
+
+    def bmsy_sweep(self, states, K, r, dtype=None):
+        """BMSY()'s sweep (models/policies.py:51-67) once per env, each under ITS (K, r) tensors: S[i] = the population
+        (states[j] + 1) * K[i] with the largest noise-free one-step growth.  fishing-v0/v1/v2/v4."""
+        dtype = self.dtype if dtype is None else dtype
+        st = torch.as_tensor(states).to(device=self.device, dtype=dtype).reshape(-1).contiguous()
+        Kt, rt = (torch.as_tensor(v).to(device=self.device, dtype=dtype).reshape(-1).contiguous() for v in (K, r))
+        if Kt.numel() != rt.numel():
+            raise ValueError("K and r need one value per env each")
+        out = torch.empty_like(Kt)
+        fn = getattr(self._lib, "fishing_bmsy_sweep_" + ("f32" if dtype == torch.float32 else "f64"))
+        with torch.cuda.device(self.device):
+            rc = fn(self._c_params(), Kt.numel(), Kt.data_ptr(), rt.data_ptr(), st.data_ptr(), st.numel(), out.data_ptr(), self._stream())
+        _capi.check(rc, "fishing_bmsy_sweep")
+        return out
 
     # the reference exposes its helpers as methods (base_fishing_env.py:100-110)
     def simulate(self, model, reps=1):

@@ -21,7 +21,7 @@ def _growth_args(env):
     """Parameters of the one-step growth BMSY / msy evaluate.  The reference sets `env.sigma = 0` around the
     call (models/policies.py:10-13,60-64); the logistic / tipping models read `self.sigma`, the zoo's growth
     functions read `params["sigma"]` and never see that override (growth_models.py:208-261) -- reproduced.
-    fishing-v4 evaluates with the (K, r) currently drawn (scalar protocol; the N-env form uses the means)."""
+    fishing-v4 evaluates with the (K, r) currently drawn (the N-env form: per env, see BMSY)."""
     kw = {} if _is_zoo(env) else {"sigma": 0.0}
     if env.MODEL == 4 and env._scalar:
         kw.update(K=float(env.K), r=float(env.r))
@@ -40,6 +40,11 @@ def _per_env_models(env):
     return env.MODEL == 11 and not env._scalar
 
 
+def _per_env_params(env):
+    """fishing-v4 with N envs: every env runs on the (K, r) it drew, so BMSY / msy are per-env quantities."""
+    return env.MODEL == 4 and not env._scalar
+
+
 def BMSY(env, n=10001):
     """models/policies.py:51-67: sweep n states of the observation Box through one population_draw() on the
     device and return the population with the largest growth.  Like the reference, this resets the
@@ -48,8 +53,8 @@ def BMSY(env, n=10001):
     fishing-v11 with N envs: what N reference envs would return, one S per env -- that of the growth function in force in
     that env when BMSY is called (growth_models.py:190-194) -- as a [N] tensor; one sweep per growth function of the
     model list, all in one launch.
-    fishing-v4 with N envs evaluates the growth curve at the parameter MEANS (one S for the batch), where N reference
-    envs would each sweep with their own drawn (K, r); the scalar protocol uses the pair drawn."""
+    fishing-v4 with N envs: likewise one S per env, each swept under the (K, r) that env has drawn
+    (fishing_bmsy_sweep_*: N x n growth evaluations in one launch) -- what N reference envs return."""
     grid = np.linspace(env.observation_space.low, env.observation_space.high, num=n,
                        dtype=env.observation_space.dtype).reshape(-1)
     dt = _sweep_dtype(env)
@@ -57,6 +62,10 @@ def BMSY(env, n=10001):
     kw = _growth_args(env)
     K = kw.get("K", float(env.params["K"]))
     x0 = (state + 1.0) * K                                       # get_fish_population :158-160
+    if _per_env_params(env):
+        S = env.bmsy_sweep(state, env.K, env.r, dtype=dt)        # (env.K / env.r: the pairs in force, before the reset below redraws them)
+        env.reset()
+        return S
     if _per_env_models(env):
         kinds = sorted({int(k) for k in env._c_params().kinds[:len(env.models)]})
         X = x0.repeat(len(kinds))
@@ -80,10 +89,11 @@ class msy:
         self.env = env
         self.S = BMSY(env)
         dt = _sweep_dtype(env)
-        if _per_env_models(env):
-            # one quota per env: f(S_i) - S_i under the growth function in force in env i NOW -- BMSY's reset has redrawn
-            # it, exactly as the reference's msy evaluates population_draw() after BMSY's env.reset() (:7-13)
-            self.msy = env.population_draw(self.S, dtype=dt) - self.S
+        if _per_env_models(env) or _per_env_params(env):
+            # one quota per env: f(S_i) - S_i under the growth function / the (K, r) in force in env i NOW -- BMSY's reset has
+            # redrawn them, exactly as the reference's msy evaluates population_draw() after BMSY's env.reset() (:7-13)
+            kw = dict(sigma=0.0, K=env.K, r=env.r) if _per_env_params(env) else {}
+            self.msy = env.population_draw(self.S, dtype=dt, **kw) - self.S
             env.reset()
             self.kernel_policy = None                            # (the fused kernel takes one scalar parameter)
             return

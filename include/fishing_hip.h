@@ -282,11 +282,24 @@ int fishing_reduce_returns_slots(const double* return_partials, int64_t slots, d
  * model_idx (ABI 6): i32[n], fishing-v11 only and required there (FISHING_ERR_NULL without, FISHING_ERR_UNSUPPORTED
  * with any other model): element i grows under growth function model_idx[i] (FISHING_KIND_*) with that function's
  * parameter set p->zoo[model_idx[i]] -- ModelUncertainty.population_draw (envs/growth_models.py:190-194: "the model
- * in force, with ITS params") for N envs, or for one sweep per growth function in a single launch. */
+ * in force, with ITS params") for N envs, or for one sweep per growth function in a single launch.
+ * r, K (ABI 6): real[n], nullable, fishing-v0/v1/v2/v4 only (FISHING_ERR_UNSUPPORTED with the zoo): element i grows under
+ * r[i] / K[i] instead of p->r / p->K -- N fishing-v4 envs, each under the pair it drew (what models/policies.py:7-13
+ * evaluates per env for msy). */
 int fishing_population_draw_f32(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
-                                void* x_out, fishing_stream_t stream);
+                                const void* r, const void* K, void* x_out, fishing_stream_t stream);
 int fishing_population_draw_f64(const FishingParams* p, int64_t n, const void* x_in, const void* z, const int32_t* model_idx,
-                                void* x_out, fishing_stream_t stream);
+                                const void* r, const void* K, void* x_out, fishing_stream_t stream);
+
+/* BMSY() (models/policies.py:51-67) for n_envs envs that each carry their own (K, r) -- what N reference fishing-v4 envs
+ * return, one call each: env i sweeps the n_states observations `states` (the observation Box's linspace) through one
+ * noise-free population_draw under K[i], r[i] (nullable => p->K / p->r) and S_out[i] = the population
+ * (states[j] + 1) * K[i] with the largest growth population_draw(x0) - x0 (np.argmax: the first maximum; NaN counts as
+ * one).  fishing-v0/v1/v2/v4 (FISHING_ERR_MODEL otherwise).  (ABI 6) */
+int fishing_bmsy_sweep_f32(const FishingParams* p, int64_t n_envs, const void* K, const void* r, const void* states,
+                           int64_t n_states, void* S_out, fishing_stream_t stream);
+int fishing_bmsy_sweep_f64(const FishingParams* p, int64_t n_envs, const void* K, const void* r, const void* states,
+                           int64_t n_states, void* S_out, fishing_stream_t stream);
 
 /* hipStreamSynchronize(stream): lets a host binding without a HIP runtime binding of its own (ctypes)
  * wait for the launches it enqueued -- the scalar gym.Env protocol reads its one env's results from

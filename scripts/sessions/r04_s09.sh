@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4, session 9: rocprofv3 records of the SURVEY 8(f) kernels (zoo steps, fused step, rollouts) + the fishing-v4 stamped step
+# round 4, session 9: rocprofv3 records of the SURVEY 8(f) kernels (zoo steps, fused step, rollouts); the fishing-v4 stamped step it
+# first carried moved to session 10 (v4t_21)
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 O="$REPO/gpurun_out/r04_s09"; mkdir -p "$O"

@@ -78,7 +78,7 @@ def sweep(tag, n=1 << 20):
                       theta=float(P.get("theta", 0.0)), q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)))
         xt, zt = hh.dev(x), hh.dev(z)
         out = torch.empty_like(xt)
-        rc = lib.fishing_population_draw_f32(p, n, xt.data_ptr(), zt.data_ptr(), None, out.data_ptr(), None)
+        rc = lib.fishing_population_draw_f32(p, n, xt.data_ptr(), zt.data_ptr(), None, None, None, out.data_ptr(), None)
         assert rc == 0, rc
         torch.cuda.synchronize()
         got = out.cpu().numpy().astype(np.float64)

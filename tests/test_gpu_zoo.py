@@ -459,7 +459,7 @@ def test_v11_population_draw_selects_the_growth_function_per_element(hh, dtype):
     xt, zt, kt = hh.dev(x), hh.dev(z), hh.dev(kinds)
     out = torch.empty_like(xt)
     fn = lib.fishing_population_draw_f32 if dtype == np.float32 else lib.fishing_population_draw_f64
-    assert fn(p, n, xt.data_ptr(), zt.data_ptr(), kt.data_ptr(), out.data_ptr(), None) == 0
+    assert fn(p, n, xt.data_ptr(), zt.data_ptr(), kt.data_ptr(), None, None, out.data_ptr(), None) == 0
     torch.cuda.synchronize()
     got = out.cpu().numpy().astype(np.float64)
     eff = np.where((kinds >= 0) & (kinds < 5), kinds, fo.KIND_BH)
@@ -475,9 +475,9 @@ def test_v11_population_draw_selects_the_growth_function_per_element(hh, dtype):
         assert np.abs(got - want)[ok].max() <= F32_ATOL * 1.5           # (populations, in units of the largest K = 1.5)
     assert (got[x == 0] == 0).all()
     # without the selector fishing-v11 has no growth function to apply; with any other model there is nothing to select
-    assert fn(p, n, xt.data_ptr(), zt.data_ptr(), None, out.data_ptr(), None) == -1        # FISHING_ERR_NULL
+    assert fn(p, n, xt.data_ptr(), zt.data_ptr(), None, None, None, out.data_ptr(), None) == -1        # FISHING_ERR_NULL
     p9 = hh.params(fo.MODEL_V9, sigma=0.1)
-    assert fn(p9, n, xt.data_ptr(), zt.data_ptr(), kt.data_ptr(), out.data_ptr(), None) == -7      # FISHING_ERR_UNSUPPORTED
+    assert fn(p9, n, xt.data_ptr(), zt.data_ptr(), kt.data_ptr(), None, None, out.data_ptr(), None) == -7      # FISHING_ERR_UNSUPPORTED
 
 
 def test_v11_num_envs_population_draw_and_bmsy_follow_each_envs_model(hh):
@@ -587,7 +587,7 @@ def test_zoo_special_values_follow_the_reference(hh, dtype):
                       theta=float(P.get("theta", 0.0)), q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)))
         xt, zt = hh.dev(X.astype(dtype)), hh.dev(Z.astype(dtype))
         out = torch.empty_like(xt)
-        assert fn(p, n, xt.data_ptr(), zt.data_ptr(), None, out.data_ptr(), None) == 0
+        assert fn(p, n, xt.data_ptr(), zt.data_ptr(), None, None, None, out.data_ptr(), None) == 0
         torch.cuda.synchronize()
         got = out.cpu().numpy().astype(np.float64)
         with np.errstate(all="ignore"):
