@@ -67,10 +67,18 @@ class GymnasiumFishingEnv(_base()):
         Attribute writes on it are forwarded (see __setattr__), so `env.unwrapped.Tmax = 50` still reaches the kernels."""
         return self
 
+    def _conform(self, obs):
+        """One env: the observation in the dtype of the declared Box (float32).  The reference hands out float64 against a
+        float32 Box (quirk B6) and old gym's Box.contains never looked at the dtype; gymnasium's does -- its env checker and
+        every wrapper that validates observations reject a float64 array for a float32 space -- so THIS flavour rounds the
+        scalar protocol's observation once (<= 6e-8; the wrapped 4-tuple env keeps the reference's float64: `env.env`)."""
+        want = getattr(self.observation_space, "dtype", None)
+        return obs.astype(want) if want is not None and hasattr(obs, "astype") and obs.dtype != want else obs
+
     def reset(self, *, seed=None, options=None):
         mask = (options or {}).get("mask") if isinstance(options, dict) else None
         obs = self.env.reset(mask, seed=seed)
-        return obs, {}
+        return (self._conform(obs) if self.env._scalar else obs), {}
 
     def step(self, action):
         env = self.env
@@ -78,7 +86,7 @@ class GymnasiumFishingEnv(_base()):
             obs, reward, done, info = env.step(action)
             terminated = bool(env.fish_population <= 0.0)
             truncated = bool(env.years_passed > env.Tmax)
-            return obs, reward, terminated, truncated, info
+            return self._conform(obs), reward, terminated, truncated, info
         resetting = bool(env.auto_reset)
         t_prev = env._t.clone() if resetting else None
         obs, reward, done, info = env.step(action)

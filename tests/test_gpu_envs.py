@@ -735,11 +735,13 @@ def test_gymnasium_api_splits_done_into_terminated_and_truncated(gf, env_id):
     # runs into the horizon (truncated, not terminated)
     e5, e4 = gf.make(env_id, api="gymnasium", Tmax=5), gf.make(env_id, Tmax=5)
     obs, info = e5.reset(seed=3)
-    assert np.array_equal(obs, e4.reset(seed=3)) and info == {}
+    # (gymnasium's Box.contains looks at the dtype: this flavour hands the scalar protocol's observation out in the Box's float32)
+    assert obs.dtype == np.float32 and np.array_equal(obs, e4.reset(seed=3).astype(np.float32)) and info == {}
     take_all = e4.get_action(10.0)
     o5, r5, term, trunc, _ = e5.step(take_all)
     o4, r4, d4, _ = e4.step(take_all)
-    assert np.array_equal(o5, o4) and r5 == r4 and d4 is True and term is True and trunc is False
+    assert o5.dtype == np.float32 and np.array_equal(o5, o4.astype(np.float32)) and r5 == r4 and d4 is True and term is True and trunc is False
+    assert e5.env.state.dtype == np.float64                     # the wrapped 4-tuple env keeps the reference's float64
     e5.reset()
     leave = e4.get_action(0.0)
     flags = [e5.step(leave)[2:4] for _ in range(6)]
