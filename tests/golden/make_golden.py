@@ -267,6 +267,13 @@ def main():
             ("v11_uncert", "fishing-v11", {}, low, 330),
             ("v11_uncert_T", "fishing-v11", {"Tmax": 6}, mid, 100)):
         run_case(tag, env_id, kw, list(range(200, 206)), n, af, out=zoo)
+    # the zoo under the non-finite and huge actions of v1_special_actions (round 4): a NaN quota harvests the whole stock
+    # (Python's min(x, nan) keeps x), the growth functions then see an extinct stock -- log(0) = -inf, exp(-inf) = 0
+    for tag, env_id, kw in (("v9_ricker_special_actions", "fishing-v9", {"sigma": 0.1, "Tmax": 9}),
+                            ("v7_may_special_actions", "fishing-v7", {"sigma": 0.1, "Tmax": 9}),
+                            ("v8_myers_special_actions", "fishing-v8", {"sigma": 0.1, "Tmax": 9}),
+                            ("v11_uncert_special_actions", "fishing-v11", {"Tmax": 9})):
+        run_case(tag, env_id, kw, [233, 234], 12, lambda g, s, e: f32(special[s]), out=zoo)
     # --- anchors from the reference's own test (tests/test-envs.py:93-106)
     env = gym.make("fishing-v2", sigma=0, init_state=0.75)
     env.reset()
