@@ -593,6 +593,12 @@ __device__ __forceinline__ double exp_f64(double y) {
     return (y != y) ? y : res;
 }
 
+template <typename W>
+__device__ __forceinline__ W int_pow(W x, int e) {        // e in 1 .. 4
+    const W x2 = x * x;
+    return e == 1 ? x : e == 2 ? x2 : e == 3 ? x2 * x : x2 * x2;
+}
+
 // Math policies of the round-trip form: W = the type mu is evaluated in
 struct MathLibF64 {          // the float64 parity layout
     typedef double W;
@@ -604,15 +610,22 @@ struct MathLibF64 {          // the float64 parity layout
     static __device__ __forceinline__ double exp(double v) { return exp_f64(v); }
 #endif
     static __device__ __forceinline__ double pow(double v, double e) { return exp(e * log(v)); }
+    // x ** e with e one of 1 .. 4 (make_growth: ipow; the reference's defaults theta = q = 3) by multiplication: <= 1 ulp from
+    // the correctly rounded np.power the reference calls, where exp(e log x) is |e log x| ulp off -- closer AND one exp (May:
+    // one log and one exp) cheaper per env.  float64 with returns at N = 2^22: fishing-v8 40.5 -> 35.7 us, fishing-v11 51.0 -> 48.8
+    // (profiles/r04_zoo_f64_ipow.jsonl)
+    static constexpr bool kIntPow = true;
 };
 struct MathHwF32 {           // FISHING_ZOO_F32_MATH 0
     typedef float W;
+    static constexpr bool kIntPow = false;     // (rounds 1-3 as they were)
     static __device__ __forceinline__ float log(float v) { return log_t<float>(v); }
     static __device__ __forceinline__ float exp(float v) { return __expf(v); }
     static __device__ __forceinline__ float pow(float v, float e) { return pow_t<float>(v, e); }
 };
 struct MathLibF32 {          // FISHING_ZOO_F32_MATH 1
     typedef float W;
+    static constexpr bool kIntPow = false;
     static __device__ __forceinline__ float log(float v) { return ::logf(v); }
     static __device__ __forceinline__ float exp(float v) { return ::expf(v); }
     static __device__ __forceinline__ float pow(float v, float e) { return ::expf(e * ::logf(v)); }
@@ -638,11 +651,12 @@ __device__ __forceinline__ T zoo_draw_round_trip(int kind_rt, T x_in, T z_in, co
             break;
         case FISHING_KIND_MYERS: {        // :247-255   (log(A), A = r + 1, comes from the host)
             const W lx = M::log(x);
-            mu = (W)P.logA + (W)P.theta * lx - M::log((W)1 + M::exp((W)P.theta * lx) / (W)P.M);   // x**theta
+            const W xt = (M::kIntPow && P.ipow) ? int_pow<W>(x, P.ipow) : M::exp((W)P.theta * lx);   // x**theta (wave-uniform choice)
+            mu = (W)P.logA + (W)P.theta * lx - M::log((W)1 + xt / (W)P.M);
             break;
         }
         case FISHING_KIND_MAY: {          // :229-242   (b**q comes from the host)
-            const W xq = M::pow(x, (W)P.q);
+            const W xq = (M::kIntPow && P.ipow) ? int_pow<W>(x, P.ipow) : M::pow(x, (W)P.q);
             const W exp_mu = x + x * (W)P.r * ((W)1 - x / (W)P.M) - (W)P.a * xq / (xq + (W)P.bq);
             mu = M::log(exp_mu);
             break;
