@@ -31,9 +31,12 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     const bool derived = kPerEnv && (p.flags & FISHING_FLAG_V4_DERIVED) != 0;   // no r / K arrays (derive_model_error)
     uint64_t origin_step = p.origin_step, origin_counter = p.origin_counter;
     if (derived) device_origin(b.counter, origin_step, origin_counter);
-    // per-env K keeps the true division.  (The power-of-two flag stays a run-time one here: at N = 2^22 this kernel is
-    // VALU-bound with 5-6 waves per SIMD to interleave, and a compile-time flag measured no gain -- unlike in the
-    // fused step kernel's two-waves-per-SIMD regime.)
+    // per-env K keeps the true division.  The power-of-two flag stays a run-time one here (a wave-uniform branch in front of each
+    // division: div_K).  A compile-time flag is worth 4 % (random policy) / 8 % (escapement) at N = 2^22 but doubles the 88
+    // instantiations; unswitching the
+    // tile loop on the flag inside the kernel (two copies behind one run-time test) gave 2 % / 7 % -- and cost fishing-v4's and
+    // fishing-v11's rollout kernels a wave of occupancy through nothing but the changed register allocation of the wrapped loop
+    // (fishing-v11 2.57 -> 2.12e11): profiles/r04_rollout_unswitch.jsonl.  Not kept.
     const DivK dk = kPerEnv ? DivK{false, 0.0f, 0.0} : dk_arg;
     // POLICY >= 0: compile-time policy (v0/v1/v2/v4); POLICY < 0: wave-uniform run-time policy (zoo,
     // to keep the number of instantiations of the transcendental-heavy bodies small)

@@ -1,0 +1,19 @@
+"""In-kernel-policy rollouts at N = 2^22 (505 steps per launch): env-steps/s by HIP events."""
+import json, os, statistics, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import gym_fishing_amd as gf
+n = 1 << 22
+for idn, pol, param in (("fishing-v1", "random", 0.0), ("fishing-v1", "escapement", 0.5), ("fishing-v0", "random", 0.0), ("fishing-v2", "random", 0.0)):
+    env = gf.make(idn, num_envs=n, seed=1, sigma=0.1, track_returns=True)
+    env.reset()
+    env.rollout(101, policy=pol, param=param)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); env.rollout(505, policy=pol, param=param); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ms = statistics.median(ts)
+    print(json.dumps({"lib": os.path.basename(os.environ.get("FISHING_HIP_LIB", "default")), "id": idn, "policy": pol, "ms": round(ms, 3),
+                      "env_steps_per_s": "%.4g" % (n * 505 / ms * 1e3)}), flush=True)
+    del env
