@@ -609,3 +609,43 @@ def test_zoo_special_values_follow_the_reference(hh, dtype):
             if not ok:
                 bad.append((env_id, float(X[i]), float(Z[i]), float(got[i]), float(want[i])))
         assert not bad, bad
+
+
+@pytest.mark.parametrize("env_id", ["fishing-v9", "fishing-v10", "fishing-v11"])
+def test_zoo_shards_reproduce_the_whole_batch_at_full_size(hh, env_id):
+    """SURVEY 8(e) for the zoo at a BASELINE-sized batch: N = 2^22 envs stepped as one batch and as 8 shards (env_offset =
+    the shard's first global index) land on the same bits -- noise, fishing-v11's model draws (reset and auto-reset) and
+    fishing-v10's drifting r are functions of the GLOBAL env index -- and two runs of the whole batch are identical."""
+    import torch
+    import gym_fishing_amd as gf
+    n, shards, steps = 1 << 22, 8, 6
+    g = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.rand((steps, n), device="cuda", generator=g) * 1.6 - 1.2
+
+    def mk(count, off):
+        kw = {} if env_id == "fishing-v11" else dict(sigma=0.1)
+        env = gf.make(env_id, num_envs=count, env_offset=off, seed=17, Tmax=4, **kw)
+        if env_id == "fishing-v11":
+            for d in env.model_params.values():
+                d["sigma"] = 0.1
+        env.reset()
+        return env
+
+    def run(env, a):
+        for s in range(steps):
+            env.step(a[s])
+        torch.cuda.synchronize()
+        extra = env._model_idx if env_id == "fishing-v11" else (env._r_arr if env_id == "fishing-v10" else None)
+        return env._obs.clone(), env._t.clone(), None if extra is None else extra.clone()
+    whole = run(mk(n, 0), acts)
+    again = run(mk(n, 0), acts)
+    for a, b in zip(whole, again):
+        assert a is None or torch.equal(a, b)
+    per = n // shards
+    for k in range(shards):
+        part = run(mk(per, k * per), acts[:, k * per:(k + 1) * per].contiguous())
+        for a, b in zip(whole, part):
+            assert a is None or torch.equal(a[k * per:(k + 1) * per], b), (env_id, k)
+    assert bool(torch.isfinite(whole[0]).all())
+    if env_id == "fishing-v11":
+        assert len(set(whole[2][:4096].cpu().tolist())) == 5
