@@ -5,9 +5,10 @@ and the device math library, so parity is tolerance-based:
   * fp64 layout: on the POPULATION x = (obs+1) K, |dx| <= 2e-14 * x per step against the golden vectors
     captured from the reference (a few ulp of exp(mu), mu = O(1)); reward, done, t exact;
   * fp32 layout: the north star's bar -- |obs - ref| <= 1e-6 and |reward - ref| <= 1e-6 per step, absolute,
-    against the reference's float64 numbers (round 4: the float32 kernels evaluate the growth function in
-    float64 and round once, fishing_common.h: FISHING_ZOO_F32_MATH; measured maxima per growth function in
-    profiles/r04_zoo_f32_error.json.  Rounds 1-3 held the population to 2e-5 relative on the hardware transcendentals).
+    against the reference's float64 numbers (round 4: the float32 kernels evaluate the growth function in the
+    algebraically equal form without the log / exp round trip, fishing_common.h: FISHING_ZOO_F32_MATH; measured maxima
+    per growth function and per build in profiles/r04_zoo_f32_error.json.  Rounds 1-3 held the population to 2e-5
+    relative on the hardware transcendentals).
 """
 import numpy as np
 import pytest
