@@ -983,6 +983,25 @@ class BaseFishingEnv(_gym_env_base()):
             return (fish_population / K - 1.0).reshape(-1, 1)
         return np.array([fish_population / K - 1])
 
+    def harvest_draw(self, quota, x=None):
+        """base_fishing_env.py:112-119: harvest = min(population, quota); population = max(population - harvest, 0.0).
+        One env: on self.fish_population, which it updates, like the reference (self.harvest too).  Tensors: `x` holds
+        the populations (default: the batch's current ones), elementwise with Python's min / max operand order (a NaN
+        quota leaves the population's side of min(), as in the step kernels); returns (harvest, population left)."""
+        if isinstance(quota, torch.Tensor) or isinstance(x, torch.Tensor) or not self._scalar:
+            if x is None:
+                x = self.get_fish_population(self._obs_view)
+            xt = torch.as_tensor(x, device=self.device)
+            q = torch.as_tensor(quota, device=self.device).to(xt.dtype).expand_as(xt) if not isinstance(quota, torch.Tensor) \
+                else quota.to(device=self.device, dtype=xt.dtype).reshape(xt.shape)
+            h = torch.where(q < xt, q, xt)                       # min(x, q): q only where q < x
+            d = xt - h
+            return h, torch.where(d.new_zeros(()) > d, d.new_zeros(()), d)     # max(d, 0.0): 0.0 only where 0.0 > d
+        pop = self.fish_population if x is None else x
+        self.harvest = min(pop, quota)
+        self.fish_population = max(pop - self.harvest, 0.0)
+        return self.harvest
+
     def population_draw(self, x=None, noise=None, sigma=None, dtype=None, r=None, K=None, model_idx=None):
         """base_fishing_env.py:121-133 (v2: fishing_tipping_env.py:24-35) over an array of
         populations -- the call BMSY() makes (models/policies.py:59-63).  `x` None uses

@@ -267,6 +267,42 @@ def test_helpers_match_reference_maps(gf, anchors):
     assert v.env_method("get_fish_population", np.array([-0.5]), indices=3)[0] == 1.0
 
 
+def test_step_equals_the_reference_sequence_of_public_helpers(gf):
+    """base_fishing_env.py:60-81 spelled out with the public methods, as a caller of the reference may: get_quota ->
+    get_fish_population -> harvest_draw -> population_draw -> get_state reproduces step() -- one env through the scalar
+    protocol (harvest_draw / population_draw on self.fish_population, self.harvest kept), and N envs on tensors."""
+    import torch
+    a, z = np.array([-0.4], dtype=np.float32), 0.3
+    stepped, manual = gf.make("fishing-v1", sigma=0.1), gf.make("fishing-v1", sigma=0.1)
+    stepped.reset()
+    manual.reset()
+    obs, rew, done, _ = stepped.step(a, noise=[z])
+    quota = manual.get_quota(a)
+    manual.get_fish_population(manual.state)
+    assert manual.fish_population == 0.75
+    h = manual.harvest_draw(quota)
+    assert h == manual.harvest == min(0.75, quota) and manual.fish_population == max(0.75 - h, 0.0)
+    x1 = manual.population_draw(noise=[z])
+    assert manual.get_state(x1)[0] == obs[0] and max(h, 0.0) == rew
+    # a quota above the stock takes the stock, nothing is left; NaN follows Python's min / max
+    manual.fish_population = 0.2
+    assert manual.harvest_draw(0.5) == 0.2 and manual.fish_population == 0.0
+    manual.fish_population = 0.2
+    assert manual.harvest_draw(float("nan")) == 0.2 and manual.fish_population == 0.0
+    # N envs: tensors in, (harvest, population left) out
+    n = 64
+    v, w = (gf.make("fishing-v1", sigma=0.1, num_envs=n, seed=3, dtype=torch.float64, auto_reset=False) for _ in range(2))
+    v.reset()
+    w.reset()
+    acts = torch.linspace(-1.2, 0.4, n, device="cuda", dtype=torch.float32)
+    zs = torch.linspace(-2.0, 2.0, n, device="cuda", dtype=torch.float64)
+    obs, rew, done, _ = v.step(acts, noise=zs)
+    hv, left = w.harvest_draw(w.get_quota(acts))
+    x1 = w.population_draw(left, noise=zs)
+    assert torch.equal(w.get_state(x1), obs.double()) and torch.equal(torch.clamp(hv, min=0.0), rew.double())
+    assert bool(done.any()) and torch.equal(done.bool(), x1 <= 0.0)          # (the quotas above the stock emptied it)
+
+
 def test_episode_record_of_a_batch_beyond_4096_tiles(gf):
     """N = 2^22 + 3 tiles: step() runs a workgroup per tile (4099 of them), the env sizes its return_partials for the
     8192 slots such a batch can touch and reduces exactly those -- the record counts every finished episode and sums

@@ -48,6 +48,25 @@ def test_constructor_kwargs_match_reference_signatures():
         assert list(got) == list(kw), "positional order differs for " + env_id
 
 
+def test_env_classes_carry_the_reference_method_names():
+    # base_fishing_env.py:60-164: the public methods of BaseFishingEnv, with the reference's argument names
+    import inspect
+    want = {"step": ["action"], "reset": [], "render": ["mode"], "close": [], "simulate": ["model", "reps"],
+            "plot": ["df", "output"], "policyfn": ["model", "reps"], "plot_policy": ["df", "output"],
+            "harvest_draw": ["quota"], "population_draw": [], "get_quota": ["action"], "get_action": ["quota"],
+            "get_fish_population": ["state"], "get_state": ["fish_population"]}
+    for env_id in gf.ENV_IDS:
+        cls = gf.env_class(env_id)
+        for name, args in want.items():
+            fn = getattr(cls, name, None)
+            assert callable(fn), (env_id, name)
+            params = [k for k in inspect.signature(fn).parameters if k != "self"]
+            assert params[:len(args)] == args, (env_id, name, params)
+            # whatever this build adds behind the reference's arguments is optional
+            extra = list(inspect.signature(fn).parameters.values())[1 + len(args):]
+            assert all(q.default is not q.empty or q.kind in (q.VAR_KEYWORD, q.VAR_POSITIONAL, q.KEYWORD_ONLY) for q in extra), (env_id, name)
+
+
 def test_no_gpu_means_loud_failure_not_cpu_fallback():
     import torch
     if torch.cuda.is_available():
