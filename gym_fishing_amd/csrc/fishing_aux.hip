@@ -102,6 +102,16 @@ reduce_returns_kernel(const double* __restrict__ partials, const int passes, dou
     }
 }
 
+// A population handed in from OUTSIDE may be negative (the step kernels' never is: harvest_draw leaves max(x - h, 0)).  The
+// reference's allen / myers / ricker take log(x) of it -> NaN (growth_models.py:208-261; May's log(exp_mu) and
+// Beverton-Holt's clip are handled where they are computed); the float32 layout's algebraic forms carry x itself as the
+// prefactor and would return 0 after the max(0, .): restore the NaN here, outside the step kernels' instruction stream.
+template <typename T>
+__device__ __forceinline__ T zoo_draw_outside(const int kind, const T x, const T out) {
+    const bool takes_log_x = kind == FISHING_KIND_ALLEN || kind == FISHING_KIND_MYERS || kind == FISHING_KIND_RICKER;
+    return (takes_log_x && x < (T)0) ? (T)__builtin_nan("") : out;
+}
+
 // population_draw() over an array of populations, as BMSY() drives it (models/policies.py:59-63)
 template <typename T, int MODEL>
 __global__ void __launch_bounds__(256)
@@ -111,7 +121,7 @@ population_draw_kernel(const ParamsT<T> p, const int kind, const int64_t n, cons
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         if constexpr (is_zoo_tag(MODEL))
-            x_out[i] = zoo_population_draw<T>(kind, x_in[i], z ? z[i] : (T)0, P);
+            x_out[i] = zoo_draw_outside<T>(kind, x_in[i], zoo_population_draw<T>(kind, x_in[i], z ? z[i] : (T)0, P));
         else        // (r_arr / K_arr: element i under ITS parameters -- N fishing-v4 envs, each with the pair it drew)
             x_out[i] = population_draw<T, MODEL>(x_in[i], z ? z[i] : (T)0, r_arr ? r_arr[i] : p.r, K_arr ? K_arr[i] : p.K, p.sigma, p.C);
     }
@@ -163,7 +173,7 @@ population_draw_mixed_kernel(const ParamsT<T> p, const int64_t n, const T* __res
         if (kind == FISHING_KIND_MYERS) out = zoo_population_draw<T, FISHING_KIND_MYERS>(kind, x, zi, p.zoo[FISHING_KIND_MYERS]);
         if (kind == FISHING_KIND_MAY) out = zoo_population_draw<T, FISHING_KIND_MAY>(kind, x, zi, p.zoo[FISHING_KIND_MAY]);
         if (kind == FISHING_KIND_RICKER) out = zoo_population_draw<T, FISHING_KIND_RICKER>(kind, x, zi, p.zoo[FISHING_KIND_RICKER]);
-        x_out[i] = out;
+        x_out[i] = zoo_draw_outside<T>(kind, x, out);
     }
 }
 

@@ -43,6 +43,25 @@ def load_zoo_cases():
     return [GoldenCase(n, npz) for n in names]
 
 
+GROWTH_PARAM_KEYS = ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a")
+GROWTH_FUNCTION_OF_KIND = ("allen", "beverton_holt", "myers", "may", "ricker")
+
+
+def load_growth_function_cases():
+    """Reference f(x, params) calls of growth_models.py:208-269 (tests/golden/make_golden.py): per case the function, its
+    parameter dict, the seed set before the three calls (vector, matrix, scalar -- in that order) and per call the
+    populations, the standard normals the reference consumed, and its result."""
+    z = np.load(os.path.join(GOLDEN, "reference_growth_functions.npz"))
+    out = []
+    for tag in sorted({k.split("/")[0] for k in z.files}):
+        params = {k: float(v) for k, v in zip(GROWTH_PARAM_KEYS, z[tag + "/params"]) if not np.isnan(v)}
+        calls = [(sh, z["%s/%s/x" % (tag, sh)], z["%s/%s/z" % (tag, sh)], z["%s/%s/out" % (tag, sh)])
+                 for sh in ("vector", "matrix", "scalar")]
+        out.append(dict(tag=tag, kind=int(z[tag + "/kind"]), name=GROWTH_FUNCTION_OF_KIND[int(z[tag + "/kind"])],
+                        seed=int(z[tag + "/seed"]), params=params, calls=calls))
+    return out
+
+
 def load_golden_cases():
     npz = np.load(os.path.join(GOLDEN, "reference_trajectories.npz"))
     names = sorted({k.split("/")[0] for k in npz.files})

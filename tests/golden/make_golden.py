@@ -274,6 +274,42 @@ def main():
                             ("v8_myers_special_actions", "fishing-v8", {"sigma": 0.1, "Tmax": 9}),
                             ("v11_uncert_special_actions", "fishing-v11", {"Tmax": 9})):
         run_case(tag, env_id, kw, [233, 234], 12, lambda g, s, e: f32(special[s]), out=zoo)
+    # --- the module-level growth functions themselves (growth_models.py:208-269), called the way a user of the
+    # reference may: f(x, params) on a scalar, a vector and a matrix of populations (zero, tiny, typical, far above K,
+    # negative), default and non-default parameter dicts, sigma = 0 and > 0.  np.random.lognormal(mu, sigma) consumes one
+    # legacy standard normal per element of mu: recorded by drawing them first and rewinding the stream.
+    from gym_fishing.envs import growth_models as gm
+    grow = {}
+    PKEYS = ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a")
+    grid = np.concatenate([[0.0, 1e-300, 1e-12, 1e-3], np.linspace(0.02, 3.0, 37), [7.5, 50.0, 1e6, -0.5]])
+    for tag, fname, P in (
+            ("allen", "allen", {"r": 0.3, "K": 1.0, "sigma": 0.0, "C": 0.5}),
+            ("allen_noise", "allen", {"r": 0.9, "K": 2.0, "sigma": 0.15, "C": 0.2}),
+            ("beverton_holt", "beverton_holt", {"r": 0.3, "K": 1, "sigma": 0.0}),
+            ("beverton_holt_noise", "beverton_holt", {"r": 0.6, "K": 2.5, "sigma": 0.2}),
+            ("beverton_holt_r0", "beverton_holt", {"r": -0.1, "K": 1.0, "sigma": 0.1}),      # clip(r, 0, inf): B = inf
+            ("myers", "myers", {"r": 1.0, "K": 1.0, "M": 1.0, "theta": 3.0, "sigma": 0.0}),
+            ("myers_noise", "myers", {"r": 0.7, "K": 1.0, "M": 1.3, "theta": 2.5, "sigma": 0.1}),
+            ("may", "may", {"r": 0.7, "K": 1.5, "M": 1.5, "q": 3, "b": 0.15, "sigma": 0.0, "a": 0.2}),
+            ("may_noise", "may", {"r": 0.5, "K": 1.5, "M": 1.2, "q": 2, "b": 0.2, "sigma": 0.1, "a": 0.1}),
+            ("ricker", "ricker", {"r": 0.3, "K": 1, "sigma": 0.0}),
+            ("ricker_noise", "ricker", {"r": 1.1, "K": 0.8, "sigma": 0.25})):
+        f = gm.population_model[fname]
+        seed = 4000 + len(grow)
+        np.random.seed(seed)            # the three calls below run on from here, in this order
+        for shape_tag, x in (("vector", grid), ("matrix", grid[4:40].reshape(4, 9)), ("scalar", np.float64(0.62))):
+            st = np.random.get_state()
+            z = np.random.normal(0, 1, np.shape(x))
+            np.random.set_state(st)
+            y = f(x, P)
+            grow["%s/%s/x" % (tag, shape_tag)] = np.asarray(x, dtype=np.float64)
+            grow["%s/%s/z" % (tag, shape_tag)] = np.asarray(z, dtype=np.float64)
+            grow["%s/%s/out" % (tag, shape_tag)] = np.asarray(y, dtype=np.float64)
+        grow[tag + "/kind"] = np.array(ZOO_MODELS.index(fname), dtype=np.int32)
+        grow[tag + "/seed"] = np.array(seed, dtype=np.int64)
+        grow[tag + "/params"] = np.array([float(P.get(k, np.nan)) for k in PKEYS])
+    np.savez_compressed(os.path.join(OUT, "reference_growth_functions.npz"), **grow)
+
     # --- anchors from the reference's own test (tests/test-envs.py:93-106)
     env = gym.make("fishing-v2", sigma=0, init_state=0.75)
     env.reset()

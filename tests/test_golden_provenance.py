@@ -19,7 +19,8 @@ def test_fixtures_regenerate_bit_for_bit(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     for name in ("reference_trajectories.npz", "reference_policy_sims.npz", "reference_zoo_trajectories.npz",
-                 "reference_seeded_sims.npz", "reference_vec_sims.npz", "reference_vec_sims_v4.npz", "reference_policyfn.npz"):
+                 "reference_seeded_sims.npz", "reference_vec_sims.npz", "reference_vec_sims_v4.npz", "reference_policyfn.npz",
+                 "reference_growth_functions.npz"):
         new, old = np.load(tmp_path / name), np.load(os.path.join(GOLDEN, name))
         assert sorted(new.files) == sorted(old.files), name
         for k in old.files:

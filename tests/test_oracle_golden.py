@@ -352,3 +352,17 @@ def test_reference_vec_sim_of_fishing_v4_uses_the_K_in_force_at_each_row():
     assert np.array_equal(got[:, [0, 4]], tab[:, [0, 4]])
     assert np.array_equal(got[:, 1], tab[:, 1]) and np.array_equal(got[:, 3], tab[:, 3])
     assert np.allclose(got[:, 2], tab[:, 2], rtol=0, atol=1e-7)     # the raw action column (float32(0.2) in the reference's table)
+
+
+def test_growth_functions_bit_exact():
+    """growth_models.py:208-269 called directly -- f(x, params) on a scalar, a vector and a matrix of populations (zero,
+    1e-300, far above K, negative; r < 0 for Beverton-Holt's clip): the oracle's zoo_population_draw on the recorded
+    normals reproduces every result bit for bit, NaN for NaN."""
+    from conftest import load_growth_function_cases
+    cases = load_growth_function_cases()
+    assert len(cases) == 11 and {c["name"] for c in cases} == {"allen", "beverton_holt", "myers", "may", "ricker"}
+    for c in cases:
+        for shape_tag, x, z, want in c["calls"]:
+            got = fo.zoo_population_draw(c["kind"], x, z, c["params"])
+            assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True), (c["tag"], shape_tag)
+
