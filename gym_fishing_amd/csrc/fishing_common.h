@@ -1001,6 +1001,15 @@ __device__ __forceinline__ double div_K<double>(double x, double K, const DivK& 
     return x / K;
 }
 
+// harvest_draw (base_fishing_env.py:112-119): h = min(x, quota), then x = max(x - h, 0.0).  That max is the identity on
+// every input: h is x itself or a quota BELOW x, so d = x - h is +0 (x - x), positive (x > quota: the difference of two
+// distinct values never rounds below +0) or NaN (inf - inf, a NaN operand) -- and Python's max(d, 0.0) returns d in all
+// three cases (`0.0 > d` is false).  It is therefore not evaluated: one compare / select pair per env-step less in the
+// VALU-bound fused kernels (tests/test_gpu_parity.py holds the kernels to the oracle's literal form, NaN / inf actions
+// and states included).
+template <typename T>
+__device__ __forceinline__ T stock_after_harvest(T x, T h) { return x - h; }
+
 // step() with a zoo growth function: quota / obs maps use the env's K (K_obs), the growth its
 // own parameter set (self.params in the reference).  `dk`: K_obs is a power of two (div_K below).
 template <typename T, int KIND = -1, bool RECOMPUTE = false>
@@ -1009,8 +1018,7 @@ __device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int
                                              int32_t& t_next, const DivK& dk = DivK{false, 0.0f, 0.0}) {
     T x = (obs + (T)1) * K_obs;
     const T h = (quota < x) ? quota : x;
-    const T d = x - h;
-    x = ((T)0 > d) ? (T)0 : d;
+    x = stock_after_harvest<T>(x, h);
     x = zoo_population_draw<T, KIND, RECOMPUTE>(kind, x, z, P);
     obs_next = div_K<T>(x, K_obs, dk) - (T)1;
     reward = ((T)0 > h) ? (T)0 : h;
@@ -1040,8 +1048,7 @@ __device__ __forceinline__ void env_step(T obs, int32_t t, T quota, T z, T r, T 
                                          int32_t& t_next, const DivK& dk = DivK{false, 0.0f, 0.0}) {
     T x = (obs + (T)1) * K;                   // get_fish_population  :159
     const T h = (quota < x) ? quota : x;      // min(x, quota)        :117
-    const T d = x - h;
-    x = ((T)0 > d) ? (T)0 : d;                // max(x - h, 0.0)      :118
+    x = stock_after_harvest<T>(x, h);         // max(x - h, 0.0)      :118 (the max is the identity: above)
     x = population_draw<T, MODEL>(x, z, r, K, sigma, C, dk);
     obs_next = div_K<T>(x, K, dk) - (T)1;     // get_state            :163
     reward = ((T)0 > h) ? (T)0 : h;           // max(harvest, 0.0)    :74

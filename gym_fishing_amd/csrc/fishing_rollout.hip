@@ -21,7 +21,7 @@ namespace fishing {
 #define FISHING_ROLLOUT_LOCAL_KEYS 1
 #endif
 
-template <typename T, int MODEL, int POLICY, bool AUTO>
+template <typename T, int MODEL, int POLICY, bool AUTO, bool KP2C = false>
 __global__ void __launch_bounds__(256)
 rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
                const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed_arg,
@@ -31,13 +31,16 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     const bool derived = kPerEnv && (p.flags & FISHING_FLAG_V4_DERIVED) != 0;   // no r / K arrays (derive_model_error)
     uint64_t origin_step = p.origin_step, origin_counter = p.origin_counter;
     if (derived) device_origin(b.counter, origin_step, origin_counter);
-    // per-env K keeps the true division.  The power-of-two flag stays a run-time one here (a wave-uniform branch in front of each
-    // division: div_K).  A compile-time flag is worth 4 % (random policy) / 8 % (escapement) at N = 2^22 but doubles the 88
-    // instantiations; unswitching the
+    // per-env K keeps the true division.  The power-of-two flag is a run-time one (a wave-uniform branch in front of each
+    // division: div_K) -- except in the KP2C twins, which the dispatch picks for the float32 auto-resetting rollouts of
+    // fishing-v0/v1/v2 with a power-of-two K (the reference's default K = 1): there it is a compile-time fact, the divisions and
+    // their branches are gone from the step loop (+4 % random policy, +8 % escapement at N = 2^22; 12 instantiations more).
+    // A compile-time flag for ALL 88 instantiations would double them; unswitching the
     // tile loop on the flag inside the kernel (two copies behind one run-time test) gave 2 % / 7 % -- and cost fishing-v4's and
     // fishing-v11's rollout kernels a wave of occupancy through nothing but the changed register allocation of the wrapped loop
-    // (fishing-v11 2.57 -> 2.12e11): profiles/r04_rollout_unswitch.jsonl.  Not kept.
-    const DivK dk = kPerEnv ? DivK{false, 0.0f, 0.0} : dk_arg;
+    // (fishing-v11 2.57 -> 2.12e11): profiles/r04_rollout_unswitch.jsonl.
+    DivK dk = kPerEnv ? DivK{false, 0.0f, 0.0} : dk_arg;
+    if constexpr (KP2C) dk.pow2 = true;
     // POLICY >= 0: compile-time policy (v0/v1/v2/v4); POLICY < 0: wave-uniform run-time policy (zoo,
     // to keep the number of instantiations of the transcendental-heavy bodies small)
     const int policy = (POLICY >= 0) ? POLICY : policy_rt;
@@ -150,7 +153,13 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_quota<T>(q, p.n_actions, KK[j]);
                     else a_c = (T)action_cts_from_quota<T>(q, KK[j], dk);
                 }
-                quota[j] = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j]) : quota_cts<T>(a_c, KK[j]);
+                if constexpr (POLICY == FISHING_POLICY_RANDOM && MODEL != FISHING_MODEL_V0) {
+                    // action_cts_from_word maps a 32-bit word into [-1, 1] exactly (word * 2^-31 - 1; 2^32 - 1 rounds up to
+                    // 2^32 -> 1.0): get_quota's clip is the identity there -- two compare / select pairs per env-step less
+                    quota[j] = (a_c + (T)1) * KK[j];
+                } else {
+                    quota[j] = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j]) : quota_cts<T>(a_c, KK[j]);
+                }
                 act_rec[j] = (MODEL == FISHING_MODEL_V0) ? (T)a_d : a_c;
             }
             T o2[4], r2[4];
@@ -167,7 +176,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                         const T x = (obs[j] + (T)1) * KK[j];
                         hv[j] = (quota[j] < x) ? quota[j] : x;
                         const T d = x - hv[j];
-                        xh[j] = ((T)0 > d) ? (T)0 : d;
+                        xh[j] = d;       // (max(d, 0.0) is the identity here: stock_after_harvest)
                         xn[j] = (T)0;
                         kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                     }
@@ -320,6 +329,21 @@ int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& b
     if constexpr (is_zoo_tag(MODEL)) {
         return FISHING_LAUNCH_ROLLOUT(-1);          // run-time policy switch
     } else {
+        if constexpr (sizeof(T) == 4 && MODEL != FISHING_MODEL_V4) {
+            // the common request -- float32, auto-reset, K a power of two -- on the twins without divisions (KP2C)
+            if ((pt.flags & FISHING_FLAG_AUTO_RESET) && dk.pow2) {
+#define FISHING_LAUNCH_ROLLOUT_KP2(POL)                                                                          \
+    launch_kernel(rollout_kernel<T, MODEL, POL, true, true>, blocks, threads, s, pt, bt, n, env_offset, policy_param, \
+                  Tsteps, traj, seed, step_counter, noise_on, policy, dk)
+                switch (policy) {
+                    case FISHING_POLICY_RANDOM: return FISHING_LAUNCH_ROLLOUT_KP2(FISHING_POLICY_RANDOM);
+                    case FISHING_POLICY_CONSTANT: return FISHING_LAUNCH_ROLLOUT_KP2(FISHING_POLICY_CONSTANT);
+                    case FISHING_POLICY_ESCAPEMENT: return FISHING_LAUNCH_ROLLOUT_KP2(FISHING_POLICY_ESCAPEMENT);
+                    default: return FISHING_LAUNCH_ROLLOUT_KP2(FISHING_POLICY_MSY);
+                }
+#undef FISHING_LAUNCH_ROLLOUT_KP2
+            }
+        }
         switch (policy) {
             case FISHING_POLICY_RANDOM: return FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_RANDOM);
             case FISHING_POLICY_CONSTANT: return FISHING_LAUNCH_ROLLOUT(FISHING_POLICY_CONSTANT);
@@ -558,7 +582,7 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                             const T x = (obs[j] + (T)1) * KK[j];
                             hv[j] = (quota < x) ? quota : x;
                             const T d = x - hv[j];
-                            xh[j] = ((T)0 > d) ? (T)0 : d;
+                            xh[j] = d;       // (max(d, 0.0) is the identity here: stock_after_harvest)
                             xn[j] = (T)0;
                             kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                         }

@@ -164,7 +164,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                     const T x = (obs[j] + (T)1) * KK[j];
                     hv[j] = (quota < x) ? quota : x;
                     const T d = x - hv[j];
-                    xh[j] = ((T)0 > d) ? (T)0 : d;
+                    xh[j] = d;       // (max(d, 0.0) is the identity here: stock_after_harvest)
                     xn[j] = (T)0;
                     kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                 }
@@ -666,7 +666,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                     const T x = (obs[j] + (T)1) * KK[j];
                     hv[j] = (quota < x) ? quota : x;
                     const T d = x - hv[j];
-                    xh[j] = ((T)0 > d) ? (T)0 : d;
+                    xh[j] = d;       // (max(d, 0.0) is the identity here: stock_after_harvest)
                     xn[j] = (T)0;
                     kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                 }
