@@ -157,6 +157,11 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     // action_cts_from_word maps a 32-bit word into [-1, 1] exactly (word * 2^-31 - 1; 2^32 - 1 rounds up to
                     // 2^32 -> 1.0): get_quota's clip is the identity there -- two compare / select pairs per env-step less
                     quota[j] = (a_c + (T)1) * KK[j];
+                } else if constexpr (KP2C && POLICY == FISHING_POLICY_ESCAPEMENT && MODEL != FISHING_MODEL_V0) {
+                    // q = max(x - S, 0.0) is >= 0 (or NaN) and K a positive power of two here: a = q / K - 1 >= -1, so only the
+                    // upper bound of get_quota's clip can bind
+                    const T av = (a_c > (T)1) ? (T)1 : a_c;
+                    quota[j] = (av + (T)1) * KK[j];
                 } else {
                     quota[j] = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j]) : quota_cts<T>(a_c, KK[j]);
                 }

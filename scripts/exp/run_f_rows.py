@@ -4,7 +4,6 @@ Prints one JSON line per workload: the kernel rocprofv3 will name, N, env-steps 
 and the rate by HIP events (back-to-back launches behind a spin-up)."""
 import json
 import os
-import statistics
 import sys
 
 import torch

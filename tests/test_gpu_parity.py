@@ -380,6 +380,39 @@ def test_fused_rollout_equals_stepwise(hh, model, dtype, policy):
         assert_same_bits(A.K.cpu().numpy(), B.K.cpu().numpy(), "K")
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("model", [fo.MODEL_V1, fo.MODEL_V2])
+@pytest.mark.parametrize("policy,param,K", [("escapement", 0.1, 0.25), ("escapement", 0.9, 0.25), ("msy", 0.7, 0.25),
+                                            ("msy", -0.05, 0.5), ("escapement", 0.1, 0.3)])
+def test_fused_rollout_policies_where_get_quotas_clip_binds(hh, model, dtype, policy, param, K):
+    """The in-kernel policies at the edges of get_quota's clip (base_fishing_env.py:143): an episode starts at x0 = 0.75 =
+    3 K, so escapement to S = 0.1 asks for a quota above 2 K (action > 1, clipped to 1) on the first step after every reset and
+    for 0 (action -1) once the stock is below S = 0.9; msy with a quota above 2 K, and with a negative one (action < -1,
+    clipped to -1).  K a power of two takes the float32 rollouts' compile-time twins, which evaluate only the side of the
+    clip that can bind there; K = 0.3 the general kernels.  Bit for bit against step() fed the oracle's policy actions."""
+    n, off, seed, T = 2052, 4, 7, 20
+    p = hh.params(model, r=0.3, K=K, auto_reset=True, **dict(ROLLOUT_KW, x0=0.75))
+    pol, _ = _policy_setup(hh, policy, model)
+    A, B = (hh.State(n, dtype, model, np.zeros(n), ep_return=True) for _ in range(2))
+    A.reset(p, seed=seed, env_offset=off)
+    B.reset(p, seed=seed, env_offset=off)
+    traj = A.rollout(p, pol, param, T, seed=seed, step_counter=0, env_offset=off, record=True)
+    env = np.arange(off, off + n)
+    hi = lo = 0
+    for s in range(T):
+        obs = B.obs.cpu().numpy()
+        a = _policy_action(policy, param, model, dtype, obs, dtype(K), seed, env, s)
+        hi += int((a > 1).sum())
+        lo += int((a <= -1).sum())
+        assert_same_bits(traj[s, 0], obs, "obs_in step %d" % s)
+        assert_same_bits(traj[s, 1], a.astype(dtype), "action step %d" % s)
+        _, rew, done, _ = B.step(p, a, seed=seed, step_counter=s, env_offset=off)
+        assert_same_bits(traj[s, 2], rew, "reward step %d" % s)
+        assert (traj[s, 3].astype(np.uint8) == done).all()
+    assert_same_bits(A.obs.cpu().numpy(), B.obs.cpu().numpy(), "final obs")
+    assert (hi if param > 0 and not (policy == "escapement" and param == 0.9) else lo) > 0      # the clip did bind
+
+
 def test_rollout_without_auto_reset_freezes_and_exits(hh):
     """Wave-ballot exit: with no auto-reset every env is frozen at its first done."""
     from gym_fishing_amd import _capi
