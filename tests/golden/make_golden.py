@@ -357,7 +357,10 @@ def main():
     # script does; the drop-in's scalar protocol must give the same table from the same seed.
     seeded = {}
     for env_id, kw in (("fishing-v1", {"sigma": 0.1}), ("fishing-v0", {"sigma": 0.1}), ("fishing-v2", {"sigma": 0.05}),
-                       ("fishing-v5", {"sigma": 0.1}), ("fishing-v9", {"sigma": 0.1}), ("fishing-v11", {})):
+                       ("fishing-v5", {"sigma": 0.1}), ("fishing-v9", {"sigma": 0.1}), ("fishing-v11", {}),
+                       # (round 4: the rest of the zoo -- fishing-v10's r drifts on EVERY population_draw(), BMSY's and msy's included)
+                       ("fishing-v6", {"sigma": 0.1}), ("fishing-v7", {"sigma": 0.1}), ("fishing-v8", {"sigma": 0.1}),
+                       ("fishing-v10", {"sigma": 0.05})):
         for pname, cls in (("msy", msy), ("escapement", escapement)):
             np.random.seed(7)
             env = gym.make(env_id, **kw)
