@@ -474,6 +474,104 @@ def test_env_v4_derived_mode_equals_the_stored_mode_and_survives_its_exits(hh):
     assert torch.equal(R._obs, D2._obs) and torch.equal(R.K, D2.K)
 
 
+@pytest.mark.parametrize("trial", range(12))
+def test_v4_random_operation_sequences_derived_equals_stored(hh, trial):
+    """The fixed walk above, randomised: 12 seeds x 60 operations drawn from step / step_many / fused step_many / fused rollout
+    (random, escapement) / full reset / masked reset (random mask, sometimes empty or all) / env.K read / env.sigma write /
+    seed() / env.K write / checkpoint-and-restore into a fresh pair, in any order -- the derived batch (no r / K arrays, origin
+    stamps after masked resets, arrays after the exits) and the stored-array batch agree bit for bit after every operation,
+    whatever parameter mode the sequence has put the derived one in; graph replay of the derived batch follows as a third."""
+    import torch
+    import gym_fishing_amd as gf
+    from gym_fishing_amd.graphs import GraphedSteps
+    rng = np.random.default_rng(4100 + trial)
+    n = int(rng.choice([1024, 2048 + 4, 4096 + 8, 1000]))
+    mk = lambda derived: gf.make("fishing-v4", num_envs=n, sigma=0.05, sigma_p=0.2, Tmax=int(rng_T), seed=9 + trial,   # noqa: E731
+                                 env_offset=16, track_returns=True, derived_params=derived)
+    rng_T = rng.integers(3, 9)
+    D, S, G = mk(None), mk(False), mk(None)
+    g = torch.Generator(device="cuda").manual_seed(trial)
+    ring = torch.rand((4, n), device="cuda", generator=g) * 1.3 - 1.15
+    graph = None
+    modes = set()
+
+    def check(tag):
+        torch.cuda.synchronize()
+        for name in ("_obs", "_t", "_ep_return"):
+            assert torch.equal(getattr(D, name), getattr(S, name)), (trial, tag, name)
+            assert torch.equal(getattr(G, name), getattr(S, name)), (trial, tag, name, "graph")
+        assert torch.equal(D.K, S.K) and torch.equal(D.r, S.r) and torch.equal(G.K, S.K), (trial, tag)
+        modes.add("stored" if not D._derived else ("stamped" if D._stamp is not None else "derived"))
+
+    for e in (D, S, G):
+        e.reset()
+    check("reset")
+    ops = ["step", "step", "step_many", "fused", "rollout_random", "rollout_escapement", "reset", "mask", "mask", "read_K",
+           "sigma", "seed", "write_K", "checkpoint", "graph", "graph"]
+    for k in range(60):
+        op = str(rng.choice(ops))
+        if op == "step":
+            for e in (D, S, G):
+                e.step(ring[k % 4])
+        elif op == "step_many":
+            m = int(rng.integers(1, 9))
+            for e in (D, S, G):
+                e.step_many(ring, m)
+        elif op == "fused":
+            m = int(rng.integers(1, 9))
+            for e in (D, S, G):
+                e.step_many(ring, m, fused=True)
+        elif op.startswith("rollout"):
+            m = int(rng.integers(1, 12))
+            pol = dict(policy="random") if op.endswith("random") else dict(policy="escapement", param=0.4)
+            for e in (D, S, G):
+                e.rollout(m, **pol)
+        elif op == "reset":
+            for e in (D, S, G):
+                e.reset()
+        elif op == "mask":
+            kind = rng.random()
+            mask = torch.zeros(n, dtype=torch.bool, device="cuda") if kind < 0.15 else (
+                torch.ones(n, dtype=torch.bool, device="cuda") if kind < 0.3 else
+                torch.as_tensor(rng.random(n) < rng.uniform(0.01, 0.6), device="cuda"))
+            for e in (D, S, G):
+                e.reset(mask)
+        elif op == "read_K":
+            assert torch.equal(D.K, S.K) and torch.equal(D.r, S.r)
+        elif op == "sigma":
+            v = float(rng.uniform(0.0, 0.1))
+            for e in (D, S, G):
+                e.sigma = v
+        elif op == "seed":
+            v = int(rng.integers(1, 1 << 30))
+            for e in (D, S, G):
+                e.seed(v)
+        elif op == "write_K":
+            v = float(rng.choice([1.25, 0.5, 2.0]))
+            for e in (D, S, G):
+                e.K = v
+        elif op == "checkpoint":
+            sds = [e.state_dict() for e in (D, S, G)]
+            D, S, G = mk(None), mk(False), mk(None)
+            for e, sd in zip((D, S, G), sds):
+                e.load_state_dict(sd)
+            graph = None
+        elif op == "graph":
+            # the third batch takes this operation as graph replays (captured once, re-captured when its launch signature moved);
+            # the other two as plain step_many
+            if graph is None or graph.env is not G:
+                graph = GraphedSteps(G, ring, n_steps=3)
+            reps = int(rng.integers(1, 4))
+            for _ in range(reps):
+                graph.replay()
+                for e in (D, S):
+                    e.step_many(ring, 3)         # (a call starts at the ring's first row, like a replay)
+        check("%d %s" % (k, op))
+    sa, sb = D.episode_stats(), S.episode_stats()
+    assert sa["n_episodes"] == sb["n_episodes"] and sa["sum_return"] == sb["sum_return"]
+    assert modes            # (which parameter modes the derived batch went through depends on the sequence; all three occur over the trials)
+
+
 def test_state_dict_round_trip_carries_sigma_and_scalar_attributes(hh):
     """load_state_dict() restores what FishingParams is built from: sigma changed after construction (env.sigma
     = ...), n_actions, C, the fishing-v4 means -- a freshly built env resumes bit for bit."""
