@@ -572,6 +572,101 @@ def test_v4_random_operation_sequences_derived_equals_stored(hh, trial):
     assert modes            # (which parameter modes the derived batch went through depends on the sequence; all three occur over the trials)
 
 
+@pytest.mark.parametrize("trial", range(5))
+@pytest.mark.parametrize("env_id", ["fishing-v0", "fishing-v1", "fishing-v2", "fishing-v5", "fishing-v7", "fishing-v8", "fishing-v10", "fishing-v11"])
+def test_random_operation_sequences_every_family_three_ways(hh, env_id, trial):
+    """The same walk for the other families: a batch on the kernels the dispatch picks, one forced onto the general kernel
+    (launch_threads=128) and one whose plain steps run as hipGraph replays take 50 random operations -- step / step_many /
+    fused step_many / fused rollouts / full and masked resets / env.sigma and env.Tmax writes / seed() / checkpoint-and-restore
+    -- and agree bit for bit after every one (float32 or float64, whole tiles or a ragged padded batch, by the trial)."""
+    import torch
+    import gym_fishing_amd as gf
+    from gym_fishing_amd.graphs import GraphedSteps
+    rng = np.random.default_rng(5200 + 17 * trial + int(env_id.split("-v")[1]))
+    n = int(rng.choice([1024, 3 * 1024 + 100, 4096, 1000]))
+    dtype = torch.float32 if rng.random() < 0.6 else torch.float64
+    kw = dict(num_envs=n, seed=3 + trial, Tmax=int(rng.integers(3, 9)), track_returns=True, dtype=dtype, env_offset=8)
+    if env_id != "fishing-v11":
+        kw["sigma"] = 0.1
+    A, B, G = gf.make(env_id, **kw), gf.make(env_id, launch_threads=128, **kw), gf.make(env_id, **kw)
+    g = torch.Generator(device="cuda").manual_seed(trial)
+    if env_id == "fishing-v0":
+        ring = torch.randint(0, 110, (4, n), device="cuda", generator=g, dtype=torch.int32)
+    else:
+        ring = torch.rand((4, n), device="cuda", generator=g) * 1.3 - 1.15
+    graph = None
+
+    def check(tag):
+        torch.cuda.synchronize()
+        for name in ("_obs", "_t", "_ep_return", "_r_arr", "_model_idx"):
+            a = getattr(A, name)
+            if a is None:
+                continue
+            for other, what in ((B, "general kernel"), (G, "graph")):
+                o = getattr(other, name)
+                assert torch.equal(a.view(torch.uint8), o.view(torch.uint8)), (env_id, trial, tag, name, what)
+
+    for e in (A, B, G):
+        e.reset()
+    check("reset")
+    ops = ["step", "step", "step_many", "fused", "rollout_random", "rollout_msy", "reset", "mask", "sigma", "Tmax", "seed",
+           "checkpoint", "graph", "graph"]
+    for k in range(50):
+        op = str(rng.choice(ops))
+        if op == "step":
+            for e in (A, B, G):
+                e.step(ring[k % 4])
+        elif op == "step_many":
+            m = int(rng.integers(1, 9))
+            for e in (A, B, G):
+                e.step_many(ring, m)
+        elif op == "fused":
+            m = int(rng.integers(1, 9))
+            for e in (A, B, G):          # (the fused kernel keeps its own launch shape: the general-kernel batch steps one by one)
+                e.step_many(ring, m, fused=e is not B)
+        elif op.startswith("rollout"):
+            m = int(rng.integers(1, 12))
+            pol = dict(policy="random") if op.endswith("random") else dict(policy="msy", param=0.05)
+            for e in (A, B, G):
+                e.rollout(m, **pol)
+        elif op == "reset":
+            for e in (A, B, G):
+                e.reset()
+        elif op == "mask":
+            mask = torch.as_tensor(rng.random(n) < rng.uniform(0.0, 0.7), device="cuda")
+            for e in (A, B, G):
+                e.reset(mask)
+        elif op == "sigma" and env_id != "fishing-v11":
+            v = float(rng.uniform(0.0, 0.15))
+            for e in (A, B, G):
+                e.sigma = v
+        elif op == "Tmax":
+            v = int(rng.integers(2, 10))
+            for e in (A, B, G):
+                e.Tmax = v
+        elif op == "seed":
+            v = int(rng.integers(1, 1 << 30))
+            for e in (A, B, G):
+                e.seed(v)
+        elif op == "checkpoint":
+            sds = [e.state_dict() for e in (A, B, G)]
+            A, B, G = gf.make(env_id, **kw), gf.make(env_id, launch_threads=128, **kw), gf.make(env_id, **kw)
+            for e, sd in zip((A, B, G), sds):
+                e.load_state_dict(sd)
+            graph = None
+        elif op == "graph":
+            if graph is None or graph.env is not G:
+                graph = GraphedSteps(G, ring, n_steps=3)
+            for _ in range(int(rng.integers(1, 4))):
+                graph.replay()
+                for e in (A, B):
+                    e.step_many(ring, 3)
+        check("%d %s" % (k, op))
+    sa, sb, sg = A.episode_stats(), B.episode_stats(), G.episode_stats()
+    assert sa["n_episodes"] == sb["n_episodes"] == sg["n_episodes"]
+    assert abs(sa["sum_return"] - sb["sum_return"]) <= 1e-9 * max(1.0, abs(sa["sum_return"]))
+
+
 def test_state_dict_round_trip_carries_sigma_and_scalar_attributes(hh):
     """load_state_dict() restores what FishingParams is built from: sigma changed after construction (env.sigma
     = ...), n_actions, C, the fishing-v4 means -- a freshly built env resumes bit for bit."""
