@@ -847,16 +847,13 @@ def test_reference_test_suite_flow(gf, tmp_path, env_id, kw):
     o, r, d, info = env.step(a)
     assert o.shape == (1,) and isinstance(r, float) and isinstance(d, bool) and isinstance(info, dict)
     user_action(env)                                       # constructed, never prompted (as in the reference)
-    reps = 3 if env_id == "fishing-v11" else 1
-    if env_id == "fishing-v11":
-        env2 = gf.make("fishing-v6", sigma=0)              # BMSY needs one growth curve: use a member model's
-        model, model2 = msy(env2), escapement(env2)
-        model.env = model2.env = env
-    else:
-        model, model2 = msy(env), escapement(env)
+    reps = 10 if env_id == "fishing-v11" else 1           # (test-envs.py:136,139: reps=10 for ModelUncertainty)
+    np.random.seed(0)                                      # (:8, :94, :130)
+    model, model2 = msy(env), escapement(env)              # fishing-v11: BMSY() under the model in force, as the reference's
     for tag, m in (("msy", model), ("escapement", model2)):
         df = env.simulate(m, reps=reps)
         assert list(df.columns) == ["time", "state", "action", "reward", "rep"] and 1 <= len(df) <= 100 * reps
+        assert set(df["rep"]) == set(range(reps)) and float(df["reward"].min()) >= 0.0
         out = env.plot(df, str(tmp_path / ("%s_%s.png" % (env_id, tag))))
         assert (tmp_path / ("%s_%s.png" % (env_id, tag))).stat().st_size > 1000 and out.endswith(".png")
     pf = env.policyfn(model2)
