@@ -1184,6 +1184,66 @@ __device__ __forceinline__ bool redraw_tile(uint64_t seed, uint64_t base, uint64
     return true;
 }
 
+// The same redraw with the wave's finished envs COMPACTED first (the fused kernels, where a wave steps its 256 envs many times
+// and the redraw is VALU time): redraw_tile runs four draws per lane whenever one of the lane's envs finished -- on a workload
+// that finishes a quarter of the envs per step every wave pays all four passes for ~64 draws.  Here every finished env takes a
+// rank in a wave-private LDS window (ballot + prefix), pass p draws for ranks 64 p .. 64 p + 63 -- one lane per finished env,
+// keyed by THAT env's global index, so the values are redraw_tile's bit for bit -- and the owners read their pair back:
+// ceil(finished / 64) passes instead of four.  `win`: kRedrawSlots entries of the wave.
+constexpr int kRedrawSlots = 256;
+template <typename T>
+struct alignas(2 * sizeof(T)) RedrawSlot {
+    T K, r;
+};
+template <typename T, int MODEL>
+__device__ __forceinline__ bool redraw_tile_compact(uint64_t seed, uint64_t base, uint64_t counter, uint32_t stream,
+                                                    T K_mean, T r_mean, T sigma_p, T x0, const bool (&fin)[4],
+                                                    T (&KK)[4], T (&rr)[4], T (&obs)[4], int32_t (&t)[4],
+                                                    RedrawSlot<T>* __restrict__ win, int lane) {
+    int slot[4];
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t bal = __ballot(fin[j]);
+        slot[j] = total + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        total += __popcll(bal);                   // wave-uniform
+    }
+    if (total == 0) return false;
+    // the id of a finished env inside the wave's 256 (lane * 4 + j) travels in the K field, as bits
+    typedef std::conditional_t<sizeof(T) == 4, uint32_t, uint64_t> bitsT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (fin[j]) *reinterpret_cast<bitsT*>(&win[slot[j]].K) = (bitsT)(lane * 4 + j);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint64_t wave_base = base - (uint64_t)(lane * 4);     // global index of the wave's first env
+    for (int c = 0; c < total; c += kWave) {                    // wave-uniform trip count
+        if (c + lane < total) {
+            const uint64_t id = (uint64_t)*reinterpret_cast<const bitsT*>(&win[c + lane].K);
+            T K2, r2;
+            draw_model_error<T>(seed, wave_base + id, counter, stream, K_mean, r_mean, sigma_p, K2, r2);
+            win[c + lane] = RedrawSlot<T>{K2, r2};
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (fin[j]) {
+            const RedrawSlot<T> v = win[slot[j]];
+            KK[j] = v.K;
+            rr[j] = v.r;
+            obs[j] = reset_obs<T, MODEL>(x0, KK[j]);
+            t[j] = 0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();              // the next step reuses the window
+    return fin[0] | fin[1] | fin[2] | fin[3];     // (this lane's own: what it has to write back)
+}
+
 // ---------------------------------------------------------------- 4-wide access helpers
 // 16-byte aligned at most: that is what the ABI guarantees for every buffer (a Vec4<double> is moved as two
 // 16-byte accesses either way)

@@ -259,9 +259,11 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                                      fin, kind))
                         kind_dirty = true;
                 }
-                if (AUTO && kPerEnv) {
-                    if (redraw_tile<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
-                                              p.K_mean, p.r_mean, p.sigma_p, p.x0, fin, KK, rr, obs, t))
+                if constexpr (AUTO && kPerEnv) {
+                    __shared__ RedrawSlot<T> rwin[4 * kRedrawSlots];       // (fishing-v4 instantiations only: 8 / 16 KB)
+                    if (redraw_tile_compact<T, MODEL>(seed, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
+                                                      p.K_mean, p.r_mean, p.sigma_p, p.x0, fin, KK, rr, obs, t,
+                                                      rwin + (threadIdx.x >> 6) * kRedrawSlots, lane))
                         kr_dirty = true;
                     if (stamped) {          // an auto-reset env is dated by its year counter again
 #pragma unroll
@@ -669,9 +671,11 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                                              ex.n_models, dn, kind))
                                 kind_dirty = true;
                         }
-                        if (kPerEnv) {      // the next episode's (K, r): the draw a later derivation would re-make
-                            if (redraw_tile<T, MODEL>(seed_s, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
-                                                      a.K_mean, a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs, t))
+                        if constexpr (kPerEnv) {      // the next episode's (K, r): the draw a later derivation would re-make
+                            __shared__ RedrawSlot<T> rwin[4 * kRedrawSlots];
+                            if (redraw_tile_compact<T, MODEL>(seed_s, env_offset + (uint64_t)base, step_counter, kStreamAutoReset,
+                                                              a.K_mean, a.r_mean, a.sigma_p, a.x0, dn, KK, rr, obs, t,
+                                                              rwin + (threadIdx.x >> 6) * kRedrawSlots, lane))
                                 kr_dirty = true;
                             if (stamped) {          // an auto-reset env is dated by its year counter again
 #pragma unroll
