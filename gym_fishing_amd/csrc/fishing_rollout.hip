@@ -21,11 +21,15 @@ namespace fishing {
 #define FISHING_ROLLOUT_LOCAL_KEYS 1
 #endif
 
-template <typename T, int MODEL, int POLICY, bool AUTO, bool KP2C = false>
+// PP: one policy parameter PER ENV (fishing_rollout_params_*: `pparams`, real[n]) instead of the scalar -- N fishing-v4 / v11
+// envs each escaping to the S its own BMSY() found (models/policies.py:22-31 per env).  Own instantiations (run-time policy,
+// auto-reset), so the scalar kernels keep their registers.
+template <typename T, int MODEL, int POLICY, bool AUTO, bool KP2C = false, bool PP = false>
 __global__ void __launch_bounds__(256)
 rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
                const T policy_param, const int32_t Tsteps, T* __restrict__ traj, const uint64_t seed_arg,
-               const uint64_t step_counter_arg, const int noise_on, const int policy_rt, const DivK dk_arg) {
+               const uint64_t step_counter_arg, const int noise_on, const int policy_rt, const DivK dk_arg,
+               const T* __restrict__ pparams = nullptr) {
     const uint64_t step_counter0 = b.counter ? (*b.counter + step_counter_arg) : step_counter_arg;
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     const bool derived = kPerEnv && (p.flags & FISHING_FLAG_V4_DERIVED) != 0;   // no r / K arrays (derive_model_error)
@@ -98,6 +102,10 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                 derive_model_error<T>(seed_arg, env_offset + (uint64_t)base + j, step_counter0, t[j], origin_step,
                                       origin_counter, p.K_mean, p.r_mean, p.sigma_p, KK[j], rr[j], st[j]);
         }
+        T pp[4] = {policy_param, policy_param, policy_param, policy_param};
+        if constexpr (PP) {
+            if (active) load4<T>(pparams, base, n, full, pp, policy_param);
+        }
         bool kind_dirty = false;
         const uint64_t quad = (env_offset + (uint64_t)base) >> 2;
         const T robs_scalar = reset_obs<T, MODEL>(p.x0, p.K);   // loop-invariant unless per-env K
@@ -139,16 +147,16 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_word(aw[j], p.n_actions);
                     else a_c = (T)action_cts_from_word(aw[j]);
                 } else if (policy == FISHING_POLICY_CONSTANT) {
-                    if (MODEL == FISHING_MODEL_V0) a_d = (int32_t)policy_param;
-                    else a_c = (T)(float)policy_param;
+                    if (MODEL == FISHING_MODEL_V0) a_d = (int32_t)pp[j];
+                    else a_c = (T)(float)pp[j];
                 } else {
                     T q;
                     if (policy == FISHING_POLICY_ESCAPEMENT) {   // policies.py:27-31
                         const T x = (obs[j] + (T)1) * KK[j];
-                        const T dq = x - policy_param;
+                        const T dq = x - pp[j];
                         q = ((T)0 > dq) ? (T)0 : dq;             // max(x - S, 0.0)
                     } else {                                     // MSY, policies.py:16-19
-                        q = policy_param;
+                        q = pp[j];
                     }
                     if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_quota<T>(q, p.n_actions, KK[j]);
                     else a_c = (T)action_cts_from_quota<T>(q, KK[j], dk);
@@ -325,14 +333,17 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
 template <typename T, int MODEL>
 int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& bt, int64_t n, uint64_t env_offset,
                           T policy_param, int32_t Tsteps, T* traj, uint64_t seed, uint64_t step_counter,
-                          int noise_on, int blocks, int threads, hipStream_t s) {
+                          int noise_on, int blocks, int threads, hipStream_t s, const T* pparams = nullptr) {
     const DivK dk = make_divk((double)pt.K);
+    if (pparams)        // one parameter per env: the run-time-policy, auto-resetting instantiation of this model (rollout_params_impl checks)
+        return launch_kernel(rollout_kernel<T, MODEL, -1, true, false, true>, blocks, threads, s, pt, bt, n, env_offset,
+                             policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk, pparams);
 #define FISHING_LAUNCH_ROLLOUT(POL)                                                                              \
     ((pt.flags & FISHING_FLAG_AUTO_RESET)                                                                        \
          ? launch_kernel(rollout_kernel<T, MODEL, POL, true>, blocks, threads, s, pt, bt, n, env_offset,         \
-                         policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk)                   \
+                         policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk, (const T*)nullptr) \
          : launch_kernel(rollout_kernel<T, MODEL, POL, false>, blocks, threads, s, pt, bt, n, env_offset,        \
-                         policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk))
+                         policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk, (const T*)nullptr))
     if constexpr (is_zoo_tag(MODEL)) {
         return FISHING_LAUNCH_ROLLOUT(-1);          // run-time policy switch
     } else {
@@ -341,7 +352,7 @@ int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& b
             if ((pt.flags & FISHING_FLAG_AUTO_RESET) && dk.pow2) {
 #define FISHING_LAUNCH_ROLLOUT_KP2(POL)                                                                          \
     launch_kernel(rollout_kernel<T, MODEL, POL, true, true>, blocks, threads, s, pt, bt, n, env_offset, policy_param, \
-                  Tsteps, traj, seed, step_counter, noise_on, policy, dk)
+                  Tsteps, traj, seed, step_counter, noise_on, policy, dk, (const T*)nullptr)
                 switch (policy) {
                     case FISHING_POLICY_RANDOM: return FISHING_LAUNCH_ROLLOUT_KP2(FISHING_POLICY_RANDOM);
                     case FISHING_POLICY_CONSTANT: return FISHING_LAUNCH_ROLLOUT_KP2(FISHING_POLICY_CONSTANT);
@@ -364,11 +375,17 @@ int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& b
 template <typename T>
 int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b, int32_t policy,
                  double policy_param, int32_t Tsteps, void* traj, uint64_t seed, uint64_t step_counter,
-                 fishing_stream_t stream) {
+                 fishing_stream_t stream, const void* policy_params = nullptr, bool per_env = false) {
     const int rc = check_common(p, n, env_offset, b);
     if (rc != FISHING_OK) return rc;
     if (policy < FISHING_POLICY_RANDOM || policy > FISHING_POLICY_MSY) return FISHING_ERR_POLICY;
     if (Tsteps < 0) return FISHING_ERR_SIZE;
+    if (per_env) {      // fishing_rollout_params_*
+        if (!policy_params) return FISHING_ERR_NULL;
+        if (((uintptr_t)policy_params) & 15u) return FISHING_ERR_ALIGN;
+        if (policy == FISHING_POLICY_RANDOM) return FISHING_ERR_POLICY;             // (takes no parameter)
+        if (!(p->flags & FISHING_FLAG_AUTO_RESET)) return FISHING_ERR_UNSUPPORTED;  // (the frozen-episode form: scalar parameter only)
+    }
     // Without auto-reset the rollout FREEZES a finished env -- its year counter stops while the step counter runs on,
     // and with it the rule that dates the env's episode (derive_model_error): such a rollout needs the r / K arrays.
     if (p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED) && !(p->flags & FISHING_FLAG_AUTO_RESET))
@@ -390,7 +407,8 @@ int rollout_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     const T pp = (T)policy_param;
     return with_model_tag(p->model, [&](auto tag) {
         return launch_rollout_policy<T, decltype(tag)::value>(policy, pt, bt, n, env_offset, pp, Tsteps, (T*)traj, seed,
-                                                              step_counter, noise_on, blocks, threads, s);
+                                                              step_counter, noise_on, blocks, threads, s,
+                                                              (const T*)policy_params);
     });
 }
 
@@ -820,6 +838,16 @@ int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, c
                         int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
                         uint64_t step_counter, fishing_stream_t stream) {
     return fishing::rollout_impl<double>(p, n, env_offset, b, policy, policy_param, T, traj, seed, step_counter, stream);
+}
+int fishing_rollout_params_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                               int32_t policy, const void* policy_params, int32_t T, void* traj, uint64_t seed,
+                               uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::rollout_impl<float>(p, n, env_offset, b, policy, 0.0, T, traj, seed, step_counter, stream, policy_params, true);
+}
+int fishing_rollout_params_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                               int32_t policy, const void* policy_params, int32_t T, void* traj, uint64_t seed,
+                               uint64_t step_counter, fishing_stream_t stream) {
+    return fishing::rollout_impl<double>(p, n, env_offset, b, policy, 0.0, T, traj, seed, step_counter, stream, policy_params, true);
 }
 
 int fishing_step_fused_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,

@@ -167,6 +167,7 @@ class BaseFishingEnv(_gym_env_base()):
         self._fn_step = getattr(self._lib, "fishing_step_" + self._suffix)
         self._fn_reset = getattr(self._lib, "fishing_reset_" + self._suffix)
         self._fn_rollout = getattr(self._lib, "fishing_rollout_" + self._suffix)
+        self._fn_rollout_params = getattr(self._lib, "fishing_rollout_params_" + self._suffix)
         self._fn_step_many = getattr(self._lib, "fishing_step_many_" + self._suffix)
         self._fn_step_fused = getattr(self._lib, "fishing_step_fused_" + self._suffix)
 
@@ -875,10 +876,25 @@ class BaseFishingEnv(_gym_env_base()):
         """n_steps of step() inside one kernel with an in-kernel policy (csrc/fishing_rollout.hip).
         record=True returns the [n_steps, 4, N] table {obs_in, action, reward, done}.  The fused kernel always
         draws from the Philox streams keyed by `seed` (also for an env built with rng="numpy": a kernel cannot
-        consume NumPy's host-side stream)."""
+        consume NumPy's host-side stream).
+        `param` as a tensor of N values: one policy parameter per env (fishing_rollout_params_*) -- env i escapes to
+        S = param[i] / fishes the quota param[i] / takes the action param[i]: N fishing-v4 or fishing-v11 envs, each with
+        the S its own BMSY() found (policies.escapement(env).kernel_policy hands that tensor over).  Needs auto-reset."""
         if isinstance(policy, tuple):                 # ("constant", a) or a policies.* kernel_policy pair
             policy, param = policy
         pol = POLICIES[policy] if isinstance(policy, str) else int(policy)
+        per_env = None
+        if isinstance(param, torch.Tensor) and param.numel() > 1:
+            if param.numel() != self.num_envs:
+                raise ValueError("a per-env policy parameter needs one value per env (%d), got %d" % (self.num_envs, param.numel()))
+            if not self.auto_reset:
+                raise ValueError("a per-env policy parameter needs auto_reset=True (the frozen-episode rollout takes a scalar)")
+            per_env = param.to(device=self.device, dtype=self.dtype).reshape(-1).contiguous()
+            if per_env.data_ptr() % 16:         # (a view into the middle of a tensor: the ABI wants 16-byte alignment)
+                per_env = per_env.clone()
+            param = 0.0
+        elif isinstance(param, torch.Tensor):
+            param = float(param.reshape(-1)[0])
         if not self.auto_reset:
             # a rollout without auto-reset freezes finished envs: their year counters stop dating their episodes
             self._leave_derived_mode()
@@ -888,9 +904,14 @@ class BaseFishingEnv(_gym_env_base()):
                 raise ValueError("record=True needs num_envs % 4 == 0")
             traj = torch.empty((int(n_steps), 4, self.num_envs), dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
-            rc = self._fn_rollout(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(),
-                                  pol, float(param), int(n_steps), traj.data_ptr() if traj is not None else None,
-                                  self._seed, 0 if self._counter is not None else self._step_count, self._stream())
+            if per_env is not None:
+                rc = self._fn_rollout_params(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(), pol,
+                                             per_env.data_ptr(), int(n_steps), traj.data_ptr() if traj is not None else None,
+                                             self._seed, 0 if self._counter is not None else self._step_count, self._stream())
+            else:
+                rc = self._fn_rollout(self._c_params(), self.num_envs, self.env_offset, self._c_buffers(),
+                                      pol, float(param), int(n_steps), traj.data_ptr() if traj is not None else None,
+                                      self._seed, 0 if self._counter is not None else self._step_count, self._stream())
             if self._counter is not None and not rc:
                 rc = self._lib.fishing_counter_add(self._counter.data_ptr(), int(n_steps), self._stream())
         _capi.check(rc, "fishing_rollout")

@@ -95,7 +95,7 @@ class msy:
             kw = dict(sigma=0.0, K=env.K, r=env.r) if _per_env_params(env) else {}
             self.msy = env.population_draw(self.S, dtype=dt, **kw) - self.S
             env.reset()
-            self.kernel_policy = None                            # (the fused kernel takes one scalar parameter)
+            self.kernel_policy = (POLICY_MSY, self.msy)          # one quota per env: fishing_rollout_params_* (ABI 7)
             return
         x = torch.tensor([self.S], dtype=dt, device=env.device)
         self.msy = float(env.population_draw(x, dtype=dt, **_growth_args(env))[0] - x[0])
@@ -116,7 +116,7 @@ class escapement:
     def __init__(self, env, **kwargs):
         self.env = env
         self.S = BMSY(env)
-        self.kernel_policy = None if isinstance(self.S, torch.Tensor) else (POLICY_ESCAPEMENT, self.S)
+        self.kernel_policy = (POLICY_ESCAPEMENT, self.S)         # (a tensor S -- one per env -- goes to fishing_rollout_params_*)
 
     def predict(self, obs, **kwargs):
         pop = self.env.get_fish_population(obs)

@@ -185,7 +185,8 @@ def _simulate_mdp_batched(env, model, n_eval_episodes):
     try:
         for b in range(batches):
             env.reset()
-            if kp is not None and env.num_envs % 4 == 0:
+            # (a per-env parameter tensor needs the auto-resetting kernel; this table freezes finished envs: step loop)
+            if kp is not None and env.num_envs % 4 == 0 and not isinstance(kp[1], torch.Tensor):
                 traj = env.rollout(env.Tmax, policy=kp[0], param=kp[1], record=True)
             else:
                 traj = torch.zeros((env.Tmax, 4, env.num_envs), dtype=env.dtype, device=env.device)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FISHING_ABI_VERSION 6
+#define FISHING_ABI_VERSION 7
 
 typedef void* fishing_stream_t; /* hipStream_t */
 
@@ -228,6 +228,19 @@ int fishing_rollout_f32(const FishingParams* p, int64_t n, int64_t env_offset, c
 int fishing_rollout_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                         int32_t policy, double policy_param, int32_t T, void* traj, uint64_t seed,
                         uint64_t step_counter, fishing_stream_t stream);
+
+/* The same rollout with one policy parameter PER ENV (ABI 7): policy_params real[n], 16-byte aligned -- env i escapes to
+ * S = policy_params[i] (FISHING_POLICY_ESCAPEMENT), fishes the quota policy_params[i] (FISHING_POLICY_MSY) or takes the
+ * action policy_params[i] (FISHING_POLICY_CONSTANT).  What N reference envs do when each builds its own escapement(env) /
+ * msy(env): BMSY() (models/policies.py:51-67) runs under the (K, r) that env drew (fishing-v4) or the growth function in
+ * force there (fishing-v11), so S differs per env.  FISHING_ERR_POLICY for FISHING_POLICY_RANDOM (no parameter),
+ * FISHING_ERR_UNSUPPORTED without FISHING_FLAG_AUTO_RESET.  Same results as fishing_rollout_* where all parameters are equal. */
+int fishing_rollout_params_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                               int32_t policy, const void* policy_params, int32_t T, void* traj, uint64_t seed,
+                               uint64_t step_counter, fishing_stream_t stream);
+int fishing_rollout_params_f64(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
+                               int32_t policy, const void* policy_params, int32_t T, void* traj, uint64_t seed,
+                               uint64_t step_counter, fishing_stream_t stream);
 
 /* n_steps consecutive step() calls in ONE launch: obs, t, (r, K,) ep_return stay in registers, step k
  * reads its actions at action + (k % ring_len) * action_stride elements (the caller's [R, n] ring) and

@@ -76,9 +76,11 @@ def main():
         del a2, rows_r, rows_d
         torch.cuda.empty_cache()
     # in-kernel-policy rollouts: no action traffic at all; VALU-bound
-    for idn, pol, param, tag in (("fishing-v1", "random", 0.0, "1, 0, true, true>"), ("fishing-v1", "escapement", 0.5, "1, 2, true, true>"),
-                                 ("fishing-v4", "random", 0.0, "4, 0, true, false>"), ("fishing-v11", "random", 0.0, "105, -1, true, false>")):
-        # (the last template argument: the compile-time power-of-two-K twin the dispatch picks for fishing-v0/v1/v2 at K = 1)
+    for idn, pol, param, tag in (("fishing-v1", "random", 0.0, "1, 0, true, true, false>"), ("fishing-v1", "escapement", 0.5, "1, 2, true, true, false>"),
+                                 ("fishing-v4", "random", 0.0, "4, 0, true, false, false>"),
+                                 ("fishing-v11", "random", 0.0, "105, -1, true, false, false>")):
+        # (template arguments 5 and 6: the compile-time power-of-two-K twin the dispatch picks for fishing-v0/v1/v2 at K = 1; one policy
+        # parameter per env -- fishing_rollout_params_*)
         env = make(idn, n)
         T = 505
         env.rollout(T, policy=pol, param=param)        # (the warm-up launch has the timed launches' length: rocprofv3's per-kernel average mixes them)

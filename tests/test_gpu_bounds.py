@@ -3,7 +3,7 @@
 Each case carves its streams out of ONE device arena, every stream flush against a 4 KiB band of a known byte on
 either side (the band behind a stream begins at the byte after its last element), drives the entry points of
 include/fishing_hip.h over it -- reset (all / masked), step, step_many, step_fused, rollout (with and without the
-trajectory rows), the fishing-v4 parameter materialisation, population_draw, the BMSY sweep, the generator hooks, the
+trajectory rows, with one policy parameter per env), the fishing-v4 parameter materialisation, population_draw, the BMSY sweep, the generator hooks, the
 return reduction -- and then reads the arena back: no byte outside the streams may have changed.  Run twice with two
 different band bytes, the streams themselves must also come out identical: a read behind a stream that reached a result
 would show there.  Sizes: one env, sub-quad, sub-tile, whole tiles, tiles + ragged tails, and the padded-tile contract
@@ -209,6 +209,12 @@ def drive(hh, fill, case, dtype, n, padded, optional, auto):
                           (_capi.POLICY_CONSTANT, -0.9)):
         if ok(roll(p, n, off, g.buffers(fusedable=True), policy, param, T, None, seed, c, None), "rollout", unsupported):
             c += T
+    # ... and with one parameter per env (ABI 7): exactly n of them
+    pparams = ar.alloc("policy_params", n, g.td, np.linspace(0.0, 0.9, n))
+    if ok(getattr(lib, "fishing_rollout_params_" + sfx)(p, n, off, g.buffers(fusedable=True), _capi.POLICY_ESCAPEMENT,
+                                                        pparams.data_ptr(), T, None, seed, c, None), "rollout_params",
+          (ERR_UNSUPPORTED,) if not auto else ()):
+        c += T
     if n % 4 == 0:
         traj = ar.alloc("traj", T * 4 * n, g.td)
         if ok(roll(p, n, off, g.buffers(fusedable=True), _capi.POLICY_RANDOM, 0.0, T, traj.data_ptr(), seed, c, None),

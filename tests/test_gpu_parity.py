@@ -413,6 +413,74 @@ def test_fused_rollout_policies_where_get_quotas_clip_binds(hh, model, dtype, po
     assert (hi if param > 0 and not (policy == "escapement" and param == 0.9) else lo) > 0      # the clip did bind
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4, fo.MODEL_V9, fo.MODEL_V11])
+@pytest.mark.parametrize("policy", ["constant", "escapement", "msy"])
+def test_fused_rollout_with_one_policy_parameter_per_env(hh, model, dtype, policy):
+    """fishing_rollout_params_* (ABI 7): one policy parameter per env.  (a) With every entry equal to the scalar it is
+    fishing_rollout_* bit for bit -- state, record and the [T, 4, n] table; (b) with the entries spread (escapement levels
+    from 0 to K, quotas from below zero to 0.6 K, actions over [-1.2, 0.2]) it equals n separate one-env-wide scalar rollouts,
+    i.e. env i under parameter i: checked against the scalar entry point run once per distinct value on the whole batch
+    (the in-kernel streams are keyed by the env index, so env i's trajectory does not depend on its neighbours' parameters)."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n, off, seed, T = 2052, 4, 31, 18
+    per_env, zoo, mixed = model == fo.MODEL_V4, model in (fo.MODEL_V9, fo.MODEL_V11), model == fo.MODEL_V11
+    kw = dict(ROLLOUT_KW)
+    if mixed:
+        kw.update(models=[0, 1, 2, 3, 4], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE])
+    p = hh.params(model, r=0.3, K=1.0, auto_reset=True, **kw)
+    pol, param = _policy_setup(hh, policy, model)
+    td = hh.TORCH_OF[np.dtype(dtype)]
+    sfx = "f32" if dtype == np.float32 else "f64"
+    fn = getattr(lib, "fishing_rollout_params_" + sfx)
+
+    def mk():
+        st = hh.State(n, dtype, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None, K=np.full(n, 1.0) if per_env else None,
+                      ep_return=True, model_idx=np.zeros(n, np.int32) if mixed else None)
+        st.reset(p, seed=seed, env_offset=off)
+        return st
+
+    def run_params(st, values):
+        traj = torch.zeros((T, 4, n), dtype=td, device="cuda")
+        pv = hh.dev(np.asarray(values, dtype=dtype))
+        rc = fn(p, n, off, st.buffers(), pol, pv.data_ptr(), T, traj.data_ptr(), seed, 0, None)
+        assert rc == 0, (rc, lib.fishing_error_string(rc))
+        torch.cuda.synchronize()
+        return traj.cpu().numpy()
+
+    # (a) all entries equal == the scalar entry point
+    A, B = mk(), mk()
+    ta = A.rollout(p, pol, param, T, seed=seed, step_counter=0, env_offset=off, record=True)
+    tb = run_params(B, np.full(n, param))
+    assert_same_bits(ta, tb, "table, equal parameters")
+    assert_same_bits(A.obs.cpu().numpy(), B.obs.cpu().numpy(), "obs")
+    assert (A.t.cpu().numpy() == B.t.cpu().numpy()).all()
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] > 0 and np.allclose(ra, rb, rtol=1e-12)
+    # (b) spread entries == the scalar rollout of each distinct value, env by env
+    vals = {"constant": [-1.2, -0.9, -0.5, 0.2] if model != fo.MODEL_V0 else [0, 3, 40, 120],
+            "escapement": [0.0, 0.3, 0.55, 1.0], "msy": [-0.1, 0.0, 0.07, 0.6]}[policy]
+    pick = np.arange(n) % len(vals)
+    C = mk()
+    tc = run_params(C, np.asarray(vals, dtype=np.float64)[pick])
+    for k, v in enumerate(vals):
+        D = mk()
+        tdv = D.rollout(p, pol, float(v), T, seed=seed, step_counter=0, env_offset=off, record=True)
+        m = pick == k
+        assert_same_bits(tc[:, :, m], tdv[:, :, m], "table, parameter %r" % v)
+        assert_same_bits(C.obs.cpu().numpy()[m], D.obs.cpu().numpy()[m], "obs, parameter %r" % v)
+    # argument checks: the random policy takes no parameter, a NULL / misaligned array, no auto-reset
+    pv = hh.dev(np.zeros(n + 4, dtype=dtype))
+    E = mk()
+    assert fn(p, n, off, E.buffers(), _capi.POLICY_RANDOM, pv.data_ptr(), T, None, seed, 0, None) == -5
+    assert fn(p, n, off, E.buffers(), pol, None, T, None, seed, 0, None) == -1
+    assert fn(p, n, off, E.buffers(), pol, pv.data_ptr() + pv.element_size(), T, None, seed, 0, None) == -3
+    q = hh.params(model, r=0.3, K=1.0, auto_reset=False, **kw)
+    assert fn(q, n, off, E.buffers(), pol, pv.data_ptr(), T, None, seed, 0, None) == -7
+
+
 def test_rollout_without_auto_reset_freezes_and_exits(hh):
     """Wave-ballot exit: with no auto-reset every env is frozen at its first done."""
     from gym_fishing_amd import _capi

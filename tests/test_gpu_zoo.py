@@ -513,7 +513,7 @@ def test_v11_num_envs_population_draw_and_bmsy_follow_each_envs_model(hh):
     want_S = np.array([per_kind[int(k)] for k in idx.cpu().tolist()], dtype=np.float32)
     assert np.array_equal(S.cpu().numpy(), want_S)
     esc = policies.escapement(env)
-    assert esc.kernel_policy is None and esc.S.shape == (n,)
+    assert esc.kernel_policy[1] is esc.S and esc.S.shape == (n,)        # (one S per env: fishing_rollout_params_*, ABI 7)
     a, _ = esc.predict(env.state)
     assert a.shape == (n, 1) and a.dtype == torch.float32
     df = env.simulate(esc)
@@ -699,3 +699,56 @@ def test_module_level_growth_functions_follow_the_reference(dtype):
         gm.allen(0.5, {"r": 0.3, "K": 1.0, "sigma": 0.0})
     with pytest.raises(ValueError):
         gm.ricker(np.ones(4), {"r": 0.3, "K": 1.0, "sigma": 0.0}, noise=np.zeros(3))
+
+
+def test_v11_fused_rollout_under_each_envs_own_escapement_level():
+    """N fishing-v11 envs, each with the S that BMSY() found for the growth function in force there (policies.escapement:
+    a tensor S), rolled out inside the fused kernel (fishing_rollout_params_*, ABI 7) == the step loop driven by the
+    policy's predict() on a twin restored from the same checkpoint -- observations, actions, rewards, dones, the models
+    redrawn at the auto-resets: bit for bit in the float64 layout; and simulate_mdp_vec takes that fused path."""
+    import torch
+    import gym_fishing_amd as gf
+    from gym_fishing_amd import policies, rollout
+    n, T = 1024, 30
+    mk = lambda: gf.make("fishing-v11", num_envs=n, seed=21, Tmax=9, dtype=torch.float64)      # noqa: E731
+    A = mk()
+    for d in A.model_params.values():
+        d["sigma"] = 0.05
+    A.reset()
+    model = policies.escapement(A)
+    S = model.kernel_policy[1]
+    assert isinstance(S, torch.Tensor) and S.shape == (n,) and len(set(S.cpu().tolist())) >= 3     # one level per growth function
+    B = mk()
+    for d in B.model_params.values():
+        d["sigma"] = 0.05
+    B.load_state_dict(A.state_dict())
+    traj = A.rollout(T, policy=model.kernel_policy, record=True)
+    model.env = B
+    bits = lambda x: x.contiguous().view(torch.int64)          # noqa: E731
+    for s in range(T):
+        o = B.state.clone()
+        a, _ = model.predict(o)
+        assert torch.equal(bits(traj[s, 0]), bits(o.reshape(-1))), s
+        assert torch.equal(bits(traj[s, 1]), bits(a.reshape(-1).to(traj.dtype))), s
+        _, rew, done, _ = B.step(a.reshape(-1))
+        assert torch.equal(bits(traj[s, 2]), bits(rew)) and torch.equal(traj[s, 3].bool(), done.bool()), s
+    assert torch.equal(bits(A.state), bits(B.state)) and torch.equal(A.model_idx, B.model_idx)
+    # simulate_mdp_vec: the fused path (kernel_policy with a tensor) and the step loop (kernel_policy hidden) build the same table
+    model.env = A
+
+    class Hidden:
+        def __init__(self, m):
+            self.m = m
+
+        def predict(self, obs, **kw):
+            return self.m.predict(obs)
+    C = mk()
+    for d in C.model_params.values():
+        d["sigma"] = 0.05
+    C.load_state_dict(A.state_dict())
+    fused = rollout.simulate_mdp_vec(A, model, n)
+    model.env = C
+    loop = rollout.simulate_mdp_vec(C, Hidden(model), n)
+    fa = fused.to_numpy(dtype=np.float64) if hasattr(fused, "to_numpy") else np.stack([fused[c] for c in rollout.COLUMNS], 1)
+    la = loop.to_numpy(dtype=np.float64) if hasattr(loop, "to_numpy") else np.stack([loop[c] for c in rollout.COLUMNS], 1)
+    assert fa.shape == la.shape == (n * 10, 5) and np.array_equal(fa, la, equal_nan=True)
