@@ -45,8 +45,9 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     // (fishing-v11 2.57 -> 2.12e11): profiles/r04_rollout_unswitch.jsonl.
     DivK dk = kPerEnv ? DivK{false, 0.0f, 0.0} : dk_arg;
     if constexpr (KP2C) dk.pow2 = true;
-    // POLICY >= 0: compile-time policy (v0/v1/v2/v4); POLICY < 0: wave-uniform run-time policy (zoo,
-    // to keep the number of instantiations of the transcendental-heavy bodies small)
+    // POLICY >= 0: compile-time policy (v0/v1/v2/v4 with auto-reset); POLICY < 0: wave-uniform run-time policy (the zoo, to keep
+    // the number of instantiations of the transcendental-heavy bodies small; the frozen-episode form -- no auto-reset: the
+    // simulate tables -- and the per-env-parameter form of every model: one instantiation each instead of four)
     const int policy = (POLICY >= 0) ? POLICY : policy_rt;
     const bool kNeedWords = (policy == FISHING_POLICY_RANDOM);
     constexpr bool kZoo = is_zoo_tag(MODEL);
@@ -342,7 +343,7 @@ int launch_rollout_policy(int policy, const ParamsT<T>& pt, const BuffersT<T>& b
     ((pt.flags & FISHING_FLAG_AUTO_RESET)                                                                        \
          ? launch_kernel(rollout_kernel<T, MODEL, POL, true>, blocks, threads, s, pt, bt, n, env_offset,         \
                          policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk, (const T*)nullptr) \
-         : launch_kernel(rollout_kernel<T, MODEL, POL, false>, blocks, threads, s, pt, bt, n, env_offset,        \
+         : launch_kernel(rollout_kernel<T, MODEL, -1, false>, blocks, threads, s, pt, bt, n, env_offset,         \
                          policy_param, Tsteps, traj, seed, step_counter, noise_on, policy, dk, (const T*)nullptr))
     if constexpr (is_zoo_tag(MODEL)) {
         return FISHING_LAUNCH_ROLLOUT(-1);          // run-time policy switch
