@@ -961,7 +961,7 @@ def test_bench_contract_json_line(gf):
     assert abs(d["value"] - (1 << 18) * 40 / (d["ms_per_step"] * 40 / 1e3)) / d["value"] < 1e-9
 
 
-@pytest.mark.parametrize("script", ["const_escapement.py", "random_rollout.py", "vec_env_numpy.py"])
+@pytest.mark.parametrize("script", ["const_escapement.py", "random_rollout.py", "vec_env_numpy.py", "parameter_uncertainty.py"])
 def test_examples_run(gf, script):
     import subprocess
     import sys
@@ -974,6 +974,8 @@ def test_examples_run(gf, script):
         assert "scalar protocol: 100 steps, return 7.675000" in out.stdout and "mean_return" in out.stdout
     elif script == "vec_env_numpy.py":
         assert "episodes 768, mean reward" in out.stdout          # 256 envs x three 101-step episodes
+    elif script == "parameter_uncertainty.py":
+        assert "own level per env" in out.stdout and "escapement levels: min" in out.stdout
     else:
         assert "env-steps/s" in out.stdout
 
