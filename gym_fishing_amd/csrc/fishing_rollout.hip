@@ -58,6 +58,20 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
+    // fishing-v0's index -> quota map (fishing_env.py:7-24, base_fishing_env.py:140: (a / n_actions) * K) as a table in LDS for the
+    // in-kernel random policy, whose index is in [0, n_actions) by construction: entry i holds quota_int(i) itself -- the IEEE
+    // division and the multiply, evaluated once per workgroup instead of once per env-step (~10 of a step's ~45 VALU instructions
+    // per env).  Up to kQuotaLut actions; beyond that the arithmetic stays in the loop.
+    constexpr bool kLutForm = (MODEL == FISHING_MODEL_V0) && (POLICY == FISHING_POLICY_RANDOM);
+    constexpr int kQuotaLut = 1024;
+    __shared__ T quota_lut[kLutForm ? kQuotaLut : 1];
+    const bool use_lut = kLutForm && p.n_actions > 0 && p.n_actions <= kQuotaLut;
+    if constexpr (kLutForm) {
+        if (use_lut) {
+            for (int i = threadIdx.x; i < p.n_actions; i += blockDim.x) quota_lut[i] = quota_int<T>(i, p.n_actions, p.K);
+            __syncthreads();
+        }
+    }
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
@@ -171,6 +185,8 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     // upper bound of get_quota's clip can bind
                     const T av = (a_c > (T)1) ? (T)1 : a_c;
                     quota[j] = (av + (T)1) * KK[j];
+                } else if constexpr (kLutForm) {
+                    quota[j] = use_lut ? quota_lut[a_d] : quota_int<T>(a_d, p.n_actions, KK[j]);      // (wave-uniform choice)
                 } else {
                     quota[j] = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j]) : quota_cts<T>(a_c, KK[j]);
                 }
@@ -501,6 +517,19 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
     const T robs_scalar = reset_obs<T, MODEL>(a.x0, a.pK);
+    // fishing-v0: the index -> quota map as an LDS table (see rollout_kernel).  The caller's indices are not validated
+    // (quirk B11: 100, 150, -3 are legal and map through the same arithmetic): a wave with an index outside [0, n_actions) --
+    // or a batch with more than kQuotaLut actions -- evaluates the arithmetic for that step instead.
+    constexpr bool kLutForm = (MODEL == FISHING_MODEL_V0) && !RAGGED;
+    constexpr int kQuotaLut = 1024;
+    __shared__ T quota_lut[kLutForm ? kQuotaLut : 1];
+    const bool use_lut = kLutForm && a.n_actions > 0 && a.n_actions <= kQuotaLut;
+    if constexpr (kLutForm) {
+        if (use_lut) {
+            for (int i = threadIdx.x; i < a.n_actions; i += blockDim.x) quota_lut[i] = quota_int<T>(i, a.n_actions, a.pK);
+            __syncthreads();
+        }
+    }
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
@@ -629,10 +658,30 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                     }
                 }
                 if (!stepped) {
+                T q_lut[4] = {(T)0, (T)0, (T)0, (T)0};
+                bool lut_ok = false;
+                if constexpr (kLutForm) {
+                    const uint32_t lim = (uint32_t)a.n_actions;
+                    lut_ok = use_lut && !__any(((uint32_t)a_i[0] >= lim) | ((uint32_t)a_i[1] >= lim) | ((uint32_t)a_i[2] >= lim) |
+                                               ((uint32_t)a_i[3] >= lim));          // wave-uniform
+                    if (lut_ok) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) q_lut[j] = quota_lut[a_i[j]];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const T quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j])
-                                                                : quota_cts<T>((T)a_f[j], KK[j]);
+                    T quota;
+                    if constexpr (kLutForm) {
+                        if (lut_ok) {
+                            quota = q_lut[j];
+                        } else {
+                            asm volatile("");       // (a real branch: the division must not be evaluated speculatively and selected)
+                            quota = quota_int<T>(a_i[j], a.n_actions, KK[j]);
+                        }
+                    } else {
+                        quota = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_i[j], a.n_actions, KK[j]) : quota_cts<T>((T)a_f[j], KK[j]);
+                    }
                     fresh[j] = auto_reset || !((t[j] > a.Tmax) || ((obs[j] + (T)1) * KK[j] <= (T)0));
                     if constexpr (zoo_mixed) {          // per-env sigma: a straight per-lane switch over the growth functions
                         const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;

@@ -481,6 +481,48 @@ def test_fused_rollout_with_one_policy_parameter_per_env(hh, model, dtype, polic
     assert fn(q, n, off, E.buffers(), pol, pv.data_ptr(), T, None, seed, 0, None) == -7
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("n_actions,K", [(1, 1.0), (37, 1.0), (100, 3.0), (1024, 0.5), (1025, 1.0), (5000, 2.0)])
+def test_v0_random_rollout_quota_table_any_number_of_actions(hh, n_actions, K, dtype):
+    """fishing-v0's index -> quota map is an LDS table in the random-policy rollout (up to 1024 actions; the arithmetic beyond):
+    the rollout equals step() fed the oracle's random-policy indices, bit for bit, for one action, a prime count, the
+    table's last size, the first size beyond it and a large one; K a power of two (the compile-time twin) and not."""
+    from gym_fishing_amd import _capi
+    n, off, seed, T = 2052, 8, 5, 16
+    p = hh.params(fo.MODEL_V0, r=0.3, K=K, n_actions=n_actions, auto_reset=True, sigma=0.1, x0=0.75 * K, Tmax=6)
+    A, B = (hh.State(n, dtype, fo.MODEL_V0, np.zeros(n), ep_return=True) for _ in range(2))
+    A.reset(p, seed=seed, env_offset=off)
+    B.reset(p, seed=seed, env_offset=off)
+    traj = A.rollout(p, _capi.POLICY_RANDOM, 0.0, T, seed=seed, step_counter=0, env_offset=off, record=True)
+    env = np.arange(off, off + n)
+    for s in range(T):
+        a = fo.policy_random_action(fo.MODEL_V0, seed, env, s, n_actions)
+        assert a.min() >= 0 and a.max() < n_actions
+        assert_same_bits(traj[s, 0], B.obs.cpu().numpy(), "obs_in step %d" % s)
+        assert_same_bits(traj[s, 1], a.astype(dtype), "action step %d" % s)
+        _, rew, done, _ = B.step(p, a, seed=seed, step_counter=s, env_offset=off)
+        assert_same_bits(traj[s, 2], rew, "reward step %d" % s)
+        assert (traj[s, 3].astype(np.uint8) == done).all()
+    assert_same_bits(A.obs.cpu().numpy(), B.obs.cpu().numpy(), "final obs")
+    # the fused K-step kernel reads the caller's indices, which nothing validates (quirk B11): rows with every index inside
+    # [0, n_actions) take the table, a row holding n_actions, 150 % of it or a negative index the arithmetic -- both equal step()
+    n2 = 2048
+    rng = np.random.default_rng(n_actions)
+    ring = rng.integers(0, n_actions, (6, n2)).astype(np.int32)
+    ring[2, 5::97] = n_actions
+    ring[4, 3::211] = n_actions + n_actions // 2 + 1
+    ring[4, 7::301] = -3
+    C, D = (hh.State(n2, dtype, fo.MODEL_V0, np.zeros(n2), ep_return=True) for _ in range(2))
+    C.reset(p, seed=seed, env_offset=off)
+    D.reset(p, seed=seed, env_offset=off)
+    rs, ds = C.step_fused(p, ring, 6, seed=seed, step_counter=3, env_offset=off)
+    for s in range(6):
+        _, rew, done, _ = D.step(p, ring[s], seed=seed, step_counter=3 + s, env_offset=off)
+        assert_same_bits(rs[s], rew, "fused reward row %d" % s)
+        assert (ds[s] == done).all()
+    assert_same_bits(C.obs.cpu().numpy(), D.obs.cpu().numpy(), "fused final obs")
+
+
 def test_rollout_without_auto_reset_freezes_and_exits(hh):
     """Wave-ballot exit: with no auto-reset every env is frozen at its first done."""
     from gym_fishing_amd import _capi
