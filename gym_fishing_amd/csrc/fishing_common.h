@@ -416,9 +416,13 @@ template <typename T>
 __device__ __forceinline__ float action_cts_from_quota(T quota, T K, const DivK& dk) {
     return (float)(div_K<T>(quota, K, dk) - (T)1);
 }
+// get_action, discrete (base_fishing_env.py:149-152): round(quota * n_actions / K) -- Python's round() of a NumPy float is
+// rint (half to even).  Rounded in T: a float32 value is exactly a double, so rintf(v) == rint((double)v).
 template <typename T>
-__device__ __forceinline__ int32_t action_int_from_quota(T quota, int32_t n_actions, T K) {
-    return (int32_t)__builtin_rint((double)(quota * (T)n_actions / K));
+__device__ __forceinline__ int32_t action_int_from_quota(T quota, int32_t n_actions, T K, const DivK& dk) {
+    const T v = div_K<T>(quota * (T)n_actions, K, dk);
+    if constexpr (sizeof(T) == 4) return (int32_t)__builtin_rintf(v);
+    else return (int32_t)__builtin_rint(v);
 }
 
 template <typename T>

@@ -62,7 +62,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     // in-kernel random policy, whose index is in [0, n_actions) by construction: entry i holds quota_int(i) itself -- the IEEE
     // division and the multiply, evaluated once per workgroup instead of once per env-step (~10 of a step's ~45 VALU instructions
     // per env).  Up to kQuotaLut actions; beyond that the arithmetic stays in the loop.
-    constexpr bool kLutForm = (MODEL == FISHING_MODEL_V0) && (POLICY == FISHING_POLICY_RANDOM);
+    constexpr bool kLutForm = (MODEL == FISHING_MODEL_V0) && (POLICY >= 0);      // (the compile-time-policy, auto-resetting forms)
     constexpr int kQuotaLut = 1024;
     __shared__ T quota_lut[kLutForm ? kQuotaLut : 1];
     const bool use_lut = kLutForm && p.n_actions > 0 && p.n_actions <= kQuotaLut;
@@ -173,7 +173,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     } else {                                     // MSY, policies.py:16-19
                         q = pp[j];
                     }
-                    if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_quota<T>(q, p.n_actions, KK[j]);
+                    if (MODEL == FISHING_MODEL_V0) a_d = action_int_from_quota<T>(q, p.n_actions, KK[j], dk);
                     else a_c = (T)action_cts_from_quota<T>(q, KK[j], dk);
                 }
                 if constexpr (POLICY == FISHING_POLICY_RANDOM && MODEL != FISHING_MODEL_V0) {
@@ -186,7 +186,16 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                     const T av = (a_c > (T)1) ? (T)1 : a_c;
                     quota[j] = (av + (T)1) * KK[j];
                 } else if constexpr (kLutForm) {
-                    quota[j] = use_lut ? quota_lut[a_d] : quota_int<T>(a_d, p.n_actions, KK[j]);      // (wave-uniform choice)
+                    // the random policy's index is in [0, n_actions) by construction; the quota-driven policies' -- round(q n / K)
+                    // -- need not be (a stock above K escaping to a low level): a wave holding one outside evaluates the arithmetic
+                    bool in_range = true;
+                    if constexpr (POLICY != FISHING_POLICY_RANDOM) in_range = !__any((uint32_t)a_d >= (uint32_t)p.n_actions);
+                    if (use_lut && in_range) {
+                        quota[j] = quota_lut[a_d];
+                    } else {
+                        asm volatile("");           // (a real branch: no speculative division)
+                        quota[j] = quota_int<T>(a_d, p.n_actions, KK[j]);
+                    }
                 } else {
                     quota[j] = (MODEL == FISHING_MODEL_V0) ? quota_int<T>(a_d, p.n_actions, KK[j]) : quota_cts<T>(a_c, KK[j]);
                 }

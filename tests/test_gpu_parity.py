@@ -523,6 +523,35 @@ def test_v0_random_rollout_quota_table_any_number_of_actions(hh, n_actions, K, d
     assert_same_bits(C.obs.cpu().numpy(), D.obs.cpu().numpy(), "fused final obs")
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("policy,param,K,n_actions", [("escapement", 0.1, 0.5, 100), ("escapement", 0.3, 1.0, 37),
+                                                      ("msy", 0.8, 0.5, 100), ("msy", 0.07, 3.0, 2000), ("escapement", 0.1, 0.3, 64)])
+def test_v0_quota_driven_policies_with_indices_beyond_the_action_count(hh, policy, param, K, n_actions, dtype):
+    """fishing-v0 under the in-kernel escapement / msy policies: the index round(q n_actions / K) is not bounded by n_actions
+    (an episode starts at 0.75 = 1.5 K for K = 0.5: escaping to 0.1 asks for index 130 of 100 -- quirk B11, no validation), so
+    the rollout's quota table serves the waves whose indices are all in range and the arithmetic the others; more actions than
+    the table holds; K a power of two and not.  Bit for bit against step() fed the oracle's policy indices."""
+    n, off, seed, T = 2052, 4, 13, 20
+    p = hh.params(fo.MODEL_V0, r=0.3, K=K, n_actions=n_actions, auto_reset=True, **dict(ROLLOUT_KW, x0=0.75))
+    pol, _ = _policy_setup(hh, policy, fo.MODEL_V0)
+    A, B = (hh.State(n, dtype, fo.MODEL_V0, np.zeros(n), ep_return=True) for _ in range(2))
+    A.reset(p, seed=seed, env_offset=off)
+    B.reset(p, seed=seed, env_offset=off)
+    traj = A.rollout(p, pol, param, T, seed=seed, step_counter=0, env_offset=off, record=True)
+    beyond = 0
+    for s in range(T):
+        obs = B.obs.cpu().numpy()
+        a = fo.policy_action(policy, param, fo.MODEL_V0, obs, dtype(K), n_actions, dtype)
+        beyond += int((a >= n_actions).sum())
+        assert_same_bits(traj[s, 0], obs, "obs_in step %d" % s)
+        assert_same_bits(traj[s, 1], a.astype(dtype), "action step %d" % s)
+        _, rew, done, _ = B.step(p, a, seed=seed, step_counter=s, env_offset=off)
+        assert_same_bits(traj[s, 2], rew, "reward step %d" % s)
+        assert (traj[s, 3].astype(np.uint8) == done).all()
+    assert_same_bits(A.obs.cpu().numpy(), B.obs.cpu().numpy(), "final obs")
+    assert beyond > 0 or (K, n_actions) in ((1.0, 37), (3.0, 2000))
+
+
 def test_rollout_without_auto_reset_freezes_and_exits(hh):
     """Wave-ballot exit: with no auto-reset every env is frozen at its first done."""
     from gym_fishing_amd import _capi
