@@ -95,6 +95,11 @@ def parse():
     ap.add_argument("--f64", action="store_true",
                     help="the float64 parity layout (bit-exact against the reference's arithmetic; 37 B/env-step); NOT the headline layout")
     ap.add_argument("--extra", action="store_true", help="also time the fused rollout and an N sweep")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` sub-record (BASELINE configs 2-5 + the HBM-resident sizes under this run's clock)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="tests only: honour FISHING_BENCH_RUNTIME (a stand-in for the device seam, tests/bench_rehearsal.py); "
+                         "without this flag the variable is ignored, so the driver's run can never be re-routed by the environment")
     return ap.parse_args()
 
 
@@ -138,7 +143,7 @@ def cpu_baseline(seconds, cfg_name):
     rate, _ = time_random_rollout(scalar_id, 20_000, seed=0, **skw)      # calibrate
     n = int(max(50_000, min(rate * seconds, 5_000_000)))
     rate, _ = time_random_rollout(scalar_id, n, seed=1, **skw)
-    out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port",
+    out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_os_cpu_count": os.cpu_count(),
            "sample": "oracle/scalar_env.py (per-env NumPy step(): the reference's arithmetic with its five helper calls and "
                      "the isinstance test inlined -- leaner than the reference it stands for): "
                      "%d env-steps of %s sigma=%g, random policy, reset on done, 1 core" % (n, scalar_id, skw["sigma"]),
@@ -147,7 +152,7 @@ def cpu_baseline(seconds, cfg_name):
                                                    "container (it cannot travel to the GPU box); the port above runs ~2.7x that"}}
     try:    # the same Python port on every core of the box's CPU share;
         # independent `python -c` workers: nothing here depends on how this file was started
-        procs = max(1, min(os.cpu_count() or 1, 16))
+        procs = max(1, os.cpu_count() or 1)          # every host core, os.cpu_count() reported
         per = max(20_000, n // 8)
         code = ("import sys; sys.path.insert(0, %r); from oracle.scalar_env import time_random_rollout; "
                 "print(time_random_rollout(%r, %d, seed=int(sys.argv[1]), sigma=%r)[0])" % (ROOT, scalar_id, per, skw["sigma"]))
@@ -156,8 +161,11 @@ def cpu_baseline(seconds, cfg_name):
         rates = [float(k.communicate(timeout=180)[0].strip().splitlines()[-1]) for k in kids]
         if all(k.returncode == 0 for k in kids):
             out["python_port_all_cores"] = {"value": sum(rates), "unit": "env-steps/s", "cores": procs,
-                                            "sample": "%d concurrent processes x %d env-steps each; sum of the "
-                                                      "per-process rates" % (procs, per)}
+                                            "os_cpu_count": os.cpu_count(),
+                                            "sched_affinity_cpus": (len(os.sched_getaffinity(0))
+                                                                    if hasattr(os, "sched_getaffinity") else None),
+                                            "sample": "%d concurrent processes (one per os.cpu_count() core) x %d env-steps "
+                                                      "each; sum of the per-process rates" % (procs, per)}
     except Exception as e:  # noqa: BLE001
         out["python_port_all_cores_error"] = repr(e)[:200]
     try:    # the NumPy-vectorised (N,) restatement, one process
@@ -258,8 +266,10 @@ class HipRuntime:
         return make_env(gf, torch, cfg_name, n, env_offset, with_returns, compact, v4_stored, f64)
 
 
-def load_runtime():
-    spec = os.environ.get("FISHING_BENCH_RUNTIME")
+def load_runtime(rehearsal=False):
+    """The HIP runtime -- unless --rehearsal was passed AND FISHING_BENCH_RUNTIME names a stand-in (tests only: the variable
+    alone does nothing, and a line produced through a stand-in carries config.rehearsal and no roofline)."""
+    spec = os.environ.get("FISHING_BENCH_RUNTIME") if rehearsal else None
     if not spec:
         return HipRuntime()
     import importlib
@@ -390,6 +400,136 @@ def graph_region(torch, gf, args, n, actions):
         return {"error": repr(e)[:300]}
 
 
+def roof(achieved_gbps, cache_resident):
+    """One way of writing a memory-roofline figure everywhere on the line.  `frac` is achieved / the 8 TB/s HBM spec and is
+    only a fraction of THE roof while HBM is the roof; streams that sit in the 256 MiB Infinity Cache (cache_resident) can be
+    served faster than HBM could -- then the figure above 1 is written as `hbm_spec_ratio`, `frac` is null, and no `frac*`
+    field of this file ever exceeds 1."""
+    f = achieved_gbps / HBM_PEAK_GBS
+    out = {"achieved_GBps": achieved_gbps, "frac": f if f <= 1.0 else None, "cache_resident": bool(cache_resident)}
+    if f > 1.0:
+        out["hbm_spec_ratio"] = f
+        out["roof_note"] = "above the HBM spec: the streams are served by the L2s / Infinity Cache, HBM is not the roof at this size"
+    return out
+
+
+def resident_bytes(cfg_name, n, with_returns, rows, f64=False, v4_stored=False, compact=False):
+    """State streams + the action ring a stepping loop keeps touching (what has to fit the Infinity Cache to be served by it)."""
+    esz = 1 if compact else 4
+    rsz = 8 if f64 else 4
+    return n * (rsz + esz + rsz + 1 + (rsz if with_returns else 0) + (rsz if cfg_name == "v4" else 0)
+                + (2 * rsz if v4_stored and cfg_name == "v4" else 0)) + rows * (n + 3072) * 4
+
+
+def steady_launch_us(torch, env, actions, launches=256, lead=16, spin_ms=60.0):
+    """Average duration of one step launch: HIP events around `launches` back-to-back launches enqueued behind a `lead`-launch
+    lead-in (the device is busy when the first event fires), after `spin_ms` of the same work -- the headline's
+    roofline.avg_launch_us, for any env."""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < spin_ms:
+        env.step_many(actions, 64)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    env.step_many(actions, lead)
+    e0.record()
+    env.step_many(actions, launches)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / launches
+
+
+# BASELINE.json's configs 2-5 at their per-GPU-shard and whole sizes, and SURVEY.md section 8(d)'s spill sizes of configs 3 / 4:
+# (key, config, log2 N, what it is)
+CONFIG_RECORDS = (
+    ("config2_v1_2p20", "v1", 20, "BASELINE config 2: fishing-v1 sigma=0.1, N = 2^20, one GPU"),
+    ("config3_v0_2p22", "v0", 22, "BASELINE config 3: fishing-v0 n_actions=100, N = 2^22, one GPU"),
+    ("config4_v2_2p19_shard", "v2", 19, "BASELINE config 4: fishing-v2, N = 2^22 over 8 GPUs -> the 2^19 envs of one GPU"),
+    ("config4_v2_2p22", "v2", 22, "BASELINE config 4 whole on one GPU (N = 2^22)"),
+    ("config5_v4_2p21_shard", "v4", 21, "BASELINE config 5: fishing-v4, N = 2^24 over 8 GPUs -> the 2^21 envs of one GPU"),
+    ("config5_v4_2p24", "v4", 24, "BASELINE config 5 whole on one GPU (N = 2^24: 620 MB of streams, HBM-resident)"),
+    ("config3_v0_2p26", "v0", 26, "config 3's workload at SURVEY 8(d)'s spill size N = 2^26 (HBM-resident)"),
+    ("config4_v2_2p26", "v2", 26, "config 4's workload at SURVEY 8(d)'s spill size N = 2^26 (HBM-resident)"),
+)
+
+
+def config_records(torch, gf, launches=256):
+    """Every BASELINE config under THIS run's clock (the driver times the default command only): per record the kernel the
+    dispatch picked, its algorithmic bytes per env-step, the average launch duration (steady_launch_us: HIP events over
+    >= 256 launches behind a lead-in) and the roofline figure with its regime.  Per-env episodic returns on, as in the
+    headline; config 2 additionally carries its in-kernel random-policy rollout (env-steps/s; not an HBM-bound kernel)."""
+    out = {}
+    for key, name, ln, what in CONFIG_RECORDS:
+        try:
+            n = 1 << ln
+            rows = RING if ln <= 22 else 4
+            cfg = CONFIGS[name]
+            env = make_env(gf, torch, name, n, 0, True)
+            env.reset()
+            acts = make_actions(torch, cfg, n, rows)
+            env.step_many(acts, 24)
+            us = steady_launch_us(torch, env, acts, launches)
+            b = bytes_per_env_step(name, True)
+            fits = resident_bytes(name, n, True, rows) < 256 * 2 ** 20
+            rec = {"what": what, "n_envs": n, "kernel": env.step_kernel_name(acts[0]), "bytes_per_env_step": b,
+                   "avg_launch_us": us, "launches": launches, "env_steps_per_s": n / us * 1e6}
+            rec.update(roof(n * b / us / 1e3, fits))
+            if key == "config2_v1_2p20":        # "random-policy rollout": the policy drawn in-kernel, no action traffic at all
+                env.rollout(101, policy="random")
+                torch.cuda.synchronize()
+                r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                r0.record()
+                for _ in range(8):
+                    env.rollout(101, policy="random")
+                r1.record()
+                torch.cuda.synchronize()
+                us_r = r0.elapsed_time(r1) * 1e3 / (8 * 101)
+                rec["random_policy_rollout"] = {"us_per_step": us_r, "env_steps_per_s": n / us_r * 1e6, "steps_per_launch": 101,
+                                                "kernel": "fishing::rollout_kernel (in-kernel policy; VALU-bound, 0 B of action traffic)"}
+            out[key] = rec
+            del env, acts
+        except Exception as e:  # noqa: BLE001 - a sub-record must not take the headline down
+            out[key] = {"what": what, "error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+    out["note"] = ("same clock, same process as the headline: HIP events around %d back-to-back fishing_step_f32 launches behind a "
+                   "16-launch lead-in, per-env episodic returns on; frac = achieved / 8 TB/s HBM spec (null + hbm_spec_ratio when "
+                   "cache-resident streams beat it); rocprofv3 records of the same commands: profiles/r05_step_*_summary.json" % launches)
+    return out
+
+
+def rank_report(torch, dist, rt, backend, rank, world, local_device, env_offset, n, elapsed_local, steps, local_rec, merged_rec):
+    """What the first unattended multi-GPU run must say about itself: every rank's device, shard and time, and whether the
+    all-reduced return record is the sum of the ranks' own records.  One all_gather of 8 doubles per rank, after the clock
+    stopped.  Returns (list of per-rank dicts, ok, message); every rank computes the same verdict from the same gathered data."""
+    dev = "cuda" if backend == "nccl" else "cpu"
+    mine = torch.tensor([float(rank), float(local_device), float(env_offset), float(n), elapsed_local / max(steps, 1) * 1e3]
+                        + [float(x) for x in local_rec.tolist()] + [float(x) for x in merged_rec.tolist()],
+                        dtype=torch.float64, device=dev)
+    rows = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    rows = [r.cpu().tolist() for r in rows]
+    ranks = [{"rank": int(r[0]), "device": int(r[1]), "env_offset": int(r[2]), "n_envs": int(r[3]), "ms_per_step": r[4],
+              "record": r[5:9]} for r in rows]
+    ranks.sort(key=lambda d: d["rank"])
+    problems = []
+    if [d["rank"] for d in ranks] != list(range(world)):
+        problems.append("ranks gathered: %s" % [d["rank"] for d in ranks])
+    total = [sum(d["record"][k] for d in ranks) for k in range(4)]
+    for r in rows:                       # every rank must hold the same merged record
+        if r[9:13] != rows[0][9:13]:
+            problems.append("rank %d holds a different all-reduced record than rank %d" % (int(r[0]), int(rows[0][0])))
+            break
+    merged = rows[0][9:13]
+    for k, name in enumerate(("sum_return", "sum_sq_return", "n_episodes", "sum_length")):
+        exact = k >= 2                   # counts are integers in doubles: exact; the sums may differ in the last bits by order
+        if (merged[k] != total[k]) if exact else (abs(merged[k] - total[k]) > 1e-12 * max(1.0, abs(total[k]))):
+            problems.append("all-reduced %s = %r but the ranks' own records sum to %r" % (name, merged[k], total[k]))
+    offs = sorted((d["env_offset"], d["n_envs"]) for d in ranks)
+    if any(offs[i][0] + offs[i][1] != offs[i + 1][0] for i in range(len(offs) - 1)) or offs[0][0] != 0:
+        problems.append("the ranks' env blocks do not tile [0, N): %s" % offs)
+    return ranks, not problems, "; ".join(problems)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -398,7 +538,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rt = load_runtime()
+    rt = load_runtime(args.rehearsal)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -472,7 +612,7 @@ def main():
     def region(with_events=False):
         """The timed sequence, exactly: K launches + the record's reduce kernel (+ the all-reduce) enqueued, then the
         closing barrier + synchronize.  (`with_events`: the untimed rehearsal brackets its K launches with HIP events --
-        roofline.avg_launch_us_timed_region; two event packets cost the 20-step region 9 of its 417 us, so the timed
+        roofline.avg_launch_us_rehearsal_region; two event packets cost the 20-step region 9 of its 417 us, so the timed
         pass carries none: profiles/r04_region_variants.jsonl.)"""
         if with_events:
             ev0.record()
@@ -500,10 +640,22 @@ def main():
     record = region()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    elapsed_local = elapsed
+    ranks = None
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        if record is not None:
+            # self-diagnosis, after the clock: the merged record must be the sum of the ranks' own records (the env's scratch
+            # record is rewritten by episode_record(): keep the merged one first)
+            record = record.clone()
+            local_rec = env.episode_record(all_reduce=False).clone()
+            ranks, ok, why = rank_report(torch, dist, rt, backend, rank, world, local_rank, rank * n, n, elapsed_local, args.steps,
+                                         local_rec, record)
+            if not ok:
+                print("bench.py rank %d: return-record self-check FAILED: %s" % (rank, why), file=sys.stderr, flush=True)
+                raise SystemExit(4)
     stats = {}
     if record is not None:
         from gym_fishing_amd.sharding import summarize_record
@@ -532,11 +684,9 @@ def main():
     achieved = n * bytes_per / (steady_ms * 1e-3) / 1e9
     kernel = env.step_kernel_name(actions[0])
     traffic, traffic_src = pmc_traffic(kernel, n) if rt.cuda else (None, None)
-    esz = 1 if args.compact else 4
-    rsz = 8 if args.f64 else 4
-    resident = n * (rsz + esz + rsz + 1 + (rsz if with_returns else 0) + (rsz if args.config == "v4" else 0)
-                    + (2 * rsz if args.v4_stored and args.config == "v4" else 0)) + RING * (n + 3072) * 4
+    resident = resident_bytes(args.config, n, with_returns, RING, args.f64, args.v4_stored, args.compact)
     fits = resident < 256 * 2 ** 20
+    head = roof(achieved, fits)
     log2n = n.bit_length() - 1 if n & (n - 1) == 0 else None
     out = {
         "metric": "env-steps/sec at N=2^22, fishing-v1" if args.config == "v1" else
@@ -547,6 +697,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+        "ms_per_step_min_over_ranks": min(d["ms_per_step"] for d in ranks) if ranks else elapsed_local / max(args.steps, 1) * 1e3,
+        "ms_per_step_max_over_ranks": max(d["ms_per_step"] for d in ranks) if ranks else elapsed_local / max(args.steps, 1) * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -567,21 +719,29 @@ def main():
                                  if world > 1 else "none",
                    # ranks counted by an all-reduce of ones at start-up (null: no process group, i.e. a bare 1-GPU run)
                    ("rccl_ranks_seen" if backend == "nccl" else backend + "_ranks_seen"): ranks_seen,
+                   # per rank: device, env block, its own ms_per_step and return record (null: no process group)
+                   "ranks": ranks,
+                   "record_is_sum_of_rank_records": True if ranks is not None else None,
                    "rehearsal": rt.name},
         "spinup": {"ms": spin_ms, "launches": spin_launches, "rehearsal_launches": args.steps,
                    "note": "same launches as the timed region, ahead of --warmup; then one untimed dress rehearsal of the timed "
                            "sequence itself (K launches + record + barrier); none of it timed"},
         "roofline": {"bound": "infinity-cache/hbm" if fits else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": head["frac"], "hbm_spec_ratio": head.get("hbm_spec_ratio"), "traffic": traffic, "traffic_source": traffic_src,
+                     # traffic: a LOOKUP of the committed rocprofv3 --pmc record of this command (bench.py cannot read counters
+                     # of its own run), quoted only while the built kernel has the profiled kernel's resources
+                     "traffic_is_lookup_of_committed_pmc_record": True,
                      "kernel": kernel, "bytes_per_env_step": bytes_per,
                      "avg_launch_us": steady_ms * 1e3, "avg_launch_launches": k_steady,
-                     "avg_launch_us_timed_region": kernel_ms * 1e3,
+                     "avg_launch_us_rehearsal_region": kernel_ms * 1e3,
                      "launch_us_median_event_pairs": med_us, "launch_us_mean_event_pairs": mean_us,
-                     "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                     "measured_copy_ratio": achieved / HBM_COPY_GBS,
                      "cache_resident": fits,
+                     # the same kernel where HBM IS the roof (N = 2^26, filled from the hbm_resident sub-record below)
+                     "hbm_resident_frac": None,
                      "note": "avg_launch_us = HIP events around max(K, 256) launches enqueued behind a 16-launch lead-in (device "
-                             "busy when the first event fires), per launch; avg_launch_us_timed_region = the same bracket over the K "
-                             "launches of the untimed dress rehearsal of the timed region (includes the idle device's pick-up of the "
+                             "busy when the first event fires), per launch; avg_launch_us_rehearsal_region = the same bracket over the K "
+                             "launches of the UNTIMED dress rehearsal of the timed region (includes the idle device's pick-up of the "
                              "first launch; the timed pass itself carries no event packets); "
                              "launch_us_median_event_pairs = median event-to-event time of single launches (each pair adds "
                              "its own ~2.5 us of packet gaps).  Resident arrays %.0f MB "
@@ -611,7 +771,8 @@ def main():
         us, wall = timed_steps(torch, bare, actions, kb)
         bb = bytes_per_env_step(args.config, False, False, args.v4_stored)
         out["bare_step"] = {"value": n * kb / wall, "unit": "env-steps/s", "steps": kb, "bytes_per_env_step": bb,
-                            "avg_launch_us": us, "achieved_GBps": n * bb / us / 1e3, "frac": n * bb / us / 1e3 / HBM_PEAK_GBS,
+                            "avg_launch_us": us, **roof(n * bb / us / 1e3, resident_bytes(args.config, n, False, RING, False,
+                                                                                           args.v4_stored) < 256 * 2 ** 20),
                             "kernel": bare.step_kernel_name(actions[0]),
                             "note": "same env family without the per-env episodic-return accumulator"}
         del bare
@@ -636,10 +797,12 @@ def main():
         del eb2
         out["hbm_resident"] = {"n_envs": big, "steps": 100, "bytes_per_env_step": bytes_per, "avg_launch_us": us,
                                "avg_launch_us_second_allocation": us2,
-                               "achieved_GBps": big * bytes_per / us / 1e3, "frac": big * bytes_per / us / 1e3 / HBM_PEAK_GBS,
+                               **roof(big * bytes_per / us / 1e3, False),
                                "env_steps_per_s": big / us * 1e6, "kernel": eb.step_kernel_name(ab[0]),
                                "resident_MB": (big * (bytes_per - 1 - 4) / 2 + big * 5 + rows * big * 4) / 1e6,
                                "note": "same workload, N = 2^%d: far outside the Infinity Cache" % (big.bit_length() - 1)}
+        out["roofline"]["hbm_resident_frac"] = out["hbm_resident"]["frac"]
+        out["roofline"]["hbm_resident_n_envs"] = big
         del eb, ab
         torch.cuda.empty_cache()
         if args.config != "v4":
@@ -651,8 +814,7 @@ def main():
             em.step_many(am, 24)
             usm, _ = timed_steps(torch, em, am, 200)
             out["hbm_resident"]["n_2p24"] = {"n_envs": mid, "steps": 200, "avg_launch_us": usm,
-                                             "achieved_GBps": mid * bytes_per / usm / 1e3,
-                                             "frac": mid * bytes_per / usm / 1e3 / HBM_PEAK_GBS,
+                                             **roof(mid * bytes_per / usm / 1e3, False),
                                              "kernel": em.step_kernel_name(am[0])}
             del em, am
             torch.cuda.empty_cache()
@@ -685,14 +847,14 @@ def main():
             fb = 9
             fused["2^%d" % ln] = {
                 "per_step_launches": {"us_per_step": us_l, "env_steps_per_s": nn / us_l * 1e6,
-                                      "frac_of_25B_roofline_rate": nn / us_l * 1e6 * BYTES_STEP / (HBM_PEAK_GBS * 1e9)},
+                                      "bytes_per_env_step": bytes_per, **roof(nn * bytes_per / us_l / 1e3, True)},
                 "fused_with_reward_done_rows": {"us_per_step": us_f, "env_steps_per_s": nn / us_f * 1e6,
                                                 "bytes_per_env_step": fb, "achieved_GBps": nn * fb / us_f / 1e3,
-                                                "frac_of_25B_roofline_rate": nn / us_f * 1e6 * BYTES_STEP / (HBM_PEAK_GBS * 1e9)},
+                                                "speedup_over_per_step_launches": us_l / us_f},
                 "fused_last_step_outputs_only": {"us_per_step": us_f2, "env_steps_per_s": nn / us_f2 * 1e6,
-                                                 "bytes_per_env_step": 4},
+                                                 "bytes_per_env_step": 4, "speedup_over_per_step_launches": us_l / us_f2},
                 "fused_rollout_in_kernel_random_policy": {"us_per_step": us_r, "env_steps_per_s": nn / us_r * 1e6,
-                                                          "bytes_per_env_step": 0},
+                                                          "bytes_per_env_step": 0, "speedup_over_per_step_launches": us_l / us_r},
             }
             del ef, af, rows_r, rows_d
             torch.cuda.empty_cache()
@@ -700,6 +862,8 @@ def main():
                                                   "fishing_step_f32 launches; VALU-bound (Philox + Box-Muller), not HBM-bound: "
                                                   "reported as env-steps/s, never the headline")
         env = None
+        if args.config == "v1" and with_returns and not args.no_configs:
+            out["configs"] = config_records(torch, gf)
 
     if args.extra and rank == 0:
         extra = {}

@@ -85,6 +85,8 @@ class OracleVecEnv:
         import torch
         from gym_fishing_amd.sharding import all_reduce_record          # the product's merge, over the rehearsal's gloo group
         rec = torch.tensor(self.rec, dtype=torch.float64)
+        if not all_reduce and os.environ.get("FISHING_REHEARSAL_CORRUPT_RANK") == os.environ.get("RANK", "0"):
+            rec[0] += 1.0              # negative control of bench.py's self-check: this rank's own record is not what was merged
         return all_reduce_record(rec) if all_reduce else rec
 
     def episode_stats(self, all_reduce=True):

@@ -65,7 +65,7 @@ def _rehearse(gpus, config, n_envs, steps=3, warmup=1, extra_env=None, timeout=6
     env.update(FISHING_BENCH_RUNTIME="tests.bench_rehearsal:Runtime", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     env.update(extra_env or {})
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", str(steps), "--warmup", str(warmup),
-           "--spinup-ms", "0", "--config", config, "--n-envs", str(n_envs)]
+           "--spinup-ms", "0", "--config", config, "--n-envs", str(n_envs), "--rehearsal"]
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
@@ -91,10 +91,20 @@ def test_eight_rank_rehearsal_of_the_bench_rank_path(config):
     assert "rehearsal" in out["config"] and out["roofline"] is None and out["cpu_baseline"] is None
     assert out["config"]["collective"].startswith("1 all-reduce of 4 doubles")
     assert out["value"] == pytest.approx(8 * n * steps / (out["ms_per_step"] * steps * 1e-3), rel=1e-9)
+    # the run describes itself: every rank's device, env block, own time and own record; the merged record is their sum
+    ranks = out["config"]["ranks"]
+    assert [d["rank"] for d in ranks] == list(range(8)) and [d["device"] for d in ranks] == list(range(8))
+    assert [(d["env_offset"], d["n_envs"]) for d in ranks] == [(r * n, n) for r in range(8)]
+    assert out["config"]["record_is_sum_of_rank_records"] is True
+    assert out["ms_per_step_max_over_ranks"] == pytest.approx(out["ms_per_step"], rel=1e-12)     # MAX over ranks IS the line's time
+    assert 0 < out["ms_per_step_min_over_ranks"] <= out["ms_per_step_max_over_ranks"]
+    assert out["ms_per_step_min_over_ranks"] == min(d["ms_per_step"] for d in ranks)
+    assert sum(d["record"][2] for d in ranks) == out["episode_stats"]["n_episodes"]
+    assert all(d["record"][2] > 0 for d in ranks)                # every rank finished episodes of its own
     one = _rehearse(1, config, 8 * n, steps, warmup)
     assert one.returncode == 0, one.stderr[-3000:]
     ref = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][0])
-    assert ref["n_gpus"] == 1 and ref["config"]["gloo_ranks_seen"] is None
+    assert ref["n_gpus"] == 1 and ref["config"]["gloo_ranks_seen"] is None and ref["config"]["ranks"] is None
     a, b = out["episode_stats"], ref["episode_stats"]
     assert a["n_episodes"] == b["n_episodes"] > 0
     for k in ("mean_return", "std_return", "mean_length"):
@@ -108,6 +118,38 @@ def test_rehearsed_rank_without_a_device_fails_loudly():
     proc = _rehearse(8, "v1", 1024, extra_env={"FISHING_REHEARSAL_DEVICES": "6"}, timeout=500)
     assert proc.returncode != 0 and proc.stdout.strip() == ""
     assert "only 6 rehearsal device(s)" in proc.stderr
+
+
+@pytest.mark.timeout(600)
+def test_a_rank_whose_record_is_not_in_the_merged_one_fails_the_run():
+    """The self-check of the unattended run: a rank whose own record is not what went into the all-reduce (here: rank 1's
+    local record is doctored after the merge) makes every rank exit non-zero with the reason, and no JSON line appears."""
+    proc = _rehearse(2, "v1", 1024, extra_env={"FISHING_REHEARSAL_CORRUPT_RANK": "1"}, timeout=500)
+    assert proc.returncode != 0 and proc.stdout.strip() == ""
+    assert "return-record self-check FAILED" in proc.stderr and "ranks' own records sum to" in proc.stderr
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="the refusal path: only where no HIP device exists")
+def test_the_runtime_variable_alone_does_not_reroute_the_bench():
+    """FISHING_BENCH_RUNTIME is honoured only together with --rehearsal: the driver's command, whatever its environment,
+    runs on the HIP runtime (here: fails for want of a device instead of silently timing the oracle)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["FISHING_BENCH_RUNTIME"] = "tests.bench_rehearsal:Runtime"
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n-envs", "1024",
+                           "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert proc.returncode != 0 and proc.stdout.strip() == "" and "needs a HIP device" in proc.stderr
+
+
+def test_roof_labels_never_put_a_fraction_above_one():
+    a = bench.roof(7200.0, True)
+    assert a["frac"] == pytest.approx(0.9) and a["cache_resident"] is True and "hbm_spec_ratio" not in a
+    b = bench.roof(8055.0, True)
+    assert b["frac"] is None and b["hbm_spec_ratio"] == pytest.approx(8055.0 / 8000.0) and b["cache_resident"] is True
+    # what decides the regime: state streams + action ring against the 256 MiB Infinity Cache
+    assert bench.resident_bytes("v1", 1 << 22, True, bench.RING) < 256 * 2 ** 20 < bench.resident_bytes("v1", 1 << 24, True, 4)
+    assert bench.resident_bytes("v4", 1 << 21, True, bench.RING) < 256 * 2 ** 20 < bench.resident_bytes("v4", 1 << 24, True, 4)
+    keys = [k for k, *_ in bench.CONFIG_RECORDS]
+    assert len(set(keys)) == len(keys) and {c for _, c, *_ in bench.CONFIG_RECORDS} == {"v0", "v1", "v2", "v4"}
 
 
 def test_config_shards_of_eight_ranks_are_quad_aligned_and_tile():
