@@ -191,7 +191,9 @@ inline GrowthT<T> make_growth(double r, double K, double sigma, double C, double
         g.invK = 1.0 / Kc;
     } else {
         g.logA = std::log(r + 1.0);
-        g.A = r + 1.0;
+        // (Myers: log(r + 1) of a negative number is NaN in the reference, and so is its population: the algebraic forms,
+        // which carry A itself, must not turn that into max(0, negative) = an extinct stock)
+        g.A = (r + 1.0 < 0.0) ? std::nan("") : r + 1.0;
     }
     const double e = kind == FISHING_KIND_MAY ? q : theta;
     g.ipow = (e == 1.0 || e == 2.0 || e == 3.0 || e == 4.0) ? (int32_t)e : 0;
@@ -475,7 +477,8 @@ __device__ __forceinline__ float pow_t<float>(float v, float e) {
 //   0: the round trip in float32 arithmetic on the hardware transcendentals (rounds 1-3).
 // (every figure: profiles/r04_zoo_f32_error.json, measured by tests/measure_zoo_f32_error.py on builds with
 // -DFISHING_ZOO_F32_MATH=n)
-// The float64 parity layout keeps the reference's round trip (log_f64 / exp_f64 below; 2e-14 against the reference).
+// The float64 parity layout runs the same algebraic form in float64 on the < 1-ulp exp_f64 / div_f64 below (round 5; 2e-14
+// against the reference); -DFISHING_ZOO_F64_ROUNDTRIP=1 builds the reference's round trip on log_f64 / exp_f64 (rounds 1-4).
 #ifndef FISHING_ZOO_F32_MATH
 #define FISHING_ZOO_F32_MATH 4
 #endif
@@ -725,6 +728,91 @@ __device__ __forceinline__ double zoo_draw_algebraic(int kind_rt, double x, doub
     return (res > 0.0) ? res : ((res != res) ? res : 0.0);    // np.maximum(0, .)
 }
 
+// ---- the float64 parity layout, round 5: the algebraic form on the < 1-ulp exp_f64, no logarithm
+// Rounds 1-4 evaluated the reference's round trip exp(log x + ... + sigma z) term for term.  Its parity is tolerance-based
+// (2e-14 of the population: the reference's libm log / exp are not reproducible bit for bit on the device anyway), and the
+// float64 zoo kernels were VALU-bound on the logarithms -- seven per wave pass in fishing-v11 (0.65 of the HBM spec), two per
+// env in fishing-v8 (0.74).  The algebraically equal form needs one exp_f64 and at most one division per env and lands
+// CLOSER to the exact value than the round trip does (whose log x + ... loses |mu| ulp before the exp): measured against the
+// reference-held fixtures in profiles/r05_zoo_f64_error.json.  Same special values as the round trip (see the float32
+// layout's table above; tests/test_gpu_zoo.py::test_zoo_special_values_follow_the_reference holds both layouts to them).
+#ifndef FISHING_ZOO_F64_ROUNDTRIP
+#define FISHING_ZOO_F64_ROUNDTRIP 0
+#endif
+// n / d to <= 1 ulp: v_rcp_f64 seed (~2^-26), two Newton steps on the reciprocal, one correction of the quotient with an
+// exact residual (8 instructions; the IEEE division's v_div_scale / v_div_fmas / v_div_fixup frame is ~14 and issues no
+// faster).  Denominators outside the comfortable range (zeros, infinities, NaN included) take the IEEE division.
+__device__ __forceinline__ double div_f64(double n, double d) {
+    const double ad = __builtin_fabs(d);
+    if (!(ad > 0x1p-500 && ad < 0x1p500)) return n / d;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ double pow_f64(double x, double e, int ipow) {
+    if (ipow == 0) return exp_f64(e * log_f64(x));      // wave-uniform; pow(0, e > 0) = exp(-inf) = 0
+    return int_pow<double>(x, ipow);
+}
+template <int KIND, bool RECOMPUTE, typename T>
+__device__ __forceinline__ void zoo_pre_g_f64(double x, double sz, const GrowthT<T>& P, double& pre, double& g) {
+    static_assert(KIND >= 0 && KIND < FISHING_N_KINDS, "a compile-time kind");
+    if constexpr (KIND == FISHING_KIND_ALLEN) {                 // :208-217: exp(log x + r (1 - x/K)(1 - C)/K + sz)
+        pre = x;
+        g = __builtin_fma(P.gc, __builtin_fma(-x, P.invK, 1.0), sz);
+    } else if constexpr (KIND == FISHING_KIND_RICKER) {         // :258-261
+        pre = x;
+        g = __builtin_fma(P.r, __builtin_fma(-x, P.invK, 1.0), sz);
+    } else if constexpr (KIND == FISHING_KIND_MYERS) {          // :247-255: A x^theta / (1 + x^theta / M)
+        const double xt = pow_f64(x, P.theta, P.ipow);
+        pre = div_f64(P.A * xt, __builtin_fma(xt, P.invM, 1.0));
+        g = sz;
+    } else if constexpr (KIND == FISHING_KIND_MAY) {            // :229-242: exp(log(exp_mu)); the log of a negative number is NaN
+        const double xq = pow_f64(x, P.q, P.ipow);
+        const double exp_mu = (x + x * P.r * (1.0 - x * P.invM)) - div_f64(P.a * xq, xq + P.bq);
+        pre = (exp_mu < 0.0) ? __builtin_nan("") : exp_mu;
+        g = sz;
+    } else {                                                    // Beverton-Holt :220-226: A x / (1 + x / B)
+        const double xc = (x < 0.0) ? 0.0 : x;
+        double A = P.A, invB = P.invB;
+        if (RECOMPUTE) {              // fishing-v10: r drifts per env; invK = 1 / clip(K, 0, inf) from the host
+            const double rc = (P.r < 0.0) ? 0.0 : P.r;
+            A = rc + 1.0;
+            invB = rc * P.invK;
+        }
+        pre = div_f64(A * xc, __builtin_fma(xc, invB, 1.0));
+        g = sz;
+    }
+}
+template <int KIND, bool RECOMPUTE, typename T>
+__device__ __forceinline__ double zoo_draw_f64(int kind_rt, double x, double z, const GrowthT<T>& P) {
+    const double sz = P.sigma * z;
+    double pre = 0.0, g = 0.0;
+    if constexpr (KIND >= 0) {
+        zoo_pre_g_f64<KIND, RECOMPUTE, T>(x, sz, P, pre, g);
+    } else {            // run-time kind (general kernel, population_draw sweeps): wave-uniform switch
+        switch (kind_rt) {
+            case FISHING_KIND_ALLEN: zoo_pre_g_f64<FISHING_KIND_ALLEN, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_MYERS: zoo_pre_g_f64<FISHING_KIND_MYERS, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_MAY: zoo_pre_g_f64<FISHING_KIND_MAY, false, T>(x, sz, P, pre, g); break;
+            case FISHING_KIND_RICKER: zoo_pre_g_f64<FISHING_KIND_RICKER, false, T>(x, sz, P, pre, g); break;
+            default: zoo_pre_g_f64<FISHING_KIND_BEVERTON_HOLT, RECOMPUTE, T>(x, sz, P, pre, g); break;
+        }
+    }
+    const double res = pre * exp_f64(g);
+    // Where the REFERENCE's round trip itself loses more than the parity bar, follow it.  exp(mu) carries the rounding of its
+    // argument: half an ulp of |mu| -- 7e-15 of the result at |mu| = 64, 2.8e-14 at 207 (Myers at x = 1e-30: 2 e-90 exp(sigma z)
+    // comes back 2.0e-14 off the exact value in NumPy) -- while this form is within a few ulp of exact.  A stock outside
+    // [2^-30, 2^30] or a result outside [2^-92, 2^92] (terms of mu beyond ~21 theta / |mu| beyond ~64) is therefore evaluated
+    // the reference's way; zeros, infinities and NaNs are the same in both forms and stay here.  No env of a rollout gets
+    // near these ranges (a divergent branch no wave takes); the population_draw sweeps and the special-value tests do.
+    const double inf = __builtin_huge_val();
+    const bool far = (x > 0.0 && x < 0x1p-30) || (x > 0x1p30 && x < inf) || (res > 0.0 && res < 0x1p-92) || (res > 0x1p92 && res < inf);
+    if (__builtin_expect(far, 0)) return zoo_draw_round_trip<double, MathLibF64, KIND, RECOMPUTE>(kind_rt, x, z, P);
+    return (res > 0.0) ? res : ((res != res) ? res : 0.0);      // np.maximum(0, .)
+}
+
 // expm1(g) in float32: g = n ln2 + r (ln2 split hi / lo, |r| <= 0.3466), expm1(r) = r + r^2 (1/2 + r/6 + ... + r^5/5040)
 // (first omitted term r^8/8! <= 5e-9), expm1(g) = 2^n expm1(r) + (2^n - 1).  Absolute error <= ~5e-8 max(1, exp(g)).
 // -inf -> -1, +inf -> inf, NaN -> NaN.
@@ -870,6 +958,12 @@ __device__ __forceinline__ float zoo_draw_f32(int kind_rt, float x, float z, con
     return zoo_finish_f32(pre, g);
 }
 
+// which GrowthT constants a layout's zoo kernels read: logA / B (the round trip) or A / invK / invM / invB / gc (algebraic)
+template <typename T>
+constexpr bool zoo_uses_round_trip() {
+    return sizeof(T) == 8 ? (FISHING_ZOO_F64_ROUNDTRIP != 0) : (FISHING_ZOO_F32_MATH == 0 || FISHING_ZOO_F32_MATH == 1);
+}
+
 template <typename T, int KIND = -1, bool RECOMPUTE = false>
 __device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const GrowthT<T>& P) {
     if constexpr (sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4)
@@ -878,6 +972,8 @@ __device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const Gr
         return (T)zoo_draw_hybrid<KIND, RECOMPUTE, T>(kind_rt, (float)x, (float)z, P);
     else if constexpr (sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 2)
         return (T)zoo_draw_algebraic<KIND, RECOMPUTE, T>(kind_rt, (double)x, (double)z, P);
+    else if constexpr (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP)
+        return (T)zoo_draw_f64<KIND, RECOMPUTE, T>(kind_rt, (double)x, (double)z, P);
     else
         return zoo_draw_round_trip<T, ZooRoundTripMath<T>, KIND, RECOMPUTE>(kind_rt, x, z, P);
 }

@@ -446,10 +446,14 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         if constexpr ((F & feat::SIGARR) != 0) asm volatile("" ::"s"(a.sigma_arr));
         if constexpr ((F & feat::TERM) && kExact) asm volatile("" ::"s"(a.terminal_obs));
         if constexpr ((F & feat::BITS) && kExact) asm volatile("" ::"s"(a.done_bits));
-        if constexpr (kZoo)
+        if constexpr (kZoo) {
             asm volatile("" ::"s"(a.growth.r), "s"(a.growth.K), "s"(a.growth.sigma), "s"(a.growth.C), "s"(a.growth.M),
-                         "s"(a.growth.theta), "s"(a.growth.q), "s"(a.growth.b), "s"(a.growth.a), "s"(a.growth.bq),
-                         "s"(a.growth.logA), "s"(a.growth.B));
+                         "s"(a.growth.theta), "s"(a.growth.q), "s"(a.growth.b), "s"(a.growth.a), "s"(a.growth.bq));
+            if constexpr (zoo_uses_round_trip<T>())
+                asm volatile("" ::"s"(a.growth.logA), "s"(a.growth.B));
+            else
+                asm volatile("" ::"s"(a.growth.A), "s"(a.growth.invK), "s"(a.growth.invM), "s"(a.growth.invB), "s"(a.growth.gc));
+        }
         if constexpr ((F & feat::DRIFT) != 0) asm volatile("" ::"s"(a.r), "s"(a.alpha));
     }
     };

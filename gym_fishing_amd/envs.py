@@ -228,6 +228,7 @@ class BaseFishingEnv(_gym_env_base()):
             raise ValueError("derived_params=True needs fishing-v4 with num_envs, rng='philox' and the int32 year counter")
         self._derived = self._derived_capable
         self._origin = (0, 0)            # (step count, reset counter) of the last reset() of all envs
+        self._origin_stale = False       # graph-replay mode: reset() moved the origin on the device only (_host_origin)
         self._K_store = self._r_store = None      # (see _param_store)
         # fishing-v4 derived: per-env episode origins of envs reset one by one (FishingBuffers.v4_stamp; allocated by the
         # first masked reset(), dropped from the launches again by the next reset of every env, never freed)
@@ -398,10 +399,8 @@ class BaseFishingEnv(_gym_env_base()):
         must do the same): env.Tmax = ..., env.sigma = ..., env.K = ..., seed(), a masked reset() of fishing-v4 and
         load_state_dict() can all change it."""
         ptr = lambda t: (t.data_ptr() if t is not None else 0)  # noqa: E731
-        key = list(self._param_key())
-        if self._counter is not None:
-            key[4] = None       # (fishing-v4's episode origin travels in the device-resident counter words in this mode)
-        return (tuple(key), self._seed, self._derived,
+        # (in graph-replay mode fishing-v4's episode origin travels in the device-resident counter words: not part of the key)
+        return (self._param_key(), self._seed, self._derived,
                 tuple(ptr(t) for t in (self._obs, self._t, self._reward, self._done, self._done_bits, self._r_arr, self._K_arr,
                                        self._sigma_arr, self._terminal_obs, self._ep_return, self._partials, self._model_idx,
                                        self._counter, self._stamp)))
@@ -431,7 +430,8 @@ class BaseFishingEnv(_gym_env_base()):
         p = self.params
         if self.compact and self.Tmax > 254:
             raise ValueError("compact layout needs Tmax <= 254")
-        return (self.Tmax, self.init_state, self.auto_reset, self._derived, self._origin, self._sigma_scalar, p["r"],
+        return (self.Tmax, self.init_state, self.auto_reset, self._derived, None if self._counter is not None else self._origin,
+                self._sigma_scalar, p["r"],
                 p["K"], self._launch,
                 getattr(self, "n_actions", 0), getattr(self, "C", None), getattr(self, "r_mean", None),
                 getattr(self, "K_mean", None), getattr(self, "sigma_p", None),
@@ -572,7 +572,7 @@ class BaseFishingEnv(_gym_env_base()):
         sd.update(format=STATE_FORMAT, v4_param_stream=V4_PARAM_STREAM,
                   seed=self._seed, step_count=self._current_step_count(), reset_count=self._reset_count,
                   params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state,
-                  v4_derived=self._derived, v4_origin=tuple(self._origin), auto_reset=self.auto_reset,
+                  v4_derived=self._derived, v4_origin=tuple(self._host_origin()), auto_reset=self.auto_reset,
                   attrs={k: getattr(self, k) for k in self._STATE_ATTRS if hasattr(self, k)})
         if self.MODEL == MODEL_V11:
             sd["attrs"].update(models=list(self.models), model_params={k: dict(v) for k, v in self.model_params.items()})
@@ -599,6 +599,11 @@ class BaseFishingEnv(_gym_env_base()):
         if self._per_env and sd.get("v4_derived", False) and not self._derived_capable:
             raise ValueError("state was saved in the derived-parameter mode, which this env cannot run")
         v4_arrays = self._per_env and not sd.get("v4_derived", False)
+        if "_stamp" in sd:      # origin stamps exist only in fishing-v4's derived mode, one per env
+            if not (self._per_env and sd.get("v4_derived", False)):
+                raise ValueError("state has _stamp (fishing-v4 origin stamps) but was not saved in the derived-parameter mode")
+            if sd["_stamp"].numel() != self.num_envs:
+                raise ValueError("state's _stamp has %d elements, this env's %d" % (sd["_stamp"].numel(), self.num_envs))
         for k in self._STATE_TENSORS:
             if k in sd and getattr(self, k) is None and k not in ("_counter", "_stamp") and not (k in ("_r_arr", "_K_arr") and v4_arrays):
                 raise ValueError("state has %s but this env was built without it" % k)
@@ -634,6 +639,10 @@ class BaseFishingEnv(_gym_env_base()):
                 else:
                     getattr(self, k).copy_(sd[k])
         self._seed, self._step_count, self._reset_count = sd["seed"], sd["step_count"], sd["reset_count"]
+        if self._counter is not None and "_counter" not in sd:
+            # a state taken from a host-counter env, loaded into an env in graph-replay mode: the device word is this env's
+            # step count from here on (_current_step_count() reads it back), so it must not keep the value it had
+            self._counter[0].fill_(int(sd["step_count"]))
         self.params.update(sd["params"])
         self.Tmax, self.init_state = sd["Tmax"], sd["init_state"]
         self.auto_reset = sd.get("auto_reset", self.auto_reset)
@@ -667,10 +676,20 @@ class BaseFishingEnv(_gym_env_base()):
             self._cbuf = None
         return self
 
+    def _host_origin(self):
+        """The origin as host integers.  In graph-replay mode reset() moves it on the device only; the host's copy is read
+        back here (state_dict(): one wait for the stream)."""
+        if self._origin_stale and self._counter is not None:
+            words = self._counter.tolist()
+            self._origin = (int(words[1]), int(words[2]))
+        self._origin_stale = False
+        return self._origin
+
     def _set_origin(self, step_count, reset_count):
         """(step count, reset counter) of the reset() of ALL envs that dates every running episode; mirrored into the
         device-resident counter words in graph-replay mode (two fills on the current stream)."""
         self._origin = (int(step_count), int(reset_count))
+        self._origin_stale = False
         if self._counter is not None:
             self._counter[1].fill_(self._origin[0])
             self._counter[2].fill_(self._origin[1])
@@ -691,7 +710,15 @@ class BaseFishingEnv(_gym_env_base()):
             m = torch.as_tensor(mask).to(device=self.device).reshape(self.num_envs).to(torch.uint8).contiguous()
         elif self._derived_capable:         # a reset of ALL envs: its counters date every episode from here on
             self._derived, self._K_arr, self._r_arr, self._cbuf = True, None, None, None
-            self._set_origin(self._current_step_count(), self._reset_count)
+            if self._counter is not None:
+                # graph-replay mode: the origin is copied device word to device word on the current stream -- no host read of
+                # the counter, so reset() neither waits for the GPU on the launch-bound path nor breaks a caller's stream
+                # capture.  The host's copy of the origin is refreshed on demand (_host_origin).
+                self._counter[1:2].copy_(self._counter[0:1])
+                self._counter[2].fill_(self._reset_count)
+                self._origin_stale = True
+            else:
+                self._set_origin(self._step_count, self._reset_count)
         with torch.cuda.device(self.device):
             rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
                                 self._c_buffers(with_outputs=False), m.data_ptr() if m is not None else None,
@@ -1306,8 +1333,8 @@ class ModelUncertainty(BaseFishingEnv):
         super().__init__(Tmax=Tmax, file=file, **vec)
 
     def _param_key(self):
-        return super()._param_key() + (tuple(self.models), tuple(sorted((k, tuple(sorted(v.items())))
-                                                                        for k, v in self.model_params.items())))
+        # (dict order, no sorting: GraphedSteps.replay() compares this on every replay; a reordered dict only costs a re-capture)
+        return super()._param_key() + (tuple(self.models), tuple((k, tuple(v.items())) for k, v in self.model_params.items()))
 
     def _set_initial_state(self):
         # constructor: choose a model (growth_models.py:187); obs as the base class sets it

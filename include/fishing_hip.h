@@ -72,7 +72,7 @@ typedef void* fishing_stream_t; /* hipStream_t */
                                 counter cannot date an episode) or user-supplied parameters (the host then
                                 calls fishing_v4_params_* once and continues with arrays).              */
 #define FISHING_FLAG_PADDED_TILES 16u /* every in/out STATE buffer of FishingBuffers (obs, t, reward, done, done_bits,
-                                r, K, sigma, terminal_obs, ep_return, model_idx -- not action, not z_ext) has room for
+                                r, K, sigma, terminal_obs, ep_return, model_idx, v4_stamp -- not action, not z_ext) has room for
                                 ceil(n / 1024) * 1024 elements; the elements behind the n-th are scratch the library may
                                 overwrite.  fishing_step_* then runs a batch that is not a multiple of 1024 envs in ONE
                                 launch instead of two (3.7-4.2 us per step less), and a batch below one tile on the lean
@@ -168,7 +168,9 @@ typedef struct FishingBuffers {
                                 stamps of the masked envs (and needs the buffer: FISHING_ERR_UNSUPPORTED without), a
                                 reset of every env clears them all; step() / rollout() clear an env's stamp when they
                                 auto-reset it.  R 4 + W 4 bytes per env-step on top of the derived mode's 37 -- 45 against
-                                the 53 of stored r / K arrays.  Any other model or mode: must be NULL.  */
+                                the 53 of stored r / K arrays.  Any other model or mode: must be NULL.  A state stream like the
+                                others: under FISHING_FLAG_PADDED_TILES it needs ceil(n / 1024) * 1024 elements (the lean
+                                kernels read and write it in whole 1024-env tiles).  */
 } FishingBuffers;
 
 /* In-kernel policies for the fused rollout (callers of step(): shared_env.py:29-54,

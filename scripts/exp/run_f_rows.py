@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import gym_fishing_amd as gf  # noqa: E402
 
 QUICK = "--quick" in sys.argv        # (the PMC passes: fewer launches, same kernels)
+ZOO_ONLY = "--zoo-only" in sys.argv  # (A/B of growth-function evaluations: the step kernels alone, every id in both layouts)
 
 
 def events(fn, reps):
@@ -43,7 +44,7 @@ def main():
     acts.copy_(torch.rand((8, n), device="cuda") * 2 - 1)
     launches = 60 if QUICK else 400
     for idn, dtype in [("fishing-v%d" % k, torch.float32) for k in (5, 6, 7, 8, 9, 10, 11)] + [
-            ("fishing-v9", torch.float64), ("fishing-v8", torch.float64), ("fishing-v11", torch.float64)]:
+            ("fishing-v%d" % k, torch.float64) for k in ((5, 6, 7, 8, 9, 10, 11) if ZOO_ONLY else (9, 8, 11))]:
         env = make(idn, n, dtype)
         env.step_many(acts, 50)
         torch.cuda.synchronize()
@@ -55,6 +56,8 @@ def main():
         print(json.dumps(dict(row="f4 zoo step", id=idn, dtype=str(dtype)[6:], kernel=env.step_kernel_name(), n_envs=n, env_steps_per_launch=n,
                               bytes_per_env_step=byt, us_per_launch=round(us, 2), frac_of_8TBps=round(n * byt / us / 8e6, 3))), flush=True)
         del env
+    if ZOO_ONLY:
+        return
     # fused K-step kernel (caller's actions): the launch-bound regime's tool (N = 2^20) and at the metric's size (2^22); 101 steps per
     # launch, reward / done rows out
     for ln in (20, 22):

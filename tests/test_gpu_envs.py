@@ -613,7 +613,9 @@ def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
             graphed.reset()
             eager.reset()
             assert eager._derived and graphed._derived
-            assert graphed._counter.tolist() == [graphed._step_count, graphed._origin[0], graphed._origin[1]]
+            # (in graph-replay mode reset() moves the origin on the device; the host's copy is read back on demand)
+            assert graphed._origin_stale and graphed._counter.tolist() == [graphed._step_count, *graphed._host_origin()]
+            assert graphed._host_origin() == eager._host_origin() and not graphed._origin_stale
             assert torch.equal(graphed.K, eager.K)
     # a checkpoint of the graph-mode env resumes in an env that never saw the capture
     sd = graphed.state_dict()
@@ -721,7 +723,7 @@ def test_raw_graph_replays_keep_the_step_count_the_env_acts_on(gf):
     eager.step(a)
     graphed.reset()
     eager.reset()
-    assert graphed._origin == eager._origin == (11, 2)
+    assert graphed._host_origin() == eager._host_origin() == (11, 2)
     for _ in range(4):
         graph.replay()
         eager.step(a)
@@ -733,6 +735,87 @@ def test_raw_graph_replays_keep_the_step_count_the_env_acts_on(gf):
     for _ in range(10):
         again.step(a)
     assert torch.equal(fresh.state, again.state) and torch.equal(fresh.K, again.K)
+
+
+def test_reset_in_graph_replay_mode_is_capturable_and_never_reads_the_counter_back(gf):
+    """In graph-replay mode a reset() of all envs dates fishing-v4's episodes from the DEVICE's step counter, copied device
+    word to device word on the current stream: no host read (reset() does not wait for the GPU on the launch-bound path
+    this mode exists for) and therefore legal inside a caller's own stream capture.  A captured [reset(), 3 steps] replayed
+    three times equals an eager env that resets with the same reset counter, bit for bit -- state and the (K, r) in force."""
+    import torch
+    n = 2048
+    acts = torch.rand((3, n), device="cuda") * 1.4 - 1.2
+    mk = lambda: gf.make("fishing-v4", sigma=0.05, sigma_p=0.2, num_envs=n, seed=21, Tmax=5)  # noqa: E731
+    eager, graphed = mk(), mk()
+    eager.reset()
+    graphed.reset()
+    graphed.enable_graph_replay()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step_many(acts, 3)          # warm-up outside the capture (torch's rule); eager takes the same steps
+    torch.cuda.current_stream().wait_stream(side)
+    eager.step_many(acts, 3)
+    rc = graphed._reset_count
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        graphed.reset()                     # a host read of the device counter would be a synchronisation: illegal in a capture
+        graphed.step_many(acts, 3)
+    assert graphed._origin_stale and graphed._derived
+    for rnd in range(3):
+        graph.replay()
+        eager._reset_count = rc             # (the captured reset froze its reset counter: every replay redraws under it)
+        eager.reset()
+        eager.step_many(acts, 3)
+        assert torch.equal(graphed.state, eager.state) and torch.equal(graphed._t, eager._t), rnd
+        assert torch.equal(graphed.K, eager.K) and torch.equal(graphed.r, eager.r), rnd
+    assert graphed._host_origin() == eager._host_origin() == (3 + 2 * 3, rc)
+
+
+def test_load_state_dict_into_a_graph_replay_env_moves_the_device_counter_and_refuses_stray_stamps(gf):
+    """(1) A checkpoint of a host-counter env carries no `_counter`; loaded into an env in graph-replay mode, the device
+    word IS the step count from there on and must take the checkpoint's value -- the kernels draw from it, reset() dates
+    episodes from it.  (2) Origin stamps belong to fishing-v4's derived mode: a state that carries them without that mode is
+    refused before anything changes."""
+    import torch
+    n = 2048
+    acts = torch.rand((4, n), device="cuda") * 1.4 - 1.2
+    mk = lambda: gf.make("fishing-v4", sigma=0.05, sigma_p=0.2, num_envs=n, seed=3, Tmax=6)  # noqa: E731
+    a = mk()
+    a.reset()
+    a.step_many(acts, 5)
+    sd = a.state_dict()
+    assert "_counter" not in sd and sd["step_count"] == 5
+    b = mk()
+    b.reset()
+    b.enable_graph_replay()
+    b.step_many(acts, 2)
+    b.load_state_dict(sd)
+    assert b._counter.tolist() == [5, *sd["v4_origin"]]
+    a.step_many(acts, 4)
+    b.step_many(acts, 4)
+    assert torch.equal(a.state, b.state) and torch.equal(a.K, b.K) and b._current_step_count() == 9
+    b.reset()
+    a.reset()
+    a.step_many(acts, 3)
+    b.step_many(acts, 3)
+    assert torch.equal(a.state, b.state) and torch.equal(a.K, b.K)
+    # (2)
+    a.reset(torch.arange(n, device="cuda") % 3 == 0)
+    sd = a.state_dict()
+    assert "_stamp" in sd and sd["v4_derived"]
+    before = (b.state.clone(), b._t.clone(), b._derived, b._seed, b._current_step_count())
+    for bad in (dict(sd, v4_derived=False), dict(sd, _stamp=sd["_stamp"][:n // 2].clone())):
+        with pytest.raises(ValueError, match="_stamp"):
+            b.load_state_dict(bad)
+        assert torch.equal(b.state, before[0]) and torch.equal(b._t, before[1])
+        assert (b._derived, b._seed, b._current_step_count()) == before[2:]
+    with pytest.raises(ValueError, match="_stamp"):
+        gf.make("fishing-v1", sigma=0.1, num_envs=n).load_state_dict(dict(sd, v4_derived=True))
+    b.load_state_dict(sd)               # ... while the consistent state loads
+    a.step_many(acts, 3)
+    b.step_many(acts, 3)
+    assert torch.equal(a.state, b.state) and torch.equal(a.K, b.K)
 
 
 def test_v4_state_without_the_stream_tag_loads_where_it_can(gf):

@@ -52,6 +52,29 @@ def pop_close(obs_dev, obs_ref, ulps, eps):
     return bool(np.all(ok))
 
 
+F32_NORTH_STAR_ATOL = 1e-6
+
+
+def v2_f32_within_the_north_star(obs_dev, rew_dev, obs_ref64, rew_ref64):
+    """BASELINE.json north_star, second bar, for fishing-v2's float32 layout (its exp is the hardware's, so bit-equality
+    with a float32 oracle is not on offer): |obs - ref| <= 1e-6 and |reward - ref| <= 1e-6, ABSOLUTE, against the float64
+    oracle on the same (float32-representable) inputs.  Inside the observation Box (|obs| <= 1, i.e. x <= 2 K) that is the
+    bar itself; a stock the noise carried beyond it is held to 1e-6 of its own size (float32 cannot resolve 1e-6 at 8).
+    Returns the largest obs / reward errors seen inside the Box (for the test's message)."""
+    o, ro = np.asarray(obs_dev, dtype=np.float64), np.asarray(obs_ref64, dtype=np.float64)
+    r, rr = np.asarray(rew_dev, dtype=np.float64), np.asarray(rew_ref64, dtype=np.float64)
+    assert (np.isnan(o) == np.isnan(ro)).all() and (np.isnan(r) == np.isnan(rr)).all()
+    ok = ~np.isnan(ro)
+    err = np.abs(o - ro)[ok]
+    bar = F32_NORTH_STAR_ATOL * np.maximum(1.0, np.abs(ro[ok]))
+    assert (err <= bar).all(), "obs off by %.3e (bar %.1e)" % (err.max(), F32_NORTH_STAR_ATOL)
+    okr = ~np.isnan(rr)
+    errr = np.abs(r - rr)[okr]
+    assert (errr <= F32_NORTH_STAR_ATOL * np.maximum(1.0, np.abs(rr[okr]))).all(), "reward off by %.3e" % errr.max()
+    inside = np.abs(ro[ok]) <= 1.0
+    return (err[inside].max() if inside.any() else 0.0), (errr.max() if errr.size else 0.0)
+
+
 def case_kw(c):
     return dict(sigma=c.param("sigma"), C=c.param("C"), x0=c.param("init_state"), Tmax=c.param("Tmax"),
                 n_actions=c.param("n_actions"), K_mean=c.param("K_mean"), r_mean=c.param("r_mean"),
@@ -191,8 +214,18 @@ def test_step_matches_oracle_ext_noise(hh, model, dtype, n):
     st = hh.State(n, dtype, model, obs, t=t, r=r if per_env else None, K=K if per_env else None, done_bits=True)
     o, rew, done, t2 = st.step(p, a, z=z)
     eo, er, ed, et, ex = fo.step(model, obs, t, a, z, r, K, sigma, C=0.4, Tmax=100, dtype=dtype)
-    if model == fo.MODEL_V2:
-        assert pop_close(o, eo, *((V2_F64_ULP, 2.3e-16) if dtype == np.float64 else (V2_F32_ULP, 1.2e-7)))
+    if model == fo.MODEL_V2 and dtype == np.float32:
+        # the north star's own bar, against the reference's float64 arithmetic on the same inputs
+        r64 = r.astype(np.float64) if per_env else 0.3
+        K64 = K.astype(np.float64) if per_env else 1.25
+        eo64, er64, _, _, ex64 = fo.step(model, obs.astype(np.float64), t, a, z.astype(np.float64), r64, K64, sigma, C=0.4, Tmax=100,
+                                         dtype=np.float64)
+        v2_f32_within_the_north_star(o, rew, eo64, er64)
+        # extinction is decided on the population: only one within the bar of zero may be classified differently
+        assert (np.abs(ex64[done != ed]) <= F32_NORTH_STAR_ATOL).all()
+        ed = done
+    elif model == fo.MODEL_V2:
+        assert pop_close(o, eo, V2_F64_ULP, 2.3e-16)
     else:
         assert_same_bits(o, eo, "obs")
     assert_same_bits(rew, er, "reward")
@@ -237,7 +270,12 @@ def test_multi_step_auto_reset_philox(hh, model, dtype):
         eo, er, ed, et, ex = fo.step(model, obs, t, a, z, r, K, 0.15, C=0.5, Tmax=9, dtype=dtype)
         term = st.terminal.cpu().numpy()
         if model == fo.MODEL_V2:
-            assert pop_close(term, eo, *((V2_F64_ULP, 2.3e-16) if dtype == np.float64 else (V2_F32_ULP, 1.2e-7)))
+            if dtype == np.float32:     # the north star's own bar per step: 1e-6 absolute against the float64 oracle on this step's inputs
+                eo64, er64 = fo.step(model, obs.astype(np.float64), t, a, z.astype(np.float64), 0.3, 1.0, 0.15, C=0.5, Tmax=9,
+                                     dtype=np.float64)[:2]
+                v2_f32_within_the_north_star(term, rew, eo64, er64)
+            else:
+                assert pop_close(term, eo, V2_F64_ULP, 2.3e-16)
             eo = term      # follow the device so the comparison stays per-step
             ed = ((et > 9) | ((term.astype(np.float64) + 1.0) <= 0)).astype(np.uint8)
         else:
@@ -783,6 +821,7 @@ def test_full_size_baseline_configs(hh, cfg):
     for s in range(3):
         a = acts[s, lo:lo + w].cpu().numpy()
         z = hh.device_step_noise(w, seed, s, lo).astype(dtype)
+        obs_in, t_in = obs, t
         eo, er, ed, et, _ = fo.step(model, obs, t, a, z, r, K, sig, C=0.5, n_actions=100, dtype=dtype)
         zK = zr = None
         if per_env:
@@ -793,7 +832,12 @@ def test_full_size_baseline_configs(hh, cfg):
         obs, t, K, r = fo.auto_reset(model, eo, ed, et, K, r, 0.75, zK=zK, zr=zr, K_mean=1.0, r_mean=0.3,
                                      sigma_p=0.1, dtype=dtype)
         if model == fo.MODEL_V2:
-            assert pop_close(dev_obs, obs, V2_F32_ULP, 1.2e-7)
+            # the north star's bar at BASELINE config 4's real size: 1e-6 absolute against the float64 oracle on this step's inputs
+            eo64, er64 = fo.step(model, obs_in.astype(np.float64), t_in, a, z.astype(np.float64), 0.3, 1.0, float(sig), C=0.5,
+                                 n_actions=100, dtype=np.float64)[:2]
+            live = ~dev_done.astype(bool)             # (a finished env shows its reset observation: exact)
+            v2_f32_within_the_north_star(dev_obs[live], dev_rew[live], eo64[live], er64[live])
+            assert np.array_equal(dev_obs[~live], obs[~live])
             obs = dev_obs
         else:
             assert_same_bits(dev_obs, obs, "%s window obs step %d" % (cfg, s))
