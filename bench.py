@@ -552,12 +552,12 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
-    wall = {}                       # where this run's wall time went (seconds per section; reported as `bench_wall_s`)
+    wall_s = {}                     # where this run's wall time went (seconds per section; reported as `bench_wall_s`)
     t_mark = [time.perf_counter()]
 
     def mark(name):
         now = time.perf_counter()
-        wall[name] = round(wall.get(name, 0.0) + now - t_mark[0], 3)
+        wall_s[name] = round(wall_s.get(name, 0.0) + now - t_mark[0], 3)
         t_mark[0] = now
 
     import torch
@@ -934,7 +934,7 @@ def main():
         mark("cpu_baseline")
     elif rank == 0:
         out["cpu_baseline"] = None
-    out["bench_wall_s"] = dict(wall, total=round(sum(wall.values()), 3))
+    out["bench_wall_s"] = dict(wall_s, total=round(sum(wall_s.values()), 3))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -228,7 +228,6 @@ class BaseFishingEnv(_gym_env_base()):
             raise ValueError("derived_params=True needs fishing-v4 with num_envs, rng='philox' and the int32 year counter")
         self._derived = self._derived_capable
         self._origin = (0, 0)            # (step count, reset counter) of the last reset() of all envs
-        self._origin_stale = False       # graph-replay mode: reset() moved the origin on the device only (_host_origin)
         self._K_store = self._r_store = None      # (see _param_store)
         # fishing-v4 derived: per-env episode origins of envs reset one by one (FishingBuffers.v4_stamp; allocated by the
         # first masked reset(), dropped from the launches again by the next reset of every env, never freed)
@@ -351,9 +350,16 @@ class BaseFishingEnv(_gym_env_base()):
         """(K, r) tensors of a fishing-v4 env in the derived mode, materialised by fishing_v4_params_* (into the pair
         `out` when given: callers that ask every step reuse one pair instead of allocating two streams per call)."""
         K, r = out if out is not None else (self._per_env_buffer(self.dtype), self._per_env_buffer(self.dtype))
+        cp = self._c_params()
+        if self._counter is not None:
+            # graph-replay mode: the episode origin lives in the device words (reset() moves it there without telling the
+            # host) and fishing_v4_params_* takes it from the struct -- read it back for this call (which waits for the
+            # stream anyway: it needs the step count)
+            cp = _capi.FishingParams.from_buffer_copy(cp)
+            cp.v4_origin_step, cp.v4_origin_counter = self._host_origin()
         with torch.cuda.device(self.device):
             rc = getattr(self._lib, "fishing_v4_params_" + self._suffix)(
-                self._c_params(), self.num_envs, self.env_offset, self._t.data_ptr(),
+                cp, self.num_envs, self.env_offset, self._t.data_ptr(),
                 self._stamp.data_ptr() if self._stamp is not None else None, K.data_ptr(), r.data_ptr(),
                 self._seed, self._current_step_count(), self._stream())
         _capi.check(rc, "fishing_v4_params")
@@ -677,19 +683,18 @@ class BaseFishingEnv(_gym_env_base()):
         return self
 
     def _host_origin(self):
-        """The origin as host integers.  In graph-replay mode reset() moves it on the device only; the host's copy is read
-        back here (state_dict(): one wait for the stream)."""
-        if self._origin_stale and self._counter is not None:
+        """The origin as host integers.  In graph-replay mode the device words are the truth -- reset() moves the origin there
+        without a host read, and a replayed graph that contains a reset() moves it without the host taking part at all -- so
+        it is read back here, every time (state_dict(), env.K / env.r: calls that wait for the stream anyway)."""
+        if self._counter is not None:
             words = self._counter.tolist()
             self._origin = (int(words[1]), int(words[2]))
-        self._origin_stale = False
         return self._origin
 
     def _set_origin(self, step_count, reset_count):
         """(step count, reset counter) of the reset() of ALL envs that dates every running episode; mirrored into the
         device-resident counter words in graph-replay mode (two fills on the current stream)."""
         self._origin = (int(step_count), int(reset_count))
-        self._origin_stale = False
         if self._counter is not None:
             self._counter[1].fill_(self._origin[0])
             self._counter[2].fill_(self._origin[1])
@@ -713,10 +718,9 @@ class BaseFishingEnv(_gym_env_base()):
             if self._counter is not None:
                 # graph-replay mode: the origin is copied device word to device word on the current stream -- no host read of
                 # the counter, so reset() neither waits for the GPU on the launch-bound path nor breaks a caller's stream
-                # capture.  The host's copy of the origin is refreshed on demand (_host_origin).
+                # capture.  The host's copy of the origin is read back on demand (_host_origin).
                 self._counter[1:2].copy_(self._counter[0:1])
                 self._counter[2].fill_(self._reset_count)
-                self._origin_stale = True
             else:
                 self._set_origin(self._step_count, self._reset_count)
         with torch.cuda.device(self.device):

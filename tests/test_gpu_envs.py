@@ -614,8 +614,8 @@ def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
             eager.reset()
             assert eager._derived and graphed._derived
             # (in graph-replay mode reset() moves the origin on the device; the host's copy is read back on demand)
-            assert graphed._origin_stale and graphed._counter.tolist() == [graphed._step_count, *graphed._host_origin()]
-            assert graphed._host_origin() == eager._host_origin() and not graphed._origin_stale
+            assert graphed._counter.tolist() == [graphed._step_count, *graphed._host_origin()]
+            assert graphed._host_origin() == eager._host_origin()
             assert torch.equal(graphed.K, eager.K)
     # a checkpoint of the graph-mode env resumes in an env that never saw the capture
     sd = graphed.state_dict()
@@ -761,7 +761,7 @@ def test_reset_in_graph_replay_mode_is_capturable_and_never_reads_the_counter_ba
     with torch.cuda.graph(graph):
         graphed.reset()                     # a host read of the device counter would be a synchronisation: illegal in a capture
         graphed.step_many(acts, 3)
-    assert graphed._origin_stale and graphed._derived
+    assert graphed._derived
     for rnd in range(3):
         graph.replay()
         eager._reset_count = rc             # (the captured reset froze its reset counter: every replay redraws under it)
