@@ -132,6 +132,30 @@ def self_launch(args):
 
 
 # --------------------------------------------------------------------------------------- CPU baselines
+def host_cores():
+    """(cores this process can actually run on, what the box reports): os.cpu_count() is the machine's logical CPU count; the
+    container may be pinned to fewer (sched affinity) or granted a CPU-time quota worth fewer (cgroup v2 cpu.max, v1 cfs
+    quota) -- a one-GPU box of this pool reports 256 CPUs with a 16-core quota, and 256 workers on a 16-core share measure
+    their own start-up contention, not the host.  "All host cores" = min of the three."""
+    info = {"os_cpu_count": os.cpu_count(),
+            "sched_affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_cpu_quota_cores": None}
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        info["cgroup_cpu_quota_cores"] = None if q == "max" else float(q) / float(period)
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            info["cgroup_cpu_quota_cores"] = None if q <= 0 else q / period
+        except Exception:  # noqa: BLE001
+            pass
+    limits = [v for v in (info["os_cpu_count"], info["sched_affinity_cpus"]) if v]
+    if info["cgroup_cpu_quota_cores"]:
+        limits.append(max(1, int(info["cgroup_cpu_quota_cores"] + 0.5)))
+    return max(1, min(limits) if limits else 1), info
+
+
 def cpu_baseline(seconds, cfg_name):
     """Reference-equivalent scalar Python port (oracle/scalar_env.py), one core, bounded sample; beside it the same
     port on every core, the NumPy-vectorised (N,) restatement and the plain-C port."""
@@ -143,7 +167,7 @@ def cpu_baseline(seconds, cfg_name):
     rate, _ = time_random_rollout(scalar_id, 20_000, seed=0, **skw)      # calibrate
     n = int(max(50_000, min(rate * seconds, 5_000_000)))
     rate, _ = time_random_rollout(scalar_id, n, seed=1, **skw)
-    out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_os_cpu_count": os.cpu_count(),
+    out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cores": host_cores()[1],
            "sample": "oracle/scalar_env.py (per-env NumPy step(): the reference's arithmetic with its five helper calls and "
                      "the isinstance test inlined -- leaner than the reference it stands for): "
                      "%d env-steps of %s sigma=%g, random policy, reset on done, 1 core" % (n, scalar_id, skw["sigma"]),
@@ -153,12 +177,12 @@ def cpu_baseline(seconds, cfg_name):
     try:    # the same Python port on every host core (os.cpu_count() workers, the count reported);
         # independent `python -c` workers: nothing here depends on how this file was started.  Every worker imports first
         # and then waits for one common start time, so the workers really run side by side (a box whose cgroup grants fewer
-        # cores than os.cpu_count() shows -- 256 vs a 16-core share on the round-5 boxes -- time-slices them): `value` is the
-        # aggregate, all env-steps / (last finish - common start); the sum of the workers' own rates is kept beside it.
-        # Bounded: ~2 n env-steps in total, whatever the core count.
-        procs = max(1, os.cpu_count() or 1)
+        # cores than os.cpu_count() shows -- 256 vs a 16-core quota on the round-5 boxes -- gets one worker per USABLE core,
+        # host_cores(), and says so): `value` is the aggregate, all env-steps / (last finish - common start); the sum of the
+        # workers' own rates is kept beside it.  Bounded: ~2 n env-steps in total, whatever the core count.
+        procs, cores_info = host_cores()
         per = max(4_000, (2 * n) // procs)
-        t_go = time.time() + 1.5 + 0.012 * procs
+        t_go = time.time() + 1.5 + 0.05 * procs
         code = ("import sys, time; sys.path.insert(0, %r); from oracle.scalar_env import time_random_rollout\n"
                 "while time.time() < %r: time.sleep(0.0005)\n"
                 "t0 = time.time(); r = time_random_rollout(%r, %d, seed=int(sys.argv[1]), sigma=%r)[0]; t1 = time.time()\n"
@@ -169,21 +193,12 @@ def cpu_baseline(seconds, cfg_name):
         if all(k.returncode == 0 for k in kids):
             late = sum(1 for r in rows if r[1] > t_go + 0.05)
             wall = max(r[2] for r in rows) - min(r[1] for r in rows)
-            quota = None
-            try:        # cgroup v2 CPU quota of this container, in cores (what "all host cores" can actually deliver)
-                q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-                quota = None if q == "max" else float(q) / float(period)
-            except Exception:  # noqa: BLE001
-                pass
-            out["python_port_all_cores"] = {"value": procs * per / wall, "unit": "env-steps/s", "cores": procs,
-                                            "os_cpu_count": os.cpu_count(),
-                                            "sched_affinity_cpus": (len(os.sched_getaffinity(0))
-                                                                    if hasattr(os, "sched_getaffinity") else None),
-                                            "cgroup_cpu_quota_cores": quota,
-                                            "sum_of_worker_rates": sum(r[0] for r in rows), "workers_started_late": late,
-                                            "sample": "%d concurrent processes (one per os.cpu_count() core) x %d env-steps "
-                                                      "each from one common start time; all env-steps / (last finish - "
-                                                      "first start)" % (procs, per)}
+            out["python_port_all_cores"] = dict({"value": procs * per / wall, "unit": "env-steps/s", "cores": procs}, **cores_info,
+                                                sum_of_worker_rates=sum(r[0] for r in rows), workers_started_late=late,
+                                                sample="%d concurrent processes -- one per core this container can run on: "
+                                                       "min(os.cpu_count(), sched affinity, cgroup CPU quota) -- x %d env-steps "
+                                                       "each from one common start time; all env-steps / (last finish - first "
+                                                       "start)" % (procs, per))
     except Exception as e:  # noqa: BLE001
         out["python_port_all_cores_error"] = repr(e)[:200]
     try:    # the NumPy-vectorised (N,) restatement, one process
@@ -204,7 +219,7 @@ def cpu_baseline(seconds, cfg_name):
     try:    # stronger CPU figure for context: the plain-C oracle over all host cores
         from oracle import c_oracle
         model = {"v0": 0, "v1": 1, "v2": 2, "v4": 1}[cfg_name]
-        threads = min(os.cpu_count() or 1, 64)
+        threads = host_cores()[0]
         c_oracle.rollout_random_f32(model, 1 << 16, 8, threads=threads)             # warm the thread pool
         nn, T = 1 << 20, 32
         t0 = time.perf_counter()

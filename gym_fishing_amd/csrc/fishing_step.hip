@@ -383,8 +383,15 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 // of each 64-byte line per instruction): a copy over the same streams takes 23.5 instead of 27.2 us at N = 2^22
 // (profiles/r02_f64_access_shape.jsonl).  A workgroup is 1024 / E threads on one 1024-env tile; the lane pair that shares
 // an env quad computes the quad's Philox block twice and keeps one Box-Muller pair each.
+// Experiment knobs (product: 1024-env tiles, E = 4 in float32).  -DFISHING_X_TILE_ENVS=512 / 2048 gives every lean kernel
+// 128- / 512-thread workgroups at E = 4; -DFISHING_X_V4_E2 sends fishing-v4's float32 config-5 request to two envs per thread
+// (512-thread workgroups on a 1024-env tile).  Measured on the fishing-v4 kernel itself at its config-5 shard, N = 2^21:
+// profiles/r05_v4_shapes.jsonl (nothing adopted: DESIGN.md section 5).  Batches of a multiple of the tile, no padded tiles.
+#ifndef FISHING_X_TILE_ENVS
+#define FISHING_X_TILE_ENVS 1024
+#endif
 template <typename T, int MODEL, int F, int E = 4>
-__global__ void __launch_bounds__(1024 / E) FISHING_LEAN_ATTRS
+__global__ void __launch_bounds__(FISHING_X_TILE_ENVS / E) FISHING_LEAN_ATTRS
 step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p, T* const ep_return_p, const int64_t n_live_p,
                  const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_t ntiles, const uint64_t env_offset,
                  const uint64_t seed, const uint64_t step_counter_arg) {
@@ -409,9 +416,11 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     static_assert(!(F & feat::STAMP) || (kOpt && kPerEnv && (F & feat::DERIVED)), "STAMP: fishing-v4's derived catch-all");
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
     static_assert((F & feat::ONE) != 0, "every lean form is a one-tile form: a workgroup of 1024 / E threads per 1024-env tile");
+#ifndef FISHING_X_V4_E2
     static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
-    constexpr int kThreads = 1024 / E;
-    constexpr int kTileEnvs = 1024;
+#endif
+    constexpr int kThreads = FISHING_X_TILE_ENVS / E;
+    constexpr int kTileEnvs = FISHING_X_TILE_ENVS;
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || ep_return_p != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -660,7 +669,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         bool stepped = false;
         if constexpr (kMixed) {
             if (!SIGARR) {      // wave-uniform: regroup the wave's envs by growth function (fishing_common.h: zoo_draw_regrouped)
-                __shared__ ZooSlot<T> win[4 * kZooWindowSlots];
+                __shared__ ZooSlot<T> win[(kThreads / kWave) * kZooWindowSlots];     // one window per wave
                 T xh[E], hv[E], xn[E];
                 int kk[E];
 #pragma unroll
@@ -971,7 +980,7 @@ int lean_launch(const LeanCall<T>& c) {
 #else
     constexpr size_t x_lds = 0;
 #endif
-    return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)nb, 1024 / E, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
+    return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)nb, FISHING_X_TILE_ENVS / E, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
                              c.a.n_live, c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
 }
 
@@ -1026,7 +1035,11 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
             FISHING_LEAN_CASE(P | DERIVED);
             FISHING_LEAN_CASE(P | DERIVED | RET);
             FISHING_LEAN_CASE(P | DERIVED | SIGARR);
+#ifdef FISHING_X_V4_E2
+            case (P | DERIVED | SIGARR | RET): return lean_launch<T, MODEL, (P | DERIVED | SIGARR | RET) | ONE, 2>(c);
+#else
             FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET);
+#endif
             default: break;
         }
     }
@@ -1089,7 +1102,7 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     const int noise = noise_mode(p, b);
     const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
     const bool derived = p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED);
-    const int64_t tile = 256 * kEnvsPerThread;
+    const int64_t tile = FISHING_X_TILE_ENVS;       // (256 * kEnvsPerThread)
     // (under FISHING_FLAG_PADDED_TILES also batches below one tile: 3.1 instead of 5.3 us per step at N = 1000)
     const bool pad_ok = (p->flags & FISHING_FLAG_PADDED_TILES) != 0 && (n % kEnvsPerThread) == 0;
     // The lean kernel runs a workgroup per tile (step_dispatch hands it at most kPartialSlots tiles); an explicit launch

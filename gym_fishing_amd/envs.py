@@ -31,6 +31,7 @@ from ._capi import (FLAG_AUTO_RESET, FLAG_PADDED_TILES, FLAG_T_U8, FLAG_V4_DERIV
                     MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11, POLICY_CONSTANT, POLICY_ESCAPEMENT,
                     POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
 from .spaces import is_discrete, space_classes
+from .v4_params import V4ParameterModes
 
 POLICIES = {"random": POLICY_RANDOM, "constant": POLICY_CONSTANT, "escapement": POLICY_ESCAPEMENT,
             "msy": POLICY_MSY}
@@ -98,7 +99,7 @@ STATE_FORMAT = 2
 V4_PARAM_STREAM = "philox2x32-10/env"
 
 
-class BaseFishingEnv(_gym_env_base()):
+class BaseFishingEnv(V4ParameterModes, _gym_env_base()):
     """base_fishing_env.py:16-164, vectorised.  See the module docstring."""
 
     metadata = {"render.modes": ["human"]}
@@ -216,26 +217,8 @@ class BaseFishingEnv(_gym_env_base()):
             self._sigma_scalar = float(self._sigma_arr[0])
         else:
             self._sigma_scalar = float(sigma)
-        # fishing-v4 on the Philox streams keeps NO r / K arrays: every kernel re-derives an env's (K, r) from the
-        # block that drew them, which the env's year counter identifies (fishing_common.h: derive_model_error) --
-        # 8 B/env-step of reads and about as much of redraw writes less.  A masked reset() keeps the mode: the envs it
-        # resets get a per-env origin stamp (4 B read + 4 B written per env-step until the next reset of all envs).  Arrays
-        # come back (once, through fishing_v4_params_*) when something makes the parameters underivable: env.K = ... /
-        # env.r = ..., seed(), an outside write to years_passed; the next full reset() returns to the derived mode.
-        self._derived_capable = (self._per_env and not self._np_rng and not self._scalar and not self.compact
-                                 and (derived_params is None or bool(derived_params)))
-        if derived_params and not self._derived_capable:
-            raise ValueError("derived_params=True needs fishing-v4 with num_envs, rng='philox' and the int32 year counter")
-        self._derived = self._derived_capable
-        self._origin = (0, 0)            # (step count, reset counter) of the last reset() of all envs
-        self._K_store = self._r_store = None      # (see _param_store)
-        # fishing-v4 derived: per-env episode origins of envs reset one by one (FishingBuffers.v4_stamp; allocated by the
-        # first masked reset(), dropped from the launches again by the next reset of every env, never freed)
-        self._stamp = self._stamp_store = None
-        if self._per_env and not self._derived:
-            self._K_arr, self._r_arr = self._param_store()
-            self._r_arr.fill_(float(params["r"]))
-            self._K_arr.fill_(float(params["K"]))
+        # fishing-v4: which parameter mode the env starts in (v4_params.py: derived from the Philox streams / stored arrays)
+        self._init_v4_modes(derived_params)
         if self.MODEL == MODEL_V10:      # the drifting growth rate is per-env state (growth_models.py:151)
             self._r_arr = self._per_env_buffer(dtype, float(params["r"]))
         self._model_idx = self._per_env_buffer(torch.int32) if self.MODEL == MODEL_V11 else None
@@ -346,25 +329,6 @@ class BaseFishingEnv(_gym_env_base()):
                else torch.full((self._cap,), fill, dtype=dtype, device=self.device))
         return buf[:self.num_envs]
 
-    def _derive_params(self, out=None):
-        """(K, r) tensors of a fishing-v4 env in the derived mode, materialised by fishing_v4_params_* (into the pair
-        `out` when given: callers that ask every step reuse one pair instead of allocating two streams per call)."""
-        K, r = out if out is not None else (self._per_env_buffer(self.dtype), self._per_env_buffer(self.dtype))
-        cp = self._c_params()
-        if self._counter is not None:
-            # graph-replay mode: the episode origin lives in the device words (reset() moves it there without telling the
-            # host) and fishing_v4_params_* takes it from the struct -- read it back for this call (which waits for the
-            # stream anyway: it needs the step count)
-            cp = _capi.FishingParams.from_buffer_copy(cp)
-            cp.v4_origin_step, cp.v4_origin_counter = self._host_origin()
-        with torch.cuda.device(self.device):
-            rc = getattr(self._lib, "fishing_v4_params_" + self._suffix)(
-                cp, self.num_envs, self.env_offset, self._t.data_ptr(),
-                self._stamp.data_ptr() if self._stamp is not None else None, K.data_ptr(), r.data_ptr(),
-                self._seed, self._current_step_count(), self._stream())
-        _capi.check(rc, "fishing_v4_params")
-        return K, r
-
     def _current_step_count(self):
         """How many step() calls this env has made.  In graph-replay mode the device-resident counter is the truth -- a
         replayed hipGraph (GraphedSteps, or a caller's own torch.cuda.CUDAGraph) advances only that -- so the host's
@@ -373,30 +337,6 @@ class BaseFishingEnv(_gym_env_base()):
         if self._counter is not None:
             self._step_count = int(self._counter[0].item())
         return self._step_count
-
-    def _param_store(self):
-        """The (K, r) arrays of a fishing-v4 env, allocated once and kept for the env's lifetime: a launch captured in a
-        hipGraph while the env ran on stored arrays keeps reading -- and, on every auto-reset, WRITING -- these addresses,
-        so they must never go back to the allocator while the env lives, whatever mode it is in by then."""
-        if self._K_store is None:
-            self._K_store, self._r_store = self._per_env_buffer(self.dtype), self._per_env_buffer(self.dtype)
-        return self._K_store, self._r_store
-
-    def _stamp_buffer(self):
-        """fishing-v4's origin stamps (int32, zeroed): one allocation for the env's lifetime, like _param_store."""
-        if self._stamp_store is None:
-            self._stamp_store = self._per_env_buffer(torch.int32)
-        else:
-            self._stamp_store.zero_()
-        return self._stamp_store
-
-    def _leave_derived_mode(self):
-        """Store the parameters in force and continue with r / K arrays (until the next full reset())."""
-        if self._derived:
-            self._K_arr, self._r_arr = self._derive_params(self._param_store())
-            self._derived = False
-            self._stamp = None              # (origin stamps belong to the derived mode)
-            self._cbuf = None
 
     def launch_signature(self):
         """Everything a captured launch has frozen: the parameter struct's source values, fishing-v4's parameter mode and
@@ -410,16 +350,6 @@ class BaseFishingEnv(_gym_env_base()):
                 tuple(ptr(t) for t in (self._obs, self._t, self._reward, self._done, self._done_bits, self._r_arr, self._K_arr,
                                        self._sigma_arr, self._terminal_obs, self._ep_return, self._partials, self._model_idx,
                                        self._counter, self._stamp)))
-
-    def _K_view(self, out=None):
-        if self._derived:
-            return self._derive_params(out)[0]
-        return float(self._K_arr[0]) if self._scalar else self._K_arr
-
-    def _r_view(self):
-        if self._derived:
-            return self._derive_params()[1]
-        return float(self._r_arr[0]) if self._scalar else self._r_arr
 
     def _set_param(self, name, v):
         if self._per_env:
@@ -594,22 +524,8 @@ class BaseFishingEnv(_gym_env_base()):
         with a warning -- the run continues exactly until the first redraw, which then follows this library's stream.  Envs
         that never use that stream (rng="numpy": the scalar protocol's default) load any fishing-v4 state."""
         # everything that can refuse the state is checked BEFORE the first field changes: a failed load leaves the env as it was
-        if self._per_env and not self._np_rng and sd.get("v4_param_stream") != V4_PARAM_STREAM:
-            if strict or sd.get("v4_derived", False):
-                raise ValueError("fishing-v4 state was written with parameter stream %r, this library draws %r: it cannot "
-                                 "resume bit-for-bit%s" % (sd.get("v4_param_stream"), V4_PARAM_STREAM,
-                                                           "" if sd.get("v4_derived", False) else " (strict=False loads the stored (K, r))"))
-            import warnings
-            warnings.warn("fishing-v4 state written with parameter stream %r: the (K, r) in force are loaded, redraws will "
-                          "follow %r" % (sd.get("v4_param_stream"), V4_PARAM_STREAM))
-        if self._per_env and sd.get("v4_derived", False) and not self._derived_capable:
-            raise ValueError("state was saved in the derived-parameter mode, which this env cannot run")
+        self._check_v4_state(sd, strict, V4_PARAM_STREAM)
         v4_arrays = self._per_env and not sd.get("v4_derived", False)
-        if "_stamp" in sd:      # origin stamps exist only in fishing-v4's derived mode, one per env
-            if not (self._per_env and sd.get("v4_derived", False)):
-                raise ValueError("state has _stamp (fishing-v4 origin stamps) but was not saved in the derived-parameter mode")
-            if sd["_stamp"].numel() != self.num_envs:
-                raise ValueError("state's _stamp has %d elements, this env's %d" % (sd["_stamp"].numel(), self.num_envs))
         for k in self._STATE_TENSORS:
             if k in sd and getattr(self, k) is None and k not in ("_counter", "_stamp") and not (k in ("_r_arr", "_K_arr") and v4_arrays):
                 raise ValueError("state has %s but this env was built without it" % k)
@@ -622,17 +538,7 @@ class BaseFishingEnv(_gym_env_base()):
                     raise ValueError("state's %s has %d elements, this env's %d" % (k, got, have))
         if self._host_mapped:
             torch.cuda.current_stream(self.device).synchronize()
-        if self._per_env:                       # fishing-v4: same parameter mode as the saved env
-            if sd.get("v4_derived", False):
-                self._derived, self._K_arr, self._r_arr = True, None, None
-                self._stamp = self._stamp_buffer() if "_stamp" in sd else None
-            elif self._derived:
-                self._derived = False
-                self._K_arr, self._r_arr = self._param_store()
-            if not self._derived:
-                self._stamp = None
-            self._origin = tuple(sd.get("v4_origin", (0, 0)))
-            self._cbuf = None
+        self._adopt_v4_mode(sd)                 # fishing-v4: same parameter mode as the saved env
         for k in self._STATE_TENSORS:
             if k in sd:
                 if getattr(self, k) is None and k == "_counter":
@@ -682,23 +588,6 @@ class BaseFishingEnv(_gym_env_base()):
             self._cbuf = None
         return self
 
-    def _host_origin(self):
-        """The origin as host integers.  In graph-replay mode the device words are the truth -- reset() moves the origin there
-        without a host read, and a replayed graph that contains a reset() moves it without the host taking part at all -- so
-        it is read back here, every time (state_dict(), env.K / env.r: calls that wait for the stream anyway)."""
-        if self._counter is not None:
-            words = self._counter.tolist()
-            self._origin = (int(words[1]), int(words[2]))
-        return self._origin
-
-    def _set_origin(self, step_count, reset_count):
-        """(step count, reset counter) of the reset() of ALL envs that dates every running episode; mirrored into the
-        device-resident counter words in graph-replay mode (two fills on the current stream)."""
-        self._origin = (int(step_count), int(reset_count))
-        if self._counter is not None:
-            self._counter[1].fill_(self._origin[0])
-            self._counter[2].fill_(self._origin[1])
-
     def reset(self, mask=None, *, seed=None, options=None):
         """base_fishing_env.py:83-91 (v4: fishing_model_error.py:41-48).  `mask` (bool[N]) resets
         a subset -- what a VecEnv wrapper without in-kernel auto-reset would call.  `seed` / `options`
@@ -708,21 +597,10 @@ class BaseFishingEnv(_gym_env_base()):
             self.seed(seed)
         m = None
         if mask is not None:
-            # envs reset at different times: in the derived mode each masked env's episode origin goes into its stamp
-            # (R 4 + W 4 per env-step from here on, until the next reset of every env) -- no r / K arrays
-            if self._derived and self._stamp is None:
-                self._stamp, self._cbuf = self._stamp_buffer(), None
+            self._begin_masked_reset()          # (fishing-v4 derived: per-env origin stamps from here on)
             m = torch.as_tensor(mask).to(device=self.device).reshape(self.num_envs).to(torch.uint8).contiguous()
-        elif self._derived_capable:         # a reset of ALL envs: its counters date every episode from here on
-            self._derived, self._K_arr, self._r_arr, self._cbuf = True, None, None, None
-            if self._counter is not None:
-                # graph-replay mode: the origin is copied device word to device word on the current stream -- no host read of
-                # the counter, so reset() neither waits for the GPU on the launch-bound path nor breaks a caller's stream
-                # capture.  The host's copy of the origin is read back on demand (_host_origin).
-                self._counter[1:2].copy_(self._counter[0:1])
-                self._counter[2].fill_(self._reset_count)
-            else:
-                self._set_origin(self._step_count, self._reset_count)
+        elif self._derived_capable:
+            self._enter_derived_mode_at_full_reset()
         with torch.cuda.device(self.device):
             rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
                                 self._c_buffers(with_outputs=False), m.data_ptr() if m is not None else None,
