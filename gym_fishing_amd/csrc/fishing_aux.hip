@@ -18,11 +18,12 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
         if (mask && !mask[i]) continue;
         T K = p.K;
         if (is_zoo_tag(MODEL) && p.model == FISHING_MODEL_V11) {
-            const uint64_t env = env_offset + (uint64_t)i;      // quad scheme of redraw_kinds
-            const Words4 w = philox_block(seed, env >> 2, reset_counter, kStreamReset);
+            const uint64_t env = env_offset + (uint64_t)i;      // quad scheme of redraw_kinds: half (env & 3) of the quad's block
+            uint32_t w0, w1;
+            model_block(seed, env >> 2, reset_counter, true, w0, w1);
             const uint32_t leg = (uint32_t)(env & 3);
-            const uint32_t word = leg == 0 ? w.w0 : leg == 1 ? w.w1 : leg == 2 ? w.w2 : w.w3;
-            b.model_idx[i] = p.kinds[action_int_from_word(word, p.n_models)];
+            const uint32_t half = leg == 0 ? (w0 & 0xFFFFu) : leg == 1 ? (w0 >> 16) : leg == 2 ? (w1 & 0xFFFFu) : (w1 >> 16);
+            b.model_idx[i] = p.kinds[model_index_from_half(half, p.n_models)];
         }
         if (MODEL == FISHING_MODEL_V4 && b.K && b.r) {      // derived mode keeps no arrays: nothing to draw here
             T r;

@@ -73,7 +73,7 @@ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32
 // `index` is the global env QUAD index (env >> 2) on the noise and policy streams -- one block
 // feeds the four envs of a thread tile: noise (w0, w1) -> Box-Muller cos / sin legs = z of envs
 // 4q, 4q+1, (w2, w3) -> z of envs 4q+2, 4q+3; policy word j -> the random action of env 4q+j --,
-// and for fishing-v11's model draw on the reset streams (redraw_kinds: word j -> env 4q + j).
+// (fishing-v11's model draw used word j of such a block for env 4q + j through round 4; now model_block below).
 // fishing-v4's (K, r) draws use a Philox2x32-10 block per ENV instead (draw_model_error).
 __device__ __forceinline__ Words4 philox_block(uint64_t seed, uint64_t index, uint64_t counter,
                                                uint32_t stream) {
@@ -1025,6 +1025,132 @@ __device__ __forceinline__ void zoo_eval_kind(ZooSlot<T>* __restrict__ win, int 
     }
 }
 
+// ---------------------------------------------------------------- fishing-v11, round 5 experiment: one division and one exp per env
+// Every growth function of the zoo is x' = max(0, pre_k(x) * exp(g_k(x, z))) in its algebraic form (above), and what differs
+// by kind is cheap: g is sigma_k z plus, for Allen and Ricker, c_k (1 - x / K_k); pre is x itself (Allen, Ricker), one
+// quotient n_k / d_k (Beverton-Holt, Myers) or a cubic minus that quotient (May).  So a lane can evaluate, for each of its
+// envs, the three (n, d) pairs and the two exponents with wave-uniform constants, SELECT by the env's kind, and run ONE
+// division and ONE exp at full lane occupancy: no LDS, no ballots, no divergent passes -- 670 -> 480 VALU and 579 -> 230 SALU
+// instructions in the float32 step kernel against the regroup-by-kind form (zoo_draw_regrouped).  Same operations on the
+// same operands as zoo_pre_g_f32 / zoo_pre_g_f64 of the env's kind: the same bits (the whole GPU suite passes on either).
+// MEASURED (profiles/r05_v11_forms.jsonl, N = 2^22, same box, alternating): float32 step 28.7 vs 29.0 us (-1 %: the step is
+// bound by its dependent chain load -> draw -> record -> redraw -> store in two rounds of waves, not by its instruction
+// count), float64 step 53.2 vs 48.6 (+9 %: five kinds' candidates in 5.3-cycle float64 instructions cost more than four
+// fifths of a pass), random-policy rollout 9.87 vs 9.42 ms (+5 %).  NOT shipped: -DFISHING_V11_FORM=1 builds it.  What IS
+// used from here: zoo_draw_select_one with the caller's sigma for the per-env-sigma path (env_step_zoo_mixed below).
+#ifndef FISHING_V11_FORM
+#define FISHING_V11_FORM 0
+#endif
+#ifndef FISHING_V11_SELECT_SERIAL
+#define FISHING_V11_SELECT_SERIAL 0
+#endif
+template <typename W>
+struct ZooSelectMath;
+template <>
+struct ZooSelectMath<float> {
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float div(float n, float d) { return div_f32(n, d); }
+    static __device__ __forceinline__ float pow(float x, float e, int ipow) { return pow_f32(x, e, ipow); }
+    static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
+};
+template <>
+struct ZooSelectMath<double> {
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ double div(double n, double d) { return div_f64(n, d); }
+    static __device__ __forceinline__ double pow(double x, double e, int ipow) { return pow_f64(x, e, ipow); }
+    static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
+};
+// `kind` in [0, FISHING_N_KINDS) (the callers map anything else to Beverton-Holt, like the regrouped form)
+template <typename T>
+__device__ __forceinline__ T zoo_draw_select_one(const int kind, const T x_in, const T z_in, const GrowthT<T> (&zoo)[FISHING_N_KINDS],
+                                                  bool& far, const bool own_sigma = false, const T sigma_env = (T)0) {
+    static_assert((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP),
+                  "the select form is the algebraic form's");
+    typedef T W;
+    typedef ZooSelectMath<W> M;
+    const GrowthT<T>& PA = zoo[FISHING_KIND_ALLEN];
+    const GrowthT<T>& PB = zoo[FISHING_KIND_BEVERTON_HOLT];
+    const GrowthT<T>& PM = zoo[FISHING_KIND_MYERS];
+    const GrowthT<T>& PY = zoo[FISHING_KIND_MAY];
+    const GrowthT<T>& PR = zoo[FISHING_KIND_RICKER];
+    const bool isA = kind == FISHING_KIND_ALLEN, isM = kind == FISHING_KIND_MYERS, isY = kind == FISHING_KIND_MAY,
+               isR = kind == FISHING_KIND_RICKER;
+    const W x = (W)x_in;
+    // sigma z of the env's own growth function
+    // (`own_sigma`, compile-time at every call site: the env's own noise scale from the caller's sigma array instead)
+    const W sg = own_sigma ? (W)sigma_env : (isA ? (W)PA.sigma : isM ? (W)PM.sigma : isY ? (W)PY.sigma : isR ? (W)PR.sigma : (W)PB.sigma);
+    const W sz = sg * (W)z_in;
+    // the exponent: Allen / Ricker carry their density dependence there, the others only the noise
+    const W gA = M::fma((W)PA.gc, M::fma(-x, (W)PA.invK, (W)1), sz);
+    const W gR = M::fma((W)PR.r, M::fma(-x, (W)PR.invK, (W)1), sz);
+    const W g = isA ? gA : (isR ? gR : sz);
+    // the quotient: Beverton-Holt A x / (1 + x / B), Myers A x^theta / (1 + x^theta / M), May's a x^q / (x^q + b^q)
+    const W xc = (x < (W)0) ? (W)0 : x;
+    const W xt = M::pow(x, (W)PM.theta, PM.ipow);
+    const W xq = M::pow(x, (W)PY.q, PY.ipow);
+    const W nB = (W)PB.A * xc, dB = M::fma(xc, (W)PB.invB, (W)1);
+    const W nM = (W)PM.A * xt, dM = M::fma(xt, (W)PM.invM, (W)1);
+    const W nY = (W)PY.a * xq, dY = xq + (W)PY.bq;
+    const W n = isM ? nM : (isY ? nY : nB);
+    const W d = isM ? dM : (isY ? dY : dB);
+    const W q = M::div(n, d);
+    // May: exp(log(exp_mu)), the log of a negative number being NaN
+    W emu;
+    if constexpr (sizeof(T) == 4) emu = M::fma(x * (W)PY.r, M::fma(-x, (W)PY.invM, (W)1), x) - q;
+    else emu = (x + x * (W)PY.r * ((W)1 - x * (W)PY.invM)) - q;
+    const W preY = (emu < (W)0) ? M::nan() : emu;
+    const W pre = (isA || isR) ? x : (isY ? preY : q);
+    if constexpr (sizeof(T) == 4) {
+        return (T)zoo_finish_f32(pre, g);
+    } else {
+        const double res = pre * exp_f64(g);
+        const double inf = __builtin_huge_val();
+        // (zoo_draw_f64: where the reference's own round trip loses more than the parity bar, the caller follows it)
+        far = (x > 0.0 && x < 0x1p-30) || (x > 0x1p30 && x < inf) || (res > 0.0 && res < 0x1p-92) || (res > 0x1p92 && res < inf);
+        return (res > 0.0) ? res : ((res != res) ? res : 0.0);
+    }
+}
+
+// the four envs of a lane; float64: the far stocks / far results of the whole tile go through ONE copy of the reference's
+// round trip (a loop over the lane's envs and over the kinds that is deliberately not unrolled: it is the cold path, and four
+// times five inlined round trips would cost the fused kernels -- which hold the envs' state across steps -- their registers)
+template <typename T>
+__device__ __forceinline__ void zoo_draw_select_tile(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
+                                                     const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[4]) {
+    bool far[4] = {false, false, false, false};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bool f = false;
+        const T v = zoo_draw_select_one<T>(kind[j] >= 0 ? kind[j] : FISHING_KIND_BEVERTON_HOLT, x[j], z[j], zoo, f);
+        out[j] = (kind[j] >= 0) ? v : out[j];
+        far[j] = f && kind[j] >= 0;
+        // float64: one env after the other -- interleaved, the four evaluations' temporaries (register pairs) push the fused
+        // kernels into scratch; float32 keeps the interleaving's ILP
+        if constexpr (sizeof(T) == 8 || FISHING_V11_SELECT_SERIAL) __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (__builtin_expect(far[0] | far[1] | far[2] | far[3], 0)) {
+            for (int j = 0; j < 4; ++j) {
+                asm volatile("" : "+s"(j));         // (keeps the loop a loop)
+                const bool fj = j == 0 ? far[0] : j == 1 ? far[1] : j == 2 ? far[2] : far[3];
+                if (!fj) continue;
+                const double xj = j == 0 ? x[0] : j == 1 ? x[1] : j == 2 ? x[2] : x[3];
+                const double zj = j == 0 ? z[0] : j == 1 ? z[1] : j == 2 ? z[2] : z[3];
+                const int kj = j == 0 ? kind[0] : j == 1 ? kind[1] : j == 2 ? kind[2] : kind[3];
+                double r = 0.0;
+                for (int k = 0; k < FISHING_N_KINDS; ++k) {
+                    asm volatile("" : "+s"(k));
+                    if (kj == k) r = zoo_draw_round_trip<double, MathLibF64, -1, false>(k, xj, zj, zoo[k]);
+                }
+                out[0] = j == 0 ? r : out[0];
+                out[1] = j == 1 ? r : out[1];
+                out[2] = j == 2 ? r : out[2];
+                out[3] = j == 3 ? r : out[3];
+            }
+        }
+    }
+}
+
 // (Round 4 also measured a branch-free "select" form for the float32 layout -- every lane evaluates the (pre, g) of all
 // kinds present in its wave for its own four envs and selects, no LDS: the same 24.2 us per step at N = 2^22 as this
 // regroup, 13 % slower in the VALU-bound random-policy rollout, since it evaluates five functions per env instead of
@@ -1033,6 +1159,11 @@ template <typename T>
 __device__ __forceinline__ void zoo_draw_regrouped(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
                                                    const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[4],
                                                    ZooSlot<T>* __restrict__ win, int lane) {
+    if constexpr (FISHING_V11_FORM == 1 && ((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP))) {
+        // round 5: per lane, one division and one exp per env, selected by kind (zoo_draw_select_tile); `win` stays unused
+        zoo_draw_select_tile<T>(kind, x, z, zoo, out);
+        return;
+    }
     int slot[4] = {-1, -1, -1, -1};
     int begin[FISHING_N_KINDS], count[FISHING_N_KINDS];
     int next = 0;
@@ -1126,6 +1257,44 @@ __device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int
     done = (t_next > Tmax) || (x <= (T)0);
 }
 
+// fishing-v11 with a per-env noise scale (the caller's sigma array): one env, its growth function chosen per lane.  The select
+// form with sigma_env in place of the kinds' own sigma (same bits as env_step_zoo<T, -1> on a copy of zoo[kind] with that sigma
+// -- what rounds 2-4 did, and what the other builds still do: a per-lane index into the kernel-argument array, which costs
+// the float64 fused kernel 760 bytes of scratch once the algebraic form reads every field of the set).
+template <typename T>
+__device__ __forceinline__ void env_step_zoo_mixed(T obs, int32_t t, T quota, T z, int kind, const GrowthT<T> (&zoo)[FISHING_N_KINDS],
+                                                   T sigma_env, T K_obs, int32_t Tmax, T& obs_next, T& reward, bool& done,
+                                                   int32_t& t_next, const DivK& dk = DivK{false, 0.0f, 0.0}) {
+    const int kk = (kind >= 0 && kind < FISHING_N_KINDS) ? kind : FISHING_KIND_BEVERTON_HOLT;
+    if constexpr ((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP)) {
+        T x = (obs + (T)1) * K_obs;
+        const T h = (quota < x) ? quota : x;
+        x = stock_after_harvest<T>(x, h);
+        bool far = false;
+        T xn = zoo_draw_select_one<T>(kk, x, z, zoo, far, true, sigma_env);
+        if constexpr (sizeof(T) == 8) {
+            if (__builtin_expect(far, 0)) {         // (zoo_draw_select_tile: the reference's own round trip, one copy, a real loop)
+                for (int k = 0; k < FISHING_N_KINDS; ++k) {
+                    asm volatile("" : "+s"(k));
+                    if (kk == k) {
+                        GrowthT<T> P = zoo[k];
+                        P.sigma = sigma_env;
+                        xn = zoo_draw_round_trip<double, MathLibF64, -1, false>(k, x, z, P);
+                    }
+                }
+            }
+        }
+        obs_next = div_K<T>(xn, K_obs, dk) - (T)1;
+        reward = ((T)0 > h) ? (T)0 : h;
+        t_next = t + 1;
+        done = (t_next > Tmax) || (xn <= (T)0);
+    } else {
+        GrowthT<T> P = zoo[kk];
+        P.sigma = sigma_env;
+        env_step_zoo<T, -1, false>(obs, t, quota, z, kind, P, K_obs, Tmax, obs_next, reward, done, t_next, dk);
+    }
+}
+
 // population_draw(): base_fishing_env.py:121-133 (logistic), fishing_tipping_env.py:24-35
 // (tipping point; the noise sits inside the exponent, scaled by x -- quirk B9).
 template <typename T, int MODEL>
@@ -1169,17 +1338,46 @@ template <>
 __device__ __forceinline__ double clip_param<double>(double v) {
     return __builtin_fmin(__builtin_fmax(v, 0.0), 1e6);
 }
-// fishing-v11 (growth_models.py:187,200): a new growth function for the finished envs of one thread's
-// 4-env tile.  One Philox block per env quad on the reset streams, word j -> env 4q + j.  Returns
-// whether any kind was redrawn.
+// fishing-v11 (growth_models.py:187,200: np.random.choice(models)): a new growth function for the finished envs of one thread's
+// 4-env tile.  Round 5: ONE Philox2x32-10 block per env QUAD on the reset streams -- half the multiplies of the Philox4x32
+// block rounds 1-4 spent here, on a workload where nearly every quad holds a finished env every step (random policy: mean
+// episode length 1.47) -- and four 16-bit draws from its two words: env 4q + j takes half j (w0 low, w0 high, w1 low, w1 high),
+// index = (half * n_models) >> 16.  Non-uniformity of np.random.choice: the 65536 halves split over n_models buckets whose
+// sizes differ by at most one -> every model's probability is within 2^-16 = 1.5e-5 (absolute) of 1 / n_models (n = 5:
+// 13108 / 13107 x 4).  Block: c0 = quad[31:0], c1 = counter[30:0] | reset-stream bit 31 (^ quad[63:32] * 0xC2B2AE35), key =
+// fishing-v4's param_key ^ a tag ^ counter[62:31] * 0x9E3779B1 -- injective in (quad, counter, stream) while quad < 2^32
+// (2^34 envs) and counter < 2^31, like param_block; mirrored in oracle/fishing_oracle.py: model_words / model_draw.
+#ifndef FISHING_V11_REDRAW_4X32
+#define FISHING_V11_REDRAW_4X32 0
+#endif
+constexpr uint32_t kModelKeyTag = 0x4D4F444Cu;
+__device__ __forceinline__ void model_block(uint64_t seed, uint64_t quad, uint64_t counter, bool reset_stream, uint32_t& w0, uint32_t& w1) {
+    // (the key -- and with it the ten round keys -- stays wave-uniform, in SGPRs: the quad's high part, zero below 2^34 envs,
+    // perturbs the counter word instead of the key)
+    const uint32_t c1 = (((uint32_t)counter & ~kParamResetBit) | (reset_stream ? kParamResetBit : 0u)) ^ ((uint32_t)(quad >> 32) * 0xC2B2AE35u);
+    const uint32_t key = param_key(seed) ^ kModelKeyTag ^ ((uint32_t)(counter >> 31) * 0x9E3779B1u);
+    philox2x32_10((uint32_t)quad, c1, key, w0, w1);
+}
+__device__ __forceinline__ int32_t model_index_from_half(uint32_t half16, int32_t n_models) {
+    return (int32_t)((half16 * (uint32_t)n_models) >> 16);
+}
+// Returns whether any kind was redrawn.
 __device__ __forceinline__ bool redraw_kinds(uint64_t seed, uint64_t base, uint64_t counter, uint32_t stream,
                                              const int32_t (&kinds)[FISHING_N_KINDS], int32_t n_models,
                                              const bool (&fin)[4], int32_t (&kind)[4]) {
     if (!(fin[0] | fin[1] | fin[2] | fin[3])) return false;
+#if FISHING_V11_REDRAW_4X32      // rounds 1-4, for A/B timing only (the oracle mirrors the 2x32 scheme)
     const Words4 w = philox_block(seed, base >> 2, counter, stream);
     const uint32_t ww[4] = {w.w0, w.w1, w.w2, w.w3};
 #pragma unroll
     for (int j = 0; j < 4; ++j) kind[j] = fin[j] ? kinds[action_int_from_word(ww[j], n_models)] : kind[j];
+#else
+    uint32_t w0, w1;
+    model_block(seed, base >> 2, counter, stream == kStreamReset, w0, w1);
+    const uint32_t hh[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kind[j] = fin[j] ? kinds[model_index_from_half(hh[j], n_models)] : kind[j];
+#endif
     return true;
 }
 

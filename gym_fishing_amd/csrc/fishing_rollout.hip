@@ -53,7 +53,9 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
     constexpr bool kZoo = is_zoo_tag(MODEL);
     constexpr int kZooKind = (kZoo && MODEL != kModelZooMixed) ? (MODEL - kModelZoo) : -1;
     constexpr bool zoo_mixed = (MODEL == kModelZooMixed);
-    const bool zoo_drift = kZoo && p.model == FISHING_MODEL_V10;
+    // (fishing-v10 is Beverton-Holt: only that tag -- and the general kernel's run-time-kind tag -- can see a drifting r)
+    constexpr bool kMayDrift = MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT || MODEL == kModelZooRT;
+    const bool zoo_drift = kMayDrift && p.model == FISHING_MODEL_V10;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
     const int64_t ntiles = (n + tile_envs - 1) / tile_envs;
@@ -519,7 +521,8 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
     const bool derived = kPerEnv && a.derived != 0;
     uint64_t origin_step = a.origin_step, origin_counter = a.origin_counter;
     if (derived) device_origin(a.counter, origin_step, origin_counter);
-    const bool drift = kZoo && a.drift != 0;
+    constexpr bool kMayDrift = MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT || MODEL == kModelZooRT;
+    const bool drift = kMayDrift && a.drift != 0;
     const bool t8 = a.t8 != 0;
     const DivK dk = RAGGED ? a.dk : (KP2 ? DivK{true, a.dk.inv_f, a.dk.inv_d} : DivK{false, 0.0f, 0.0});
     const int64_t tile_envs = (int64_t)blockDim.x * kEnvsPerThread;
@@ -693,11 +696,8 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                     }
                     fresh[j] = auto_reset || !((t[j] > a.Tmax) || ((obs[j] + (T)1) * KK[j] <= (T)0));
                     if constexpr (zoo_mixed) {          // per-env sigma: a straight per-lane switch over the growth functions
-                        const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
-                        GrowthT<T> P = ex.zoo[kk];
-                        P.sigma = sg[j];
-                        env_step_zoo<T, -1, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], a.Tmax, o2[j], rew[j], dn[j],
-                                                   t2[j]);
+                        env_step_zoo_mixed<T>(obs[j], t[j], quota, z[j], kind[j], ex.zoo, sg[j], KK[j], a.Tmax, o2[j], rew[j], dn[j],
+                                              t2[j]);
                     } else if constexpr (kZoo) {
                         GrowthT<T> P = a.growth;
                         if (a.sigma_arr) P.sigma = sg[j];

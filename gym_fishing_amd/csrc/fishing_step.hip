@@ -86,7 +86,8 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
     if (derived) device_origin(b.counter, origin_step, origin_counter);
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
     // zoo (fishing-v5..v11): wave-uniform facts about the family
-    const bool zoo_drift = kZoo && p.model == FISHING_MODEL_V10;       // r += alpha every draw
+    // (fishing-v10 is Beverton-Holt: only the run-time-kind tag of this kernel can see a drifting r -- not fishing-v11's)
+    const bool zoo_drift = kZoo && MODEL != kModelZooMixed && p.model == FISHING_MODEL_V10;       // r += alpha every draw
     const int zoo_kind = kZoo ? p.kind : FISHING_KIND_BEVERTON_HOLT;
     const GrowthT<T> zoo_base = p.growth;
 
@@ -702,11 +703,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                                                         : quota_cts<T>((T)a_f[j], KK[j]);
             if (RET && LATCH) stale[j] = was_done<T>(obs[j], t[j], KK[j], a.Tmax);
             if constexpr (kMixed) {         // per-env sigma: a straight per-lane switch over the growth functions
-                const int kk = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
-                GrowthT<T> P = ex.zoo[kk];
-                P.sigma = sg[j];
-                env_step_zoo<T, -1, false>(obs[j], t[j], quota, z[j], kind[j], P, KK[j], a.Tmax, obs_next[j], rew[j], dn[j],
-                                           t_next[j], a.dk);
+                env_step_zoo_mixed<T>(obs[j], t[j], quota, z[j], kind[j], ex.zoo, sg[j], KK[j], a.Tmax, obs_next[j], rew[j], dn[j],
+                                      t_next[j], a.dk);
             } else if constexpr (kZoo) {
                 GrowthT<T> P = a.growth;
                 if (SIGARR) P.sigma = sg[j];

@@ -325,8 +325,8 @@ int fishing_stream_synchronize(fishing_stream_t stream);
  * the Philox4x32-10 block on stream `stream_tag`, z0 / z1 = the cos / sin legs of the Box-Muller
  * pair of words (0, 1).  What the index means per stream: tags 0 (step noise) and 3 (random-policy
  * actions of the fused rollout) index by env QUAD (global env >> 2), see fishing_step_normals_f32;
- * tags 1 / 2 (reset streams) by env QUAD for fishing-v11 (word j = the model draw of env 4q + j);
- * fishing-v4's parameter draws on those tags are Philox2x32 blocks, see fishing_reset_normals_f32.
+ * the reset streams (tags 1 / 2) draw from Philox2x32-10 blocks instead: fishing-v4's (K, r) per env, see
+ * fishing_reset_normals_f32; fishing-v11's model choice per env quad (four 16-bit draws from one block).
  * Any output pointer may be NULL. */
 int fishing_noise_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
                       uint32_t* words, float* z0, float* z1, fishing_stream_t stream);

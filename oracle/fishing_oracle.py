@@ -257,9 +257,8 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def philox_words(seed, env_index, step_counter, stream):
     """Counter layout shared with csrc/fishing_common.h (`env_index` = the Philox index:
-    the env QUAD index on the noise and policy streams (noise_normal, policy_random_action) and for
-    fishing-v11's model draw on the reset streams (model_draw); fishing-v4's parameter draws use
-    param_words instead):
+    the env QUAD index on the noise and policy streams (noise_normal, policy_random_action); fishing-v4's
+    parameter draws use param_words, fishing-v11's model draw model_words instead):
     c0 = index[31:0], c1 = stream<<24 | index[55:32], c2 = step[31:0], c3 = step[63:32];
     key = (seed[31:0], seed[63:32])."""
     env = np.asarray(env_index, dtype=np.uint64)
@@ -314,17 +313,37 @@ def noise_normal(seed, env_index, step_counter):
 
 def quad_word(seed, env_index, counter, stream):
     """Word (env & 3) of the Philox block of env quad (env >> 2) on `stream`: the per-env word of
-    the policy stream (random actions) and of the reset streams' fishing-v11 model draw."""
+    the policy stream (random actions)."""
     env, ws = _quad_words(seed, env_index, counter, stream)
     leg = (env & np.uint64(3)).astype(np.int64)
     return np.choose(leg, [np.broadcast_to(x, leg.shape) for x in ws]).astype(np.uint32)
 
 
+def model_words(seed, env_index, counter, stream):
+    """The 16-bit half behind fishing-v11's model draw of env `env_index` (fishing_common.h: model_block): ONE Philox2x32-10
+    block per env QUAD -- c0 = quad[31:0], c1 = (counter[30:0] | 1 << 31 on the reset stream) ^ quad[63:32] * 0xC2B2AE35, key =
+    seed[31:0] ^ seed[63:32] * 0x85EBCA6B ^ 0x4D4F444C ^ counter[62:31] * 0x9E3779B1 -- whose two words give four halves: env 4q + j takes
+    w0 & 0xFFFF, w0 >> 16, w1 & 0xFFFF, w1 >> 16 for j = 0 .. 3."""
+    env = np.asarray(env_index, dtype=np.uint64)
+    quad = env >> np.uint64(2)
+    counter, seed, stream = int(counter), int(seed), int(stream)
+    m32 = 0xFFFFFFFF
+    key = np.uint32(((seed & m32) ^ (((seed >> 32) * 0x85EBCA6B) & m32)) ^ 0x4D4F444C ^ ((((counter >> 31) & m32) * 0x9E3779B1) & m32))
+    c0 = (quad & _MASK).astype(np.uint32)
+    c1 = (np.uint64((counter & 0x7FFFFFFF) | (0x80000000 if stream == STREAM_RESET else 0))
+          ^ (((quad >> np.uint64(32)) * np.uint64(0xC2B2AE35)) & np.uint64(m32))).astype(np.uint32)
+    w0, w1 = philox2x32_10(c0, c1, key)
+    leg = (env & np.uint64(3)).astype(np.int64)
+    w = np.where(leg < 2, w0, w1)
+    return np.where(leg & 1, w >> np.uint32(16), w & np.uint32(0xFFFF)).astype(np.uint32)
+
+
 def model_draw(seed, env_index, counter, stream, kinds):
-    """fishing-v11 (growth_models.py:187,200): index into the model list, (w * n_models) >> 32,
-    mapped to its FISHING_KIND_*."""
-    w = quad_word(seed, env_index, counter, stream).astype(np.uint64)
-    idx = ((w * np.uint64(len(kinds))) >> np.uint64(32)).astype(np.int64)
+    """fishing-v11 (growth_models.py:187,200: np.random.choice(models)): index into the model list, (half * n_models) >> 16
+    of the env's 16-bit half (model_words), mapped to its FISHING_KIND_*.  Every model's probability is within 2^-16 of
+    1 / n_models."""
+    h = model_words(seed, env_index, counter, stream).astype(np.uint64)
+    idx = ((h * np.uint64(len(kinds))) >> np.uint64(16)).astype(np.int64)
     return np.asarray(kinds, dtype=np.int32)[idx]
 
 

@@ -13,6 +13,7 @@ import gym_fishing_amd as gf  # noqa: E402
 
 QUICK = "--quick" in sys.argv        # (the PMC passes: fewer launches, same kernels)
 ZOO_ONLY = "--zoo-only" in sys.argv  # (A/B of growth-function evaluations: the step kernels alone, every id in both layouts)
+V11_ONLY = "--v11-only" in sys.argv  # (A/B of fishing-v11's forms: its step kernels in both layouts and its random-policy rollout)
 
 
 def events(fn, reps):
@@ -43,8 +44,10 @@ def main():
     acts = ring[:, :n]
     acts.copy_(torch.rand((8, n), device="cuda") * 2 - 1)
     launches = 60 if QUICK else 400
-    for idn, dtype in [("fishing-v%d" % k, torch.float32) for k in (5, 6, 7, 8, 9, 10, 11)] + [
-            ("fishing-v%d" % k, torch.float64) for k in ((5, 6, 7, 8, 9, 10, 11) if ZOO_ONLY else (9, 8, 11))]:
+    ids32, ids64 = (5, 6, 7, 8, 9, 10, 11), ((5, 6, 7, 8, 9, 10, 11) if ZOO_ONLY else (9, 8, 11))
+    if V11_ONLY:
+        ids32 = ids64 = (11,)
+    for idn, dtype in [("fishing-v%d" % k, torch.float32) for k in ids32] + [("fishing-v%d" % k, torch.float64) for k in ids64]:
         env = make(idn, n, dtype)
         env.step_many(acts, 50)
         torch.cuda.synchronize()
@@ -60,7 +63,7 @@ def main():
         return
     # fused K-step kernel (caller's actions): the launch-bound regime's tool (N = 2^20) and at the metric's size (2^22); 101 steps per
     # launch, reward / done rows out
-    for ln in (20, 22):
+    for ln in (() if V11_ONLY else (20, 22)):
         nn = 1 << ln
         a2 = torch.empty((8, nn + 3072), device="cuda")[:, :nn]
         a2.copy_(torch.rand((8, nn), device="cuda") * 2 - 1)
@@ -82,6 +85,8 @@ def main():
     for idn, pol, param, tag in (("fishing-v1", "random", 0.0, "1, 0, true, true, false>"), ("fishing-v1", "escapement", 0.5, "1, 2, true, true, false>"),
                                  ("fishing-v4", "random", 0.0, "4, 0, true, false, false>"),
                                  ("fishing-v11", "random", 0.0, "105, -1, true, false, false>")):
+        if V11_ONLY and idn != "fishing-v11":
+            continue
         # (template arguments 5 and 6: the compile-time power-of-two-K twin the dispatch picks for fishing-v0/v1/v2 at K = 1; one policy
         # parameter per env -- fishing_rollout_params_*)
         env = make(idn, n)

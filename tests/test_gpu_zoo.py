@@ -138,6 +138,37 @@ def test_zoo_scalar_protocol_follows_reference(env_id):
                 assert env.model in ("allen", "beverton_holt", "myers", "may", "ricker")
 
 
+def test_v11_model_draw_is_the_oracles_and_uniform_to_two_to_the_minus_sixteen(hh):
+    """growth_models.py:187,200: np.random.choice(models) per episode.  The device draws it from one Philox2x32-10 block per
+    env quad, 16 bits per env (fishing_common.h: redraw_kinds): the reset kernel's and the step kernel's draws are the
+    oracle's bit for bit -- any env offset, both reset streams, model lists of 1 .. 5 -- and over 2^20 envs x 3 draws the
+    model frequencies pass a chi-square test at 1 / n each (the scheme's own bias is <= 2^-16 per model: invisible here)."""
+    n, seed = 1 << 20, 4242
+    p = hh.params(fo.MODEL_V11, sigma=0.0, Tmax=0, auto_reset=True, models=[0, 1, 2, 3, 4], zoo_table=[dict(d) for d in fo.V11_TABLE])
+    counts = np.zeros(5)
+    for off, counter in ((0, 0), (12, 5), (1 << 20, 1 << 20)):
+        st = hh.State(n, np.float32, fo.MODEL_V11, np.zeros(n), model_idx=np.zeros(n, np.int32))
+        st.reset(p, seed=seed, counter=counter, env_offset=off)
+        got = st.model_idx.cpu().numpy()
+        env = np.arange(off, off + n, dtype=np.uint64)
+        assert np.array_equal(got, fo.model_draw(seed, env, counter, fo.STREAM_RESET, [0, 1, 2, 3, 4]))
+        counts += np.bincount(got, minlength=5)
+        # Tmax = 0: every env finishes on its first step -> every env redraws on the auto-reset stream, keyed by the step counter
+        st.step(p, np.full(n, -1.0, np.float32), seed=seed, step_counter=counter + 7, env_offset=off)
+        again = st.model_idx.cpu().numpy()
+        assert np.array_equal(again, fo.model_draw(seed, env, counter + 7, fo.STREAM_AUTORESET, [0, 1, 2, 3, 4]))
+        assert (again != got).mean() > 0.7          # (another block: 4 in 5 envs change their model)
+    expect = counts.sum() / 5
+    chi2 = ((counts - expect) ** 2 / expect).sum()
+    assert chi2 < 18.5, (chi2, counts)              # 4 degrees of freedom: P(chi2 > 18.5) = 1e-3
+    for models in ([2], [4, 1], [3, 3, 0], [4, 0, 3, 1]):     # shorter lists, any order, repeats allowed
+        pm = hh.params(fo.MODEL_V11, sigma=0.0, Tmax=5, models=models, zoo_table=[dict(d) for d in fo.V11_TABLE])
+        st = hh.State(4099, np.float64, fo.MODEL_V11, np.zeros(4099), model_idx=np.zeros(4099, np.int32))
+        st.reset(pm, seed=9, counter=3, env_offset=8)
+        assert np.array_equal(st.model_idx.cpu().numpy(),
+                              fo.model_draw(9, np.arange(8, 8 + 4099, dtype=np.uint64), 3, fo.STREAM_RESET, models))
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("model", [fo.MODEL_V5, fo.MODEL_V7, fo.MODEL_V8, fo.MODEL_V10, fo.MODEL_V11])
 def test_zoo_philox_auto_reset_vs_oracle(hh, model, dtype):
@@ -167,10 +198,8 @@ def test_zoo_philox_auto_reset_vs_oracle(hh, model, dtype):
     kind = st.model_idx.cpu().numpy() if model == fo.MODEL_V11 else None
     if model == fo.MODEL_V11:
         want = fo.model_draw(seed, np.arange(off, off + n, dtype=np.uint64), 0, fo.STREAM_RESET, [4, 0, 3])
+        # (one Philox2x32-10 block per env quad, four 16-bit draws: oracle.model_words mirrors fishing_common.h: model_block)
         assert np.array_equal(kind, want) and set(np.unique(kind)) == {0, 3, 4}
-        w = hh.device_noise(n // 4, seed, 0, fo.STREAM_RESET, off // 4)[0]          # the device's own words, by quad
-        assert np.array_equal(np.array([4, 0, 3])[((w.reshape(-1)[:n].astype(np.uint64) * np.uint64(3))
-                                                    >> np.uint64(32)).astype(int)], want[:4 * (n // 4)])
     rtol = F64_RTOL
     for s in range(T):
         a = rng.uniform(-1, -0.6, n).astype(np.float32)

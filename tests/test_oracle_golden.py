@@ -195,6 +195,34 @@ def test_v4_parameter_draw_statistics_and_origin_rule():
     assert stream.tolist() == [fo.STREAM_RESET, fo.STREAM_AUTORESET] and counter.tolist() == [3, 57]
 
 
+def test_v11_model_draw_scheme():
+    """fishing-v11's model choice (growth_models.py:187,200: np.random.choice(models)) as the kernels draw it: one Philox2x32-10
+    block per env QUAD, four 16-bit halves.  The index map (half * n) >> 16 splits the 65536 halves into n buckets whose sizes
+    differ by at most one -- every model within 2^-16 of 1 / n --, the four envs of a quad take the four halves of ONE block
+    (a Random123 known answer), the two reset streams and consecutive counters give unrelated draws."""
+    for n in (1, 2, 3, 4, 5):
+        sizes = np.bincount((np.arange(65536, dtype=np.uint64) * np.uint64(n) >> np.uint64(16)).astype(int), minlength=n)
+        assert sizes.sum() == 65536 and sizes.max() - sizes.min() <= 1
+        assert np.abs(sizes / 65536.0 - 1.0 / n).max() <= 2.0 ** -16
+    # seed 0, counter 0, auto-reset stream, quad 0: key = 0 ^ tag, counter words (0, 0)
+    w0, w1 = fo.philox2x32_10(np.uint32(0), np.uint32(0), np.uint32(0x4D4F444C))
+    halves = fo.model_words(0, np.arange(4, dtype=np.uint64), 0, fo.STREAM_AUTORESET)
+    assert halves.tolist() == [int(w0) & 0xFFFF, int(w0) >> 16, int(w1) & 0xFFFF, int(w1) >> 16]
+    # the block of quad q on the reset stream: c1 carries bit 31
+    w0, w1 = fo.philox2x32_10(np.uint32(7), np.uint32(0x80000003), np.uint32(0x4D4F444C ^ 5))
+    assert int(fo.model_words(5, np.uint64(4 * 7 + 2), 3, fo.STREAM_RESET)) == int(w1) & 0xFFFF
+    env = np.arange(1 << 18, dtype=np.uint64)
+    a = fo.model_draw(1, env, 0, fo.STREAM_RESET, [0, 1, 2, 3, 4])
+    b = fo.model_draw(1, env, 0, fo.STREAM_AUTORESET, [0, 1, 2, 3, 4])
+    c = fo.model_draw(1, env, 1, fo.STREAM_AUTORESET, [0, 1, 2, 3, 4])
+    for u, v in ((a, b), (b, c), (a, c)):
+        assert abs((u == v).mean() - 0.2) < 0.01            # independent draws agree one time in five
+    counts = np.bincount(a, minlength=5)
+    assert (((counts - counts.sum() / 5) ** 2) / (counts.sum() / 5)).sum() < 18.5
+    # neighbouring envs of one quad are as unrelated as envs of different quads
+    assert abs((a[0::4] == a[1::4]).mean() - 0.2) < 0.01 and abs((a[1::4] == a[2::4]).mean() - 0.2) < 0.01
+
+
 def test_noise_statistics():
     """The Philox + Box-Muller stream is standard normal and independent of sharding."""
     n = 1 << 16
