@@ -10,7 +10,7 @@ import os
 c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 c_dbl, c_vp = ctypes.c_double, ctypes.c_void_p
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4 = 0, 1, 2, 4
 MODEL_V5, MODEL_V6, MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11 = 5, 6, 7, 8, 9, 10, 11

@@ -739,6 +739,9 @@ __device__ __forceinline__ double zoo_draw_algebraic(int kind_rt, double x, doub
 #ifndef FISHING_ZOO_F64_ROUNDTRIP
 #define FISHING_ZOO_F64_ROUNDTRIP 0
 #endif
+#ifndef FISHING_ZOO_F64_FAR
+#define FISHING_ZOO_F64_FAR 1
+#endif
 // n / d to <= 1 ulp: v_rcp_f64 seed (~2^-26), two Newton steps on the reciprocal, one correction of the quotient with an
 // exact residual (8 instructions; the IEEE division's v_div_scale / v_div_fmas / v_div_fixup frame is ~14 and issues no
 // faster).  Denominators outside the comfortable range (zeros, infinities, NaN included) take the IEEE division.
@@ -809,7 +812,9 @@ __device__ __forceinline__ double zoo_draw_f64(int kind_rt, double x, double z, 
     // near these ranges (a divergent branch no wave takes); the population_draw sweeps and the special-value tests do.
     const double inf = __builtin_huge_val();
     const bool far = (x > 0.0 && x < 0x1p-30) || (x > 0x1p30 && x < inf) || (res > 0.0 && res < 0x1p-92) || (res > 0x1p92 && res < inf);
+#if FISHING_ZOO_F64_FAR       // (0: instruction-count analysis of the hot path only -- never a product build)
     if (__builtin_expect(far, 0)) return zoo_draw_round_trip<double, MathLibF64, KIND, RECOMPUTE>(kind_rt, x, z, P);
+#endif
     return (res > 0.0) ? res : ((res != res) ? res : 0.0);      // np.maximum(0, .)
 }
 

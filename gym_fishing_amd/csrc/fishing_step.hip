@@ -391,6 +391,9 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_X_TILE_ENVS
 #define FISHING_X_TILE_ENVS 1024
 #endif
+#ifndef FISHING_ZOO_F64_EXACT
+#define FISHING_ZOO_F64_EXACT 1
+#endif
 template <typename T, int MODEL, int F, int E = 4>
 __global__ void __launch_bounds__(FISHING_X_TILE_ENVS / E) FISHING_LEAN_ATTRS
 step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p, T* const ep_return_p, const int64_t n_live_p,
@@ -1078,6 +1081,26 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
     }
     if constexpr (sizeof(T) == 8 && MODEL != kModelZooMixed) {
         if (c.two_per_thread) {
+#if FISHING_ZOO_F64_EXACT
+            // the float64 zoo's hot requests as exact two-envs-per-thread forms: 370 instead of 484 VALU instructions per thread.
+            // Round 4, on the log / exp round trip, they ran within noise of the catch-alls (profiles/r04_zoo_f64_exact.jsonl);
+            // on the algebraic form they are worth 1-2 % (fishing-v5 33.5 -> 32.8 us = 0.85 of the spec, v9 33.7 -> 33.1, v8 and
+            // v7 unchanged: profiles/r05_zoo_f64_exact.jsonl) -- the layout sits 6 % behind fishing-v1's 31.1 us whatever it executes
+            if constexpr (is_zoo_tag(MODEL)) {
+                switch (req) {
+                    case (P): return lean_launch<T, MODEL, (P | ONE), 2>(c);
+                    case (P | RET): return lean_launch<T, MODEL, (P | RET | ONE), 2>(c);
+                    default: break;
+                }
+                if constexpr (MODEL == kModelZoo + FISHING_KIND_BEVERTON_HOLT) {
+                    switch (req) {
+                        case (P | DRIFT): return lean_launch<T, MODEL, (P | DRIFT | ONE), 2>(c);
+                        case (P | DRIFT | RET): return lean_launch<T, MODEL, (P | DRIFT | RET | ONE), 2>(c);
+                        default: break;
+                    }
+                }
+            }
+#endif
             if constexpr (!is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
                 switch (req) {
                     case (P | KP2): return lean_launch<T, MODEL, (P | KP2 | ONE), 2>(c);

@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define FISHING_ABI_VERSION 7
+/* 8: same entry points and structs as 7; fishing-v11's per-episode model choice is drawn from one Philox2x32-10 block per env
+ * quad (four 16-bit draws) instead of a Philox4x32-10 block -- a run of a fishing-v11 batch continues with other model draws
+ * than under ABI 7; the float64 zoo evaluates the growth functions' algebraic form (same 2e-14 bar). */
+#define FISHING_ABI_VERSION 8
 
 typedef void* fishing_stream_t; /* hipStream_t */
 

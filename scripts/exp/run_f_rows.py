@@ -44,7 +44,7 @@ def main():
     acts = ring[:, :n]
     acts.copy_(torch.rand((8, n), device="cuda") * 2 - 1)
     launches = 60 if QUICK else 400
-    ids32, ids64 = (5, 6, 7, 8, 9, 10, 11), ((5, 6, 7, 8, 9, 10, 11) if ZOO_ONLY else (9, 8, 11))
+    ids32 = ids64 = (5, 6, 7, 8, 9, 10, 11)
     if V11_ONLY:
         ids32 = ids64 = (11,)
     for idn, dtype in [("fishing-v%d" % k, torch.float32) for k in ids32] + [("fishing-v%d" % k, torch.float64) for k in ids64]:
