@@ -1723,7 +1723,7 @@ __device__ __forceinline__ double row_sum_fields(const double (&acc)[kPartialFie
 // are bitwise reproducible for a fixed launch shape.  Must be reached by every thread of the
 // workgroup with all lanes active (it contains a barrier and whole-wave DPP moves).
 template <int MAX_WAVES, int STATIC_WAVES = 0>
-__device__ __forceinline__ void add_block_partials(const double (&acc)[kPartialFields], double* partials) {
+__device__ __forceinline__ void add_block_partials(const double (&acc)[kPartialFields], double* partials, const int64_t slot = -1) {
     constexpr int kRows = kWave / 16;
     __shared__ double red[MAX_WAVES * kRows][kPartialFields];
     const int lane = threadIdx.x & (kWave - 1);
@@ -1738,7 +1738,8 @@ __device__ __forceinline__ void add_block_partials(const double (&acc)[kPartialF
         // The slot belongs to this workgroup alone, so a hardware no-return atomic add gives the same
         // bits as a read-modify-write (one add per slot per launch, launches are stream-ordered) without
         // the dependent load -> add -> store round trip at the very end of the kernel.
-        if (tot != 0.0) unsafeAtomicAdd(&partials[(int64_t)blockIdx.x * kPartialFields + threadIdx.x], tot);
+        // (`slot`: the tile's own slot where a workgroup steps more than one tile; default = the workgroup's)
+        if (tot != 0.0) unsafeAtomicAdd(&partials[(slot >= 0 ? slot : (int64_t)blockIdx.x) * kPartialFields + threadIdx.x], tot);
     }
 }
 

@@ -394,6 +394,12 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_ZOO_F64_EXACT
 #define FISHING_ZOO_F64_EXACT 1
 #endif
+// TPW (experiment, -DFISHING_X_TPW=2): tiles per workgroup.  2 = a workgroup loads TWO adjacent tiles up front, steps and stores
+// the first while the second's loads land, then the second -- software pipelining inside a wave for the batches that run as
+// one or two rounds of waves (profiles/r05_two_tiles_per_workgroup.jsonl).  Product: 1.
+#ifndef FISHING_X_TPW
+#define FISHING_X_TPW 1
+#endif
 template <typename T, int MODEL, int F, int E = 4>
 __global__ void __launch_bounds__(FISHING_X_TILE_ENVS / E) FISHING_LEAN_ATTRS
 step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p, T* const ep_return_p, const int64_t n_live_p,
@@ -407,6 +413,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     // 6.04 -> 5.75 us, 2^22 21.41 -> 20.87 (1.1 % above the same-shape copy), 2^19 unchanged
     // (profiles/r03_small_n/s15_kernarg_preload_product.jsonl; harness sweep of 4 .. 14 dwords: s14_*).  Firmware
     // without the feature runs the kernel's own s_load prologue.
+    constexpr int TPW = FISHING_X_TPW;      // (a build-wide experiment knob, not a template parameter: the kernels keep their names)
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     constexpr bool kMixed = (MODEL == kModelZooMixed);    // fishing-v11: growth function per env
     constexpr bool kZoo = is_zoo_tag(MODEL) && !kMixed;   // one growth function of the zoo, compile-time kind
@@ -491,7 +498,19 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
     const T robs_scalar = (MODEL == FISHING_MODEL_V4) ? a.x0 : a.robs;       // (reset_obs<T, MODEL>(a.x0, a.pK))
 
+#if FISHING_X_TPW > 1
+    struct TileIn {     // what a tile's load phase hands to its step phase (registers; TPW = 2 holds two of them)
+        int64_t it, tile, base;
+        bool live;
+        uint64_t seed_it;
+        T obs[E], rr[E], KK[E], z[E], er[E], sg[E];
+        int32_t t[E], a_i[E], kind[E], st[E];
+        float a_f[E];
+    };
+    auto load_tile = [&](const int64_t it, TileIn& in) {
+#else       // the product: one lambda, one tile (the experiment's split changes the register allocation: kept textually apart)
     auto do_tile = [&](const int64_t it) {
+#endif
         // ZZ: odd steps walk the tiles backwards, so what the previous step touched LAST is what this one reads FIRST -- while
         // it is still cached.  Backwards IN GROUPS OF EIGHT: workgroups are dealt round-robin over the 8 XCDs, each with its
         // own 4 MiB L2 that keeps its lines across launches; tile % 8 == workgroup % 8 in both directions keeps every tile on
@@ -503,8 +522,10 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // 406 us forward, 347 zig-zag: profiles/r03_zz_nta_one_tile.jsonl).
         int64_t tile = it;
         if (ZZ && (step_counter & 1)) {
-            const int64_t whole = ntiles & ~(int64_t)7;       // (a last partial group of < 8 tiles keeps its place)
-            if (it < whole) tile = (whole - 8 - (it & ~(int64_t)7)) + (it & 7);
+            // (TPW tiles per workgroup: groups of 8 * TPW, so that a tile stays on the XCD of the workgroup that owns it)
+            constexpr int64_t G = 8 * TPW;
+            const int64_t whole = ntiles & ~(G - 1);          // (a last partial group keeps its place)
+            if (it < whole) tile = (whole - G - (it & ~(G - 1))) + (it & (G - 1));
         }
         const int64_t base = (tile * kThreads + threadIdx.x) * E;
         // FISHING_FLAG_PADDED_TILES: the state buffers have room for whole tiles, so a batch that is not a multiple of 1024
@@ -628,6 +649,49 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 for (int j = 0; j < E; ++j) z[j] = qz.v[j];
             }
         }
+#if FISHING_X_TPW > 1
+        in.it = it;
+        in.tile = tile;
+        in.base = base;
+        in.live = live;
+        in.seed_it = seed_it;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            in.obs[j] = obs[j];
+            in.rr[j] = rr[j];
+            in.KK[j] = KK[j];
+            in.z[j] = z[j];
+            in.er[j] = er[j];
+            in.sg[j] = sg[j];
+            in.t[j] = t[j];
+            in.a_i[j] = a_i[j];
+            in.kind[j] = kind[j];
+            in.st[j] = st[j];
+            in.a_f[j] = a_f[j];
+        }
+    };
+    auto run_tile = [&](TileIn& in) {
+        const int64_t tile = in.tile, base = in.base;
+        const bool live = in.live;
+        const uint64_t seed_it = in.seed_it;
+        T obs[E], rr[E], KK[E], z[E], er[E], sg[E];
+        int32_t t[E], a_i[E], kind[E], st[E];
+        float a_f[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            obs[j] = in.obs[j];
+            rr[j] = in.rr[j];
+            KK[j] = in.KK[j];
+            z[j] = in.z[j];
+            er[j] = in.er[j];
+            sg[j] = in.sg[j];
+            t[j] = in.t[j];
+            a_i[j] = in.a_i[j];
+            kind[j] = in.kind[j];
+            st[j] = in.st[j];
+            a_f[j] = in.a_f[j];
+        }
+#endif
         // the loads above must be in flight BEFORE the ~100-instruction Philox block starts: without
         // this fence the scheduler hoists the (independent) generator above them in some variants
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
@@ -771,7 +835,11 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 for (int j = 0; j < E; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
             }
             // the record's atomic first, the tile's stores behind it
+#if FISHING_X_TPW > 1
+            if (a.partials) add_block_partials<kThreads / kWave, kThreads / kWave>(acc, a.partials, in.it);     // (a slot per tile)
+#else
             if (a.partials) add_block_partials<kThreads / kWave, kThreads / kWave>(acc, a.partials);
+#endif
             store_outputs();
             VecE<T, E> qe;
 #pragma unroll
@@ -846,7 +914,26 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     // (Round 4 tried starting a CU's eight workgroups of fishing-v4's one-round grid at N = 2^21 in two phases -- s_sleep of
     // 0.2 .. 14 us in every other workgroup of a CU -- so that one half computes while the other half's loads fly: 13.0-13.5 us
     // against 13.2 at the short sleeps, worse beyond: profiles/r04_v4_stagger.jsonl.  Not kept.)
+#if FISHING_X_TPW == 1
+    static_assert(TPW == 1, "the product steps one tile per workgroup");
     do_tile(blockIdx.x);
+#else
+    {
+        static_assert(TPW == 2, "one or two tiles per workgroup");
+        const int64_t it0 = (int64_t)blockIdx.x * 2;
+        const bool two = it0 + 1 < ntiles;          // (wave-uniform: an odd tile count leaves the last workgroup one tile)
+        TileIn in0, in1;
+        load_tile(it0, in0);
+        if (two) load_tile(it0 + 1, in1);
+        run_tile(in0);
+        if (two) {
+            __syncthreads();                        // (the record's LDS rows are reused)
+#pragma unroll
+            for (int k = 0; k < kPartialFields; ++k) acc[k] = 0.0;
+            run_tile(in1);
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- host side
@@ -981,7 +1068,8 @@ int lean_launch(const LeanCall<T>& c) {
 #else
     constexpr size_t x_lds = 0;
 #endif
-    return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)nb, FISHING_X_TILE_ENVS / E, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
+    return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)((nb + FISHING_X_TPW - 1) / FISHING_X_TPW),
+                             FISHING_X_TILE_ENVS / E, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
                              c.a.n_live, c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
 }
 
