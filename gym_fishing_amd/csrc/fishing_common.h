@@ -1044,7 +1044,10 @@ __device__ __forceinline__ void zoo_eval_kind(ZooSlot<T>* __restrict__ win, int 
 // fifths of a pass), random-policy rollout 9.87 vs 9.42 ms (+5 %).  NOT shipped: -DFISHING_V11_FORM=1 builds it.  What IS
 // used from here: zoo_draw_select_one with the caller's sigma for the per-env-sigma path (env_step_zoo_mixed below).
 #ifndef FISHING_V11_FORM
-#define FISHING_V11_FORM 0
+#define FISHING_V11_FORM 2
+#endif
+#ifndef FISHING_V11_LUT_INT_POW_ONLY
+#define FISHING_V11_LUT_INT_POW_ONLY 0
 #endif
 #ifndef FISHING_V11_SELECT_SERIAL
 #define FISHING_V11_SELECT_SERIAL 0
@@ -1156,6 +1159,127 @@ __device__ __forceinline__ void zoo_draw_select_tile(const int (&kind)[4], const
     }
 }
 
+// ---------------------------------------------------------------- fishing-v11: the growth function's coefficients from an LDS table
+// (-DFISHING_V11_FORM=2.)  The select form above pays for choosing between wave-uniform constants per lane: a VALU instruction
+// reads ONE scalar register on this architecture, so every `kind == k ? c_k : ...` first moves its constants into vector
+// registers (70 v_mov in the float32 step kernel; 755 VALU instructions in all, against the regroup's 662).  Here the five
+// kinds' coefficients sit in a 5 x 8 table in LDS, written once per workgroup, and an env fetches ITS row with two 16-byte LDS
+// reads (four in float64) -- no selects of constants, no ballots, no passes:
+//     row k = { sigma, cg, cK, c1, c2, c3, cr, - }
+//     g   = cg (1 - x cK) + sigma z          Allen: cg = r (1 - C) / K, cK = 1 / K;  Ricker: cg = r, cK = 1 / K;  others cg = 0
+//     q   = c1 w / (c2 + c3 w)               w = clip(x) (Beverton-Holt: c1 = A, c2 = 1, c3 = 1 / B) or x ** p (Myers: A, 1, 1 / M;
+//                                            May: a, b ** q, 1);  Allen / Ricker: c1 = c3 = 0, c2 = 1 -> q = 0, unused
+//     pre = x (Allen, Ricker) | q (Beverton-Holt, Myers) | x + x cr (1 - x cK) - q, NaN below zero (May: cr = r, cK = 1 / M)
+//     x'  = max(0, pre exp(g))
+// -- the operations of zoo_pre_g_f32 / zoo_pre_g_f64 of the env's kind on the same operands (the zero coefficients contribute
+// exact zeros; fma(w, 1, b ** q) IS w + b ** q), hence the same bits.
+constexpr int kZooLutRow = 8;
+constexpr int kZooLutSize = FISHING_N_KINDS * kZooLutRow;
+// by the lanes 0 of whichever waves call it (uniform values: every caller writes the same table); the caller synchronises
+template <typename T>
+__device__ __forceinline__ void zoo_lut_fill(T* __restrict__ lut, const GrowthT<T> (&zoo)[FISHING_N_KINDS]) {
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        const GrowthT<T>& PA = zoo[FISHING_KIND_ALLEN];
+        const GrowthT<T>& PB = zoo[FISHING_KIND_BEVERTON_HOLT];
+        const GrowthT<T>& PM = zoo[FISHING_KIND_MYERS];
+        const GrowthT<T>& PY = zoo[FISHING_KIND_MAY];
+        const GrowthT<T>& PR = zoo[FISHING_KIND_RICKER];
+        const T rows[FISHING_N_KINDS][kZooLutRow] = {
+            {(T)PA.sigma, (T)PA.gc, (T)PA.invK, (T)0, (T)1, (T)0, (T)0, (T)0},           // FISHING_KIND_ALLEN
+            {(T)PB.sigma, (T)0, (T)0, (T)PB.A, (T)1, (T)PB.invB, (T)0, (T)0},            // FISHING_KIND_BEVERTON_HOLT
+            {(T)PM.sigma, (T)0, (T)0, (T)PM.A, (T)1, (T)PM.invM, (T)0, (T)0},            // FISHING_KIND_MYERS
+            {(T)PY.sigma, (T)0, (T)PY.invM, (T)PY.a, (T)PY.bq, (T)1, (T)PY.r, (T)0},     // FISHING_KIND_MAY
+            {(T)PR.sigma, (T)PR.r, (T)PR.invK, (T)0, (T)1, (T)0, (T)0, (T)0}};           // FISHING_KIND_RICKER
+#pragma unroll
+        for (int k = 0; k < FISHING_N_KINDS; ++k)
+#pragma unroll
+            for (int f = 0; f < kZooLutRow; ++f) lut[k * kZooLutRow + f] = rows[k][f];
+    }
+}
+template <typename T>
+__device__ __forceinline__ T zoo_draw_lut_one(const int kind, const T x, const T z_in, const T* __restrict__ lut, const int ipowM,
+                                              const int ipowY, const T thetaM, const T qY, bool& far) {
+    typedef ZooSelectMath<T> M;
+    struct alignas(4 * sizeof(T)) Quad { T v[4]; };
+    const Quad lo = *reinterpret_cast<const Quad*>(lut + kind * kZooLutRow);
+    const Quad hi = *reinterpret_cast<const Quad*>(lut + kind * kZooLutRow + 4);
+    const T sg = lo.v[0], cg = lo.v[1], cK = lo.v[2], c1 = lo.v[3], c2 = hi.v[0], c3 = hi.v[1], cr = hi.v[2];
+    const bool isB = kind == FISHING_KIND_BEVERTON_HOLT, isY = kind == FISHING_KIND_MAY;
+    const bool isAR = kind == FISHING_KIND_ALLEN || kind == FISHING_KIND_RICKER;
+    const T sz = sg * z_in;
+    const T lin = M::fma(-x, cK, (T)1);
+    const T g = M::fma(cg, lin, sz);
+    const T xc = (x < (T)0) ? (T)0 : x;
+    // x ** theta (Myers) / x ** q (May): wave-uniform choices (equal small integer powers -- the defaults -- share the product)
+#if FISHING_V11_LUT_INT_POW_ONLY     // (analysis builds: what the table form costs without the general-power fallback compiled in)
+    const T u = (ipowM == ipowY) ? int_pow<T>(x, ipowM) : (isY ? int_pow<T>(x, ipowY) : int_pow<T>(x, ipowM));
+#else
+    const T u = (ipowM == ipowY && ipowM != 0) ? int_pow<T>(x, ipowM) : (isY ? M::pow(x, qY, ipowY) : M::pow(x, thetaM, ipowM));
+#endif
+    const T w = isB ? xc : u;
+    const T q = M::div(c1 * w, M::fma(w, c3, c2));
+    T emu;
+    if constexpr (sizeof(T) == 4) emu = M::fma(x * cr, lin, x) - q;
+    else emu = (x + x * cr * ((T)1 - x * cK)) - q;          // (zoo_pre_g_f64's May: separately rounded operations)
+    const T preY = (emu < (T)0) ? M::nan() : emu;
+    const T pre = isAR ? x : (isY ? preY : q);
+    if constexpr (sizeof(T) == 4) {
+        return (T)zoo_finish_f32(pre, g);
+    } else {
+        const double res = pre * exp_f64(g);
+        const double inf = __builtin_huge_val();
+        far = (x > 0.0 && x < 0x1p-30) || (x > 0x1p30 && x < inf) || (res > 0.0 && res < 0x1p-92) || (res > 0x1p92 && res < inf);
+        return (res > 0.0) ? res : ((res != res) ? res : 0.0);
+    }
+}
+// the N envs of a lane (4; 2 in the float64 layout's two-envs-per-thread forms)
+template <typename T, int N>
+__device__ __forceinline__ void zoo_draw_lut_tile(const int (&kind)[N], const T (&x)[N], const T (&z)[N],
+                                                  const GrowthT<T> (&zoo)[FISHING_N_KINDS], const T* __restrict__ lut, T (&out)[N]) {
+    const int ipowM = zoo[FISHING_KIND_MYERS].ipow, ipowY = zoo[FISHING_KIND_MAY].ipow;
+    bool far[N];
+    bool any_far = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        bool f = false;
+        const T v = zoo_draw_lut_one<T>(kind[j] >= 0 ? kind[j] : FISHING_KIND_BEVERTON_HOLT, x[j], z[j], lut, ipowM, ipowY,
+                                        (T)zoo[FISHING_KIND_MYERS].theta, (T)zoo[FISHING_KIND_MAY].q, f);
+        out[j] = (kind[j] >= 0) ? v : out[j];
+        far[j] = f && kind[j] >= 0;
+        any_far |= far[j];
+        if constexpr (sizeof(T) == 8 || FISHING_V11_SELECT_SERIAL) __builtin_amdgcn_sched_barrier(0);      // (one env after the other: zoo_draw_select_tile)
+    }
+    if constexpr (sizeof(T) == 8 && FISHING_ZOO_F64_FAR) {
+        if (__builtin_expect(any_far, 0)) {         // (zoo_draw_f64: follow the reference's round trip there; ONE copy, real loops)
+            for (int j = 0; j < N; ++j) {
+                asm volatile("" : "+s"(j));
+                bool fj = far[0];
+                double xj = x[0], zj = z[0];
+                int kj = kind[0];
+#pragma unroll
+                for (int k = 1; k < N; ++k) {
+                    fj = (j == k) ? far[k] : fj;
+                    xj = (j == k) ? (double)x[k] : xj;
+                    zj = (j == k) ? (double)z[k] : zj;
+                    kj = (j == k) ? kind[k] : kj;
+                }
+                if (!fj) continue;
+                // (one compile-time kind per case: the run-time-kind instantiation needs 30 more registers than any of these)
+                double r;
+                switch (kj) {
+                    case FISHING_KIND_ALLEN: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_ALLEN, false>(kj, xj, zj, zoo[FISHING_KIND_ALLEN]); break;
+                    case FISHING_KIND_MYERS: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_MYERS, false>(kj, xj, zj, zoo[FISHING_KIND_MYERS]); break;
+                    case FISHING_KIND_MAY: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_MAY, false>(kj, xj, zj, zoo[FISHING_KIND_MAY]); break;
+                    case FISHING_KIND_RICKER: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_RICKER, false>(kj, xj, zj, zoo[FISHING_KIND_RICKER]); break;
+                    default: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_BEVERTON_HOLT, false>(kj, xj, zj, zoo[FISHING_KIND_BEVERTON_HOLT]); break;
+                }
+#pragma unroll
+                for (int k = 0; k < N; ++k) out[k] = (j == k) ? (T)r : out[k];
+            }
+        }
+    }
+}
+
 // (Round 4 also measured a branch-free "select" form for the float32 layout -- every lane evaluates the (pre, g) of all
 // kinds present in its wave for its own four envs and selects, no LDS: the same 24.2 us per step at N = 2^22 as this
 // regroup, 13 % slower in the VALU-bound random-policy rollout, since it evaluates five functions per env instead of
@@ -1163,7 +1287,12 @@ __device__ __forceinline__ void zoo_draw_select_tile(const int (&kind)[4], const
 template <typename T>
 __device__ __forceinline__ void zoo_draw_regrouped(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
                                                    const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[4],
-                                                   ZooSlot<T>* __restrict__ win, int lane) {
+                                                   ZooSlot<T>* __restrict__ win, int lane, const T* __restrict__ lut = nullptr) {
+    if constexpr (FISHING_V11_FORM == 2 && ((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP))) {
+        // the coefficients from the workgroup's LDS table (every caller of this build hands one over)
+        zoo_draw_lut_tile<T, 4>(kind, x, z, zoo, lut, out);
+        return;
+    }
     if constexpr (FISHING_V11_FORM == 1 && ((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP))) {
         // round 5: per lane, one division and one exp per env, selected by kind (zoo_draw_select_tile); `win` stays unused
         zoo_draw_select_tile<T>(kind, x, z, zoo, out);
@@ -1366,12 +1495,19 @@ __device__ __forceinline__ void model_block(uint64_t seed, uint64_t quad, uint64
 __device__ __forceinline__ int32_t model_index_from_half(uint32_t half16, int32_t n_models) {
     return (int32_t)((half16 * (uint32_t)n_models) >> 16);
 }
-// Returns whether any kind was redrawn.
+// Returns whether any kind was redrawn.  N = 4: the thread holds the quad; N = 2 (the float64 two-envs-per-thread forms): the thread
+// holds the quad's lower or upper pair (base & 2) and takes that pair's halves of the quad's block.
+template <int N>
 __device__ __forceinline__ bool redraw_kinds(uint64_t seed, uint64_t base, uint64_t counter, uint32_t stream,
                                              const int32_t (&kinds)[FISHING_N_KINDS], int32_t n_models,
-                                             const bool (&fin)[4], int32_t (&kind)[4]) {
-    if (!(fin[0] | fin[1] | fin[2] | fin[3])) return false;
+                                             const bool (&fin)[N], int32_t (&kind)[N]) {
+    static_assert(N == 4 || N == 2, "a quad or a pair");
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) any |= fin[j];
+    if (!any) return false;
 #if FISHING_V11_REDRAW_4X32      // rounds 1-4, for A/B timing only (the oracle mirrors the 2x32 scheme)
+    static_assert(N == 4, "the A/B build has no pair form");
     const Words4 w = philox_block(seed, base >> 2, counter, stream);
     const uint32_t ww[4] = {w.w0, w.w1, w.w2, w.w3};
 #pragma unroll
@@ -1379,9 +1515,15 @@ __device__ __forceinline__ bool redraw_kinds(uint64_t seed, uint64_t base, uint6
 #else
     uint32_t w0, w1;
     model_block(seed, base >> 2, counter, stream == kStreamReset, w0, w1);
-    const uint32_t hh[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
+    if constexpr (N == 4) {
+        const uint32_t hh[4] = {w0 & 0xFFFFu, w0 >> 16, w1 & 0xFFFFu, w1 >> 16};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) kind[j] = fin[j] ? kinds[model_index_from_half(hh[j], n_models)] : kind[j];
+        for (int j = 0; j < 4; ++j) kind[j] = fin[j] ? kinds[model_index_from_half(hh[j], n_models)] : kind[j];
+    } else {
+        const uint32_t w = (base & 2u) ? w1 : w0;
+        kind[0] = fin[0] ? kinds[model_index_from_half(w & 0xFFFFu, n_models)] : kind[0];
+        kind[1] = fin[1] ? kinds[model_index_from_half(w >> 16, n_models)] : kind[1];
+    }
 #endif
     return true;
 }

@@ -75,6 +75,14 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         }
     }
 
+    // fishing-v11, -DFISHING_V11_FORM=2: the growth functions' coefficients as a table in LDS (fishing_common.h: zoo_lut_fill), written
+    // once per launch
+    __shared__ alignas(16) T zoo_lut[(zoo_mixed && FISHING_V11_FORM == 2) ? kZooLutSize : 4];
+    if constexpr (zoo_mixed && FISHING_V11_FORM == 2) {
+        if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, p.zoo);
+        __syncthreads();
+    }
+
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
         const bool active = base < n;
@@ -221,7 +229,8 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                         xn[j] = (T)0;
                         kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                     }
-                    zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane);
+                    zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane,
+                                          FISHING_V11_FORM == 2 ? zoo_lut : nullptr);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         o2[j] = xn[j] / KK[j] - (T)1;
@@ -543,6 +552,13 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
         }
     }
 
+    // (fishing-v11, -DFISHING_V11_FORM=2: see rollout_kernel)
+    __shared__ alignas(16) T zoo_lut[(zoo_mixed && FISHING_V11_FORM == 2) ? kZooLutSize : 4];
+    if constexpr (zoo_mixed && FISHING_V11_FORM == 2) {
+        if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, ex.zoo);
+        __syncthreads();
+    }
+
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
         const bool active = RAGGED ? base < n : true;
@@ -653,7 +669,8 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                             xn[j] = (T)0;
                             kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                         }
-                        zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane);
+                        zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane,
+                                              FISHING_V11_FORM == 2 ? zoo_lut : nullptr);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             o2[j] = xn[j] / KK[j] - (T)1;

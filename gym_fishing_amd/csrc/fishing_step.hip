@@ -91,6 +91,13 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
     const int zoo_kind = kZoo ? p.kind : FISHING_KIND_BEVERTON_HOLT;
     const GrowthT<T> zoo_base = p.growth;
 
+    // (fishing-v11, -DFISHING_V11_FORM=2: the growth functions' coefficients as a table in LDS, fishing_common.h: zoo_lut_fill)
+    __shared__ alignas(16) T zoo_lut[(zoo_mixed && FISHING_V11_FORM == 2) ? kZooLutSize : 4];
+    if constexpr (zoo_mixed && FISHING_V11_FORM == 2) {
+        if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, p.zoo);
+        __syncthreads();
+    }
+
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = (tile * blockDim.x + threadIdx.x) * kEnvsPerThread;
         const bool active = base < n;
@@ -169,7 +176,8 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                     xn[j] = (T)0;
                     kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                 }
-                zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane);
+                zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane,
+                                      FISHING_V11_FORM == 2 ? zoo_lut : nullptr);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     obs_next[j] = xn[j] / KK[j] - (T)1;
@@ -428,7 +436,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
     static_assert((F & feat::ONE) != 0, "every lean form is a one-tile form: a workgroup of 1024 / E threads per 1024-env tile");
 #ifndef FISHING_X_V4_E2
-    static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && !kMixed), "E = 2: the float64 layout");
+    // (fishing-v11 too since its growth function's coefficients come from an LDS table: the regroup needed a lane's four envs)
+    static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && (!kMixed || FISHING_V11_FORM == 2)), "E = 2: the float64 layout");
 #endif
     constexpr int kThreads = FISHING_X_TILE_ENVS / E;
     constexpr int kTileEnvs = FISHING_X_TILE_ENVS;
@@ -738,6 +747,11 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         if constexpr (kMixed) {
             if (!SIGARR) {      // wave-uniform: regroup the wave's envs by growth function (fishing_common.h: zoo_draw_regrouped)
                 __shared__ ZooSlot<T> win[(kThreads / kWave) * kZooWindowSlots];     // one window per wave
+                __shared__ alignas(16) T zoo_lut[kZooLutSize];
+                if constexpr (FISHING_V11_FORM == 2) {      // (the tile's loads are in flight: the table is written under them)
+                    if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, ex.zoo);
+                    __syncthreads();
+                }
                 T xh[E], hv[E], xn[E];
                 int kk[E];
 #pragma unroll
@@ -751,8 +765,11 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                     xn[j] = (T)0;
                     kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                 }
-                zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots,
-                                      (int)(threadIdx.x & (kWave - 1)));
+                if constexpr (FISHING_V11_FORM == 2)
+                    zoo_draw_lut_tile<T, E>(kk, xh, z, ex.zoo, zoo_lut, xn);
+                else if constexpr (E == 4)
+                    zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots,
+                                          (int)(threadIdx.x & (kWave - 1)));
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     obs_next[j] = div_K<T>(xn[j], KK[j], a.dk) - (T)1;       // (the env's scalar K: a multiply when it is a power of two)
@@ -848,8 +865,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         }
         if constexpr (kMixed) {     // growth_models.py:200: a new model for the next episode
             if (auto_reset && __any(lane_done)) {
-                if (redraw_kinds(seed_it, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, ex.kinds, ex.n_models, dn,
-                                 kind)) {
+                if (redraw_kinds<E>(seed_it, env_offset + (uint64_t)base, step_counter, kStreamAutoReset, ex.kinds, ex.n_models, dn,
+                                    kind)) {
                     VecE<int32_t, E> qk;
 #pragma unroll
                     for (int j = 0; j < E; ++j) qk.v[j] = kind[j];
@@ -1161,6 +1178,15 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
     // run-time test, plus the straight per-lane switch of the per-env-sigma path: five inlined growth functions for each of
     // a thread's four envs -- spilled (36 B of scratch per lane, 16 SGPRs) at 105 VGPRs; the two hot requests get exact forms
     if constexpr (sizeof(T) == 8 && MODEL == kModelZooMixed) {
+#if FISHING_V11_FORM == 2       // (round 5: no regroup any more, so the float64 layout's two-envs-per-thread shape is open to fishing-v11 too)
+        if (c.two_per_thread) {
+            switch (req) {
+                case (P): return lean_launch<T, MODEL, (P | ONE), 2>(c);
+                case (P | RET): return lean_launch<T, MODEL, (P | RET | ONE), 2>(c);
+                default: return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE, 2>(c);
+            }
+        }
+#endif
         switch (req) {
             case (P): return lean_launch<T, MODEL, (P | ONE)>(c);
             case (P | RET): return lean_launch<T, MODEL, (P | RET | ONE)>(c);

@@ -230,7 +230,7 @@ def test_kernel_names_follow_the_dispatch(hh):
     b11 = hh.State(4096, np.float32, fo.MODEL_V11, np.zeros(4096), model_idx=np.zeros(4096, np.int32), ep_return=True)
     full11 = b11.buffers(b11.action_tensor(np.zeros(4096, np.float32)))
     assert hh.kernel_name(p11, n, full11) == "fishing::step_kernel_lean<float, 105, 8198>"
-    assert hh.kernel_name(p11, n, full11, np.float64) == "fishing::step_kernel_lean<double, 105, 8198>"
+    assert hh.kernel_name(p11, n, full11, np.float64) == "fishing::step_kernel_lean<double, 105, 8198, 2>"     # (two envs per thread: round 5)
 
 
 # ------------------------------------------------------------------ the host mirror in the derived mode

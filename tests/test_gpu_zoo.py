@@ -402,8 +402,8 @@ def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 def test_v11_lean_and_general_kernels_agree(hh, ret, dtype):
-    """fishing-v11 takes the lean step kernel too (growth function per env: the wave regroups its envs by kind through
-    LDS; the kinds are redrawn at every auto-reset) -- exact instantiations in both layouts (float64: round 4; the catch-all's
+    """fishing-v11 takes the lean step kernel too (growth function per env: its coefficients come from a table in LDS -- rounds
+    2-4 regrouped the wave's envs by kind --; the kinds are redrawn at every auto-reset) -- exact instantiations in both layouts (float64: round 4; the catch-all's
     one-tile form in round 3, the general kernel before): same bits as the general kernel on every stream and on the kind array
     over 14 auto-resetting steps, three-model list in a non-default order, ragged tail included."""
     import torch
@@ -414,8 +414,10 @@ def test_v11_lean_and_general_kernels_agree(hh, ret, dtype):
     pa, pb = hh.params(fo.MODEL_V11, **kw), hh.params(fo.MODEL_V11, general=True, **kw)
     A, B = (hh.State(n, dtype, fo.MODEL_V11, np.zeros(n), ep_return=ret, model_idx=np.zeros(n, np.int32)) for _ in range(2))
     f32 = dtype == np.float32
-    assert hh.kernel_name(pa, n, A.buffers(A.obs), dtype) == "fishing::step_kernel_lean<%s, 105, %d>" % (
-        "float" if f32 else "double", 8198 if ret else 8194)
+    # (float64: two envs per thread at cache-resident sizes, like every other model of the layout -- round 5, once the
+    # growth function's coefficients came from an LDS table instead of a regroup of the lane's four envs)
+    assert hh.kernel_name(pa, n, A.buffers(A.obs), dtype) == "fishing::step_kernel_lean<%s, 105, %d%s>" % (
+        "float" if f32 else "double", 8198 if ret else 8194, "" if f32 else ", 2")
     assert hh.kernel_name(pb, n, B.buffers(B.obs), dtype) == "fishing::step_kernel<%s, 105>" % ("float" if f32 else "double")
     step = lib.fishing_step_f32 if f32 else lib.fishing_step_f64
     A.reset(pa, seed=5, env_offset=12)
