@@ -1030,19 +1030,24 @@ __device__ __forceinline__ void zoo_eval_kind(ZooSlot<T>* __restrict__ win, int 
     }
 }
 
-// ---------------------------------------------------------------- fishing-v11, round 5 experiment: one division and one exp per env
+// ---------------------------------------------------------------- fishing-v11, round 5: one division and one exp per env
 // Every growth function of the zoo is x' = max(0, pre_k(x) * exp(g_k(x, z))) in its algebraic form (above), and what differs
 // by kind is cheap: g is sigma_k z plus, for Allen and Ricker, c_k (1 - x / K_k); pre is x itself (Allen, Ricker), one
-// quotient n_k / d_k (Beverton-Holt, Myers) or a cubic minus that quotient (May).  So a lane can evaluate, for each of its
-// envs, the three (n, d) pairs and the two exponents with wave-uniform constants, SELECT by the env's kind, and run ONE
-// division and ONE exp at full lane occupancy: no LDS, no ballots, no divergent passes -- 670 -> 480 VALU and 579 -> 230 SALU
-// instructions in the float32 step kernel against the regroup-by-kind form (zoo_draw_regrouped).  Same operations on the
-// same operands as zoo_pre_g_f32 / zoo_pre_g_f64 of the env's kind: the same bits (the whole GPU suite passes on either).
-// MEASURED (profiles/r05_v11_forms.jsonl, N = 2^22, same box, alternating): float32 step 28.7 vs 29.0 us (-1 %: the step is
-// bound by its dependent chain load -> draw -> record -> redraw -> store in two rounds of waves, not by its instruction
-// count), float64 step 53.2 vs 48.6 (+9 %: five kinds' candidates in 5.3-cycle float64 instructions cost more than four
-// fifths of a pass), random-policy rollout 9.87 vs 9.42 ms (+5 %).  NOT shipped: -DFISHING_V11_FORM=1 builds it.  What IS
-// used from here: zoo_draw_select_one with the caller's sigma for the per-env-sigma path (env_step_zoo_mixed below).
+// quotient n_k / d_k (Beverton-Holt, Myers) or a cubic minus that quotient (May).  So a lane can evaluate ONE division and ONE
+// exp per env at full lane occupancy -- no ballots, no divergent passes -- if it gets hold of its env's coefficients.  Two ways:
+//   FISHING_V11_FORM 1 ("select"): evaluate the three quotients' (n, d) and the two exponents with wave-uniform constants and
+//       select by kind.  A VALU instruction reads ONE scalar register on this architecture, so every `kind == k ? c_k : ...`
+//       first moves its constants into vector registers: 755 VALU / 651 SALU instructions in the float32 step kernel against the
+//       regroup's 662 / 603 -- float32 step 28.7 -> 28.2 us, float64 48.4 -> 53.2, rollout -2.5 %.  Not shipped.
+//   FISHING_V11_FORM 2 ("table", below; ships): the coefficients from a 5 x 8 table in LDS, two 16-byte LDS reads per env.
+//       float32 step 28.7 -> 27.2 us (0.75 -> 0.79 of the HBM spec at 41 B; rocprofv3 26.3 = 0.82), random-policy rollout
+//       7.94 -> 6.05 ms (2.67 -> 3.5e11 env-steps/s), and -- a lane's four envs no longer have to be regrouped -- the float64
+//       layout's two-envs-per-thread shape for fishing-v11 too: 48.4 -> 41.8 us (0.66 -> 0.77 at 61 B).
+//   FISHING_V11_FORM 0: the regroup-by-kind form of rounds 2-4 (zoo_draw_regrouped: 20 ballot / mbcnt ranks, three LDS phases,
+//       5-7 passes per wave at ~80 % lane occupancy, each with its own scalar parameter fetch and exec-mask frame).
+// All three run the operations of zoo_pre_g_f32 / zoo_pre_g_f64 of the env's kind on the same operands: the same bits (the GPU
+// suite passes on each; profiles/r05_v11_forms.jsonl).  zoo_draw_select_one also serves the per-env-sigma path
+// (env_step_zoo_mixed below) in every build.
 #ifndef FISHING_V11_FORM
 #define FISHING_V11_FORM 2
 #endif
@@ -1160,11 +1165,9 @@ __device__ __forceinline__ void zoo_draw_select_tile(const int (&kind)[4], const
 }
 
 // ---------------------------------------------------------------- fishing-v11: the growth function's coefficients from an LDS table
-// (-DFISHING_V11_FORM=2.)  The select form above pays for choosing between wave-uniform constants per lane: a VALU instruction
-// reads ONE scalar register on this architecture, so every `kind == k ? c_k : ...` first moves its constants into vector
-// registers (70 v_mov in the float32 step kernel; 755 VALU instructions in all, against the regroup's 662).  Here the five
-// kinds' coefficients sit in a 5 x 8 table in LDS, written once per workgroup, and an env fetches ITS row with two 16-byte LDS
-// reads (four in float64) -- no selects of constants, no ballots, no passes:
+// (FISHING_V11_FORM 2, the product.)  The five kinds' coefficients sit in a 5 x 8 table in LDS, written once per workgroup (by its
+// first wave, while the tile's loads are in flight; once per launch in the rollout kernels), and an env fetches ITS row with two
+// 16-byte LDS reads (four in float64) -- no selects of constants, no ballots, no passes:
 //     row k = { sigma, cg, cK, c1, c2, c3, cr, - }
 //     g   = cg (1 - x cK) + sigma z          Allen: cg = r (1 - C) / K, cK = 1 / K;  Ricker: cg = r, cK = 1 / K;  others cg = 0
 //     q   = c1 w / (c2 + c3 w)               w = clip(x) (Beverton-Holt: c1 = A, c2 = 1, c3 = 1 / B) or x ** p (Myers: A, 1, 1 / M;

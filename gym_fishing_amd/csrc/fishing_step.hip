@@ -507,6 +507,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     double acc[kPartialFields] = {0.0, 0.0, 0.0, 0.0};
     const T robs_scalar = (MODEL == FISHING_MODEL_V4) ? a.x0 : a.robs;       // (reset_obs<T, MODEL>(a.x0, a.pK))
 
+    __shared__ alignas(16) T zoo_lut[kMixed ? kZooLutSize : 4];     // (fishing-v11 only; unused -- and not allocated -- elsewhere)
 #if FISHING_X_TPW > 1
     struct TileIn {     // what a tile's load phase hands to its step phase (registers; TPW = 2 holds two of them)
         int64_t it, tile, base;
@@ -704,6 +705,12 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // the loads above must be in flight BEFORE the ~100-instruction Philox block starts: without
         // this fence the scheduler hoists the (independent) generator above them in some variants
         if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kMixed && FISHING_V11_FORM == 2) {
+            // fishing-v11: the growth functions' coefficient table (fishing_common.h: zoo_lut_fill), written by the first wave while
+            // the tile's loads are in flight and ahead of its own noise block, so that the workgroup barrier in front of the
+            // first lookup finds it done
+            if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, ex.zoo);
+        }
         if constexpr (FISHING_LEAN_BATCH_ARGS == 1) batch_args();
         if (!ZZ) step_counter = read_counter();
         if (noise == kNoisePhilox) {
@@ -747,11 +754,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         if constexpr (kMixed) {
             if (!SIGARR) {      // wave-uniform: regroup the wave's envs by growth function (fishing_common.h: zoo_draw_regrouped)
                 __shared__ ZooSlot<T> win[(kThreads / kWave) * kZooWindowSlots];     // one window per wave
-                __shared__ alignas(16) T zoo_lut[kZooLutSize];
-                if constexpr (FISHING_V11_FORM == 2) {      // (the tile's loads are in flight: the table is written under them)
-                    if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, ex.zoo);
-                    __syncthreads();
-                }
+                if constexpr (FISHING_V11_FORM == 2) __syncthreads();      // (the table: written by wave 0 right behind the tile's loads)
                 T xh[E], hv[E], xn[E];
                 int kk[E];
 #pragma unroll
