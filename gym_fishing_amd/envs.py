@@ -18,7 +18,9 @@ own draws from NumPy's global legacy stream, in its order, handed to the kernel 
 ``np.random.seed(s)`` reproduces the reference's trajectories.
 
 All arithmetic happens in the HIP kernels (csrc/); this file only owns buffers, counters
-and argument plumbing.  No CPU fallback: without the library or a HIP device the
+and argument plumbing.  Three concerns live in mixins of their own: fishing-v4's parameter-mode
+machine (v4_params.py), checkpoints / graph replay (checkpoint.py), the reference's helper
+methods -- get_quota ... population_draw, simulate, plot -- (reference_helpers.py).  No CPU fallback: without the library or a HIP device the
 constructor raises FishingLibraryError.
 """
 import csv
@@ -30,7 +32,9 @@ from . import _capi
 from ._capi import (FLAG_AUTO_RESET, FLAG_PADDED_TILES, FLAG_T_U8, FLAG_V4_DERIVED, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
                     MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11, POLICY_CONSTANT, POLICY_ESCAPEMENT,
                     POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
-from .spaces import is_discrete, space_classes
+from .spaces import space_classes
+from .checkpoint import STATE_FORMAT, V4_PARAM_STREAM, CheckpointAndReplay  # noqa: F401  (re-exported)
+from .reference_helpers import ReferenceHelpers
 from .v4_params import V4ParameterModes
 
 POLICIES = {"random": POLICY_RANDOM, "constant": POLICY_CONSTANT, "escapement": POLICY_ESCAPEMENT,
@@ -93,13 +97,7 @@ def _gym_env_base():
         return object
 
 
-# state_dict() format.  2: carries `format` and `v4_param_stream` (what draws fishing-v4's (K, r): one Philox2x32-10 block
-# per env, fishing_common.h: param_block); _counter holds {step counter, v4 origin step, v4 origin counter}.
-STATE_FORMAT = 2
-V4_PARAM_STREAM = "philox2x32-10/env"
-
-
-class BaseFishingEnv(V4ParameterModes, _gym_env_base()):
+class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _gym_env_base()):
     """base_fishing_env.py:16-164, vectorised.  See the module docstring."""
 
     metadata = {"render.modes": ["human"]}
@@ -329,28 +327,6 @@ class BaseFishingEnv(V4ParameterModes, _gym_env_base()):
                else torch.full((self._cap,), fill, dtype=dtype, device=self.device))
         return buf[:self.num_envs]
 
-    def _current_step_count(self):
-        """How many step() calls this env has made.  In graph-replay mode the device-resident counter is the truth -- a
-        replayed hipGraph (GraphedSteps, or a caller's own torch.cuda.CUDAGraph) advances only that -- so the host's
-        copy is refreshed from it here (one 8-byte read that waits for the stream: reset(), env.K / env.r, state_dict()
-        and leaving the derived mode ask, step() never does)."""
-        if self._counter is not None:
-            self._step_count = int(self._counter[0].item())
-        return self._step_count
-
-    def launch_signature(self):
-        """Everything a captured launch has frozen: the parameter struct's source values, fishing-v4's parameter mode and
-        the address of every stream.  A hipGraph captured from this env replays correctly only while this value is what it
-        was at capture time (GraphedSteps checks it on every replay and re-captures; a caller's own torch.cuda.CUDAGraph
-        must do the same): env.Tmax = ..., env.sigma = ..., env.K = ..., seed(), a masked reset() of fishing-v4 and
-        load_state_dict() can all change it."""
-        ptr = lambda t: (t.data_ptr() if t is not None else 0)  # noqa: E731
-        # (in graph-replay mode fishing-v4's episode origin travels in the device-resident counter words: not part of the key)
-        return (self._param_key(), self._seed, self._derived,
-                tuple(ptr(t) for t in (self._obs, self._t, self._reward, self._done, self._done_bits, self._r_arr, self._K_arr,
-                                       self._sigma_arr, self._terminal_obs, self._ep_return, self._partials, self._model_idx,
-                                       self._counter, self._stamp)))
-
     def _set_param(self, name, v):
         if self._per_env:
             self._leave_derived_mode()
@@ -493,100 +469,6 @@ class BaseFishingEnv(V4ParameterModes, _gym_env_base()):
         if self._counter is not None:
             self._counter.zero_()
         return [self._seed]
-
-    # ------------------------------------------------------------------ checkpoint / resume
-    _STATE_TENSORS = ("_obs", "_t", "_reward", "_done", "_r_arr", "_K_arr", "_sigma_arr", "_ep_return", "_partials",
-                      "_model_idx", "_counter", "_stamp")
-    _STATE_ATTRS = ("_sigma_scalar", "n_actions", "C", "K_mean", "r_mean", "sigma_p")
-
-    def state_dict(self):
-        """Everything a rollout needs to resume bit-for-bit: the per-env streams, the counters that
-        key the noise, the seed.  (The reference has no checkpointing; its env is a few scalars.)"""
-        if self._scalar:
-            torch.cuda.current_stream(self.device).synchronize()
-        sd = {k: getattr(self, k).clone() for k in self._STATE_TENSORS if getattr(self, k) is not None}
-        sd.update(format=STATE_FORMAT, v4_param_stream=V4_PARAM_STREAM,
-                  seed=self._seed, step_count=self._current_step_count(), reset_count=self._reset_count,
-                  params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state,
-                  v4_derived=self._derived, v4_origin=tuple(self._host_origin()), auto_reset=self.auto_reset,
-                  attrs={k: getattr(self, k) for k in self._STATE_ATTRS if hasattr(self, k)})
-        if self.MODEL == MODEL_V11:
-            sd["attrs"].update(models=list(self.models), model_params={k: dict(v) for k, v in self.model_params.items()})
-        if self._np_rng:        # rng="numpy": the noise source is NumPy's global stream -- part of the state
-            sd["numpy_rng_state"] = np.random.get_state()
-        return sd
-
-    def load_state_dict(self, sd, strict=True):
-        """Resume from state_dict().  fishing-v4 on the Philox streams redraws (K, r) at every reset from a generator that
-        is part of the state's meaning (`v4_param_stream`): a state written under another scheme (round 1: one Philox4x32
-        block per env PAIR; no tag at all before format 2) is refused in the derived mode, where the parameters in force
-        themselves would come out different.  A stored-array state carries its (K, r) in force, so `strict=False` loads it
-        with a warning -- the run continues exactly until the first redraw, which then follows this library's stream.  Envs
-        that never use that stream (rng="numpy": the scalar protocol's default) load any fishing-v4 state."""
-        # everything that can refuse the state is checked BEFORE the first field changes: a failed load leaves the env as it was
-        self._check_v4_state(sd, strict, V4_PARAM_STREAM)
-        v4_arrays = self._per_env and not sd.get("v4_derived", False)
-        for k in self._STATE_TENSORS:
-            if k in sd and getattr(self, k) is None and k not in ("_counter", "_stamp") and not (k in ("_r_arr", "_K_arr") and v4_arrays):
-                raise ValueError("state has %s but this env was built without it" % k)
-            # sizes too: a state of another batch size must not get as far as the first copy_.  (return_partials grew with
-            # ABI 5 for batches beyond 2^22 envs: an older, shorter buffer loads into the first slots -- the record is
-            # the sum over slots -- a longer one cannot.)
-            if k in sd and getattr(self, k) is not None and k != "_counter":
-                have, got = getattr(self, k).numel(), sd[k].numel()
-                if got != have and not (k == "_partials" and got < have):
-                    raise ValueError("state's %s has %d elements, this env's %d" % (k, got, have))
-        if self._host_mapped:
-            torch.cuda.current_stream(self.device).synchronize()
-        self._adopt_v4_mode(sd)                 # fishing-v4: same parameter mode as the saved env
-        for k in self._STATE_TENSORS:
-            if k in sd:
-                if getattr(self, k) is None and k == "_counter":
-                    self.enable_graph_replay()
-                if k == "_counter":         # (format 1 kept the step counter alone; the origin words follow _origin below)
-                    self._counter[:sd[k].numel()].copy_(sd[k])
-                elif k == "_partials" and sd[k].numel() < self._partials.numel():
-                    self._partials.zero_()
-                    self._partials[:sd[k].numel()].copy_(sd[k])
-                else:
-                    getattr(self, k).copy_(sd[k])
-        self._seed, self._step_count, self._reset_count = sd["seed"], sd["step_count"], sd["reset_count"]
-        if self._counter is not None and "_counter" not in sd:
-            # a state taken from a host-counter env, loaded into an env in graph-replay mode: the device word is this env's
-            # step count from here on (_current_step_count() reads it back), so it must not keep the value it had
-            self._counter[0].fill_(int(sd["step_count"]))
-        self.params.update(sd["params"])
-        self.Tmax, self.init_state = sd["Tmax"], sd["init_state"]
-        self.auto_reset = sd.get("auto_reset", self.auto_reset)
-        for k, v in sd.get("attrs", {}).items():          # the scalar attributes FishingParams is built from
-            setattr(self, k, [*v] if k == "models" else ({m: dict(d) for m, d in v.items()} if k == "model_params" else v))
-        if self._sigma_arr is None and "_sigma_scalar" not in sd.get("attrs", {}):
-            self._sigma_scalar = float(self.params["sigma"])
-        if self._np_rng and "numpy_rng_state" in sd:
-            np.random.set_state(sd["numpy_rng_state"])
-        if self._per_env:
-            self._set_origin(*self._origin)
-        self._publish_scalar_state()
-        return self
-
-    def enable_graph_replay(self):
-        """Keep the step counter in device memory from now on.  step() / step_many() / rollout()
-        then launch with frozen arguments plus a one-thread counter bump, so a hipGraph that
-        captured them (gym_fishing_amd.graphs.GraphedSteps, or a caller's own torch.cuda.CUDAGraph) draws
-        fresh noise on every replay.  Same noise stream as the host-counter mode.
-        What a capture freezes besides the counter: every scalar of the parameter struct, fishing-v4's parameter mode
-        (derived / stored arrays) and every stream's address -- launch_signature().  GraphedSteps re-captures when that
-        changes; a caller replaying a torch.cuda.CUDAGraph of its own must compare launch_signature() itself.  The env
-        never frees a stream a capture may still reference (fishing-v4's r / K arrays live as long as the env)."""
-        if self._counter is None:
-            # {step counter, v4 origin step, v4 origin counter}: a captured launch freezes FishingParams, and with them the
-            # origin that the derived fishing-v4 parameters date episodes from -- so in this mode the kernels read the
-            # origin from these words (include/fishing_hip.h: FishingBuffers.counter), which reset() rewrites.  fishing-v4
-            # stays in the derived mode under graph replay (ABI 4; round 2 fell back to r / K arrays for good).
-            self._counter = torch.tensor([self._step_count, self._origin[0], self._origin[1]], dtype=torch.int64,
-                                         device=self.device)
-            self._cbuf = None
-        return self
 
     def reset(self, mask=None, *, seed=None, options=None):
         """base_fishing_env.py:83-91 (v4: fishing_model_error.py:41-48).  `mask` (bool[N]) resets
@@ -862,190 +744,6 @@ class BaseFishingEnv(V4ParameterModes, _gym_env_base()):
         fn = getattr(self._lib, "fishing_step_kernel_name_" + self._suffix)
         _capi.check(fn(self._c_params(), self.num_envs, self._c_buffers(a), out, 160), "fishing_step_kernel_name")
         return out.value.decode()
-
-    # ------------------------------------------------------------------ helpers (base_fishing_env.py:135-164)
-    def _K_for_math(self):
-        if self._per_env:
-            return self._K_view()
-        return self.params["K"]
-
-    def get_quota(self, action):
-        """base_fishing_env.py:135-147 (elementwise on tensors in vec mode)."""
-        K = self._K_for_math()
-        if is_discrete(self.action_space):
-            if isinstance(action, torch.Tensor):
-                return (action.to(torch.float64) / self.n_actions) * K
-            return (action / self.n_actions) * K
-        # the action passes through the float32 action Box (np.clip against its float32 bounds),
-        # then the quota is formed in float64 (SURVEY.md Appendix A.3)
-        if isinstance(action, torch.Tensor):
-            return (action.to(torch.float32).to(torch.float64).clamp(-1.0, 1.0).reshape(-1) + 1.0) * K
-        a = np.clip(np.asarray(action, dtype=np.float32).astype(np.float64), -1.0, 1.0).reshape(-1)[0]
-        return (a + 1) * K
-
-    def get_action(self, quota):
-        """base_fishing_env.py:149-156."""
-        K = self._K_for_math()
-        if is_discrete(self.action_space):
-            if isinstance(quota, torch.Tensor):
-                return torch.round(quota * self.n_actions / K).to(torch.int64)
-            return round(quota * self.n_actions / K)
-        return quota / K - 1
-
-    def get_fish_population(self, state):
-        """base_fishing_env.py:158-160."""
-        K = self._K_for_math()
-        if isinstance(state, torch.Tensor):
-            pop = (state.to(torch.float64).reshape(-1) + 1.0) * K
-            return pop
-        # (state[0] + 1) * K: a (1,) observation gives a scalar, the reference's VecEnv idiom
-        # get_fish_population((obs_i,)) (shared_env.py:17-19) an array of shape (1,)
-        s0 = state if np.ndim(state) == 0 else state[0]
-        pop = (np.asarray(s0, dtype=np.float64) + 1) * K
-        if self._scalar:
-            self.fish_population = pop
-        return pop
-
-    def get_state(self, fish_population):
-        """base_fishing_env.py:162-164."""
-        K = self._K_for_math()
-        if isinstance(fish_population, torch.Tensor):
-            return (fish_population / K - 1.0).reshape(-1, 1)
-        return np.array([fish_population / K - 1])
-
-    def harvest_draw(self, quota, x=None):
-        """base_fishing_env.py:112-119: harvest = min(population, quota); population = max(population - harvest, 0.0).
-        One env: on self.fish_population, which it updates, like the reference (self.harvest too).  Tensors: `x` holds
-        the populations (default: the batch's current ones), elementwise with Python's min / max operand order (a NaN
-        quota leaves the population's side of min(), as in the step kernels); returns (harvest, population left)."""
-        if isinstance(quota, torch.Tensor) or isinstance(x, torch.Tensor) or not self._scalar:
-            if x is None:
-                x = self.get_fish_population(self._obs_view)
-            xt = torch.as_tensor(x, device=self.device)
-            q = torch.as_tensor(quota, device=self.device).to(xt.dtype).expand_as(xt) if not isinstance(quota, torch.Tensor) \
-                else quota.to(device=self.device, dtype=xt.dtype).reshape(xt.shape)
-            h = torch.where(q < xt, q, xt)                       # min(x, q): q only where q < x
-            d = xt - h
-            return h, torch.where(d.new_zeros(()) > d, d.new_zeros(()), d)     # max(d, 0.0): 0.0 only where 0.0 > d
-        pop = self.fish_population if x is None else x
-        self.harvest = min(pop, quota)
-        self.fish_population = max(pop - self.harvest, 0.0)
-        return self.harvest
-
-    def population_draw(self, x=None, noise=None, sigma=None, dtype=None, r=None, K=None, model_idx=None):
-        """base_fishing_env.py:121-133 (v2: fishing_tipping_env.py:24-35) over an array of
-        populations -- the call BMSY() makes (models/policies.py:59-63).  `x` None uses
-        self.fish_population like the reference's zero-argument form (scalar protocol).
-        `dtype` picks the arithmetic (default: the env's layout); `sigma`, `r`, `K` override the
-        scalar parameters for this call only (`r` / `K` as tensors: one value per population).
-        fishing-v11 (growth_models.py:190-194: the growth function in force, with ITS parameter set).  One env: its
-        model.  N envs: `x` holds one population per env and env i grows under model_idx[i], the function in force
-        there -- or pass `model_idx` (int32, one FISHING_KIND per element of `x`) to choose per element, e.g. one sweep
-        per growth function in a single launch (policies.BMSY does)."""
-        use_attr = x is None
-        if use_attr:
-            x = self.fish_population
-        dtype = self.dtype if dtype is None else dtype
-        xt = torch.as_tensor(x).to(device=self.device, dtype=dtype).reshape(-1).contiguous()
-        zt = None
-        if noise is not None:
-            zt = torch.as_tensor(noise).to(device=self.device, dtype=dtype).reshape(-1).contiguous()
-        elif self._np_rng:
-            # the reference draws here whatever sigma is: one np.random.normal(0, 1) for the logistic / tipping
-            # models (base_fishing_env.py:130), np.random.lognormal(mu, sigma) -- one normal per ELEMENT of mu --
-            # for the zoo (growth_models.py:217-261); consume the global stream the same way
-            zoo = self.MODEL not in (MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4)
-            z = np.random.normal(0, 1, xt.numel()) if (zoo and xt.numel() > 1) else np.full(xt.numel(), np.random.normal(0, 1))
-            zt = torch.as_tensor(z).to(device=self.device, dtype=dtype)
-        out = torch.empty_like(xt)
-        cp = self._c_params()
-        if self.MODEL == MODEL_V10 and self._scalar and r is None:
-            # growth_models.py:151: every population_draw() call -- BMSY()'s and msy()'s sweeps included -- first
-            # moves r by alpha, and keeps the moved value
-            r = float(self._r_arr[0]) + float(self.params.get("alpha", 0.0))
-            self._r_arr.fill_(r)
-        # `r` / `K` as tensors (one value per population): element i under ITS parameters -- N fishing-v4 envs, each with the
-        # pair it drew (policies.msy); scalars override the struct's for this call
-        r_arr = K_arr = None
-        if isinstance(r, torch.Tensor) or isinstance(K, torch.Tensor):
-            if self.MODEL not in (MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4):
-                raise ValueError("per-population r / K are the logistic / tipping models'")
-            if isinstance(r, torch.Tensor):
-                r_arr, r = r.to(device=self.device, dtype=dtype).reshape(-1).contiguous(), None
-            if isinstance(K, torch.Tensor):
-                K_arr, K = K.to(device=self.device, dtype=dtype).reshape(-1).contiguous(), None
-            if any(a is not None and a.numel() != xt.numel() for a in (r_arr, K_arr)):
-                raise ValueError("r / K tensors need one value per population (%d)" % xt.numel())
-        if sigma is not None or r is not None or K is not None:     # never edit the cached struct step() uses
-            cp = _capi.FishingParams.from_buffer_copy(cp)
-            if sigma is not None:
-                cp.sigma = float(sigma)
-            if r is not None:
-                cp.r = float(r)
-            if K is not None:
-                cp.K = float(K)
-        kinds = None
-        if model_idx is not None and self.MODEL != MODEL_V11:
-            raise ValueError("model_idx selects fishing-v11's growth function per element; %s has one" % type(self).__name__)
-        if self.MODEL == MODEL_V11:
-            # growth_models.py:190-194: the growth function currently in force, with ITS parameter set
-            if model_idx is not None:
-                kinds = torch.as_tensor(model_idx).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
-                if kinds.numel() != xt.numel():
-                    raise ValueError("model_idx needs one entry per population (%d), got %d" % (xt.numel(), kinds.numel()))
-            elif self._scalar:
-                kinds = self._model_idx[:1].expand(xt.numel()).contiguous()      # one env, one model in force
-            elif xt.numel() == self.num_envs:
-                kinds = self._model_idx                                          # env i under the model in force there
-            else:
-                raise ValueError("fishing-v11 with num_envs=%d: pass one population per env (each grows under its env's "
-                                 "model in force) or model_idx= with one growth-function kind per population"
-                                 % self.num_envs)
-        fn = getattr(self._lib, "fishing_population_draw_" + ("f32" if dtype == torch.float32 else "f64"))
-        with torch.cuda.device(self.device):
-            rc = fn(cp, xt.numel(), xt.data_ptr(), zt.data_ptr() if zt is not None else None,
-                    kinds.data_ptr() if kinds is not None else None, r_arr.data_ptr() if r_arr is not None else None,
-                    K_arr.data_ptr() if K_arr is not None else None, out.data_ptr(), self._stream())
-        _capi.check(rc, "fishing_population_draw")
-        if isinstance(x, torch.Tensor):
-            return out.reshape(x.shape)
-        res = out.cpu().numpy().astype(np.float64)
-        res = res.reshape(np.shape(x)) if np.ndim(x) else float(res[0])
-        if use_attr:
-            self.fish_population = res
-        return res
-
-    def bmsy_sweep(self, states, K, r, dtype=None):
-        """BMSY()'s sweep (models/policies.py:51-67) once per env, each under ITS (K, r) tensors: S[i] = the population
-        (states[j] + 1) * K[i] with the largest noise-free one-step growth.  fishing-v0/v1/v2/v4."""
-        dtype = self.dtype if dtype is None else dtype
-        st = torch.as_tensor(states).to(device=self.device, dtype=dtype).reshape(-1).contiguous()
-        Kt, rt = (torch.as_tensor(v).to(device=self.device, dtype=dtype).reshape(-1).contiguous() for v in (K, r))
-        if Kt.numel() != rt.numel():
-            raise ValueError("K and r need one value per env each")
-        out = torch.empty_like(Kt)
-        fn = getattr(self._lib, "fishing_bmsy_sweep_" + ("f32" if dtype == torch.float32 else "f64"))
-        with torch.cuda.device(self.device):
-            rc = fn(self._c_params(), Kt.numel(), Kt.data_ptr(), rt.data_ptr(), st.data_ptr(), st.numel(), out.data_ptr(), self._stream())
-        _capi.check(rc, "fishing_bmsy_sweep")
-        return out
-
-    # the reference exposes its helpers as methods (base_fishing_env.py:100-110)
-    def simulate(self, model, reps=1):
-        from .rollout import simulate_mdp
-        return simulate_mdp(self, model, reps)
-
-    def policyfn(self, model, reps=1):
-        from .rollout import estimate_policyfn
-        return estimate_policyfn(self, model, reps)
-
-    def plot(self, df, output="results.png"):
-        from .plotting import plot_mdp
-        return plot_mdp(df, output)
-
-    def plot_policy(self, df, output="results.png"):
-        from .plotting import plot_policyfn
-        return plot_policyfn(df, output)
 
     # ------------------------------------------------------------------ render / close
     def render(self, mode="human", index=0):
