@@ -399,6 +399,55 @@ def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
             assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12) and ra[2] > 0
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("powers", [(3.0, 3.0), (2.0, 4.0), (2.5, 3.0), (3.0, 1.7), (2.5, 1.7)],
+                         ids=["theta3_q3", "theta2_q4", "theta2p5_q3", "theta3_q1p7", "theta2p5_q1p7"])
+def test_v11_coefficient_table_equals_the_single_kind_kernels_bit_for_bit(hh, dtype, powers):
+    """fishing-v11's step evaluates its env's growth function from a per-kind coefficient table (fishing_common.h:
+    zoo_draw_lut_one): one division and one exp per env, the zero coefficients of the other kinds contributing exact zeros.  Held
+    here to the kernels that carry ONE growth function as a compile-time fact (fishing-v5 / v6 / v8 / v7 / v9 with the same
+    parameter set): all envs of a batch assigned kind k must come out with the same bits as that model's kernel on the same
+    states, actions and noise -- obs, reward, done -- for every kind, with Myers' theta and May's q equal small integers (one shared
+    product), different small integers, and non-integers (exp2(e log2 x) / exp(e log x) per lane); and against the oracle within
+    the layout's tolerance."""
+    theta, q = powers
+    n = 4096 + 8
+    rng = np.random.default_rng(int(10 * theta + 100 * q))
+    table = [dict(d, sigma=0.07 + 0.01 * k) for k, d in enumerate(fo.V11_TABLE)]
+    table[fo.KIND_MYERS]["theta"] = theta
+    table[fo.KIND_MAY]["q"] = q
+    table[fo.KIND_MAY]["K"] = 1.0         # (May's growth reads M, not K; K = 1 gives its own kernel fishing-v11's obs / quota maps)
+    obs = rng.uniform(-1.0, 0.9, n).astype(dtype)
+    obs[::61] = -1.0
+    t = rng.integers(0, 90, n).astype(np.int32)
+    a = rng.uniform(-1.1, 0.3, n).astype(np.float32)
+    z = rng.standard_normal(n).astype(dtype)
+    model_of_kind = {fo.KIND_ALLEN: fo.MODEL_V5, fo.KIND_BH: fo.MODEL_V6, fo.KIND_MYERS: fo.MODEL_V8, fo.KIND_MAY: fo.MODEL_V7,
+                     fo.KIND_RICKER: fo.MODEL_V9}
+    p11 = hh.params(fo.MODEL_V11, sigma=0.0, K=1.0, x0=0.75, Tmax=100, models=[0, 1, 2, 3, 4], zoo_table=table)
+    for kind, model in model_of_kind.items():
+        P = table[kind]
+        one = hh.State(n, dtype, model, obs, t=t)
+        assert float(P["K"]) == 1.0     # (the single-kind env's obs / quota maps use ITS K, fishing-v11's the env core's K = 1)
+        pk = hh.params(model, r=float(P["r"]), K=1.0, sigma=float(P["sigma"]), C=float(P.get("C", 0.5)), M=float(P.get("M", 0.0)),
+                       theta=float(P.get("theta", 0.0)), q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)),
+                       x0=0.75, Tmax=100)
+        o1, r1, d1, t1 = one.step(pk, a, z=z)
+        mixed = hh.State(n, dtype, fo.MODEL_V11, obs, t=t, model_idx=np.full(n, kind, np.int32))
+        o2, r2, d2, t2 = mixed.step(p11, a, z=z)
+        it = {4: np.uint32, 8: np.uint64}[np.dtype(dtype).itemsize]
+        assert np.array_equal(o1.view(it), o2.view(it)), ("obs", kind, powers)
+        assert np.array_equal(r1.view(it), r2.view(it)) and np.array_equal(d1, d2) and np.array_equal(t1, t2), (kind, powers)
+    # every kind at once, against the oracle (float64 arithmetic of the reference's round trip)
+    kinds = rng.integers(0, 5, n).astype(np.int32)
+    mixed = hh.State(n, dtype, fo.MODEL_V11, obs, t=t, model_idx=kinds)
+    o, rew, done, t2 = mixed.step(p11, a, z=z)
+    eo, er, ed, et, ex = fo.step_zoo(fo.MODEL_V11, obs.astype(np.float64), t, a, z.astype(np.float64), table, 1.0, Tmax=100, kind=kinds)
+    pop_close(o, eo, 1.0, F64_RTOL)
+    assert np.abs(rew.astype(np.float64) - er).max() <= (0 if dtype == np.float64 else F32_ATOL)
+    assert (ex[done != ed] < 1e-6).all() and (t2 == et).all()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 def test_v11_lean_and_general_kernels_agree(hh, ret, dtype):
