@@ -808,11 +808,12 @@ __device__ __forceinline__ double zoo_draw_f64(int kind_rt, double x, double z, 
     // argument: half an ulp of |mu| -- 7e-15 of the result at |mu| = 64, 2.8e-14 at 207 (Myers at x = 1e-30: 2 e-90 exp(sigma z)
     // comes back 2.0e-14 off the exact value in NumPy) -- while this form is within a few ulp of exact.  A stock outside
     // [2^-30, 2^30] or a result outside [2^-92, 2^92] (terms of mu beyond ~21 theta / |mu| beyond ~64) is therefore evaluated
-    // the reference's way; zeros, infinities and NaNs are the same in both forms and stay here.  No env of a rollout gets
-    // near these ranges (a divergent branch no wave takes); the population_draw sweeps and the special-value tests do.
+    // the reference's way; zeros, infinities and NaNs are the same in both forms and stay here.  Compiled into population_draw
+    // (fishing_aux.hip: BMSY sweeps, the module-level growth functions, the special-value tests), which hands x' out itself; the
+    // step / rollout translation units leave it out -- obs = x' / K - 1 cannot carry the difference (fishing_step.hip, top).
     const double inf = __builtin_huge_val();
     const bool far = (x > 0.0 && x < 0x1p-30) || (x > 0x1p30 && x < inf) || (res > 0.0 && res < 0x1p-92) || (res > 0x1p92 && res < inf);
-#if FISHING_ZOO_F64_FAR       // (0: instruction-count analysis of the hot path only -- never a product build)
+#if FISHING_ZOO_F64_FAR       // (0 in the step / rollout translation units: fishing_step.hip says why; 1 in population_draw's)
     if (__builtin_expect(far, 0)) return zoo_draw_round_trip<double, MathLibF64, KIND, RECOMPUTE>(kind_rt, x, z, P);
 #endif
     return (res > 0.0) ? res : ((res != res) ? res : 0.0);      // np.maximum(0, .)
@@ -1141,7 +1142,7 @@ __device__ __forceinline__ void zoo_draw_select_tile(const int (&kind)[4], const
         // kernels into scratch; float32 keeps the interleaving's ILP
         if constexpr (sizeof(T) == 8 || FISHING_V11_SELECT_SERIAL) __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (sizeof(T) == 8) {
+    if constexpr (sizeof(T) == 8 && FISHING_ZOO_F64_FAR) {
         if (__builtin_expect(far[0] | far[1] | far[2] | far[3], 0)) {
             for (int j = 0; j < 4; ++j) {
                 asm volatile("" : "+s"(j));         // (keeps the loop a loop)
@@ -1409,7 +1410,7 @@ __device__ __forceinline__ void env_step_zoo_mixed(T obs, int32_t t, T quota, T 
         x = stock_after_harvest<T>(x, h);
         bool far = false;
         T xn = zoo_draw_select_one<T>(kk, x, z, zoo, far, true, sigma_env);
-        if constexpr (sizeof(T) == 8) {
+        if constexpr (sizeof(T) == 8 && FISHING_ZOO_F64_FAR) {
             if (__builtin_expect(far, 0)) {         // (zoo_draw_select_tile: the reference's own round trip, one copy, a real loop)
                 for (int k = 0; k < FISHING_N_KINDS; ++k) {
                     asm volatile("" : "+s"(k));

@@ -12,6 +12,14 @@
 // Wave-ballot termination: without FISHING_FLAG_AUTO_RESET a finished env is frozen (the
 // reference's simulate loop breaks on done, shared_env.py:51-52) and a wave whose 256 envs
 // have all finished leaves the time loop (__all over the per-lane masks).
+// (the float64 zoo's hand-over to the reference's round trip for far stocks / far results is compiled out of the step, fused-step and
+// rollout kernels: fishing_step.hip says why)
+#ifndef FISHING_ZOO_F64_FAR_IN_STEP_KERNELS
+#define FISHING_ZOO_F64_FAR_IN_STEP_KERNELS 0
+#endif
+#ifndef FISHING_ZOO_F64_FAR
+#define FISHING_ZOO_F64_FAR FISHING_ZOO_F64_FAR_IN_STEP_KERNELS
+#endif
 #include "fishing_common.h"
 #include "fishing_host.h"
 

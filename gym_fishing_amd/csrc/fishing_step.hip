@@ -18,6 +18,23 @@
 //                                  are instantiated (lean_table below).
 //   step_kernel<T, MODEL>          the general kernel: ragged tails, batches below one tile, fishing-v11,
 //                                  custom launch shapes.  Everything optional is a run-time decision.
+// The float64 zoo's growth functions run on the algebraic form (fishing_common.h: zoo_draw_f64) and follow the reference's own
+// log / exp round trip where ITS rounding exceeds the 2e-14 bar: stocks outside [2^-30, 2^30], results outside [2^-92, 2^92].  In
+// THIS translation unit that hand-over is compiled out (FISHING_ZOO_F64_FAR_IN_STEP_KERNELS=1 builds it back in): a step's outputs
+// cannot carry the difference.  The state leaves a step as obs = x' / K - 1, whose spacing near -1 is 1.1e-16 -- a population below
+// 2^-53 K comes out as obs = -1 in the reference and here alike, and for a stock below 2^-30 K the two evaluations differ by
+// < 1e-13 of a result that obs resolves to 1e-7 of itself at best; reward is the harvest (no growth function in it); done tests
+// x' <= 0, and zeros are zeros in both forms.  The other end -- obs beyond 1e9 -- lies nine orders of magnitude outside anything the
+// dynamics reach (a stock cannot grow past ~10 K in a step) and outside the observation space.  population_draw (fishing_aux.hip),
+// which hands x' out itself -- BMSY sweeps, the module-level growth functions, the special-value tests -- keeps the hand-over.  What it
+// costs a kernel that never takes it: 16-32 VGPRs for the inlined logarithms of the cold branch -- fishing-v11 float64 41.9 -> 39.8
+// us at N = 2^22 (0.76 -> 0.80 of the HBM spec), fishing-v8 33.9 -> 33.0, v9 33.0 -> 32.6 (profiles/r05_zoo_f64_far_path.jsonl).
+#ifndef FISHING_ZOO_F64_FAR_IN_STEP_KERNELS
+#define FISHING_ZOO_F64_FAR_IN_STEP_KERNELS 0
+#endif
+#ifndef FISHING_ZOO_F64_FAR
+#define FISHING_ZOO_F64_FAR FISHING_ZOO_F64_FAR_IN_STEP_KERNELS
+#endif
 #include "fishing_common.h"
 #include "fishing_host.h"
 
