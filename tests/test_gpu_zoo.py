@@ -4,9 +4,11 @@ These models go through log / exp / pow, which are not bit-reproducible between 
 and the device math library, so parity is tolerance-based:
   * fp64 layout: on the POPULATION x = (obs+1) K, |dx| <= 2e-14 * x per step against the golden vectors
     captured from the reference (a few ulp of exp(mu), mu = O(1)); reward, done, t exact.  Round 5: the float64 kernels
-    evaluate the algebraically equal form on a < 1-ulp exp (fishing_common.h: zoo_draw_f64) and follow the reference's own
-    round trip where ITS rounding exceeds this bar (stocks outside [2^-30, 2^30], results outside [2^-92, 2^92]): same
-    tolerance, measured maxima in profiles/r05_zoo_f64_error.json;
+    evaluate the algebraically equal form on a < 1-ulp exp (fishing_common.h: zoo_draw_f64); population_draw -- which hands
+    populations out itself -- follows the reference's own round trip where ITS rounding exceeds this bar (stocks outside
+    [2^-30, 2^30], results outside [2^-92, 2^92]), the step kernels -- whose obs = x / K - 1 cannot carry that difference
+    (test_zoo_f64_step_outputs_do_not_depend_on_how_a_far_stock_is_evaluated) -- do not: same tolerance, measured maxima in
+    profiles/r05_zoo_f64_error.json;
   * fp32 layout: the north star's bar -- |obs - ref| <= 1e-6 and |reward - ref| <= 1e-6 per step, absolute,
     against the reference's float64 numbers (round 4: the float32 kernels evaluate the growth function in the
     algebraically equal form without the log / exp round trip, fishing_common.h: FISHING_ZOO_F32_MATH; measured maxima
@@ -397,6 +399,43 @@ def test_zoo_lean_and_general_kernels_agree(hh, model, ret):
         if ret:
             ra, rb = A.record(), B.record()
             assert ra[2] == rb[2] and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12) and ra[2] > 0
+
+
+def test_zoo_f64_step_outputs_do_not_depend_on_how_a_far_stock_is_evaluated(hh):
+    """The float64 growth functions hand far stocks / far results over to the reference's own log / exp round trip only in
+    population_draw; the step kernels evaluate the algebraic form everywhere (fishing_step.hip, top).  Why that is no loss of
+    parity: a step's state leaves as obs = x' / K - 1, and for stocks of 2^-31 ... 2^-50 K -- far below the hand-over line -- the
+    float64 oracle (the reference's round trip) and the kernel produce the SAME obs bits, the same reward and done, for every
+    growth function: the difference between the two evaluations (< 1e-13 of x') is far below what obs can hold (1.1e-16 absolute)."""
+    n = 4096
+    rng = np.random.default_rng(11)
+    expo = rng.integers(31, 51, n)
+    obs = (np.ldexp(1.0, -expo) - 1.0).astype(np.float64)           # x = (obs + 1) K = 2^-e exactly (K = 1)
+    assert ((obs + 1.0) == np.ldexp(1.0, -expo)).all()
+    t = rng.integers(0, 50, n).astype(np.int32)
+    a = np.full(n, -1.0, np.float32)                                # quota 0: the stock after harvest is x itself
+    z = rng.standard_normal(n)
+    table = [dict(d, sigma=0.1, K=1.0) for d in fo.V11_TABLE]
+    model_of_kind = {fo.KIND_ALLEN: fo.MODEL_V5, fo.KIND_BH: fo.MODEL_V6, fo.KIND_MYERS: fo.MODEL_V8, fo.KIND_MAY: fo.MODEL_V7,
+                     fo.KIND_RICKER: fo.MODEL_V9}
+    for kind, model in model_of_kind.items():
+        P = table[kind]
+        pk = hh.params(model, r=float(P["r"]), K=1.0, sigma=0.1, C=float(P.get("C", 0.5)), M=float(P.get("M", 0.0)),
+                       theta=float(P.get("theta", 0.0)), q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)), a=float(P.get("a", 0.0)),
+                       x0=0.75, Tmax=100)
+        st = hh.State(n, np.float64, model, obs, t=t)
+        o, rew, done, t2 = st.step(pk, a, z=z)
+        eo, er, ed, et, ex = fo.step_zoo(model, obs, t, a, z, dict(P, init_state=0.75), 1.0, Tmax=100)
+        assert (ex > 0).all() and (ex < 2.0 ** -25).all()           # tiny, live stocks -- the regime the hand-over exists for
+        assert np.array_equal(o.view(np.uint64), np.asarray(eo, np.float64).view(np.uint64)), kind
+        assert np.array_equal(rew, er) and np.array_equal(done, ed) and np.array_equal(t2, et), kind
+    kinds = rng.integers(0, 5, n).astype(np.int32)
+    p11 = hh.params(fo.MODEL_V11, sigma=0.0, K=1.0, x0=0.75, Tmax=100, models=[0, 1, 2, 3, 4], zoo_table=table)
+    st = hh.State(n, np.float64, fo.MODEL_V11, obs, t=t, model_idx=kinds)
+    o, rew, done, t2 = st.step(p11, a, z=z)
+    eo, er, ed, et, ex = fo.step_zoo(fo.MODEL_V11, obs, t, a, z, table, 1.0, Tmax=100, kind=kinds)
+    assert np.array_equal(o.view(np.uint64), np.asarray(eo, np.float64).view(np.uint64))
+    assert np.array_equal(rew, er) and np.array_equal(done, ed)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
