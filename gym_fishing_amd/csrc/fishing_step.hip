@@ -59,6 +59,9 @@ namespace fishing {
                                  // loads behind the generator: 16.6 -> 16.3 us bare, 21.6 -> 21.5 us with
                                  // returns (bits 1, 2, 3 measure the same; profiles/r01f_lean_fence_ab.txt)
 #endif
+#ifndef FISHING_LEAN_PIN_NOISE
+#define FISHING_LEAN_PIN_NOISE 1
+#endif
 #ifndef FISHING_LEAN_BATCH_ARGS
 #define FISHING_LEAN_BATCH_ARGS 1
 #endif
@@ -739,10 +742,24 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 const bool upper = ((env_offset + (uint64_t)base) & 2u) != 0;
                 box_muller(upper ? w.w2 : w.w0, upper ? w.w3 : w.w1, zq[0], zq[1]);
             }
+            // ... and the generator (which needs none of the loaded data) runs under their latency: the first s_waitcnt vmcnt
+            // lands after it, at the first use of a loaded register -- IF the normals are computed here.  Where control flow
+            // follows (fishing-v4's (K, r) derivation, the power / quotient branches of Beverton-Holt, Myers and May), LLVM sinks
+            // the whole generator into the block that first reads z, BEHIND the wait for the tile's loads (an IR-level move:
+            // no scheduling fence binds it).  An empty asm that reads the normals pins them here.
+            // Only where it is needed (the kernels without such control flow keep their order by themselves, and pay 0.5 % for the
+            // constraint): 13.03 -> 12.43 us for fishing-v4's config-5 shard, 1-2 % for fishing-v6 / v7 / v8 / v10 in both layouts
+            // (profiles/r05_noise_pin.jsonl).
+            constexpr bool kPinNoise = FISHING_LEAN_PIN_NOISE != 0 &&
+                                       ((kPerEnv && (F & feat::DERIVED) != 0) ||
+                                        (kZoo && (kZooKind == FISHING_KIND_BEVERTON_HOLT || kZooKind == FISHING_KIND_MYERS ||
+                                                  kZooKind == FISHING_KIND_MAY)));
+            if constexpr (kPinNoise) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) asm volatile("" : "+v"(zq[j]));
+            }
 #pragma unroll
             for (int j = 0; j < E; ++j) z[j] = (T)zq[j];
-            // ... and the generator (which needs none of the loaded data) runs under their latency:
-            // the first s_waitcnt vmcnt lands after it, at the first use of a loaded register
             if (FISHING_LEAN_FENCE & 2) __builtin_amdgcn_sched_barrier(0);
         }
         if (DERIVED) {      // needs the year counters: after the noise block, which hid their latency
