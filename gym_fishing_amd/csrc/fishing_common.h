@@ -1180,24 +1180,32 @@ __device__ __forceinline__ void zoo_draw_select_tile(const int (&kind)[4], const
 constexpr int kZooLutRow = 8;
 constexpr int kZooLutSize = FISHING_N_KINDS * kZooLutRow;
 // by the lanes 0 of whichever waves call it (uniform values: every caller writes the same table); the caller synchronises
+// (host and device: a launch may bring the table ready-made in its arguments -- the same conversions either way)
+template <typename T>
+__host__ __device__ __forceinline__ void zoo_lut_rows(const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[kZooLutSize]) {
+    const GrowthT<T>& PA = zoo[FISHING_KIND_ALLEN];
+    const GrowthT<T>& PB = zoo[FISHING_KIND_BEVERTON_HOLT];
+    const GrowthT<T>& PM = zoo[FISHING_KIND_MYERS];
+    const GrowthT<T>& PY = zoo[FISHING_KIND_MAY];
+    const GrowthT<T>& PR = zoo[FISHING_KIND_RICKER];
+    const T rows[FISHING_N_KINDS][kZooLutRow] = {
+        {(T)PA.sigma, (T)PA.gc, (T)PA.invK, (T)0, (T)1, (T)0, (T)0, (T)0},           // FISHING_KIND_ALLEN
+        {(T)PB.sigma, (T)0, (T)0, (T)PB.A, (T)1, (T)PB.invB, (T)0, (T)0},            // FISHING_KIND_BEVERTON_HOLT
+        {(T)PM.sigma, (T)0, (T)0, (T)PM.A, (T)1, (T)PM.invM, (T)0, (T)0},            // FISHING_KIND_MYERS
+        {(T)PY.sigma, (T)0, (T)PY.invM, (T)PY.a, (T)PY.bq, (T)1, (T)PY.r, (T)0},     // FISHING_KIND_MAY
+        {(T)PR.sigma, (T)PR.r, (T)PR.invK, (T)0, (T)1, (T)0, (T)0, (T)0}};           // FISHING_KIND_RICKER
+#pragma unroll
+    for (int k = 0; k < FISHING_N_KINDS; ++k)
+#pragma unroll
+        for (int f = 0; f < kZooLutRow; ++f) out[k * kZooLutRow + f] = rows[k][f];
+}
 template <typename T>
 __device__ __forceinline__ void zoo_lut_fill(T* __restrict__ lut, const GrowthT<T> (&zoo)[FISHING_N_KINDS]) {
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        const GrowthT<T>& PA = zoo[FISHING_KIND_ALLEN];
-        const GrowthT<T>& PB = zoo[FISHING_KIND_BEVERTON_HOLT];
-        const GrowthT<T>& PM = zoo[FISHING_KIND_MYERS];
-        const GrowthT<T>& PY = zoo[FISHING_KIND_MAY];
-        const GrowthT<T>& PR = zoo[FISHING_KIND_RICKER];
-        const T rows[FISHING_N_KINDS][kZooLutRow] = {
-            {(T)PA.sigma, (T)PA.gc, (T)PA.invK, (T)0, (T)1, (T)0, (T)0, (T)0},           // FISHING_KIND_ALLEN
-            {(T)PB.sigma, (T)0, (T)0, (T)PB.A, (T)1, (T)PB.invB, (T)0, (T)0},            // FISHING_KIND_BEVERTON_HOLT
-            {(T)PM.sigma, (T)0, (T)0, (T)PM.A, (T)1, (T)PM.invM, (T)0, (T)0},            // FISHING_KIND_MYERS
-            {(T)PY.sigma, (T)0, (T)PY.invM, (T)PY.a, (T)PY.bq, (T)1, (T)PY.r, (T)0},     // FISHING_KIND_MAY
-            {(T)PR.sigma, (T)PR.r, (T)PR.invK, (T)0, (T)1, (T)0, (T)0, (T)0}};           // FISHING_KIND_RICKER
+        T rows[kZooLutSize];
+        zoo_lut_rows<T>(zoo, rows);
 #pragma unroll
-        for (int k = 0; k < FISHING_N_KINDS; ++k)
-#pragma unroll
-            for (int f = 0; f < kZooLutRow; ++f) lut[k * kZooLutRow + f] = rows[k][f];
+        for (int k = 0; k < kZooLutSize; ++k) lut[k] = rows[k];
     }
 }
 template <typename T>

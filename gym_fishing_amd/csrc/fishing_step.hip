@@ -399,6 +399,7 @@ struct LeanMixedArgs {
     int32_t n_models;
     int32_t kinds[FISHING_N_KINDS];
     GrowthT<T> zoo[FISHING_N_KINDS];
+    T lut[kZooLutSize];      // zoo_lut_rows(zoo): the coefficient table, converted on the host (FISHING_V11_LUT_HOST)
 };
 struct LeanNoExtra {};
 template <typename T, int MODEL>
@@ -407,6 +408,8 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_LEAN_ATTRS
 #define FISHING_LEAN_ATTRS
 #endif
+// (fishing-v11's float32 kernel with returns needs 65 VGPRs, one above what eight waves per SIMD allow: compiled for eight --
+// amdgpu_waves_per_eu(8, 8) -- it spills 24 bytes per lane; left at seven)
 // E = envs per thread: 4 everywhere (16-byte accesses on the 4-byte streams) except the float64 parity layout at
 // cache-resident sizes, which runs E = 2 -- 16 bytes per lane on ITS streams instead of 32 (two 16-byte accesses, half
 // of each 64-byte line per instruction): a copy over the same streams takes 23.5 instead of 27.2 us at N = 2^22
@@ -428,19 +431,39 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_X_TPW
 #define FISHING_X_TPW 1
 #endif
+#ifndef FISHING_V11_LUT_HOST
+#define FISHING_V11_LUT_HOST 1
+#endif
+
+// The launch's walk in the preloaded n_live argument (0: LeanArgs::zz_rt / nta_rt and the step's parity, rounds 4 - 5a).
+#ifndef FISHING_WALK_PRELOADED
+#define FISHING_WALK_PRELOADED 1
+#endif
+// n_live_p, the fifth leading argument:  bits 0-39 the envs that exist (all ones: no bound), bits 40-57 how many tiles
+// THIS launch walks backwards (0, or ntiles & ~7 on a zig-zag launch's odd steps when the host holds the step counter),
+// bit 58: a zig-zag launch whose step counter lives in device memory (the kernel finds the parity itself), bit 59:
+// nontemporal action loads.
+constexpr int64_t kLiveMask = (1ll << 40) - 1;
+constexpr int kWalkShift = 40;
+constexpr int64_t kWalkMask = (1ll << 18) - 1;
+constexpr int64_t kWalkDeviceParityBit = 1ll << 58;
+constexpr int64_t kWalkNtaBit = 1ll << 59;
 template <typename T, int MODEL, int F, int E = 4>
 __global__ void __launch_bounds__(FISHING_X_TILE_ENVS / E) FISHING_LEAN_ATTRS
 step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p, T* const ep_return_p, const int64_t n_live_p,
                  const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_t ntiles, const uint64_t env_offset,
                  const uint64_t seed, const uint64_t step_counter_arg) {
-    // The four streams every tile reads first (and the padded-tile bound the action address needs) are LEADING SCALAR
-    // arguments: this translation unit is built with -mllvm -amdgpu-kernarg-preload-count=10 (build.py), which has the
-    // command processor place the first ten kernarg dwords in SGPRs at wave launch -- a one-tile form issues its four
-    // global loads before any s_load has returned (a by-value struct is not preloaded), and fetches the rest of its
-    // arguments in one batch behind them.  Per step, back to back, against the same kernel without preload: N = 2^20
-    // 6.04 -> 5.75 us, 2^22 21.41 -> 20.87 (1.1 % above the same-shape copy), 2^19 unchanged
-    // (profiles/r03_small_n/s15_kernarg_preload_product.jsonl; harness sweep of 4 .. 14 dwords: s14_*).  Firmware
-    // without the feature runs the kernel's own s_load prologue.
+    // The four streams every tile reads first, the padded-tile bound the action address needs and the launch's walk (n_live_p:
+    // see kLiveMask) are LEADING SCALAR arguments: this translation unit is built with -mllvm
+    // -amdgpu-kernarg-preload-count=10 (build.py), which has the command processor place the first ten kernarg dwords in
+    // SGPRs at wave launch -- a wave finds its tile and its four addresses without a single s_load (a by-value struct is
+    // not preloaded), and fetches the rest of its arguments in one batch.  Per step, back to back, against the same kernel
+    // without preload: N = 2^20 6.04 -> 5.75 us, 2^22 21.41 -> 20.87, 2^19 unchanged
+    // (profiles/r03_small_n/s15_kernarg_preload_product.jsonl; harness sweep of 4 .. 14 dwords: s14_*).  Firmware without
+    // the feature runs the kernel's own s_load prologue.  Round 4 made the zig-zag walk a run-time field of the struct and
+    // so put FOUR dependent s_load round trips back into every wave (the walk's flag, the step's parity, the batch, the
+    // counter); with the walk in the preloaded word there are two, one of them hidden behind the tile's loads: N = 2^19
+    // 4.67 -> 4.34 us, 2^20 6.0 -> 5.8, 2^22 18.94 -> 18.76 (profiles/r05_walk_word.jsonl).
     constexpr int TPW = FISHING_X_TPW;      // (a build-wide experiment knob, not a template parameter: the kernels keep their names)
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     constexpr bool kMixed = (MODEL == kModelZooMixed);    // fishing-v11: growth function per env
@@ -470,14 +493,32 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool DERIVED = (F & feat::DERIVED) && (kExact || a.derived_rt != 0);
     const bool STAMP = (F & feat::STAMP) && DERIVED && a.stamp != nullptr;
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
-    const bool ZZ = a.zz_rt != 0;       // (run-time in every form: round 3's exact zig-zag twins of the tile loop went when
-                                        // every batch up to 2^26 envs got a workgroup per tile)
+    // (run-time in every form: round 3's exact zig-zag twins of the tile loop went when every batch up to 2^26 envs got a
+    // workgroup per tile)
+#if FISHING_WALK_PRELOADED
+    // ... and decided by the HOST, in the preloaded n_live argument: as fields of the by-value struct, the walk's flags put one
+    // s_load round trip in front of every wave's first global load -- what the kernarg preload had taken away.
+    const int64_t n_live = n_live_p & kLiveMask;
+#ifdef FISHING_X_WALK_NO_DEVICE     // (experiment: what the branch below costs -- launches with a device counter walk wrong)
+    constexpr bool ZZ = false;
+#else
+    const bool ZZ = (n_live_p & kWalkDeviceParityBit) != 0;     // (the walks that need the step counter BEFORE the tile's loads)
+#endif
+    int64_t walk_back = (n_live_p >> kWalkShift) & kWalkMask;
+#else
+    const bool ZZ = a.zz_rt != 0;
+    const int64_t n_live = n_live_p;
+#endif
     // The caller's action stream is read once per step and never again: from ~200 MB per step (N >= 2^23) the zig-zag forms
     // load it nontemporal, so that it does not evict the state lines the reversed walk is about to re-hit.  N = 2^26:
     // 283 -> 262 us bare, 398 -> 380 with returns; 2^25: 128.5 -> 124, 181.5 -> 172.6; 2^23 bare 32.1 -> 31.0.  Not at 2^22:
     // the action ring itself is cache-resident there, the hint costs 6-11 % (profiles/r03_nt_action_loads.jsonl,
     // r03_xcd_zigzag.jsonl).  (Streaming the state STORES of all but the walk's last 128-224 MB as well: < 1 %.)
+#if FISHING_WALK_PRELOADED
+    const bool NTA = (n_live_p & kWalkNtaBit) != 0;
+#else
     const bool NTA = ZZ && a.nta_rt != 0;
+#endif
     const int noise = ((F & feat::kNoiseMask) == feat::kNoiseRT) ? a.noise_rt : (F & feat::kNoiseMask);
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
@@ -517,9 +558,21 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         return c + step_counter_arg;
     };
     // (... unless the launch walks zig-zag: the tile index needs the step's parity)
+#if FISHING_WALK_PRELOADED
+    uint64_t step_counter = 0;
+    if (ZZ) {       // (graph replay at the zig-zag sizes)
+        asm volatile("");       // a real branch: flattened, its tests wait for the struct's s_loads in every launch
+        step_counter = read_counter();
+        constexpr int64_t G = 8 * TPW;
+        walk_back = (step_counter & 1) ? (ntiles & ~(G - 1)) : 0;
+    }
+#else
     uint64_t step_counter = !ZZ ? step_counter_arg : read_counter();
+#endif
     uint64_t origin_step = a.origin_step, origin_counter = a.origin_counter;
+#if !FISHING_WALK_PRELOADED
     if (DERIVED) device_origin(a.counter, origin_step, origin_counter);
+#endif
     // an exact RET instantiation is only ever launched with auto-reset on (the dispatch sends RET without it to the
     // catch-all, which carries the LATCH): the flag is a compile-time fact there
     const bool auto_reset = (kExact && (F & feat::RET)) ? true : a.auto_reset != 0;
@@ -551,12 +604,28 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // better --, and the 256 MiB Infinity Cache at the HBM-resident sizes (N = 2^26 with returns, a workgroup per tile:
         // 406 us forward, 347 zig-zag: profiles/r03_zz_nta_one_tile.jsonl).
         int64_t tile = it;
+#if FISHING_V11_LUT_HOST
+        // fishing-v11's coefficient table comes ready-made in the launch's arguments (LeanMixedArgs::lut): its one vector load goes
+        // out FIRST, so that the wave's wait for it does not wait for the tile's loads as well (loads return in order)
+        T lut_word = (T)0;
+        if constexpr (kMixed && FISHING_V11_FORM == 2) {
+            if (threadIdx.x < kZooLutSize) lut_word = ex.lut[threadIdx.x];
+        }
+#endif
+#if FISHING_WALK_PRELOADED
+        {
+            constexpr int64_t G = 8 * TPW;
+            const int64_t whole = walk_back;
+            if (it < whole) tile = (whole - G - (it & ~(G - 1))) + (it & (G - 1));
+        }
+#else
         if (ZZ && (step_counter & 1)) {
             // (TPW tiles per workgroup: groups of 8 * TPW, so that a tile stays on the XCD of the workgroup that owns it)
             constexpr int64_t G = 8 * TPW;
             const int64_t whole = ntiles & ~(G - 1);          // (a last partial group keeps its place)
             if (it < whole) tile = (whole - G - (it & ~(G - 1))) + (it & (G - 1));
         }
+#endif
         const int64_t base = (tile * kThreads + threadIdx.x) * E;
         // FISHING_FLAG_PADDED_TILES: the state buffers have room for whole tiles, so a batch that is not a multiple of 1024
         // envs still runs in this ONE launch (no second, one-workgroup launch for the tail: 3.7-4.2 us per step).  The
@@ -564,7 +633,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // redrawn), and the streams the CALLER owns -- actions, external noise -- are read at the last quad that exists
         // instead of past their end.  `live` is true everywhere otherwise.
         // (the tile's share of n_live is a scalar; per lane one 32-bit compare and one 32-bit select)
-        const int64_t tile_left = n_live_p - tile * kTileEnvs;                     // wave-uniform
+        const int64_t tile_left = n_live - tile * kTileEnvs;                     // wave-uniform
         const uint32_t left32 = tile_left >= kTileEnvs ? (uint32_t)kTileEnvs : (tile_left > 0 ? (uint32_t)tile_left : 0u);
         const uint32_t lane_env = threadIdx.x * (uint32_t)E;
         const bool live = lane_env < left32;
@@ -729,10 +798,25 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             // fishing-v11: the growth functions' coefficient table (fishing_common.h: zoo_lut_fill), written by the first wave while
             // the tile's loads are in flight and ahead of its own noise block, so that the workgroup barrier in front of the
             // first lookup finds it done
+#if !FISHING_V11_LUT_HOST
             if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, ex.zoo);
+#endif
         }
         if constexpr (FISHING_LEAN_BATCH_ARGS == 1) batch_args();
+#if FISHING_WALK_PRELOADED
+        // (graph replay: the origin of the last reset() sits next to the step counter and is read behind the tile's loads like it,
+        // in the same batch -- SCALAR loads: as a vector load it sat in the queue the tile's loads return through)
+        if (DERIVED && a.counter) {
+            uint64_t c = 0;
+            asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %3, 0x8\n\ts_load_dwordx2 %2, %3, 0x10\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(c), "=&s"(origin_step), "=&s"(origin_counter) : "s"(a.counter) : "memory");
+            if (!ZZ) step_counter = c + step_counter_arg;
+        } else if (!ZZ) {
+            step_counter = read_counter();
+        }
+#else
         if (!ZZ) step_counter = read_counter();
+#endif
         if (noise == kNoisePhilox) {
             float zq[E];
             if constexpr (E == 4) {
@@ -749,9 +833,9 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             // no scheduling fence binds it).  An empty asm that reads the normals pins them here.
             // Only where it is needed (the kernels without such control flow keep their order by themselves, and pay 0.5 % for the
             // constraint): 13.03 -> 12.43 us for fishing-v4's config-5 shard, 1-2 % for fishing-v6 / v7 / v8 / v10 in both layouts
-            // (profiles/r05_noise_pin.jsonl).
+            // (profiles/r05_noise_pin.jsonl).  fishing-v11: the generator stays in front of the table's barrier.
             constexpr bool kPinNoise = FISHING_LEAN_PIN_NOISE != 0 &&
-                                       ((kPerEnv && (F & feat::DERIVED) != 0) ||
+                                       ((kPerEnv && (F & feat::DERIVED) != 0) || (kMixed && FISHING_V11_LUT_HOST != 0) ||
                                         (kZoo && (kZooKind == FISHING_KIND_BEVERTON_HOLT || kZooKind == FISHING_KIND_MYERS ||
                                                   kZooKind == FISHING_KIND_MAY)));
             if constexpr (kPinNoise) {
@@ -788,7 +872,15 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         if constexpr (kMixed) {
             if (!SIGARR) {      // wave-uniform: regroup the wave's envs by growth function (fishing_common.h: zoo_draw_regrouped)
                 __shared__ ZooSlot<T> win[(kThreads / kWave) * kZooWindowSlots];     // one window per wave
-                if constexpr (FISHING_V11_FORM == 2) __syncthreads();      // (the table: written by wave 0 right behind the tile's loads)
+                if constexpr (FISHING_V11_FORM == 2) {
+#if FISHING_V11_LUT_HOST
+                    // (one LDS store of the word loaded at the tile's start, behind the noise block that hid its latency -- filled
+                    // from ex.zoo, the first wave strung nine dependent s_load batches and 35 conversions in front of this barrier,
+                    // at which its three sister waves wait)
+                    if (threadIdx.x < kZooLutSize) zoo_lut[threadIdx.x] = lut_word;
+#endif
+                    __syncthreads();      // (the table)
+                }
                 T xh[E], hv[E], xn[E];
                 int kk[E];
 #pragma unroll
@@ -1100,6 +1192,23 @@ struct LeanCall {
     bool two_per_thread;     // float64: E = 2 (512-thread workgroups)
 };
 
+// the fifth leading argument of a launch (see kLiveMask)
+template <typename T>
+int64_t walk_word(const LeanCall<T>& c, const int64_t ntiles) {
+#if FISHING_WALK_PRELOADED
+    int64_t w = c.a.n_live & kLiveMask;
+    if (c.a.zz_rt) {
+        constexpr int64_t G = 8 * FISHING_X_TPW;
+        if (c.a.counter) w |= kWalkDeviceParityBit;
+        else if ((c.step_counter & 1) && ntiles <= kWalkMask) w |= (ntiles & ~(G - 1)) << kWalkShift;
+        if (c.a.nta_rt) w |= kWalkNtaBit;
+    }
+    return w;
+#else
+    return c.a.n_live;
+#endif
+}
+
 template <typename T, int MODEL, int F, int E = 4>
 int lean_launch(const LeanCall<T>& c) {
     if (c.name) {
@@ -1108,6 +1217,7 @@ int lean_launch(const LeanCall<T>& c) {
         *c.name = buf;
         return FISHING_OK;
     }
+    if (c.a.n_live != INT64_MAX && c.a.n_live > kLiveMask) return FISHING_ERR_SIZE;     // (a launch steps at most 2^26 envs)
     LeanExtra<T, MODEL> ex{};
     if constexpr (MODEL == kModelZooMixed) ex = *static_cast<const LeanMixedArgs<T>*>(c.extra);
     // a workgroup of 1024 / E threads per 1024-env tile (feat::ONE): 256 x 4 envs, or 512 x 2 for the float64 layout at
@@ -1124,7 +1234,7 @@ int lean_launch(const LeanCall<T>& c) {
 #endif
     return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)((nb + FISHING_X_TPW - 1) / FISHING_X_TPW),
                              FISHING_X_TILE_ENVS / E, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
-                             c.a.n_live, c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
+                             walk_word(c, nt), c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
 }
 
 // the catch-all mask of a (T, MODEL): every optional stream "may be there", noise mode at run time
@@ -1332,6 +1442,7 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
             mixed.kinds[k] = pt.kinds[k];
             mixed.zoo[k] = pt.zoo[k];
         }
+        zoo_lut_rows<T>(mixed.zoo, mixed.lut);
     }
     // float64 with two envs per thread up to ~512 MB per step (N <= 2^23); four per thread beyond, where the access shape
     // stops mattering.  As 512-thread one-tile workgroups the two-per-thread forms win from the smallest batch on -- exact
