@@ -434,6 +434,9 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_V11_LUT_HOST
 #define FISHING_V11_LUT_HOST 1
 #endif
+#ifndef FISHING_X_V11_CLAMP_AT_LOAD
+#define FISHING_X_V11_CLAMP_AT_LOAD 1
+#endif
 
 // The launch's walk in the preloaded n_live argument (0: LeanArgs::zz_rt / nta_rt and the step's parity, rounds 4 - 5a).
 #ifndef FISHING_WALK_PRELOADED
@@ -672,6 +675,13 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 const VecE<int32_t, E> qk = *reinterpret_cast<const VecE<int32_t, E>*>(ex.model_idx + base);
 #pragma unroll
                 for (int j = 0; j < E; ++j) kind[j] = qk.v[j];
+#if FISHING_X_V11_CLAMP_AT_LOAD
+                // (an index outside the zoo steps as Beverton-Holt in every kernel: clamped HERE, once -- a second, clamped copy next to
+                // the loaded one, kept for the quad's write-back after a redraw, cost the float32 kernel its eighth wave per SIMD)
+#pragma unroll
+                for (int j = 0; j < E; ++j)
+                    kind[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+#endif
             }
             if (SIGARR) {
                 const VecE<T, E> qs = *reinterpret_cast<const VecE<T, E>*>(a.sigma_arr + base);
@@ -803,6 +813,10 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #endif
         }
         if constexpr (FISHING_LEAN_BATCH_ARGS == 1) batch_args();
+        // (The zoo's kernels branch per env, and in every such block LLVM re-loads the wave-uniform arguments it needs from the
+        // kernarg segment -- ten s_load + s_waitcnt lgkmcnt(0) round trips through fishing-v11's arithmetic.  Pinning them in SGPRs
+        // through an empty asm removes the loads and gains nothing: eight waves per SIMD hide them; the single-function float32
+        // kernels lose 1 %: profiles/r05_pin_zoo_args.jsonl.)
 #if FISHING_WALK_PRELOADED
         // (graph replay: the origin of the last reset() sits next to the step counter and is read behind the tile's loads like it,
         // in the same batch -- SCALAR loads: as a vector load it sat in the queue the tile's loads return through)
@@ -892,7 +906,11 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                     const T d = x - hv[j];
                     xh[j] = d;       // (max(d, 0.0) is the identity here: stock_after_harvest)
                     xn[j] = (T)0;
+#if FISHING_X_V11_CLAMP_AT_LOAD
+                    kk[j] = kind[j];
+#else
                     kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+#endif
                 }
                 if constexpr (FISHING_V11_FORM == 2)
                     zoo_draw_lut_tile<T, E>(kk, xh, z, ex.zoo, zoo_lut, xn);

@@ -152,7 +152,9 @@ typedef struct FishingBuffers {
                                 {sum R, sum R^2, n_episodes, sum length} over finished episodes;
                                 needs ep_return; nullable                                         */
     int32_t* model_idx;  /* i32   in/out  fishing-v11: FISHING_KIND_* in force per env (redrawn
-                                          at reset, growth_models.py:187,200); else nullable      */
+                                          at reset, growth_models.py:187,200); else nullable.  An
+                                          index outside [0, FISHING_N_KINDS) steps as Beverton-Holt
+                                          and may be written back as FISHING_KIND_BEVERTON_HOLT     */
     const uint64_t* counter; /* u64[1] in  device-resident step counter, nullable.  When set, the
                                 noise of fishing_step_* / fishing_rollout_* is keyed by
                                 *counter + step_counter instead of step_counter alone, so a

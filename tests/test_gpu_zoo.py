@@ -488,6 +488,36 @@ def test_v11_coefficient_table_equals_the_single_kind_kernels_bit_for_bit(hh, dt
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("n", [4096, 4099], ids=["lean", "general"])
+def test_v11_index_outside_the_zoo_steps_as_beverton_holt(hh, n, dtype):
+    """include/fishing_hip.h, FishingBuffers.model_idx: an index outside [0, FISHING_N_KINDS) steps as Beverton-Holt -- in the lean
+    kernels (which clamp where they load it, round 5) and in the general kernel alike -- and whatever is written back for it is
+    Beverton-Holt's index or the index itself."""
+    rng = np.random.default_rng(11)
+    table = [dict(d, sigma=0.1) for d in fo.V11_TABLE]
+    p11 = hh.params(fo.MODEL_V11, sigma=0.0, K=1.0, x0=0.75, Tmax=100, models=[0, 1, 2, 3, 4], zoo_table=table)
+    obs = rng.uniform(-0.9, 0.4, n).astype(dtype)
+    t = rng.integers(0, 90, n).astype(np.int32)
+    a = rng.uniform(-1.1, 0.3, n).astype(np.float32)
+    z = rng.standard_normal(n).astype(dtype)
+    kinds = rng.integers(0, 5, n).astype(np.int32)
+    wild = kinds.copy()
+    where = rng.random(n) < 0.2
+    wild[where] = rng.choice(np.array([-7, -1, 5, 6, 1 << 20, -(1 << 31)], np.int64), int(where.sum())).astype(np.int32)
+    tame = np.where(where, fo.KIND_BH, kinds).astype(np.int32)
+    A = hh.State(n, dtype, fo.MODEL_V11, obs, t=t, model_idx=wild)
+    B = hh.State(n, dtype, fo.MODEL_V11, obs, t=t, model_idx=tame)
+    it = {4: np.uint32, 8: np.uint64}[np.dtype(dtype).itemsize]
+    for k in range(3):      # (auto-reset on: finished envs redraw their index, neighbours in the quad are written back with them)
+        oa, ra, da, ta = A.step(p11, a, z=z, seed=3, step_counter=k)
+        ob, rb, db, tb = B.step(p11, a, z=z, seed=3, step_counter=k)
+        assert np.array_equal(oa.view(it), ob.view(it)) and np.array_equal(ra.view(it), rb.view(it)), k
+        assert np.array_equal(da, db) and np.array_equal(ta, tb), k
+        ka, kb = A.model_idx.cpu().numpy(), B.model_idx.cpu().numpy()
+        assert ((ka == kb) | ((ka == wild) & (kb == fo.KIND_BH))).all(), k
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("ret", [False, True], ids=["plain", "returns"])
 def test_v11_lean_and_general_kernels_agree(hh, ret, dtype):
     """fishing-v11 takes the lean step kernel too (growth function per env: its coefficients come from a table in LDS -- rounds
