@@ -434,6 +434,16 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_V11_LUT_HOST
 #define FISHING_V11_LUT_HOST 1
 #endif
+#ifndef FISHING_X_V11_KINDS_LATE
+#define FISHING_X_V11_KINDS_LATE 1
+#endif
+#ifndef FISHING_X_T_LATE
+#define FISHING_X_T_LATE 1
+#endif
+#ifndef FISHING_X_V4_T_FIRST
+#define FISHING_X_V4_T_FIRST 1
+#endif
+
 #ifndef FISHING_X_V11_CLAMP_AT_LOAD
 #define FISHING_X_V11_CLAMP_AT_LOAD 1
 #endif
@@ -487,6 +497,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #endif
     constexpr int kThreads = FISHING_X_TILE_ENVS / E;
     constexpr int kTileEnvs = FISHING_X_TILE_ENVS;
+    // fishing-v4's derived-parameter exact kernels issue the year counters' load first (see the tile's loads)
+    constexpr bool kTFirst = FISHING_X_V4_T_FIRST != 0 && kExact && kPerEnv && (F & feat::DERIVED) != 0;
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || ep_return_p != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -661,6 +673,29 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         }
         float a_f[E];
         {
+            // the year counters: fishing-v4's derivation of (K, r) is the one piece of arithmetic that needs loaded data before it can
+            // start (the reset origin of each env), and loads return in the order they were issued -- in the derived-parameter exact
+            // kernels this load goes out FIRST (-DFISHING_X_V4_T_FIRST=0: third, behind the sigma array's and the observations'):
+            // config 5's shard 12.3 -> 11.85 us, N = 2^22 22.4 -> 22.1 (profiles/r05_v4_t_first.jsonl).  (LLVM's wait in front of the
+            // derivation covers the observations' load too, vmcnt(3) of five -- they return right behind the counters; an explicit
+            // s_waitcnt vmcnt(4) in front of it changes nothing: the compiler's own follows.)
+            auto load_t = [&]() {
+                VecE<int32_t, E> qt;
+                if (T8) {
+                    typedef std::conditional_t<E == 4, uint32_t, uint16_t> bytesE;
+                    const uint32_t w = *reinterpret_cast<const bytesE*>(reinterpret_cast<const uint8_t*>(t_p) + base);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) qt.v[j] = (int32_t)((w >> (8 * j)) & 255u);
+                } else {
+                    qt = *reinterpret_cast<const VecE<int32_t, E>*>(t_p + base);
+                }
+                return qt;
+            };
+            VecE<int32_t, E> qt;
+            if constexpr (kTFirst) {
+                qt = load_t();
+                if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
+            }
             if (STAMP) {
                 const VecE<int32_t, E> qs = *reinterpret_cast<const VecE<int32_t, E>*>(a.stamp + base);
 #pragma unroll
@@ -671,37 +706,43 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 sg[j] = a.sigma;
                 er[j] = (T)0;
             }
-            if constexpr (kMixed) {
-                const VecE<int32_t, E> qk = *reinterpret_cast<const VecE<int32_t, E>*>(ex.model_idx + base);
+            // (fishing-v11's indices: their pointer is a field of the struct -- in the exact kernels the load goes out behind the ones
+            // that need nothing but preloaded arguments, -DFISHING_X_V11_KINDS_LATE=0: in front of them)
+            auto load_kinds = [&]() {
+                if constexpr (kMixed) {
+                    const VecE<int32_t, E> qk = *reinterpret_cast<const VecE<int32_t, E>*>(ex.model_idx + base);
+    #pragma unroll
+                    for (int j = 0; j < E; ++j) kind[j] = qk.v[j];
+    #if FISHING_X_V11_CLAMP_AT_LOAD
+                    // (an index outside the zoo steps as Beverton-Holt in every kernel: clamped HERE, once -- a second, clamped copy next to
+                    // the loaded one, kept for the quad's write-back after a redraw, cost the float32 kernel its eighth wave per SIMD)
+    #pragma unroll
+                    for (int j = 0; j < E; ++j)
+                        kind[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
+    #endif
+                }
+            };
+            constexpr bool kKindsLate = FISHING_X_V11_KINDS_LATE != 0 && kExact && kMixed;
+            if constexpr (!kKindsLate) load_kinds();
+            auto load_sigma = [&]() {
+                if (SIGARR) {
+                    const VecE<T, E> qs = *reinterpret_cast<const VecE<T, E>*>(a.sigma_arr + base);
 #pragma unroll
-                for (int j = 0; j < E; ++j) kind[j] = qk.v[j];
-#if FISHING_X_V11_CLAMP_AT_LOAD
-                // (an index outside the zoo steps as Beverton-Holt in every kernel: clamped HERE, once -- a second, clamped copy next to
-                // the loaded one, kept for the quad's write-back after a redraw, cost the float32 kernel its eighth wave per SIMD)
-#pragma unroll
-                for (int j = 0; j < E; ++j)
-                    kind[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
-#endif
-            }
-            if (SIGARR) {
-                const VecE<T, E> qs = *reinterpret_cast<const VecE<T, E>*>(a.sigma_arr + base);
-#pragma unroll
-                for (int j = 0; j < E; ++j) sg[j] = qs.v[j];
-            }
+                    for (int j = 0; j < E; ++j) sg[j] = qs.v[j];
+                }
+            };
+            if constexpr (!kTFirst) load_sigma();       // (kTFirst: last -- its pointer is a field of the struct, and nothing needs it early)
             const VecE<T, E> q = *reinterpret_cast<const VecE<T, E>*>(obs_p + base);
-            VecE<int32_t, E> qt;
-            if (T8) {
-                typedef std::conditional_t<E == 4, uint32_t, uint16_t> bytesE;
-                const uint32_t w = *reinterpret_cast<const bytesE*>(reinterpret_cast<const uint8_t*>(t_p) + base);
-#pragma unroll
-                for (int j = 0; j < E; ++j) qt.v[j] = (int32_t)((w >> (8 * j)) & 255u);
-            } else {
-                qt = *reinterpret_cast<const VecE<int32_t, E>*>(t_p + base);
-            }
+            // In every other exact kernel the year counters' load goes out BEHIND the actions' (-DFISHING_X_T_LATE=0: in front): the
+            // arithmetic starts on observations and actions -- first wait vmcnt(2) of four loads instead of vmcnt(1) --, the counters
+            // are needed at its end.  Builds alternating (profiles/r05_t_late.jsonl): the metric 18.92 -> 18.67 us, fishing-v0 at 2^22
+            // 18.93 -> 18.73, fishing-v11 float32 24.7 -> 24.3; N = 2^21 (one exact round of waves, forward walk) 8.33 -> 8.53: the one
+            // size that loses; below 2^21 the better of the two within a noisy box.
+            constexpr bool kTLate = FISHING_X_T_LATE != 0 && kExact && !kTFirst;
+            if constexpr (!kTFirst && !kTLate) qt = load_t();
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 obs[j] = q.v[j];
-                t[j] = qt.v[j];
                 rr[j] = a.pr;
                 KK[j] = a.pK;
                 z[j] = (T)0;
@@ -733,6 +774,11 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #pragma unroll
                 for (int j = 0; j < E; ++j) a_f[j] = qa.v[j];
             }
+            if constexpr (kTLate) qt = load_t();
+            if constexpr (kKindsLate) load_kinds();
+#pragma unroll
+            for (int j = 0; j < E; ++j) t[j] = qt.v[j];
+            if constexpr (kTFirst) load_sigma();
             if (kPerEnv && !DERIVED) {
                 const VecE<T, E> qr = *reinterpret_cast<const VecE<T, E>*>(a.r + base);
                 const VecE<T, E> qk = *reinterpret_cast<const VecE<T, E>*>(a.K + base);
