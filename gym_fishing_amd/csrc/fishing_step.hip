@@ -1044,7 +1044,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #pragma unroll
                 for (int j = 0; j < E; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
             }
-            // the record's atomic first, the tile's stores behind it
+            // the record's atomic first, the tile's stores behind it (round 3's A/B; re-measured in round 5 the other way round:
+            // within noise at every size, 18.66 / 18.63 us at N = 2^22)
 #if FISHING_X_TPW > 1
             if (a.partials) add_block_partials<kThreads / kWave, kThreads / kWave>(acc, a.partials, in.it);     // (a slot per tile)
 #else
