@@ -1124,6 +1124,53 @@ def test_xcd_aware_zigzag_keeps_results_with_a_partial_last_group(hh, tiles, ret
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("model", ["v1", "v4_derived", "v11"])
+@pytest.mark.parametrize("where", ["host_counter", "device_counter"])
+def test_walk_word_carries_the_padded_bound_next_to_the_walk(hh, where, model):
+    """Round 5: a lean launch's fifth leading argument is a WORD -- bits 0-39 the envs that exist (FISHING_FLAG_PADDED_TILES), bits
+    40-57 the tiles walked backwards on a zig-zag launch's odd steps (host-held counter), bit 58 "the counter lives in device memory"
+    (the kernel finds the parity), bit 59 nontemporal action loads.  4099 tiles + a padded last one (a zig-zag size: > 100 MB per
+    step, a partial last group of the walk), odd and even steps, counter on the host or on the device, against the general
+    kernel: every stream bit for bit over the envs that exist, the same episode counts, and nothing behind the last env finishes."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n = 4099 * 1024 + 516
+    cap = -(-n // 1024) * 1024
+    mid = {"v1": fo.MODEL_V1, "v4_derived": fo.MODEL_V4, "v11": fo.MODEL_V11}[model]
+    kw = dict(sigma=0.1, Tmax=2, auto_reset=True, sigma_p=0.2, derived=model == "v4_derived", origin=(0, 0))
+    if mid == fo.MODEL_V11:
+        kw.update(models=[2, 0, 4], zoo_table=[dict(d, sigma=0.1) for d in fo.V11_TABLE])
+    pa, pb = hh.params(mid, padded=True, **kw), hh.params(mid, general=True, **kw)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    a = (torch.rand(n, device="cuda", generator=g) * 1.4 - 1.2).float()
+    counter = torch.zeros(3, dtype=torch.int64, device="cuda") if where == "device_counter" else None     # {counter, origin step, origin counter}
+    outs = []
+    for p, size in ((pa, cap), (pb, n)):
+        st = hh.State(size, np.float32, mid, np.float32(-0.25), ep_return=True,
+                      model_idx=(np.arange(size) % 5).astype(np.int32) if mid == fo.MODEL_V11 else None)
+        if p is pa:
+            name = hh.kernel_name(p, n, st.buffers(a))
+            assert "step_kernel_lean" in name and int(name.rstrip(">").split(",")[-1]) & 8192, name       # one launch, one-tile form
+        for s in range(4):
+            b = _capi.FishingBuffers.from_buffer_copy(st.buffers(a))
+            if counter is not None:
+                counter[0] = 5 + s
+                b.counter = counter.data_ptr()
+            assert lib.fishing_step_f32(p, n, 0, b, 11, 0 if counter is not None else 5 + s, None) == 0
+            torch.cuda.synchronize()
+        outs.append(st)
+    A, B = outs
+    for nm in ("obs", "reward", "done", "t", "ep_return") + (("model_idx",) if mid == fo.MODEL_V11 else ()):
+        x, y = getattr(A, nm)[:n], getattr(B, nm)[:n]
+        it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]
+        assert torch.equal(x.view(it), y.view(it)), nm
+    ra, rb = A.record(), B.record()
+    assert ra[2] == rb[2] > n and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12)
+    del A, B, outs
+    torch.cuda.empty_cache()
+
+
 def test_batches_beyond_65536_tiles_run_as_ranges(hh):
     """Round 3: a launch covers at most 65536 tiles (N = 2^26: a workgroup and a return_partials slot per tile); a larger
     batch is stepped range by range on the same stream, odd steps last range first.  N = 2^26 + 2^20 + 5 (a second,
