@@ -437,6 +437,9 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_X_V11_KINDS_LATE
 #define FISHING_X_V11_KINDS_LATE 1
 #endif
+#ifndef FISHING_X_ZEXT_IN_NOISE_BRANCH
+#define FISHING_X_ZEXT_IN_NOISE_BRANCH 1
+#endif
 #ifndef FISHING_X_T_LATE
 #define FISHING_X_T_LATE 1
 #endif
@@ -798,11 +801,13 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #pragma unroll
                 for (int j = 0; j < E; ++j) er[j] = qe.v[j];
             }
+#if !FISHING_X_ZEXT_IN_NOISE_BRANCH
             if (noise == kNoiseExt) {
                 const VecE<T, E> qz = *reinterpret_cast<const VecE<T, E>*>(a.z_ext + cbase);
 #pragma unroll
                 for (int j = 0; j < E; ++j) z[j] = qz.v[j];
             }
+#endif
         }
 #if FISHING_X_TPW > 1
         in.it = it;
@@ -906,6 +911,16 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             for (int j = 0; j < E; ++j) z[j] = (T)zq[j];
             if (FISHING_LEAN_FENCE & 2) __builtin_amdgcn_sched_barrier(0);
         }
+#if FISHING_X_ZEXT_IN_NOISE_BRANCH
+        // The caller's normals are loaded HERE, in the generator's else: issued with the tile's other loads, their destination
+        // registers are the generator's too, and the catch-alls (noise mode at run time) then wait for EVERY load of the tile
+        // -- s_waitcnt vmcnt(0) -- before the generator's first write to them, on the path that never issued that load.
+        else if (noise == kNoiseExt) {
+            const VecE<T, E> qz = *reinterpret_cast<const VecE<T, E>*>(a.z_ext + cbase);
+#pragma unroll
+            for (int j = 0; j < E; ++j) z[j] = qz.v[j];
+        }
+#endif
         if (DERIVED) {      // needs the year counters: after the noise block, which hid their latency
             // (tile-uniform: the last env of this workgroup's tile and the counters all below 2^32 -> 32-bit integer work)
             if (derive_fits_32(env_offset + (uint64_t)(tile + 1) * (uint64_t)kTileEnvs - 1u, step_counter, origin_step, origin_counter)) {
