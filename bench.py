@@ -706,16 +706,10 @@ def main():
     # hold K kernel durations and nothing else.  (The bracket over the timed region above also contains the idle
     # device's pick-up of the first launch, ~10-25 us once: 0.5 us per step at K = 20, invisible at K = 5050.)
     if rt.cuda:
-        lead = 16
-        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
         k_steady = max(args.steps, 256)          # (at the driver's K = 20 the events' own few us would be 1-2 % of the bracket)
-        env.step_many(actions, lead)
-        s0.record()
-        env.step_many(actions, k_steady)
-        s1.record()
-        torch.cuda.synchronize()
-        steady_ms = s0.elapsed_time(s1) / k_steady
+        # (the recipe of every `configs` entry: behind 60 ms of the same work -- host work since the timed region has let the device
+        # idle, and 256 launches = 5 ms on a device still ramping read 19.2-19.4 us where rocprofv3 and K = 5050 read 18.7-18.8)
+        steady_ms = steady_launch_us(torch, env, actions, k_steady, lead=16, spin_ms=60.0) / 1e3
         med_us, mean_us = per_launch_us(torch, env, actions, max(1, min(args.steps, 200)))
     else:               # a rehearsal measures nothing about a kernel
         k_steady, steady_ms, med_us, mean_us = args.steps, kernel_ms, None, None
@@ -782,7 +776,8 @@ def main():
                      # the same kernel where HBM IS the roof (N = 2^26, filled from the hbm_resident sub-record below)
                      "hbm_resident_frac": None,
                      "note": "avg_launch_us = HIP events around max(K, 256) launches enqueued behind a 16-launch lead-in (device "
-                             "busy when the first event fires), per launch; avg_launch_us_rehearsal_region = the same bracket over the K "
+                             "busy when the first event fires) after 60 ms of the same launches, per launch -- the recipe of every "
+                             "`configs` entry; avg_launch_us_rehearsal_region = the same bracket over the K "
                              "launches of the UNTIMED dress rehearsal of the timed region (includes the idle device's pick-up of the "
                              "first launch; the timed pass itself carries no event packets); "
                              "launch_us_median_event_pairs = median event-to-event time of single launches (each pair adds "
