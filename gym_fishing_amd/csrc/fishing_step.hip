@@ -431,26 +431,26 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_X_TPW
 #define FISHING_X_TPW 1
 #endif
-#ifndef FISHING_V11_LUT_HOST
-#define FISHING_V11_LUT_HOST 1
+// Round 5's readings of the ISA, each behind a switch that builds the form before it (1 = the product; the records name the
+// sessions that measured both):
+#ifndef FISHING_V11_LUT_HOST             // fishing-v11's coefficient table made on the host, copied by one vector load
+#define FISHING_V11_LUT_HOST 1           //   (0: filled by the first wave from the per-kind structs)  profiles/r05_walk_word.jsonl
 #endif
-#ifndef FISHING_X_V11_KINDS_LATE
-#define FISHING_X_V11_KINDS_LATE 1
+#ifndef FISHING_X_V11_CLAMP_AT_LOAD      // fishing-v11's indices clamped into the zoo where they are loaded (one copy in registers)
+#define FISHING_X_V11_CLAMP_AT_LOAD 1    //   profiles/r05_v11_clamp_at_load.jsonl
 #endif
-#ifndef FISHING_X_ZEXT_IN_NOISE_BRANCH
-#define FISHING_X_ZEXT_IN_NOISE_BRANCH 1
+#ifndef FISHING_X_V11_KINDS_LATE         // ... and loaded behind the loads that need only preloaded arguments
+#define FISHING_X_V11_KINDS_LATE 1       //   profiles/r05_v11_kinds_late.jsonl
 #endif
-#ifndef FISHING_X_T_LATE
-#define FISHING_X_T_LATE 1
+#ifndef FISHING_X_V4_T_FIRST             // fishing-v4 derived: the year counters' load first, the sigma array's last
+#define FISHING_X_V4_T_FIRST 1           //   profiles/r05_v4_t_first.jsonl
 #endif
-#ifndef FISHING_X_V4_T_FIRST
-#define FISHING_X_V4_T_FIRST 1
+#ifndef FISHING_X_T_LATE                 // every other exact kernel: the year counters' load behind the actions'
+#define FISHING_X_T_LATE 1               //   profiles/r05_t_late.jsonl
 #endif
-
-#ifndef FISHING_X_V11_CLAMP_AT_LOAD
-#define FISHING_X_V11_CLAMP_AT_LOAD 1
+#ifndef FISHING_X_ZEXT_IN_NOISE_BRANCH   // the catch-alls' external-noise load in the generator's else (no wait for every load of
+#define FISHING_X_ZEXT_IN_NOISE_BRANCH 1 //   the tile in front of the generator)  profiles/r05_catch_all_noise_wait.jsonl
 #endif
-
 // The launch's walk in the preloaded n_live argument (0: LeanArgs::zz_rt / nta_rt and the step's parity, rounds 4 - 5a).
 #ifndef FISHING_WALK_PRELOADED
 #define FISHING_WALK_PRELOADED 1
