@@ -431,6 +431,10 @@ using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, 
 #ifndef FISHING_X_TPW
 #define FISHING_X_TPW 1
 #endif
+#if FISHING_X_TPW > 1       // (the two-tile experiment splits a tile's body into a load and a step phase: it keeps the forms it was measured with)
+#define FISHING_V11_LUT_HOST 0
+#define FISHING_X_ZEXT_IN_NOISE_BRANCH 0
+#endif
 // Round 5's readings of the ISA, each behind a switch that builds the form before it (1 = the product; the records name the
 // sessions that measured both):
 #ifndef FISHING_V11_LUT_HOST             // fishing-v11's coefficient table made on the host, copied by one vector load
