@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""One-off widening of the randomised differential tests (tests/test_gpu_fused_and_dispatch.py): the same test bodies over trial
+numbers far beyond the parametrised ranges -- every trial draws its own request from its number --
+
+    python scripts/exp/fuzz_differential.py [--requests 1500] [--big 40] [--sequences 12] > gpurun_out/.../fuzz.jsonl
+
+* requests: test_randomised_requests_agree_across_dispatch_general_and_fused (dispatch vs general kernel vs ONE fused launch),
+* big:      test_randomised_requests_beyond_4096_tiles (N in (2^22, 1.5 * 2^23]: the zig-zag walk, ranges),
+* sequences: test_random_operation_sequences_every_family_three_ways (50 random operations per env id and trial, three ways).
+One JSON line per family: trials run, failures (trial number + the assertion's first line), seconds."""
+import argparse
+import json
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--requests", type=int, default=1500)
+    ap.add_argument("--big", type=int, default=40)
+    ap.add_argument("--sequences", type=int, default=12)
+    a = ap.parse_args()
+    import hip_harness as hh
+    import test_gpu_fused_and_dispatch as T
+
+    def run(name, fn, trials, **kw):
+        t0, bad = time.time(), []
+        for k in trials:
+            try:
+                fn(hh, trial=k, **kw)
+            except Exception as e:  # noqa: BLE001  (an assertion = a finding; anything else too)
+                bad.append({"trial": k, "error": (str(e) or traceback.format_exc()).splitlines()[0][:300], **kw})
+        return {"family": name, "trials": len(list(trials)), "first": trials[0], "last": trials[-1], "failures": bad,
+                "seconds": round(time.time() - t0, 1), **kw}
+
+    # (the committed parametrisations end at 48 / 10 / 5: everything from there on is new ground)
+    print(json.dumps(run("requests", T.test_randomised_requests_agree_across_dispatch_general_and_fused, range(48, 48 + a.requests))), flush=True)
+    print(json.dumps(run("beyond_4096_tiles", T.test_randomised_requests_beyond_4096_tiles, range(10, 10 + a.big))), flush=True)
+    for env_id in ("fishing-v0", "fishing-v1", "fishing-v2", "fishing-v4", "fishing-v5", "fishing-v7", "fishing-v8", "fishing-v10", "fishing-v11"):
+        fn = T.test_random_operation_sequences_every_family_three_ways
+        if env_id == "fishing-v4":
+            continue        # (fishing-v4's walk is its own test: tests/test_gpu_v4_params.py)
+        print(json.dumps(run("sequences", fn, range(5, 5 + a.sequences), env_id=env_id)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
