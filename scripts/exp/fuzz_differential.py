@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--requests", type=int, default=1500)
     ap.add_argument("--big", type=int, default=40)
     ap.add_argument("--sequences", type=int, default=12)
+    ap.add_argument("--only-v4", action="store_true")
     a = ap.parse_args()
     import hip_harness as hh
     import test_gpu_fused_and_dispatch as T
@@ -39,13 +40,19 @@ def main():
         return {"family": name, "trials": len(list(trials)), "first": trials[0], "last": trials[-1], "failures": bad,
                 "seconds": round(time.time() - t0, 1), **kw}
 
-    # (the committed parametrisations end at 48 / 10 / 5: everything from there on is new ground)
-    print(json.dumps(run("requests", T.test_randomised_requests_agree_across_dispatch_general_and_fused, range(48, 48 + a.requests))), flush=True)
-    print(json.dumps(run("beyond_4096_tiles", T.test_randomised_requests_beyond_4096_tiles, range(10, 10 + a.big))), flush=True)
+    # (the committed parametrisations end at 48 / 10 / 5 / 12: everything from there on is new ground)
+    if not a.only_v4:
+      print(json.dumps(run("requests", T.test_randomised_requests_agree_across_dispatch_general_and_fused, range(48, 48 + a.requests))), flush=True)
+      print(json.dumps(run("beyond_4096_tiles", T.test_randomised_requests_beyond_4096_tiles, range(10, 10 + a.big))), flush=True)
     for env_id in ("fishing-v0", "fishing-v1", "fishing-v2", "fishing-v4", "fishing-v5", "fishing-v7", "fishing-v8", "fishing-v10", "fishing-v11"):
         fn = T.test_random_operation_sequences_every_family_three_ways
-        if env_id == "fishing-v4":
-            continue        # (fishing-v4's walk is its own test: tests/test_gpu_v4_params.py)
+        if a.only_v4 and env_id != "fishing-v4":
+            continue
+        if env_id == "fishing-v4":      # (fishing-v4's walk is its own test: derived parameters vs stored arrays vs graph replay)
+            import test_gpu_v4_params as V
+            print(json.dumps(run("sequences fishing-v4", V.test_v4_random_operation_sequences_derived_equals_stored,
+                                 range(12, 12 + a.sequences))), flush=True)
+            continue
         print(json.dumps(run("sequences", fn, range(5, 5 + a.sequences), env_id=env_id)), flush=True)
 
 

@@ -295,12 +295,16 @@ def test_v4_random_operation_sequences_derived_equals_stored(hh, trial):
     graph = None
     modes = set()
 
+    def same_bits(x, y):     # (NaN == NaN: a drawn K of 0 -- five standard deviations out, once in ~50 of these sequences -- makes the
+        it = {1: torch.uint8, 4: torch.int32, 8: torch.int64}[x.element_size()]     # env's observations NaN in both batches)
+        return x.shape == y.shape and torch.equal(x.contiguous().view(it), y.contiguous().view(it))
+
     def check(tag):
         torch.cuda.synchronize()
         for name in ("_obs", "_t", "_ep_return"):
-            assert torch.equal(getattr(D, name), getattr(S, name)), (trial, tag, name)
-            assert torch.equal(getattr(G, name), getattr(S, name)), (trial, tag, name, "graph")
-        assert torch.equal(D.K, S.K) and torch.equal(D.r, S.r) and torch.equal(G.K, S.K), (trial, tag)
+            assert same_bits(getattr(D, name), getattr(S, name)), (trial, tag, name)
+            assert same_bits(getattr(G, name), getattr(S, name)), (trial, tag, name, "graph")
+        assert same_bits(D.K, S.K) and same_bits(D.r, S.r) and same_bits(G.K, S.K), (trial, tag)
         modes.add("stored" if not D._derived else ("stamped" if D._stamp is not None else "derived"))
 
     for e in (D, S, G):
@@ -337,7 +341,7 @@ def test_v4_random_operation_sequences_derived_equals_stored(hh, trial):
             for e in (D, S, G):
                 e.reset(mask)
         elif op == "read_K":
-            assert torch.equal(D.K, S.K) and torch.equal(D.r, S.r)
+            assert same_bits(D.K, S.K) and same_bits(D.r, S.r)
         elif op == "sigma":
             v = float(rng.uniform(0.0, 0.1))
             for e in (D, S, G):
@@ -368,7 +372,7 @@ def test_v4_random_operation_sequences_derived_equals_stored(hh, trial):
                     e.step_many(ring, 3)         # (a call starts at the ring's first row, like a replay)
         check("%d %s" % (k, op))
     sa, sb = D.episode_stats(), S.episode_stats()
-    assert sa["n_episodes"] == sb["n_episodes"] and sa["sum_return"] == sb["sum_return"]
+    assert sa["n_episodes"] == sb["n_episodes"] and np.array_equal(sa["sum_return"], sb["sum_return"], equal_nan=True)
     assert modes            # (which parameter modes the derived batch went through depends on the sequence; all three occur over the trials)
 
 @pytest.mark.parametrize("where", ["step_counter_crosses_2^32", "env_index_crosses_2^32", "both_far_beyond_2^32"])
