@@ -744,7 +744,8 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             // arithmetic starts on observations and actions -- first wait vmcnt(2) of four loads instead of vmcnt(1) --, the counters
             // are needed at its end.  Builds alternating (profiles/r05_t_late.jsonl): the metric 18.92 -> 18.67 us, fishing-v0 at 2^22
             // 18.93 -> 18.73, fishing-v11 float32 24.7 -> 24.3; N = 2^21 (one exact round of waves, forward walk) 8.33 -> 8.53: the one
-            // size that loses; below 2^21 the better of the two within a noisy box.
+            // size that loses; below 2^21 the better of the two within a noisy box.  (The actions' load in FRONT of the observations' --
+            // the one stream that is never in the L2s first -- loses: its address takes 20 instructions more, 18.57 -> 18.80 us.)
             constexpr bool kTLate = FISHING_X_T_LATE != 0 && kExact && !kTFirst;
             if constexpr (!kTFirst && !kTLate) qt = load_t();
 #pragma unroll
