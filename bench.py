@@ -501,11 +501,16 @@ def config_records(torch, gf, launches=256):
             env.reset()
             acts = make_actions(torch, cfg, n, rows)
             env.step_many(acts, 24)
-            us = steady_launch_us(torch, env, acts, launches)
+            # (the launch-bound sizes swing with the device's power state from one millisecond bracket to the next -- 4.3 / 5.4 us at
+            # N = 2^19 on one box within one minute --: five brackets, the median reported, every one listed)
+            runs = [steady_launch_us(torch, env, acts, launches, spin_ms=60.0 if i == 0 else 10.0) for i in range(5 if ln <= 21 else 1)]
+            us = statistics.median(runs)
             b = bytes_per_env_step(name, True)
             fits = resident_bytes(name, n, True, rows) < 256 * 2 ** 20
             rec = {"what": what, "n_envs": n, "kernel": env.step_kernel_name(acts[0]), "bytes_per_env_step": b,
                    "avg_launch_us": us, "launches": launches, "env_steps_per_s": n / us * 1e6}
+            if len(runs) > 1:
+                rec["avg_launch_us_brackets"] = [round(r, 3) for r in runs]
             rec.update(roof(n * b / us / 1e3, fits))
             if key == "config2_v1_2p20":        # "random-policy rollout": the policy drawn in-kernel, no action traffic at all
                 env.rollout(101, policy="random")
