@@ -243,6 +243,15 @@ def main():
     run_case("v4_random", "fishing-v4", {"sigma": 0.1, "sigma_p": 0.3, "K_mean": 1.5,
                                           "r_mean": 0.4, "init_state": 0.6, "Tmax": 12},
              list(range(91, 97)), 80, lambda g, s, e: f32(g.uniform(-1, 0.2)))
+    # the draws' clip bounds (fishing_model_error.py:37-38, 41-42: np.clip(N(mean, sigma_p), 0, 1e6)).  A mean far below zero pins the
+    # drawn value to exactly 0: with K = 0 the stock is 0 * (1 - 0 / 0) = NaN from the first step on, the reward 0 and `done` only ever
+    # the year counter's; with r = 0 the stock only shrinks; a mean far above 1e6 pins K to 1e6
+    run_case("v4_K_clipped_to_zero", "fishing-v4", {"sigma": 0.05, "K_mean": -5.0, "Tmax": 6}, [101, 102, 103], 16,
+             lambda g, s, e: f32(g.uniform(-1, 0.5)))
+    run_case("v4_r_clipped_to_zero", "fishing-v4", {"sigma": 0.05, "r_mean": -5.0, "Tmax": 6}, [104, 105, 106], 16,
+             lambda g, s, e: f32(g.uniform(-1, -0.6)))
+    run_case("v4_K_clipped_to_1e6", "fishing-v4", {"sigma": 0.05, "K_mean": 3.0e6, "sigma_p": 0.2, "Tmax": 6}, [107, 108], 16,
+             lambda g, s, e: f32(g.uniform(-1, -0.6)))
     # v4 before the first reset(): constructor draws, obs = x0/K_mean - 1 (quirk a9)
     run_case("v4_noinitreset", "fishing-v4", {"sigma": 0.05}, [97, 98], 20,
              lambda g, s, e: f32(g.uniform(-1, -0.7)), init_reset=False)
