@@ -221,6 +221,14 @@ def main():
                1e30, -1e30]
     run_case("v1_special_actions", "fishing-v1", {"sigma": 0.1, "Tmax": 9}, [33, 34], 12,
              lambda g, s, e: f32(special[s]))
+    # constructor corner values: a stock that starts extinct (done on every first step), a horizon of zero years (done after one
+    # step whatever the stock), a negative growth rate
+    run_case("v1_starts_extinct", "fishing-v1", {"sigma": 0.1, "init_state": 0.0}, [35, 36], 6,
+             lambda g, s, e: f32(g.uniform(-1, 0)))
+    run_case("v1_Tmax0", "fishing-v1", {"sigma": 0.1, "Tmax": 0}, [37, 38], 6,
+             lambda g, s, e: f32(g.uniform(-1, -0.8)))
+    run_case("v1_negative_r", "fishing-v1", {"sigma": 0.1, "r": -0.4, "Tmax": 12}, [39, 40], 30,
+             lambda g, s, e: f32(g.uniform(-1, -0.8)))
     # --- fishing-v0 (BASELINE config 3 at toy N)
     run_case("v0_sigma01_random", "fishing-v0", {"sigma": 0.1}, list(range(41, 49)), 130,
              lambda g, s, e: g.randint(0, 100))
