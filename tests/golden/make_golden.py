@@ -291,6 +291,13 @@ def main():
                             ("v8_myers_special_actions", "fishing-v8", {"sigma": 0.1, "Tmax": 9}),
                             ("v11_uncert_special_actions", "fishing-v11", {"Tmax": 9})):
         run_case(tag, env_id, kw, [233, 234], 12, lambda g, s, e: f32(special[s]), out=zoo)
+    # corner parameters (round 5): Myers with r < -1 (log(r + 1) is NaN: the stock is NaN from the first step), Beverton-Holt with
+    # r = 0 (B = K / r: a division by zero inside the reference), Ricker with a negative rate, May with a non-integer exponent
+    for tag, env_id, kw in (("v8_myers_r_below_minus_one", "fishing-v8", {"sigma": 0.1, "r": -1.5, "Tmax": 6}),
+                            ("v6_bh_r_zero", "fishing-v6", {"sigma": 0.05, "r": 0.0, "Tmax": 8}),
+                            ("v9_ricker_negative_r", "fishing-v9", {"sigma": 0.1, "r": -0.3, "Tmax": 10}),
+                            ("v7_may_q_two_and_a_half", "fishing-v7", {"sigma": 0.05, "q": 2.5, "Tmax": 12})):
+        run_case(tag, env_id, kw, [235, 236], 16, low, out=zoo)
     # --- the module-level growth functions themselves (growth_models.py:208-269), called the way a user of the
     # reference may: f(x, params) on a scalar, a vector and a matrix of populations (zero, tiny, typical, far above K,
     # negative), default and non-default parameter dicts, sigma = 0 and > 0.  np.random.lognormal(mu, sigma) consumes one

@@ -96,10 +96,11 @@ def test_zoo_golden_single_steps(hh, c, dtype):
     obs, rew, done, t = st.step(hip_params(hh, c), c.action.reshape(-1), z=c.z.reshape(-1))
     pop_close(obs, c.obs.reshape(-1), K, F64_RTOL)
     if dtype == np.float64:
-        assert np.array_equal(rew, c.reward.reshape(-1))
+        assert np.array_equal(rew, c.reward.reshape(-1), equal_nan=True)      # (v8_myers_r_below_minus_one: NaN stock, NaN harvest)
         assert (done == c.done.reshape(-1)).all()
     else:
-        assert np.abs(rew - c.reward.reshape(-1)).max() <= F32_ATOL
+        ref = c.reward.reshape(-1)
+        assert (np.isnan(rew) == np.isnan(ref)).all() and (np.abs(rew - ref)[~np.isnan(ref)] <= F32_ATOL).all()
         # an f32 population within 1e-6 of zero may flip the extinction flag: none in the fixtures
         assert (done == c.done.reshape(-1)).all()
     assert (t == c.t.reshape(-1)).all()
@@ -129,8 +130,12 @@ def test_zoo_scalar_protocol_follows_reference(env_id):
                 if env_id == "fishing-v10":
                     assert abs(env.r - c.params_r[e, s]) < 1e-12
                 obs, rew, done, info = env.step(np.array([c.action[e, s]], dtype=np.float32), noise=[c.z[e, s]])
-                assert abs((obs[0] + 1) * K - (c.obs[e, s] + 1) * K) <= 1e-12 * max(1.0, abs(c.obs[e, s] + 1) * K)
-                assert abs(rew - c.reward[e, s]) <= 1e-12 and done == bool(c.done[e, s])
+                if np.isnan(c.obs[e, s]):         # (v8_myers_r_below_minus_one: the reference's stock is NaN, and so must this one's be)
+                    assert np.isnan(obs[0]), (name, e, s)
+                else:
+                    assert abs((obs[0] + 1) * K - (c.obs[e, s] + 1) * K) <= 1e-12 * max(1.0, abs(c.obs[e, s] + 1) * K)
+                assert (np.isnan(rew) and np.isnan(c.reward[e, s])) or abs(rew - c.reward[e, s]) <= 1e-12, (name, e, s)
+                assert done == bool(c.done[e, s])
                 # keep following the reference exactly so ulp-level differences cannot accumulate
                 env._obs.fill_(float(c.obs[e, s]))
                 if done:
@@ -582,8 +587,8 @@ def test_zoo_scalar_protocol_seeded_like_the_reference(name):
             obs, rew, done, _ = env.step(a)
             if c.id == "fishing-v10":
                 assert float(env.r) == c.params_r[e, s] + c.kwargs["alpha"]      # drifted once more by this step
-            assert np.isclose((obs[0] + 1.0) * K, (c.obs[e, s] + 1.0) * K, rtol=1e-9, atol=1e-12), (name, e, s)
-            assert np.isclose(rew, c.reward[e, s], rtol=1e-9, atol=1e-12) and done == bool(c.done[e, s])
+            assert np.isclose((obs[0] + 1.0) * K, (c.obs[e, s] + 1.0) * K, rtol=1e-9, atol=1e-12, equal_nan=True), (name, e, s)
+            assert np.isclose(rew, c.reward[e, s], rtol=1e-9, atol=1e-12, equal_nan=True) and done == bool(c.done[e, s])
             if done:
                 obs = env.reset()
                 assert obs[0] == c.reset_obs[e, s + 1]
