@@ -236,6 +236,11 @@ def main():
              lambda g, s, e: g.randint(0, 8))
     run_case("v0_edge", "fishing-v0", {"sigma": 0.1, "Tmax": 8}, [53], 12,
              lambda g, s, e: [0, 10, 99, 0, 100, 150, 3, 7, 1, 0, 2, 5][s], auto_reset=True)
+    # one action only (every index >= 1 is a quota >= K: the whole stock), a thousand actions (a finer quota grid than the default 100)
+    run_case("v0_one_action", "fishing-v0", {"sigma": 0.1, "n_actions": 1, "Tmax": 7}, [54, 55], 12,
+             lambda g, s, e: [0, 0, 0, 1, 0, 0, 2, 0, 0, 0, 0, 1][s])
+    run_case("v0_thousand_actions", "fishing-v0", {"sigma": 0.1, "n_actions": 1000, "Tmax": 30}, [56, 57, 58], 40,
+             lambda g, s, e: g.randint(0, 300))
     # --- fishing-v2 tipping point (BASELINE config 4 at toy N)
     run_case("v2_sigma01_low", "fishing-v2", {"sigma": 0.1}, list(range(61, 69)), 130,
              lambda g, s, e: f32(g.uniform(-1, -0.8)))
@@ -245,6 +250,11 @@ def main():
              lambda g, s, e: f32(-1.0), auto_reset=False)
     run_case("v2_sigma0_zeroquota_low", "fishing-v2", {"sigma": 0.0, "init_state": 0.3}, [0], 3,
              lambda g, s, e: f32(-1.0), auto_reset=False)
+    # the tipping point at zero (no tipping: the factor (x - C) never changes sign) and above the carrying capacity (every stock below it shrinks)
+    run_case("v2_C_zero", "fishing-v2", {"sigma": 0.1, "C": 0.0, "Tmax": 20}, [78, 79], 30,
+             lambda g, s, e: f32(g.uniform(-1, -0.7)))
+    run_case("v2_C_above_K", "fishing-v2", {"sigma": 0.1, "C": 1.5, "Tmax": 20}, [80, 81], 30,
+             lambda g, s, e: f32(g.uniform(-1, -0.7)))
     # --- fishing-v4 per-episode parameter uncertainty (BASELINE config 5 at toy N)
     run_case("v4_sigma005", "fishing-v4", {"sigma": 0.05, "sigma_p": 0.1}, list(range(81, 89)), 240,
              lambda g, s, e: f32(g.uniform(-1, -0.7)))

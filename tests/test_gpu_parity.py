@@ -109,7 +109,7 @@ def test_golden_single_steps_f64(hh, c):
 
 
 # (env, step) pairs of the fixtures where the float32 layout may classify the extinction flag differently from the
-# reference: a reference population within 1e-6 of zero.  None of the 22 cases holds one (the smallest live stock is
+# reference: a reference population within 1e-6 of zero.  None of the 26 cases holds one (the smallest live stock is
 # 1.1e-4; extinct stocks are exact zeros on both sides) -- the list is here so that a new fixture has a place to name its own.
 F32_DONE_EXCEPTIONS = {}
 
