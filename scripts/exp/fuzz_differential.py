@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--big", type=int, default=40)
     ap.add_argument("--sequences", type=int, default=12)
     ap.add_argument("--only-v4", action="store_true")
+    ap.add_argument("--oracle-sweeps", type=int, default=0, help="further seeds of tests/test_gpu_parity.py::test_random_parameter_sets_match_oracle")
+    ap.add_argument("--only-oracle", action="store_true")
     a = ap.parse_args()
     import hip_harness as hh
     import test_gpu_fused_and_dispatch as T
@@ -41,9 +43,26 @@ def main():
                 "seconds": round(time.time() - t0, 1), **kw}
 
     # (the committed parametrisations end at 48 / 10 / 5 / 12: everything from there on is new ground)
-    if not a.only_v4:
+    if not a.only_v4 and not a.only_oracle:
       print(json.dumps(run("requests", T.test_randomised_requests_agree_across_dispatch_general_and_fused, range(48, 48 + a.requests))), flush=True)
       print(json.dumps(run("beyond_4096_tiles", T.test_randomised_requests_beyond_4096_tiles, range(10, 10 + a.big))), flush=True)
+    if a.oracle_sweeps:
+        import numpy as np
+        import test_gpu_parity as P
+        from oracle import fishing_oracle as fo
+        for model in (fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4):
+            for dtype in (np.float64, np.float32):
+                t0, bad = time.time(), []
+                for k in range(1, 1 + a.oracle_sweeps):
+                    try:
+                        P.test_random_parameter_sets_match_oracle(hh, model, dtype, seed_offset=k)
+                    except Exception as e:  # noqa: BLE001
+                        bad.append({"seed_offset": k, "error": (str(e) or traceback.format_exc()).splitlines()[0][:300]})
+                print(json.dumps({"family": "oracle parameter sweep (30 parameter sets x 6 steps x 1003 envs per trial)", "model": int(model),
+                                  "dtype": np.dtype(dtype).name, "trials": a.oracle_sweeps, "failures": bad,
+                                  "seconds": round(time.time() - t0, 1)}), flush=True)
+        if a.only_oracle:
+            return
     for env_id in ("fishing-v0", "fishing-v1", "fishing-v2", "fishing-v4", "fishing-v5", "fishing-v7", "fishing-v8", "fishing-v10", "fishing-v11"):
         fn = T.test_random_operation_sequences_every_family_three_ways
         if a.only_v4 and env_id != "fishing-v4":

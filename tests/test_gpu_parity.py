@@ -880,12 +880,13 @@ def test_full_size_baseline_configs(hh, cfg):
 # ------------------------------------------------------------------ randomised parameter sweep
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
-def test_random_parameter_sets_match_oracle(hh, model, dtype):
+def test_random_parameter_sets_match_oracle(hh, model, dtype, seed_offset=0):
     """30 random constructor-parameter sets per model (r, K, sigma, C, x0, Tmax, n_actions far
     from the defaults, incl. K = 0 reachable in fishing-v4 and sigma large enough to drive
     stocks extinct), 6 steps each with fused auto-reset and external noise: every output of
-    every step against the oracle -- bit-exact (v2: population tolerance)."""
-    rng = np.random.default_rng(900 + model)
+    every step against the oracle -- bit-exact (v2: population tolerance).
+    (`seed_offset`: scripts/exp/fuzz_differential.py runs the same body from other seeds.)"""
+    rng = np.random.default_rng(900 + model + 1000 * seed_offset)
     n = 1003
     per_env = model == fo.MODEL_V4
     for trial in range(30):
