@@ -758,6 +758,17 @@ __device__ __forceinline__ double pow_f64(double x, double e, int ipow) {
     if (ipow == 0) return exp_f64(e * log_f64(x));      // wave-uniform; pow(0, e > 0) = exp(-inf) = 0
     return int_pow<double>(x, ipow);
 }
+// x / M as the REFERENCE rounds it (an IEEE division) from the host's correctly rounded reciprocal: one Newton step on the
+// quotient -- q0 = x * (1 / M) is within an ulp, its residual x - q0 M is exact in an fma, and the corrected quotient is the
+// correctly rounded one (Markstein).  May's exp_mu = x + x r (1 - x / M) - a x^q / (x^q + b^q) is a difference of terms up to 60 times
+// its own size when the stock stands above M: there the ulp a bare reciprocal multiply may be off came back as 2.5e-13 of the
+// population (found by the random parameter sweep against the oracle, tests/test_gpu_zoo.py).  Non-finite cases (x = inf, M = 0
+// or inf) fall back to the plain product, which has the division's value there.
+__device__ __forceinline__ double div_by_reciprocal_f64(const double x, const double M, const double invM) {
+    const double q0 = x * invM;
+    const double q = __builtin_fma(__builtin_fma(-q0, M, x), invM, q0);
+    return (q == q) ? q : q0;
+}
 template <int KIND, bool RECOMPUTE, typename T>
 __device__ __forceinline__ void zoo_pre_g_f64(double x, double sz, const GrowthT<T>& P, double& pre, double& g) {
     static_assert(KIND >= 0 && KIND < FISHING_N_KINDS, "a compile-time kind");
@@ -773,7 +784,7 @@ __device__ __forceinline__ void zoo_pre_g_f64(double x, double sz, const GrowthT
         g = sz;
     } else if constexpr (KIND == FISHING_KIND_MAY) {            // :229-242: exp(log(exp_mu)); the log of a negative number is NaN
         const double xq = pow_f64(x, P.q, P.ipow);
-        const double exp_mu = (x + x * P.r * (1.0 - x * P.invM)) - div_f64(P.a * xq, xq + P.bq);
+        const double exp_mu = (x + x * P.r * (1.0 - div_by_reciprocal_f64(x, P.M, P.invM))) - div_f64(P.a * xq, xq + P.bq);
         pre = (exp_mu < 0.0) ? __builtin_nan("") : exp_mu;
         g = sz;
     } else {                                                    // Beverton-Holt :220-226: A x / (1 + x / B)
@@ -1111,7 +1122,7 @@ __device__ __forceinline__ T zoo_draw_select_one(const int kind, const T x_in, c
     // May: exp(log(exp_mu)), the log of a negative number being NaN
     W emu;
     if constexpr (sizeof(T) == 4) emu = M::fma(x * (W)PY.r, M::fma(-x, (W)PY.invM, (W)1), x) - q;
-    else emu = (x + x * (W)PY.r * ((W)1 - x * (W)PY.invM)) - q;
+    else emu = (x + x * (W)PY.r * ((W)1 - (W)div_by_reciprocal_f64((double)x, PY.M, PY.invM))) - q;      // (x / M to the reference's rounding)
     const W preY = (emu < (W)0) ? M::nan() : emu;
     const W pre = (isA || isR) ? x : (isY ? preY : q);
     if constexpr (sizeof(T) == 4) {
@@ -1169,7 +1180,7 @@ __device__ __forceinline__ void zoo_draw_select_tile(const int (&kind)[4], const
 // (FISHING_V11_FORM 2, the product.)  The five kinds' coefficients sit in a 5 x 8 table in LDS, written once per workgroup (by its
 // first wave, while the tile's loads are in flight; once per launch in the rollout kernels), and an env fetches ITS row with two
 // 16-byte LDS reads (four in float64) -- no selects of constants, no ballots, no passes:
-//     row k = { sigma, cg, cK, c1, c2, c3, cr, - }
+//     row k = { sigma, cg, cK, c1, c2, c3, cr, M (May, float64 layout) }
 //     g   = cg (1 - x cK) + sigma z          Allen: cg = r (1 - C) / K, cK = 1 / K;  Ricker: cg = r, cK = 1 / K;  others cg = 0
 //     q   = c1 w / (c2 + c3 w)               w = clip(x) (Beverton-Holt: c1 = A, c2 = 1, c3 = 1 / B) or x ** p (Myers: A, 1, 1 / M;
 //                                            May: a, b ** q, 1);  Allen / Ricker: c1 = c3 = 0, c2 = 1 -> q = 0, unused
@@ -1192,7 +1203,7 @@ __host__ __device__ __forceinline__ void zoo_lut_rows(const GrowthT<T> (&zoo)[FI
         {(T)PA.sigma, (T)PA.gc, (T)PA.invK, (T)0, (T)1, (T)0, (T)0, (T)0},           // FISHING_KIND_ALLEN
         {(T)PB.sigma, (T)0, (T)0, (T)PB.A, (T)1, (T)PB.invB, (T)0, (T)0},            // FISHING_KIND_BEVERTON_HOLT
         {(T)PM.sigma, (T)0, (T)0, (T)PM.A, (T)1, (T)PM.invM, (T)0, (T)0},            // FISHING_KIND_MYERS
-        {(T)PY.sigma, (T)0, (T)PY.invM, (T)PY.a, (T)PY.bq, (T)1, (T)PY.r, (T)0},     // FISHING_KIND_MAY
+        {(T)PY.sigma, (T)0, (T)PY.invM, (T)PY.a, (T)PY.bq, (T)1, (T)PY.r, (T)PY.M},  // FISHING_KIND_MAY (M: the float64 layout's x / M)
         {(T)PR.sigma, (T)PR.r, (T)PR.invK, (T)0, (T)1, (T)0, (T)0, (T)0}};           // FISHING_KIND_RICKER
 #pragma unroll
     for (int k = 0; k < FISHING_N_KINDS; ++k)
@@ -1232,7 +1243,8 @@ __device__ __forceinline__ T zoo_draw_lut_one(const int kind, const T x, const T
     const T q = M::div(c1 * w, M::fma(w, c3, c2));
     T emu;
     if constexpr (sizeof(T) == 4) emu = M::fma(x * cr, lin, x) - q;
-    else emu = (x + x * cr * ((T)1 - x * cK)) - q;          // (zoo_pre_g_f64's May: separately rounded operations)
+    else emu = (x + x * cr * ((T)1 - (T)div_by_reciprocal_f64((double)x, (double)hi.v[3], (double)cK))) - q;      // (zoo_pre_g_f64's May: separately
+                                                                                                            // rounded operations, x / M included)
     const T preY = (emu < (T)0) ? M::nan() : emu;
     const T pre = isAR ? x : (isY ? preY : q);
     if constexpr (sizeof(T) == 4) {

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--only-v4", action="store_true")
     ap.add_argument("--oracle-sweeps", type=int, default=0, help="further seeds of tests/test_gpu_parity.py::test_random_parameter_sets_match_oracle")
     ap.add_argument("--only-oracle", action="store_true")
+    ap.add_argument("--only-zoo", action="store_true", help="with --oracle-sweeps: the zoo's sweep alone")
     a = ap.parse_args()
     import hip_harness as hh
     import test_gpu_fused_and_dispatch as T
@@ -50,7 +51,7 @@ def main():
         import numpy as np
         import test_gpu_parity as P
         from oracle import fishing_oracle as fo
-        for model in (fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4):
+        for model in (() if a.only_zoo else (fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4)):
             for dtype in (np.float64, np.float32):
                 t0, bad = time.time(), []
                 for k in range(1, 1 + a.oracle_sweeps):
@@ -60,6 +61,18 @@ def main():
                         bad.append({"seed_offset": k, "error": (str(e) or traceback.format_exc()).splitlines()[0][:300]})
                 print(json.dumps({"family": "oracle parameter sweep (30 parameter sets x 6 steps x 1003 envs per trial)", "model": int(model),
                                   "dtype": np.dtype(dtype).name, "trials": a.oracle_sweeps, "failures": bad,
+                                  "seconds": round(time.time() - t0, 1)}), flush=True)
+        import test_gpu_zoo as Z
+        for model in (fo.MODEL_V5, fo.MODEL_V6, fo.MODEL_V7, fo.MODEL_V8, fo.MODEL_V9):
+            for dtype in (np.float64, np.float32):
+                t0, bad = time.time(), []
+                for k in range(1, 1 + a.oracle_sweeps):
+                    try:
+                        Z.test_zoo_random_parameter_sets_match_oracle(hh, model, dtype, seed_offset=k)
+                    except Exception as e:  # noqa: BLE001
+                        bad.append({"seed_offset": k, "error": (str(e) or traceback.format_exc()).splitlines()[0][:400]})
+                print(json.dumps({"family": "zoo oracle parameter sweep (24 parameter sets x 4 steps x 1027 envs per trial)", "model": int(model),
+                                  "dtype": np.dtype(dtype).name, "trials": a.oracle_sweeps, "failures": bad[:20], "n_failures": len(bad),
                                   "seconds": round(time.time() - t0, 1)}), flush=True)
         if a.only_oracle:
             return

@@ -492,6 +492,66 @@ def test_v11_coefficient_table_equals_the_single_kind_kernels_bit_for_bit(hh, dt
     assert (ex[done != ed] < 1e-6).all() and (t2 == et).all()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("model", [fo.MODEL_V5, fo.MODEL_V6, fo.MODEL_V7, fo.MODEL_V8, fo.MODEL_V9])
+def test_zoo_random_parameter_sets_match_oracle(hh, model, dtype, seed_offset=0):
+    """The zoo's counterpart of test_gpu_parity.py::test_random_parameter_sets_match_oracle: 24 random parameter sets per growth
+    function -- r (Ricker: negative too), K, sigma, Allen's C, May's M / q / b / a, Myers' M / theta (integer and non-integer
+    exponents) far from the defaults --, stocks from extinct to 1.6 K, 4 auto-resetting steps with external noise, every output of
+    every step against the oracle's float64 evaluation of growth_models.py:208-261: float64 within 2e-14 of the population and the
+    reward exact, float32 within (1e-6 + 2e-6 * population) * max(1, e^|r|) (the north star's absolute 1e-6 is a statement at the
+    defaults -- K = 1, r = 0.3; a stock of 3 K has a float32 spacing of 2.4e-7 itself, and what is left of it after a harvest that
+    nearly takes it all carries that spacing into a growth step that multiplies a small stock by up to e^r: 1.4e-6 was seen at
+    r = 1.56 under Ricker), `done` equal except where the population is within the bar of zero.  (`seed_offset`: scripts/exp/fuzz_differential.py runs the same body from other seeds.)"""
+    rng = np.random.default_rng(8800 + model + 1000 * seed_offset)
+    n = 1027
+    kind = fo.KIND_OF_MODEL[model]
+    for trial in range(24):
+        K = float(rng.choice([0.5, 1.0, 1.0, 2.0, 1.5]))
+        P = dict(r=float(rng.uniform(0.05, 1.6)), K=K, sigma=float(rng.choice([0.0, 0.05, 0.2])), C=float(rng.uniform(0.05, 0.8)) * K,
+                 M=float(rng.uniform(0.6, 2.0)) * K, theta=float(rng.choice([1.0, 2.0, 3.0, 1.5, 2.5])),
+                 q=float(rng.choice([1.0, 2.0, 3.0, 2.5])), b=float(rng.uniform(0.1, 0.4)) * K, a=float(rng.uniform(0.0, 0.2)) * K)
+        if kind == fo.KIND_RICKER and trial % 4 == 0:
+            P["r"] = float(rng.uniform(-0.4, 0.0))
+        x0, Tmax = 0.75 * K, int(rng.integers(2, 7))
+        p = hh.params(model, r=P["r"], K=K, sigma=P["sigma"], C=P["C"], M=P["M"], theta=P["theta"], q=P["q"], b=P["b"], a=P["a"],
+                      x0=x0, Tmax=Tmax, auto_reset=True)
+        obs = rng.uniform(-1.0, 0.6, n).astype(dtype)
+        obs[::97] = -1.0                                        # extinct stocks: log(0) inside every growth function
+        t = rng.integers(0, Tmax + 1, n).astype(np.int32)
+        st = hh.State(n, dtype, model, obs, t=t, terminal=True)
+        for s in range(4):
+            a = rng.uniform(-1.2, 0.2, n).astype(np.float32)
+            z = rng.standard_normal(n).astype(dtype)
+            o, rew, done, t2 = st.step(p, a, z=z, seed=trial, step_counter=s)
+            eo, er, ed, et, ex = fo.step_zoo(model, obs.astype(np.float64), t, a, z.astype(np.float64), P, K, Tmax=Tmax)
+            term = st.terminal.cpu().numpy().astype(np.float64)
+            pop, ref = (term + 1.0) * K, (eo + 1.0) * K
+            # (a Ricker stock above K under a NEGATIVE rate runs away -- 1e185 fish after four steps were seen: the reference's
+            # exp(mu) then carries the rounding of mu itself, half an ulp of |mu| = 426, which the algebraic form does not
+            # (fishing_common.h: zoo_draw_f64) -- the bar grows by that much; float32 overflows to inf beyond 3.4e38)
+            with np.errstate(all="ignore"):
+                mu_ulp = 2.3e-16 * np.abs(np.log(np.abs(ref)))
+            mu_ulp = np.where(np.isfinite(mu_ulp), mu_ulp, 0.0)
+            if dtype == np.float64:
+                bad = ~((np.abs(pop - ref) <= (F64_RTOL + mu_ulp) * np.abs(ref) + 2 * 2.3e-16 * K) | (np.isnan(pop) & np.isnan(ref)))
+                assert not bad.any(), (kind, trial, s, P, np.argwhere(bad)[0], pop[bad][0], ref[bad][0])
+                assert np.array_equal(rew, er, equal_nan=True), (kind, trial, s)
+            else:
+                amp = max(1.0, float(np.exp(abs(P["r"]))))
+                bad = ~((np.abs(pop - ref) <= (1e-6 + 2e-6 * np.abs(ref)) * amp) | (np.isnan(pop) & np.isnan(ref))
+                        | (np.isinf(pop) & (np.abs(ref) > 1e38) & (np.sign(pop) == np.sign(ref))))
+                assert not bad.any(), (kind, trial, s, P, np.argwhere(bad)[0], pop[bad][0], ref[bad][0])
+                assert ((np.abs(rew.astype(np.float64) - er) <= 1e-6 + 2e-6 * np.abs(er)) | (np.isnan(rew) & np.isnan(er))
+                        | (np.isinf(rew) & (np.abs(er) > 1e38))).all(), (kind, trial, s)
+            differ = done != ed
+            assert (np.abs(ex[differ]) <= 1e-6 * max(1.0, float(np.exp(abs(P["r"]))))).all() and (t2 == np.where(done.astype(bool), 0, et)).all(), (kind, trial, s)
+            m = done.astype(bool)                               # follow the device's state: errors must not compound in the comparison
+            obs = np.where(m, dtype(x0 / K - 1.0), st.terminal.cpu().numpy()).astype(dtype)
+            assert np.array_equal(o, obs, equal_nan=True), (kind, trial, s)
+            t = np.where(m, 0, et).astype(np.int32)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("n", [4096, 4099], ids=["lean", "general"])
 def test_v11_index_outside_the_zoo_steps_as_beverton_holt(hh, n, dtype):
