@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""One-off widening of the randomised differential tests (tests/test_gpu_fused_and_dispatch.py): the same test bodies over trial
+"""(Test infrastructure -- it drives test bodies and, through them, the oracle: it lives in tests/.)
+One-off widening of the randomised differential tests (tests/test_gpu_fused_and_dispatch.py): the same test bodies over trial
 numbers far beyond the parametrised ranges -- every trial draws its own request from its number --
 
-    python scripts/exp/fuzz_differential.py [--requests 1500] [--big 40] [--sequences 12] > gpurun_out/.../fuzz.jsonl
+    python tests/fuzz_differential.py [--requests 1500] [--big 40] [--sequences 12] > gpurun_out/.../fuzz.jsonl
 
 * requests: test_randomised_requests_agree_across_dispatch_general_and_fused (dispatch vs general kernel vs ONE fused launch),
 * big:      test_randomised_requests_beyond_4096_tiles (N in (2^22, 1.5 * 2^23]: the zig-zag walk, ranges),
@@ -15,7 +16,7 @@ import sys
 import time
 import traceback
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

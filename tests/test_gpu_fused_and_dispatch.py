@@ -525,7 +525,7 @@ def test_randomised_requests_beyond_4096_tiles(hh, trial):
     from gym_fishing_amd import _capi
     lib = _capi.lib()
     rng = np.random.default_rng(7700 + trial)
-    kind = ["v1", "v0", "v2", "v4d", "v9", "v1", "v4s", "v1", "v2", "v10"][trial % 10]     # (scripts/exp/fuzz_differential.py runs trials beyond 9)
+    kind = ["v1", "v0", "v2", "v4d", "v9", "v1", "v4s", "v1", "v2", "v10"][trial % 10]     # (tests/fuzz_differential.py runs trials beyond 9)
     model = {"v0": fo.MODEL_V0, "v1": fo.MODEL_V1, "v2": fo.MODEL_V2, "v4s": fo.MODEL_V4, "v4d": fo.MODEL_V4, "v9": fo.MODEL_V9,
              "v10": fo.MODEL_V10}[kind]
     dtype = np.float64 if trial % 10 in (5, 7, 8) else np.float32

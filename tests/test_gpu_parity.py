@@ -885,7 +885,7 @@ def test_random_parameter_sets_match_oracle(hh, model, dtype, seed_offset=0):
     from the defaults, incl. K = 0 reachable in fishing-v4 and sigma large enough to drive
     stocks extinct), 6 steps each with fused auto-reset and external noise: every output of
     every step against the oracle -- bit-exact (v2: population tolerance).
-    (`seed_offset`: scripts/exp/fuzz_differential.py runs the same body from other seeds.)"""
+    (`seed_offset`: tests/fuzz_differential.py runs the same body from other seeds.)"""
     rng = np.random.default_rng(900 + model + 1000 * seed_offset)
     n = 1003
     per_env = model == fo.MODEL_V4

@@ -502,7 +502,7 @@ def test_zoo_random_parameter_sets_match_oracle(hh, model, dtype, seed_offset=0)
     reward exact, float32 within (1e-6 + 2e-6 * population) * max(1, e^|r|) (the north star's absolute 1e-6 is a statement at the
     defaults -- K = 1, r = 0.3; a stock of 3 K has a float32 spacing of 2.4e-7 itself, and what is left of it after a harvest that
     nearly takes it all carries that spacing into a growth step that multiplies a small stock by up to e^r: 1.4e-6 was seen at
-    r = 1.56 under Ricker), `done` equal except where the population is within the bar of zero.  (`seed_offset`: scripts/exp/fuzz_differential.py runs the same body from other seeds.)"""
+    r = 1.56 under Ricker), `done` equal except where the population is within the bar of zero.  (`seed_offset`: tests/fuzz_differential.py runs the same body from other seeds.)"""
     rng = np.random.default_rng(8800 + model + 1000 * seed_offset)
     n = 1027
     kind = fo.KIND_OF_MODEL[model]
