@@ -49,9 +49,11 @@ def golden(tag):
         with np.errstate(invalid="ignore", divide="ignore"):
             rel = np.abs((obs + 1.0) * K - x) / np.maximum(np.abs(x), 1e-300)
         live = np.isfinite(x) & (x > 1e-3)          # (obs = x / K - 1 cannot resolve a population near extinction)
-        print(json.dumps(dict(tag=tag, kind="golden", case=c.name, id=c.id, steps=int(n),
-                              max_rel_population=float(rel[live].max()), in_units_of_the_bar=float(rel[live].max() / BAR),
-                              reward_bit_equal=bool(np.array_equal(rew, c.reward.reshape(-1))),
+        worst = float(rel[live].max()) if live.any() else 0.0       # (v8_myers_r_below_minus_one: every stock NaN, on both sides)
+        print(json.dumps(dict(tag=tag, kind="golden", case=c.name, id=c.id, steps=int(n), live_steps=int(live.sum()),
+                              nan_pattern_equal=bool(np.array_equal(np.isnan(obs), np.isnan(ref))),
+                              max_rel_population=worst, in_units_of_the_bar=worst / BAR,
+                              reward_bit_equal=bool(np.array_equal(rew, c.reward.reshape(-1), equal_nan=True)),
                               done_mismatches=int((done != c.done.reshape(-1)).sum()))), flush=True)
 
 
