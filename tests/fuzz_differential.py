@@ -63,6 +63,20 @@ def main():
                 print(json.dumps({"family": "oracle parameter sweep (30 parameter sets x 6 steps x 1003 envs per trial)", "model": int(model),
                                   "dtype": np.dtype(dtype).name, "trials": a.oracle_sweeps, "failures": bad,
                                   "seconds": round(time.time() - t0, 1)}), flush=True)
+        if not a.only_zoo:
+            for policy in ("random", "constant", "escapement", "msy"):
+                t0, bad, cnt = time.time(), [], 0
+                for k in range(1, 1 + max(1, a.oracle_sweeps // 4)):
+                    for model in (fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4):
+                        for dtype in (np.float64, np.float32):
+                            cnt += 1
+                            try:
+                                P.test_fused_rollout_equals_stepwise(hh, model, dtype, policy, seed_offset=k)
+                            except Exception as e:  # noqa: BLE001
+                                bad.append({"seed_offset": k, "model": int(model), "dtype": np.dtype(dtype).name,
+                                            "error": (str(e) or traceback.format_exc()).splitlines()[0][:300]})
+                print(json.dumps({"family": "fused rollout == stepwise under the oracle's policy actions (random K, r, sigma, policy parameter, seed, batch)",
+                                  "policy": policy, "trials": cnt, "failures": bad[:20], "n_failures": len(bad), "seconds": round(time.time() - t0, 1)}), flush=True)
         import test_gpu_zoo as Z
         for model in (fo.MODEL_V5, fo.MODEL_V6, fo.MODEL_V7, fo.MODEL_V8, fo.MODEL_V9):
             for dtype in (np.float64, np.float32):

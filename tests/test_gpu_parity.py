@@ -418,13 +418,26 @@ ROLLOUT_KW = dict(sigma=0.1, C=0.5, x0=0.75, Tmax=7, sigma_p=0.15)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
 @pytest.mark.parametrize("policy", ["random", "constant", "escapement", "msy"])
-def test_fused_rollout_equals_stepwise(hh, model, dtype, policy):
+def test_fused_rollout_equals_stepwise(hh, model, dtype, policy, seed_offset=0):
     """T steps inside one kernel == T step() calls fed the policy's actions (bit-exact: both
-    run the same device arithmetic and the same Philox blocks)."""
+    run the same device arithmetic and the same Philox blocks).
+    (`seed_offset` != 0, tests/fuzz_differential.py: the same body with K, r, the noise scale, the policy's parameter, the seed, the env
+    offset and the batch size drawn from that number -- power-of-two and other K, whole tiles and ragged batches.)"""
     n, off, seed, T = 2052, 4, 99, 25
     per_env = model == fo.MODEL_V4
-    p = hh.params(model, r=0.3, K=1.0, auto_reset=True, **ROLLOUT_KW)
+    r0, K0, kw = 0.3, 1.0, dict(ROLLOUT_KW)
     pol, param = _policy_setup(hh, policy, model)
+    if seed_offset:
+        rng = np.random.default_rng(31000 + seed_offset)
+        n, off, seed, T = int(rng.choice([2052, 1024, 4096, 3000, 780])), 4 * int(rng.integers(0, 40)), int(rng.integers(1, 1 << 40)), int(rng.integers(5, 30))
+        r0, K0 = float(rng.uniform(0.05, 1.2)), float(rng.choice([1.0, 1.0, 0.5, 2.0, 1.5, 0.3]))
+        kw.update(sigma=float(rng.choice([0.0, 0.05, 0.2])), x0=0.75 * K0, Tmax=int(rng.integers(2, 12)), C=0.5 * K0)
+        if model == fo.MODEL_V4:
+            r0, K0 = 0.3, 1.0           # (the stored arrays below; the means stay the harness's defaults)
+            kw.update(x0=0.75, C=0.5)
+        param = {"random": 0.0, "constant": float(rng.integers(0, 60)) if model == fo.MODEL_V0 else float(rng.uniform(-1.1, -0.3)),
+                 "escapement": float(rng.uniform(0.1, 0.9)) * K0, "msy": float(rng.uniform(0.0, 0.3)) * K0}[policy]
+    p = hh.params(model, r=r0, K=K0, auto_reset=True, **kw)
     mk = lambda: hh.State(n, dtype, model, np.zeros(n), r=np.full(n, 0.3) if per_env else None,   # noqa: E731
                           K=np.full(n, 1.0) if per_env else None, ep_return=True)
     A, B = mk(), mk()
@@ -434,7 +447,7 @@ def test_fused_rollout_equals_stepwise(hh, model, dtype, policy):
     env = np.arange(off, off + n)
     for s in range(T):
         obs = B.obs.cpu().numpy()
-        Kh = B.K.cpu().numpy() if per_env else dtype(1.0)
+        Kh = B.K.cpu().numpy() if per_env else dtype(K0)
         a = _policy_action(policy, param, model, dtype, obs, Kh, seed, env, s)
         assert_same_bits(traj[s, 0], obs, "obs_in step %d" % s)
         assert_same_bits(traj[s, 1], a.astype(dtype), "action step %d" % s)
@@ -445,7 +458,7 @@ def test_fused_rollout_equals_stepwise(hh, model, dtype, policy):
     assert (A.t.cpu().numpy() == B.t.cpu().numpy()).all()
     assert_same_bits(A.ep_return.cpu().numpy(), B.ep_return.cpu().numpy(), "ep_return")
     ra, rb = A.record(), B.record()
-    assert ra[2] == rb[2] and ra[2] >= n and np.allclose(ra, rb, rtol=1e-12)
+    assert ra[2] == rb[2] and (ra[2] >= n or seed_offset) and np.allclose(ra, rb, rtol=1e-12, equal_nan=True)
     if per_env:
         assert_same_bits(A.K.cpu().numpy(), B.K.cpu().numpy(), "K")
 
