@@ -236,14 +236,7 @@ math_kernel(const int64_t n, const int fn, const double* __restrict__ in, double
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const double v = in[i];
-        double r;
-        switch (fn) {          // wave-uniform
-            case FISHING_MATH_LOG_F64: r = log_f64(v); break;
-            case FISHING_MATH_EXP_F64: r = exp_f64(v); break;
-            case FISHING_MATH_LOG_MID: r = log_mid(v); break;
-            case FISHING_MATH_EXP_MID: r = exp_mid(v); break;
-            default: r = (double)expm1_f32((float)v); break;
-        }
+        const double r = (fn == FISHING_MATH_LOG_F64) ? log_f64(v) : exp_f64(v);          // wave-uniform
         out[i] = r;
     }
 }
@@ -444,7 +437,7 @@ int fishing_step_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint6
 }
 
 int fishing_math_f64(int64_t n, int32_t fn, const double* in, double* out, fishing_stream_t stream) {
-    if (n < 0 || fn < FISHING_MATH_LOG_F64 || fn > FISHING_MATH_EXPM1_F32) return FISHING_ERR_SIZE;
+    if (n < 0 || fn < FISHING_MATH_LOG_F64 || fn > FISHING_MATH_EXP_F64) return FISHING_ERR_SIZE;
     if (!in || !out) return FISHING_ERR_NULL;
     if (n == 0) return FISHING_OK;
     return fishing::launch_kernel(fishing::math_kernel, fishing::grid_for(n, 2048), 256, (hipStream_t)stream, n, (int)fn, in, out);

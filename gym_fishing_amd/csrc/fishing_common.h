@@ -73,7 +73,7 @@ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32
 // `index` is the global env QUAD index (env >> 2) on the noise and policy streams -- one block
 // feeds the four envs of a thread tile: noise (w0, w1) -> Box-Muller cos / sin legs = z of envs
 // 4q, 4q+1, (w2, w3) -> z of envs 4q+2, 4q+3; policy word j -> the random action of env 4q+j --,
-// (fishing-v11's model draw used word j of such a block for env 4q + j through round 4; now model_block below).
+// (fishing-v11's model draw: model_block below.)
 // fishing-v4's (K, r) draws use a Philox2x32-10 block per ENV instead (draw_model_error).
 __device__ __forceinline__ Words4 philox_block(uint64_t seed, uint64_t index, uint64_t counter,
                                                uint32_t stream) {
@@ -98,16 +98,14 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
     o1 = c1;
 }
 
-// Block of the per-env parameter draw (mirrored in oracle/fishing_oracle.py: param_words; round 3 layout):
+// Block of the per-env parameter draw (mirrored in oracle/fishing_oracle.py: param_words):
 //   c0  = env[31:0]
 //   c1  = counter[30:0] | (stream == kStreamReset ? 1 << 31 : 0)
 //   key = seed[31:0] ^ seed[63:32] * 0x85EBCA6B ^ counter[62:31] * 0x9E3779B1 ^ env[63:32] * 0xC2B2AE35
-// While env < 2^32 and counter < 2^31 -- every run so far: 2^31 steps are 15 hours at 25 us per step -- the block is an
-// injective function of (env, counter, stream): the reset() draws and the auto-reset draws can never meet, whatever the
-// two counters (round 2 told the streams apart by XOR-ing a tag into c1, which made reset counter a and step counter b
-// share a block whenever a ^ b equalled the difference of the tags, b ~ 2.1e9).  There the key is wave-uniform and its
-// ten round keys stay in SGPRs, like the noise block's; beyond, the high parts perturb the key per lane.
-// Key space: Philox2x32 takes ONE 32-bit key, so the 64-bit seed is folded -- two seeds share their parameter stream with
+// While env < 2^32 and counter < 2^31 (2^31 steps are 15 hours at 25 us per step) the block is an injective function of
+// (env, counter, stream): the reset() draws and the auto-reset draws can never meet, whatever the two counters.  There the
+// key is wave-uniform and its ten round keys stay in SGPRs, like the noise block's; beyond, the high parts perturb the key per
+// lane.  Philox2x32 takes ONE 32-bit key, so the 64-bit seed is folded -- two seeds share their parameter stream with
 // probability 2^-32 (the noise stream, Philox4x32, carries the full 64-bit seed and is not affected).
 constexpr uint32_t kParamResetBit = 0x80000000u;
 __device__ __forceinline__ uint32_t param_key(uint64_t seed) {
@@ -156,16 +154,16 @@ constexpr int kModelZooRT = kModelZooMixed + 1;    // general kernel: one growth
 constexpr bool is_zoo_tag(int model_tag) { return model_tag >= kModelZoo && model_tag <= kModelZooRT; }
 
 // One growth function's parameter set (FishingGrowthParams) plus per-launch constants evaluated once on the host in
-// double (libm).  Every field is a double whatever the layout T: the float32 kernels evaluate the growth function in float64
-// (zoo_population_draw below), and a float32-rounded r or log(A) alone would cost 3e-8 of the 1e-6 the layout is held to;
-// wave-uniform, so they live in SGPR pairs and only the fields a kernel's growth function reads are ever loaded.
+// double (libm; fishing_host.h: make_growth).  Every field is a double whatever the layout T (the float32 kernels narrow
+// what they read): wave-uniform, so they live in SGPR pairs and only the fields a kernel's growth function reads are ever
+// loaded.
 template <typename T>
 struct GrowthT {
     double r, K, sigma, C, M, theta, q, b, a;
     double bq;      // May:            b ** q                       (growth_models.py:238)
     double logA;    // B-H / Myers:    log(clip(r, 0, inf) + 1) / log(r + 1)   (:222,:225 / :248,:251)
     double B;       // Beverton-Holt:  clip(K, 0, inf) / clip(r, 0, inf)       (:224)
-    // the algebraic form of the float32 layout (FISHING_ZOO_F32_MATH 2):
+    // the algebraic form (both layouts):
     double A;       // B-H: clip(r, 0, inf) + 1;  Myers: r + 1
     double invK;    // 1 / K        (Allen, Ricker;  B-H under drift: 1 / clip(K, 0, inf))
     double invM;    // 1 / M        (May, Myers)
@@ -173,48 +171,6 @@ struct GrowthT {
     double gc;      // Allen: r (1 - C) / K, the coefficient of (1 - x / K) in mu - log x
     int32_t ipow;   // May's q / Myers' theta when it is one of 1, 2, 3, 4 (x ** e by multiplication), else 0
 };
-
-template <typename T>
-inline GrowthT<T> make_growth(double r, double K, double sigma, double C, double M, double theta, double q,
-                              double b, double a, int kind) {
-    GrowthT<T> g{r, K, sigma, C, M, theta, q, b, a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0};
-    g.gc = r * (1.0 - C) / K;
-    g.bq = std::pow(b, q);
-    g.invK = 1.0 / K;
-    g.invM = 1.0 / M;
-    if (kind == FISHING_KIND_BEVERTON_HOLT) {
-        const double rc = r < 0 ? 0 : r, Kc = K < 0 ? 0 : K;
-        g.logA = std::log(rc + 1.0);
-        g.A = rc + 1.0;
-        g.B = Kc / rc;
-        g.invB = rc / Kc;
-        g.invK = 1.0 / Kc;
-    } else {
-        g.logA = std::log(r + 1.0);
-        // (Myers: log(r + 1) of a negative number is NaN in the reference, and so is its population: the algebraic forms,
-        // which carry A itself, must not turn that into max(0, negative) = an extinct stock)
-        g.A = (r + 1.0 < 0.0) ? std::nan("") : r + 1.0;
-    }
-    const double e = kind == FISHING_KIND_MAY ? q : theta;
-    g.ipow = (e == 1.0 || e == 2.0 || e == 3.0 || e == 4.0) ? (int32_t)e : 0;
-    return g;
-}
-
-inline bool is_zoo_model(int model) { return model >= FISHING_MODEL_V5 && model <= FISHING_MODEL_V11; }
-inline bool is_core_model(int model) {
-    return model == FISHING_MODEL_V0 || model == FISHING_MODEL_V1 || model == FISHING_MODEL_V2 || model == FISHING_MODEL_V4;
-}
-
-// growth-function kind of a single-kind zoo model (v11 carries it per env)
-inline int kind_of_model(int model) {
-    switch (model) {
-        case FISHING_MODEL_V5: return FISHING_KIND_ALLEN;
-        case FISHING_MODEL_V7: return FISHING_KIND_MAY;
-        case FISHING_MODEL_V8: return FISHING_KIND_MYERS;
-        case FISHING_MODEL_V9: return FISHING_KIND_RICKER;
-        default: return FISHING_KIND_BEVERTON_HOLT;   // v6, v10
-    }
-}
 
 template <typename T>
 struct ParamsT {
@@ -229,46 +185,6 @@ struct ParamsT {
     int32_t kinds[FISHING_N_KINDS];
     GrowthT<T> zoo[FISHING_N_KINDS];
 };
-
-template <typename T>
-inline ParamsT<T> narrow_params(const FishingParams& p) {
-    ParamsT<T> q;
-    q.model = p.model;
-    q.n_actions = p.n_actions;
-    q.Tmax = p.Tmax;
-    q.flags = p.flags;
-    q.r = (T)p.r;
-    q.K = (T)p.K;
-    q.sigma = (T)p.sigma;
-    q.C = (T)p.C;
-    q.x0 = (T)p.x0;
-    q.r_mean = (T)p.r_mean;
-    q.K_mean = (T)p.K_mean;
-    q.sigma_p = (T)p.sigma_p;
-    q.M = (T)p.M;
-    q.theta = (T)p.theta;
-    q.q = (T)p.q;
-    q.b = (T)p.b;
-    q.a = (T)p.a;
-    q.alpha = (T)p.alpha;
-    q.n_models = p.n_models;
-    q.kind = kind_of_model(p.model);
-    q.origin_step = p.v4_origin_step;
-    q.origin_counter = p.v4_origin_counter;
-    // the host-side constants (pow / log) only where a growth function of the zoo will read them
-    q.growth = GrowthT<T>{};
-    if (is_zoo_model(p.model) && p.model != FISHING_MODEL_V11)
-        q.growth = make_growth<T>(p.r, p.K, p.sigma, p.C, p.M, p.theta, p.q, p.b, p.a, kind_of_model(p.model));
-    for (int k = 0; k < FISHING_N_KINDS; ++k) {
-        q.kinds[k] = p.kinds[k];
-        q.zoo[k] = GrowthT<T>{};
-        if (p.model == FISHING_MODEL_V11) {
-            const FishingGrowthParams& g = p.zoo[k];
-            q.zoo[k] = make_growth<T>(g.r, g.K, g.sigma, g.C, g.M, g.theta, g.q, g.b, g.a, k);
-        }
-    }
-    return q;
-}
 
 template <typename T>
 struct BuffersT {
@@ -289,89 +205,6 @@ struct BuffersT {
     const uint64_t* counter;
     int32_t* stamp;
 };
-
-template <typename T>
-inline BuffersT<T> typed_buffers(const FishingBuffers& b) {
-    BuffersT<T> q;
-    q.obs = (T*)b.obs;
-    q.action = b.action;
-    q.reward = (T*)b.reward;
-    q.done = b.done;
-    q.done_bits = b.done_bits;
-    q.t = b.t;
-    q.r = (T*)b.r;
-    q.K = (T*)b.K;
-    q.sigma = (const T*)b.sigma;
-    q.z_ext = (const T*)b.z_ext;
-    q.terminal_obs = (T*)b.terminal_obs;
-    q.ep_return = (T*)b.ep_return;
-    q.partials = b.return_partials;
-    q.model_idx = b.model_idx;
-    q.counter = b.counter;
-    q.stamp = b.v4_stamp;
-    return q;
-}
-
-// Host-side tag dispatch: calls f(std::integral_constant<int, TAG>{}) with the kernel template tag
-// of `model` (the model id itself for fishing-v0/v1/v2/v4; kModelZoo + kind for v5..v10;
-// kModelZooMixed for v11).  Keeps the run-time -> compile-time switch in one place.
-template <int TAG>
-using ModelTag = std::integral_constant<int, TAG>;
-
-template <typename F>
-inline int with_model_tag(int model, F&& f) {
-    switch (model) {
-        case FISHING_MODEL_V0: return f(ModelTag<FISHING_MODEL_V0>{});
-        case FISHING_MODEL_V1: return f(ModelTag<FISHING_MODEL_V1>{});
-        case FISHING_MODEL_V2: return f(ModelTag<FISHING_MODEL_V2>{});
-        case FISHING_MODEL_V4: return f(ModelTag<FISHING_MODEL_V4>{});
-        case FISHING_MODEL_V11: return f(ModelTag<kModelZooMixed>{});
-        default: break;
-    }
-    if (!is_zoo_model(model)) return FISHING_ERR_MODEL;
-    switch (kind_of_model(model)) {
-        case FISHING_KIND_ALLEN: return f(ModelTag<kModelZoo + FISHING_KIND_ALLEN>{});
-        case FISHING_KIND_MYERS: return f(ModelTag<kModelZoo + FISHING_KIND_MYERS>{});
-        case FISHING_KIND_MAY: return f(ModelTag<kModelZoo + FISHING_KIND_MAY>{});
-        case FISHING_KIND_RICKER: return f(ModelTag<kModelZoo + FISHING_KIND_RICKER>{});
-        default: return f(ModelTag<kModelZoo + FISHING_KIND_BEVERTON_HOLT>{});
-    }
-}
-
-// the same for the general step kernel, which keeps the zoo's growth-function kind a run-time value
-template <typename F>
-inline int with_general_tag(int model, F&& f) {
-    switch (model) {
-        case FISHING_MODEL_V0: return f(ModelTag<FISHING_MODEL_V0>{});
-        case FISHING_MODEL_V1: return f(ModelTag<FISHING_MODEL_V1>{});
-        case FISHING_MODEL_V2: return f(ModelTag<FISHING_MODEL_V2>{});
-        case FISHING_MODEL_V4: return f(ModelTag<FISHING_MODEL_V4>{});
-        case FISHING_MODEL_V11: return f(ModelTag<kModelZooMixed>{});
-        default: break;
-    }
-    if (!is_zoo_model(model)) return FISHING_ERR_MODEL;
-    return f(ModelTag<kModelZooRT>{});
-}
-
-// Launch status of THIS launch (hipLaunchKernel's own return value), not whatever sticky error an
-// unrelated earlier call left on the thread -- and without consuming that state either.
-// `dyn_lds` bytes of (unused) dynamic LDS per workgroup cap how many workgroups a CU holds at once -- a launch-time
-// occupancy limit (launch_kernel_lds).
-template <typename... P, typename... A>
-inline int launch_kernel_lds(void (*kernel)(P...), int blocks, int threads, size_t dyn_lds, hipStream_t stream, A&&... args) {
-    std::tuple<P...> packed{static_cast<P>(args)...};
-    return std::apply(
-        [&](auto&... a) {
-            void* argv[] = {(void*)&a...};
-            return (int)hipLaunchKernel((const void*)kernel, dim3((unsigned)blocks), dim3((unsigned)threads), argv, dyn_lds,
-                                        stream);
-        },
-        packed);
-}
-template <typename... P, typename... A>
-inline int launch_kernel(void (*kernel)(P...), int blocks, int threads, hipStream_t stream, A&&... args) {
-    return launch_kernel_lds(kernel, blocks, threads, 0, stream, std::forward<A>(args)...);
-}
 
 // ---------------------------------------------------------------- the env arithmetic
 template <typename T>
@@ -427,119 +260,23 @@ __device__ __forceinline__ int32_t action_int_from_quota(T quota, int32_t n_acti
     else return (int32_t)__builtin_rint(v);
 }
 
-template <typename T>
-__device__ __forceinline__ T log_t(T v);
-template <>
-__device__ __forceinline__ double log_t<double>(double v) {
-    return log(v);
-}
-template <>
-__device__ __forceinline__ float log_t<float>(float v) {
-    return __builtin_amdgcn_logf(v) * 0.6931471805599453f;          // v_log_f32 is log2
-}
-// x ** e for x >= 0 as exp(e * log x): one log + one exp instead of the library pow (which
-// carries full special-case handling and is ~4x the instructions); pow(0, e > 0) = exp(-inf) = 0,
-// inf and NaN propagate.  Error ~ |e log x| ulp, far inside the zoo's parity tolerance.
-template <typename T>
-__device__ __forceinline__ T pow_t(T v, T e);
-template <>
-__device__ __forceinline__ double pow_t<double>(double v, double e) {
-    return exp(e * log(v));
-}
-template <>
-__device__ __forceinline__ float pow_t<float>(float v, float e) {
-    return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(v));    // v_exp_f32 is 2**x
-}
-
-// ---------------------------------------------------------------- the zoo's float32 layout: how the growth function is evaluated
-// The growth functions of fishing-v5..v11 are exp(mu(x) + sigma z) with mu = log(x) + ... : a round trip through log and
-// exp whose O(1) intermediate terms each carry a float32 rounding of 6e-8 when evaluated in float32.  Against the
-// reference's float64 numbers that form lands up to 4.5e-7 off on the reference-held fixtures and 1.06e-6 off (Myers) on a
-// dense sweep of the state space (profiles/r04_zoo_f32_error.json) -- at the edge of the north star's "obs within 1e-6".
-// The float32 kernels therefore evaluate the algebraically equal form WITHOUT the round trip,
-//     x' = pre(x) * exp(g(x, z)):   pre = x,                             g = r (1 - x/K) (1 - C)/K + sigma z    Allen
-//                                   pre = x,                             g = r (1 - x/K) + sigma z              Ricker
-//                                   pre = A x / (1 + x/B),               g = sigma z                            Beverton-Holt
-//                                   pre = A x^theta / (1 + x^theta/M),   g = sigma z                            Myers
-//                                   pre = exp_mu(x)  (NaN when < 0),     g = sigma z                            May
+// ---------------------------------------------------------------- the zoo (fishing-v5..v11): how a growth function is evaluated
+// The growth functions of growth_models.py:208-261 are exp(mu(x) + sigma z) with mu = log(x) + ... : a round trip through log and
+// exp.  Both layouts evaluate the algebraically equal form WITHOUT the round trip,
+//     x' = max(0, pre(x) * exp(g(x, z))):   pre = x,                             g = r (1 - x/K) (1 - C)/K + sigma z    Allen
+//                                           pre = x,                             g = r (1 - x/K) + sigma z              Ricker
+//                                           pre = A x / (1 + x/B),               g = sigma z                            Beverton-Holt
+//                                           pre = A x^theta / (1 + x^theta/M),   g = sigma z                            Myers
+//                                           pre = exp_mu(x)  (NaN when < 0),     g = sigma z                            May
 // whose special values agree with the reference's (x = 0 -> 0, x = inf -> NaN, exp_mu < 0 -> NaN, NaN -> NaN; K, M, B of
-// 0 or inf as IEEE division has them).
-//   FISHING_ZOO_F32_MATH 4 (default): all of it in float32 -- g by fma chains, pre with one <= 1-ulp division (div_f32),
-//       exp on the hardware (v_exp_f32 behind one scaling multiply), one multiply.  No logarithm at all, so faster than
-//       the round trip of rounds 1-3 AND closer to the reference: <= 3.2e-7 on the fixtures, <= 4.7e-7 on the sweep
-//       (the round trip: 4.5e-7 / 1.06e-6); fishing-v5 14.8 us per step at N = 2^22 against 15.3.
-//   3 ("hybrid"): g and expm1(g) in float32 (expm1 by argument reduction + a degree-7 polynomial), pre in float64 (a
-//       handful of multiply-adds and one div_mid), x' = fma(pre, expm1(g), pre) in float64, rounded to float32 ONCE:
-//       <= 2.3e-7 / 2.2e-7; +0-8 % step time, the VALU-bound fishing-v11 rollouts -40 %.
-//   2: everything in float64 (exp_mid, a ~1e-11 polynomial exp): <= 2.3e-7 / 1.4e-7 -- the fixtures' figure is the
-//       float32 rounding of the INPUTS, which no evaluation can remove; +3-10 % step time, fused rollouts at half speed.
-//   1: the round trip in float32 arithmetic with the library's ~1-ulp logf / expf (4.5e-7 / 9.3e-7).
-//   0: the round trip in float32 arithmetic on the hardware transcendentals (rounds 1-3).
-// (every figure: profiles/r04_zoo_f32_error.json, measured by tests/measure_zoo_f32_error.py on builds with
-// -DFISHING_ZOO_F32_MATH=n)
-// The float64 parity layout runs the same algebraic form in float64 on the < 1-ulp exp_f64 / div_f64 below (round 5; 2e-14
-// against the reference); -DFISHING_ZOO_F64_ROUNDTRIP=1 builds the reference's round trip on log_f64 / exp_f64 (rounds 1-4).
-#ifndef FISHING_ZOO_F32_MATH
-#define FISHING_ZOO_F32_MATH 4
-#endif
-
-// a / b to ~1e-14 relative: v_rcp_f32 seed + one Newton step in float64 (5 instructions; the IEEE float64 division is
-// ~25).  Denominators outside float32's comfortable range (zeros, infinities, NaN included) take the IEEE division.
-__device__ __forceinline__ double div_mid(double a, double b) {
-    const double ab = __builtin_fabs(b);
-    if (!(ab > 0x1p-100 && ab < 0x1p100)) return a / b;
-    const double r0 = (double)__builtin_amdgcn_rcpf((float)b);
-    return a * __builtin_fma(__builtin_fma(-b, r0, 1.0), r0, r0);
-}
-// log(v) to ~2e-12 relative for finite v > 0 (0 -> -inf; negatives, inf, NaN, extremes: the library).
-// v = m 2^e with m in [sqrt(1/2), sqrt(2)): log v = e ln2 + 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.1716,
-// atanh(s) = s (1 + s^2/3 + ... + s^12/13) -- the first omitted term is s^14/15 <= 1.3e-12.
-__device__ __forceinline__ double log_mid(double v) {
-    if (!(v > 0x1p-1000 && v < 0x1p1000) && v != 0.0) return log(v);
-    double m = __builtin_amdgcn_frexp_mant(v);                 // [0.5, 1)
-    int e = __builtin_amdgcn_frexp_exp(v);
-    const bool low = m < 0.70710678118654752;
-    m = low ? m + m : m;
-    e = low ? e - 1 : e;
-    const double s = div_mid(m - 1.0, m + 1.0);
-    const double s2 = s * s;
-    double q = 1.0 / 13.0;
-    q = __builtin_fma(q, s2, 1.0 / 11.0);
-    q = __builtin_fma(q, s2, 1.0 / 9.0);
-    q = __builtin_fma(q, s2, 1.0 / 7.0);
-    q = __builtin_fma(q, s2, 1.0 / 5.0);
-    q = __builtin_fma(q, s2, 1.0 / 3.0);
-    q = __builtin_fma(q, s2, 1.0);
-    const double r = __builtin_fma((double)e, 0.69314718055994530942, (s + s) * q);
-    return (v == 0.0) ? -__builtin_huge_val() : r;
-}
-// exp(y) to ~1e-11 relative: y = n ln2 + r, |r| <= 0.3466, Taylor to r^9/9! (remainder 7e-12), v_ldexp_f64 (which
-// saturates to inf / flushes to 0 by itself).  -inf -> 0, +inf -> inf, NaN -> NaN.
-__device__ __forceinline__ double exp_mid(double y) {
-    const double yc = __builtin_fmin(__builtin_fmax(y, -746.0), 710.0);
-    const double n = __builtin_rint(yc * 1.4426950408889634074);
-    double r = __builtin_fma(-n, 0x1.62e42fefa39efp-1, yc);
-    r = __builtin_fma(-n, 0x1.abc9e3b39803fp-56, r);
-    double p = 1.0 / 362880.0;
-    p = __builtin_fma(p, r, 1.0 / 40320.0);
-    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    const double res = __builtin_amdgcn_ldexp(p, (int)n);
-    return (y != y) ? y : res;
-}
-// x ** e for x >= 0: by multiplication when e is one of 1 .. 4 (make_growth: ipow; the defaults q = theta = 3), else
-// exp(e log x).  pow(0, e > 0) = 0 and NaN propagates either way.
-__device__ __forceinline__ double pow_mid(double x, double e, int ipow) {
-    if (ipow == 0) return exp_mid(e * log_mid(x));      // wave-uniform
-    const double x2 = x * x;
-    return ipow == 1 ? x : ipow == 2 ? x2 : ipow == 3 ? x2 * x : x2 * x2;
-}
+// 0 or inf as IEEE division has them).  One exp and at most one division per env, no logarithm:
+//   float32 layout: fma chains, one <= 1-ulp division (div_f32), exp on the hardware (v_exp_f32): <= 4.7e-7 of the reference's
+//       float64 numbers on a dense sweep of the state space (the literal round trip in float32: 1.06e-6);
+//   float64 parity layout: the same form on the < 1-ulp exp_f64 / div_f64 below: <= 2e-14 of the reference's numbers, closer to
+//       the exact value than the reference's own round trip (whose log x + ... loses |mu| ulp before the exp).
+// The alternatives that were measured and dropped (hardware / libm round trips, a float64 and a hybrid evaluation for the float32
+// layout, the library's log / exp) and their error tables: profiles/NOTES_r01_r05.md, profiles/r04_zoo_f32_error.json,
+// profiles/r05_zoo_f64_error.json.
 
 // ---------------------------------------------------------------- float64 log / exp of the parity layout's zoo
 // The float64 zoo kernels are VALU-bound on their transcendentals: the device library's log is 98 VALU instructions (a
@@ -550,10 +287,6 @@ __device__ __forceinline__ double pow_mid(double x, double e, int ipow) {
 // negative -> NaN, inf -> inf; exp: -inf -> 0, overflow -> inf; NaN -> NaN; subnormal arguments and results handled by
 // v_frexp / v_ldexp).  Held to the zoo's float64 tolerance (2e-14 of the population against the reference's numbers;
 // the two routines themselves measure <= 1 ulp against libm: tests/test_gpu_zoo.py::test_zoo_f64_log_exp_are_within_one_ulp).
-// -DFISHING_ZOO_F64_LIBM=1 builds the library calls back in (rounds 1-3).
-#ifndef FISHING_ZOO_F64_LIBM
-#define FISHING_ZOO_F64_LIBM 0
-#endif
 // n / d for d in [1.5, 2.6]: rcp seed (~2^-26), two Newton steps on the reciprocal, one correction of the quotient
 __device__ __forceinline__ double div_safe_range(double n, double d) {
     double r = __builtin_amdgcn_rcp(d);
@@ -606,48 +339,23 @@ __device__ __forceinline__ W int_pow(W x, int e) {        // e in 1 .. 4
     return e == 1 ? x : e == 2 ? x2 : e == 3 ? x2 * x : x2 * x2;
 }
 
-// Math policies of the round-trip form: W = the type mu is evaluated in
-struct MathLibF64 {          // the float64 parity layout
+// The five growth functions as the reference writes them (growth_models.py:208-261): each ends in
+// np.maximum(0, np.random.lognormal(mu, sigma)) = max(0, exp(mu + sigma z)), a round trip through log and exp (also at
+// sigma = 0).  The float64 layout's cold path (zoo_draw_f64 below: far stocks / far results).  x ** e with e one of 1 .. 4
+// (make_growth: ipow; the reference's defaults theta = q = 3) by multiplication: <= 1 ulp from the correctly rounded np.power.
+// RECOMPUTE: P.r changed on the device (fishing-v10 drift) -> logA / B are evaluated here
+struct MathF64 {
     typedef double W;
-#if FISHING_ZOO_F64_LIBM
-    static __device__ __forceinline__ double log(double v) { return ::log(v); }
-    static __device__ __forceinline__ double exp(double v) { return ::exp(v); }
-#else
+    static constexpr bool kIntPow = true;
     static __device__ __forceinline__ double log(double v) { return log_f64(v); }
     static __device__ __forceinline__ double exp(double v) { return exp_f64(v); }
-#endif
     static __device__ __forceinline__ double pow(double v, double e) { return exp(e * log(v)); }
-    // x ** e with e one of 1 .. 4 (make_growth: ipow; the reference's defaults theta = q = 3) by multiplication: <= 1 ulp from
-    // the correctly rounded np.power the reference calls, where exp(e log x) is |e log x| ulp off -- closer AND one exp (May:
-    // one log and one exp) cheaper per env.  float64 with returns at N = 2^22: fishing-v8 40.5 -> 35.7 us, fishing-v11 51.0 -> 48.8
-    // (profiles/r04_zoo_f64_ipow.jsonl)
-    static constexpr bool kIntPow = true;
 };
-struct MathHwF32 {           // FISHING_ZOO_F32_MATH 0
-    typedef float W;
-    static constexpr bool kIntPow = false;     // (rounds 1-3 as they were)
-    static __device__ __forceinline__ float log(float v) { return log_t<float>(v); }
-    static __device__ __forceinline__ float exp(float v) { return __expf(v); }
-    static __device__ __forceinline__ float pow(float v, float e) { return pow_t<float>(v, e); }
-};
-struct MathLibF32 {          // FISHING_ZOO_F32_MATH 1
-    typedef float W;
-    static constexpr bool kIntPow = false;
-    static __device__ __forceinline__ float log(float v) { return ::logf(v); }
-    static __device__ __forceinline__ float exp(float v) { return ::expf(v); }
-    static __device__ __forceinline__ float pow(float v, float e) { return ::expf(e * ::logf(v)); }
-};
-template <typename T>
-using ZooRoundTripMath = std::conditional_t<sizeof(T) == 8, MathLibF64,
-                                            std::conditional_t<FISHING_ZOO_F32_MATH == 1, MathLibF32, MathHwF32>>;
-
-// The five growth functions of growth_models.py:208-261; each ends in
-// np.maximum(0, np.random.lognormal(mu, sigma)) = max(0, exp(mu + sigma z)).  The reference
-// really does round-trip through log and exp (also at sigma = 0); so does this form -- the float64 parity layout's.
-// RECOMPUTE: P.r changed on the device (fishing-v10 drift) -> logA / B are evaluated here
-template <typename T, typename M, int KIND, bool RECOMPUTE>
+template <int KIND, bool RECOMPUTE, typename T>
 __device__ __forceinline__ T zoo_draw_round_trip(int kind_rt, T x_in, T z_in, const GrowthT<T>& P) {
-    typedef typename M::W W;
+    static_assert(sizeof(T) == 8, "the float64 parity layout's");
+    typedef MathF64 M;
+    typedef double W;
     const W inf = (W)__builtin_huge_val();
     const W x = (W)x_in, z = (W)z_in;
     const int kind = (KIND >= 0) ? KIND : kind_rt;      // compile-time kind folds the switch away
@@ -688,57 +396,15 @@ __device__ __forceinline__ T zoo_draw_round_trip(int kind_rt, T x_in, T z_in, co
     return (T)((g > (W)0) ? g : ((g != g) ? g : (W)0));    // np.maximum(0, g)
 }
 
-// The same five functions without the round trip, in float64, for the float32 layout (see FISHING_ZOO_F32_MATH above):
-// exp(log(x) + g + sigma z) = x exp(g + sigma z), and so on.
-template <int KIND, bool RECOMPUTE, typename T>
-__device__ __forceinline__ double zoo_draw_algebraic(int kind_rt, double x, double z, const GrowthT<T>& P) {
-    const int kind = (KIND >= 0) ? KIND : kind_rt;
-    const double sz = P.sigma * z;
-    double res;
-    switch (kind) {
-        case FISHING_KIND_ALLEN:          // :208-217
-            res = x * exp_mid(P.r * (1.0 - x * P.invK) * (1.0 - P.C) * P.invK + sz);
-            break;
-        case FISHING_KIND_MYERS: {        // :247-255: exp(log A + theta log x - log(1 + x^theta / M)) = A x^theta / (1 + x^theta / M)
-            const double xt = pow_mid(x, P.theta, P.ipow);
-            res = div_mid(P.A * xt, 1.0 + xt * P.invM) * exp_mid(sz);
-            break;
-        }
-        case FISHING_KIND_MAY: {          // :229-242: exp(log(exp_mu)) = exp_mu; log of a negative number is NaN there
-            const double xq = pow_mid(x, P.q, P.ipow);
-            const double exp_mu = x + x * P.r * (1.0 - x * P.invM) - div_mid(P.a * xq, xq + P.bq);
-            res = (exp_mu < 0.0) ? __builtin_nan("") : exp_mu * exp_mid(sz);
-            break;
-        }
-        case FISHING_KIND_RICKER:         // :258-261
-            res = x * exp_mid(P.r * (1.0 - x * P.invK) + sz);
-            break;
-        default: {                        // Beverton-Holt :220-226: A x / (1 + x / B)
-            const double xc = (x < 0.0) ? 0.0 : x;
-            double A = P.A, invB = P.invB;
-            if (RECOMPUTE) {              // fishing-v10: r drifts per env; invK = 1 / clip(K, 0, inf) from the host
-                const double rc = (P.r < 0.0) ? 0.0 : P.r;
-                A = rc + 1.0;
-                invB = rc * P.invK;
-            }
-            res = div_mid(A * xc, 1.0 + xc * invB) * exp_mid(sz);
-            break;
-        }
-    }
-    return (res > 0.0) ? res : ((res != res) ? res : 0.0);    // np.maximum(0, .)
-}
-
-// ---- the float64 parity layout, round 5: the algebraic form on the < 1-ulp exp_f64, no logarithm
-// Rounds 1-4 evaluated the reference's round trip exp(log x + ... + sigma z) term for term.  Its parity is tolerance-based
-// (2e-14 of the population: the reference's libm log / exp are not reproducible bit for bit on the device anyway), and the
-// float64 zoo kernels were VALU-bound on the logarithms -- seven per wave pass in fishing-v11 (0.65 of the HBM spec), two per
-// env in fishing-v8 (0.74).  The algebraically equal form needs one exp_f64 and at most one division per env and lands
-// CLOSER to the exact value than the round trip does (whose log x + ... loses |mu| ulp before the exp): measured against the
-// reference-held fixtures in profiles/r05_zoo_f64_error.json.  Same special values as the round trip (see the float32
-// layout's table above; tests/test_gpu_zoo.py::test_zoo_special_values_follow_the_reference holds both layouts to them).
-#ifndef FISHING_ZOO_F64_ROUNDTRIP
-#define FISHING_ZOO_F64_ROUNDTRIP 0
-#endif
+// ---- the float64 parity layout: the algebraic form on the < 1-ulp exp_f64
+// Parity is tolerance-based (2e-14 of the population: the reference's libm log / exp are not reproducible bit for bit on the
+// device anyway).  Same special values as the round trip (tests/test_gpu_zoo.py::test_zoo_special_values_follow_the_reference
+// holds both layouts to them).
+// FISHING_ZOO_F64_FAR: where the REFERENCE's round trip itself loses more than the parity bar, follow it (zoo_draw_f64).  A
+// per-translation-unit setting: 1 in fishing_aux.hip (population_draw hands x' out itself), 0 in fishing_step.hip /
+// fishing_rollout.hip (their outputs cannot carry the difference: fishing_step.hip, top).  The inline device templates below
+// therefore have different bodies per translation unit -- sound only because every unit is its own device link (build.py:
+// -fno-gpu-rdc; no device symbol crosses units).
 #ifndef FISHING_ZOO_F64_FAR
 #define FISHING_ZOO_F64_FAR 1
 #endif
@@ -823,91 +489,14 @@ __device__ __forceinline__ double zoo_draw_f64(int kind_rt, double x, double z, 
     // (fishing_aux.hip: BMSY sweeps, the module-level growth functions, the special-value tests), which hands x' out itself; the
     // step / rollout translation units leave it out -- obs = x' / K - 1 cannot carry the difference (fishing_step.hip, top).
     const double inf = __builtin_huge_val();
-    const bool far = (x > 0.0 && x < 0x1p-30) || (x > 0x1p30 && x < inf) || (res > 0.0 && res < 0x1p-92) || (res > 0x1p92 && res < inf);
-#if FISHING_ZOO_F64_FAR       // (0 in the step / rollout translation units: fishing_step.hip says why; 1 in population_draw's)
-    if (__builtin_expect(far, 0)) return zoo_draw_round_trip<double, MathLibF64, KIND, RECOMPUTE>(kind_rt, x, z, P);
-#endif
+    [[maybe_unused]] const bool far = (x > 0.0 && x < 0x1p-30) || (x > 0x1p30 && x < inf) || (res > 0.0 && res < 0x1p-92) || (res > 0x1p92 && res < inf);
+    if constexpr (FISHING_ZOO_F64_FAR != 0) {    // (0 in the step / rollout translation units, 1 in population_draw's)
+        if (__builtin_expect(far, 0)) return zoo_draw_round_trip<KIND, RECOMPUTE, T>(kind_rt, x, z, P);
+    }
     return (res > 0.0) ? res : ((res != res) ? res : 0.0);      // np.maximum(0, .)
 }
 
-// expm1(g) in float32: g = n ln2 + r (ln2 split hi / lo, |r| <= 0.3466), expm1(r) = r + r^2 (1/2 + r/6 + ... + r^5/5040)
-// (first omitted term r^8/8! <= 5e-9), expm1(g) = 2^n expm1(r) + (2^n - 1).  Absolute error <= ~5e-8 max(1, exp(g)).
-// -inf -> -1, +inf -> inf, NaN -> NaN.
-__device__ __forceinline__ float expm1_f32(float g) {
-    const float gc = __builtin_fminf(__builtin_fmaxf(g, -104.0f), 89.0f);
-    const float n = __builtin_rintf(gc * 1.44269504088896341f);
-    float r = __builtin_fmaf(-n, 0.693145751953125f, gc);
-    r = __builtin_fmaf(-n, 1.428606765330187e-06f, r);
-    float q = 1.0f / 5040.0f;
-    q = __builtin_fmaf(q, r, 1.0f / 720.0f);
-    q = __builtin_fmaf(q, r, 1.0f / 120.0f);
-    q = __builtin_fmaf(q, r, 1.0f / 24.0f);
-    q = __builtin_fmaf(q, r, 1.0f / 6.0f);
-    q = __builtin_fmaf(q, r, 0.5f);
-    const float p = __builtin_fmaf(r, q * r, r);
-    const float s = __builtin_amdgcn_ldexpf(1.0f, (int)n);
-    const float e = __builtin_fmaf(s, p, s - 1.0f);
-    return (g != g) ? g : e;
-}
-
-// (pre, g) of one growth function, the hybrid form: pre in float64, g in float32 (see FISHING_ZOO_F32_MATH above).
-// `sz` = sigma * z, already formed in float32.
-template <int KIND, bool RECOMPUTE, typename T>
-__device__ __forceinline__ void zoo_pre_g(float x, float sz, const GrowthT<T>& P, double& pre, float& g) {
-    static_assert(KIND >= 0 && KIND < FISHING_N_KINDS, "a compile-time kind");
-    const double xd = (double)x;
-    if constexpr (KIND == FISHING_KIND_ALLEN) {                 // :208-217
-        pre = xd;
-        g = __builtin_fmaf((float)P.gc, __builtin_fmaf(-x, (float)P.invK, 1.0f), sz);
-    } else if constexpr (KIND == FISHING_KIND_RICKER) {         // :258-261
-        pre = xd;
-        g = __builtin_fmaf((float)P.r, __builtin_fmaf(-x, (float)P.invK, 1.0f), sz);
-    } else if constexpr (KIND == FISHING_KIND_MYERS) {          // :247-255
-        const double xt = pow_mid(xd, P.theta, P.ipow);
-        pre = div_mid(P.A * xt, __builtin_fma(xt, P.invM, 1.0));
-        g = sz;
-    } else if constexpr (KIND == FISHING_KIND_MAY) {            // :229-242
-        const double xq = pow_mid(xd, P.q, P.ipow);
-        const double exp_mu = xd + xd * P.r * (1.0 - xd * P.invM) - div_mid(P.a * xq, xq + P.bq);
-        pre = (exp_mu < 0.0) ? __builtin_nan("") : exp_mu;
-        g = sz;
-    } else {                                                    // Beverton-Holt :220-226
-        const double xc = (xd < 0.0) ? 0.0 : xd;
-        double A = P.A, invB = P.invB;
-        if (RECOMPUTE) {              // fishing-v10: r drifts per env; invK = 1 / clip(K, 0, inf) from the host
-            const double rc = (P.r < 0.0) ? 0.0 : P.r;
-            A = rc + 1.0;
-            invB = rc * P.invK;
-        }
-        pre = div_mid(A * xc, __builtin_fma(xc, invB, 1.0));
-        g = sz;
-    }
-}
-// x' = max(0, pre + pre expm1(g)), one rounding to float32
-__device__ __forceinline__ float zoo_finish_hybrid(double pre, float g) {
-    const double res = __builtin_fma(pre, (double)expm1_f32(g), pre);
-    return (float)((res > 0.0) ? res : ((res != res) ? res : 0.0));     // np.maximum(0, .)
-}
-template <int KIND, bool RECOMPUTE, typename T>
-__device__ __forceinline__ float zoo_draw_hybrid(int kind_rt, float x, float z, const GrowthT<T>& P) {
-    const float sz = (float)P.sigma * z;
-    double pre = 0.0;
-    float g = 0.0f;
-    if constexpr (KIND >= 0) {
-        zoo_pre_g<KIND, RECOMPUTE, T>(x, sz, P, pre, g);
-    } else {            // run-time kind (the general kernel's single-kind zoo, population_draw sweeps): wave-uniform switch
-        switch (kind_rt) {
-            case FISHING_KIND_ALLEN: zoo_pre_g<FISHING_KIND_ALLEN, false, T>(x, sz, P, pre, g); break;
-            case FISHING_KIND_MYERS: zoo_pre_g<FISHING_KIND_MYERS, false, T>(x, sz, P, pre, g); break;
-            case FISHING_KIND_MAY: zoo_pre_g<FISHING_KIND_MAY, false, T>(x, sz, P, pre, g); break;
-            case FISHING_KIND_RICKER: zoo_pre_g<FISHING_KIND_RICKER, false, T>(x, sz, P, pre, g); break;
-            default: zoo_pre_g<FISHING_KIND_BEVERTON_HOLT, RECOMPUTE, T>(x, sz, P, pre, g); break;
-        }
-    }
-    return zoo_finish_hybrid(pre, g);
-}
-
-// ---- FISHING_ZOO_F32_MATH 4: the same algebraic form entirely in float32 on the hardware exp (v_exp_f32)
+// ---- the float32 layout: the same algebraic form entirely in float32 on the hardware exp (v_exp_f32)
 // n / d to <= 1 ulp: v_rcp_f32 + one correction of the quotient (4 instructions; the IEEE float32 division is ~10).
 // Denominators outside the comfortable range (zeros, infinities, NaN included) take the IEEE division.
 __device__ __forceinline__ float div_f32(float n, float d) {
@@ -975,100 +564,20 @@ __device__ __forceinline__ float zoo_draw_f32(int kind_rt, float x, float z, con
     return zoo_finish_f32(pre, g);
 }
 
-// which GrowthT constants a layout's zoo kernels read: logA / B (the round trip) or A / invK / invM / invB / gc (algebraic)
-template <typename T>
-constexpr bool zoo_uses_round_trip() {
-    return sizeof(T) == 8 ? (FISHING_ZOO_F64_ROUNDTRIP != 0) : (FISHING_ZOO_F32_MATH == 0 || FISHING_ZOO_F32_MATH == 1);
-}
-
 template <typename T, int KIND = -1, bool RECOMPUTE = false>
 __device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const GrowthT<T>& P) {
-    if constexpr (sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4)
-        return (T)zoo_draw_f32<KIND, RECOMPUTE, T>(kind_rt, (float)x, (float)z, P);
-    else if constexpr (sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 3)
-        return (T)zoo_draw_hybrid<KIND, RECOMPUTE, T>(kind_rt, (float)x, (float)z, P);
-    else if constexpr (sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 2)
-        return (T)zoo_draw_algebraic<KIND, RECOMPUTE, T>(kind_rt, (double)x, (double)z, P);
-    else if constexpr (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP)
-        return (T)zoo_draw_f64<KIND, RECOMPUTE, T>(kind_rt, (double)x, (double)z, P);
-    else
-        return zoo_draw_round_trip<T, ZooRoundTripMath<T>, KIND, RECOMPUTE>(kind_rt, x, z, P);
+    if constexpr (sizeof(T) == 4) return (T)zoo_draw_f32<KIND, RECOMPUTE, T>(kind_rt, (float)x, (float)z, P);
+    else return (T)zoo_draw_f64<KIND, RECOMPUTE, T>(kind_rt, (double)x, (double)z, P);
 }
 
-// fishing-v11: the growth function differs per env, so a straight per-lane switch runs all five
-// functions for every one of a thread's four envs (20 masked passes per wave, most lanes idle in
-// each).  Instead each wave regroups its 256 envs BY KIND through a wave-private LDS window, ONCE for
-// all kinds: every env gets a slot = start of its kind's segment + its rank inside the kind (ballot +
-// mbcnt), (x, z) pairs go to their slots in one write phase, the wave evaluates growth function k on
-// segment k in chunks of 64 slots with wave-uniform parameters (ceil(n_k / 64) passes per kind, 5-7 in
-// total), and every env reads its result back from its slot: three LDS phases per tile whatever the
-// number of kinds.  Same function on the same inputs as zoo_population_draw<T, k>: identical bits.
-// Must be called by all 64 lanes of the wave (envs that do not take part pass kind < 0).
-// `win` is this wave's window: kZooWindowSlots pairs, one per env of the wave -- the segments follow each other
-// without padding (a chunk is read by `count - c` lanes of ONE kind's pass, so a chunk never mixes kinds whatever
-// its start; rounds 1-3 padded every segment to whole chunks and needed twice the LDS: 33 KB per workgroup in
-// float64 = four workgroups per CU).
-constexpr int kZooWindowSlots = 256;
-template <typename T>
-struct alignas(2 * sizeof(T)) ZooSlot {
-    T x, z;
-};
-
-template <typename T, int K>
-__device__ __forceinline__ void zoo_rank_kind(const int (&kind)[4], int (&slot)[4], int& begin, int& count, int& next) {
-    int total = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool mine = kind[j] == K;
-        const uint64_t bal = __ballot(mine);
-        const int pos = next + total +
-                        (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        slot[j] = mine ? pos : slot[j];
-        total += __popcll(bal);                   // wave-uniform
-    }
-    begin = next;
-    count = total;
-    next += total;
-}
-
-template <typename T, int K>
-__device__ __forceinline__ void zoo_eval_kind(ZooSlot<T>* __restrict__ win, int begin, int count, const GrowthT<T>& P,
-                                              int lane) {
-    for (int c = 0; c < count; c += kWave) {      // wave-uniform trip count
-        if (c + lane < count) {
-            const ZooSlot<T> v = win[begin + c + lane];
-            win[begin + c + lane].x = zoo_population_draw<T, K, false>(K, v.x, v.z, P);
-        }
-    }
-}
-
-// ---------------------------------------------------------------- fishing-v11, round 5: one division and one exp per env
-// Every growth function of the zoo is x' = max(0, pre_k(x) * exp(g_k(x, z))) in its algebraic form (above), and what differs
-// by kind is cheap: g is sigma_k z plus, for Allen and Ricker, c_k (1 - x / K_k); pre is x itself (Allen, Ricker), one
-// quotient n_k / d_k (Beverton-Holt, Myers) or a cubic minus that quotient (May).  So a lane can evaluate ONE division and ONE
-// exp per env at full lane occupancy -- no ballots, no divergent passes -- if it gets hold of its env's coefficients.  Two ways:
-//   FISHING_V11_FORM 1 ("select"): evaluate the three quotients' (n, d) and the two exponents with wave-uniform constants and
-//       select by kind.  A VALU instruction reads ONE scalar register on this architecture, so every `kind == k ? c_k : ...`
-//       first moves its constants into vector registers: 755 VALU / 651 SALU instructions in the float32 step kernel against the
-//       regroup's 662 / 603 -- float32 step 28.7 -> 28.2 us, float64 48.4 -> 53.2, rollout -2.5 %.  Not shipped.
-//   FISHING_V11_FORM 2 ("table", below; ships): the coefficients from a 5 x 8 table in LDS, two 16-byte LDS reads per env.
-//       float32 step 28.7 -> 27.2 us (0.75 -> 0.79 of the HBM spec at 41 B; rocprofv3 26.3 = 0.82), random-policy rollout
-//       7.94 -> 6.05 ms (2.67 -> 3.5e11 env-steps/s), and -- a lane's four envs no longer have to be regrouped -- the float64
-//       layout's two-envs-per-thread shape for fishing-v11 too: 48.4 -> 41.8 us (0.66 -> 0.77 at 61 B).
-//   FISHING_V11_FORM 0: the regroup-by-kind form of rounds 2-4 (zoo_draw_regrouped: 20 ballot / mbcnt ranks, three LDS phases,
-//       5-7 passes per wave at ~80 % lane occupancy, each with its own scalar parameter fetch and exec-mask frame).
-// All three run the operations of zoo_pre_g_f32 / zoo_pre_g_f64 of the env's kind on the same operands: the same bits (the GPU
-// suite passes on each; profiles/r05_v11_forms.jsonl).  zoo_draw_select_one also serves the per-env-sigma path
-// (env_step_zoo_mixed below) in every build.
-#ifndef FISHING_V11_FORM
-#define FISHING_V11_FORM 2
-#endif
-#ifndef FISHING_V11_LUT_INT_POW_ONLY
-#define FISHING_V11_LUT_INT_POW_ONLY 0
-#endif
-#ifndef FISHING_V11_SELECT_SERIAL
-#define FISHING_V11_SELECT_SERIAL 0
-#endif
+// ---------------------------------------------------------------- fishing-v11: one division and one exp per env, whatever its kind
+// Every growth function is x' = max(0, pre_k(x) * exp(g_k(x, z))), and what differs by kind is cheap: g is sigma_k z plus, for
+// Allen and Ricker, c_k (1 - x / K_k); pre is x itself (Allen, Ricker), one quotient n_k / d_k (Beverton-Holt, Myers) or a cubic
+// minus that quotient (May).  So a lane evaluates ONE division and ONE exp per env at full lane occupancy -- no ballots, no
+// divergent passes -- once it has its env's coefficients: from a 5 x 8 table in LDS (zoo_draw_lut_tile, the step / rollout
+// kernels) or, on the per-env-sigma path, by selects over the wave-uniform parameter sets (zoo_draw_select_one).  Both run the
+// operations of zoo_pre_g_f32 / zoo_pre_g_f64 of the env's kind on the same operands: the same bits.  (The regroup-by-kind form of
+// rounds 2-4 and the measurements of all three: profiles/NOTES_r01_r05.md, profiles/r05_v11_forms.jsonl.)
 template <typename W>
 struct ZooSelectMath;
 template <>
@@ -1085,12 +594,10 @@ struct ZooSelectMath<double> {
     static __device__ __forceinline__ double pow(double x, double e, int ipow) { return pow_f64(x, e, ipow); }
     static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
 };
-// `kind` in [0, FISHING_N_KINDS) (the callers map anything else to Beverton-Holt, like the regrouped form)
+// `kind` in [0, FISHING_N_KINDS) (the callers map anything else to Beverton-Holt)
 template <typename T>
 __device__ __forceinline__ T zoo_draw_select_one(const int kind, const T x_in, const T z_in, const GrowthT<T> (&zoo)[FISHING_N_KINDS],
                                                   bool& far, const bool own_sigma = false, const T sigma_env = (T)0) {
-    static_assert((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP),
-                  "the select form is the algebraic form's");
     typedef T W;
     typedef ZooSelectMath<W> M;
     const GrowthT<T>& PA = zoo[FISHING_KIND_ALLEN];
@@ -1136,48 +643,8 @@ __device__ __forceinline__ T zoo_draw_select_one(const int kind, const T x_in, c
     }
 }
 
-// the four envs of a lane; float64: the far stocks / far results of the whole tile go through ONE copy of the reference's
-// round trip (a loop over the lane's envs and over the kinds that is deliberately not unrolled: it is the cold path, and four
-// times five inlined round trips would cost the fused kernels -- which hold the envs' state across steps -- their registers)
-template <typename T>
-__device__ __forceinline__ void zoo_draw_select_tile(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
-                                                     const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[4]) {
-    bool far[4] = {false, false, false, false};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        bool f = false;
-        const T v = zoo_draw_select_one<T>(kind[j] >= 0 ? kind[j] : FISHING_KIND_BEVERTON_HOLT, x[j], z[j], zoo, f);
-        out[j] = (kind[j] >= 0) ? v : out[j];
-        far[j] = f && kind[j] >= 0;
-        // float64: one env after the other -- interleaved, the four evaluations' temporaries (register pairs) push the fused
-        // kernels into scratch; float32 keeps the interleaving's ILP
-        if constexpr (sizeof(T) == 8 || FISHING_V11_SELECT_SERIAL) __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (sizeof(T) == 8 && FISHING_ZOO_F64_FAR) {
-        if (__builtin_expect(far[0] | far[1] | far[2] | far[3], 0)) {
-            for (int j = 0; j < 4; ++j) {
-                asm volatile("" : "+s"(j));         // (keeps the loop a loop)
-                const bool fj = j == 0 ? far[0] : j == 1 ? far[1] : j == 2 ? far[2] : far[3];
-                if (!fj) continue;
-                const double xj = j == 0 ? x[0] : j == 1 ? x[1] : j == 2 ? x[2] : x[3];
-                const double zj = j == 0 ? z[0] : j == 1 ? z[1] : j == 2 ? z[2] : z[3];
-                const int kj = j == 0 ? kind[0] : j == 1 ? kind[1] : j == 2 ? kind[2] : kind[3];
-                double r = 0.0;
-                for (int k = 0; k < FISHING_N_KINDS; ++k) {
-                    asm volatile("" : "+s"(k));
-                    if (kj == k) r = zoo_draw_round_trip<double, MathLibF64, -1, false>(k, xj, zj, zoo[k]);
-                }
-                out[0] = j == 0 ? r : out[0];
-                out[1] = j == 1 ? r : out[1];
-                out[2] = j == 2 ? r : out[2];
-                out[3] = j == 3 ? r : out[3];
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------- fishing-v11: the growth function's coefficients from an LDS table
-// (FISHING_V11_FORM 2, the product.)  The five kinds' coefficients sit in a 5 x 8 table in LDS, written once per workgroup (by its
+// The five kinds' coefficients sit in a 5 x 8 table in LDS, written once per workgroup (by its
 // first wave, while the tile's loads are in flight; once per launch in the rollout kernels), and an env fetches ITS row with two
 // 16-byte LDS reads (four in float64) -- no selects of constants, no ballots, no passes:
 //     row k = { sigma, cg, cK, c1, c2, c3, cr, M (May, float64 layout) }
@@ -1223,7 +690,7 @@ template <typename T>
 __device__ __forceinline__ T zoo_draw_lut_one(const int kind, const T x, const T z_in, const T* __restrict__ lut, const int ipowM,
                                               const int ipowY, const T thetaM, const T qY, bool& far) {
     typedef ZooSelectMath<T> M;
-    struct alignas(4 * sizeof(T)) Quad { T v[4]; };
+    struct alignas(16) Quad { T v[4]; };     // (the tables are declared alignas(16); float64: two 16-byte reads per Quad)
     const Quad lo = *reinterpret_cast<const Quad*>(lut + kind * kZooLutRow);
     const Quad hi = *reinterpret_cast<const Quad*>(lut + kind * kZooLutRow + 4);
     const T sg = lo.v[0], cg = lo.v[1], cK = lo.v[2], c1 = lo.v[3], c2 = hi.v[0], c3 = hi.v[1], cr = hi.v[2];
@@ -1234,11 +701,7 @@ __device__ __forceinline__ T zoo_draw_lut_one(const int kind, const T x, const T
     const T g = M::fma(cg, lin, sz);
     const T xc = (x < (T)0) ? (T)0 : x;
     // x ** theta (Myers) / x ** q (May): wave-uniform choices (equal small integer powers -- the defaults -- share the product)
-#if FISHING_V11_LUT_INT_POW_ONLY     // (analysis builds: what the table form costs without the general-power fallback compiled in)
-    const T u = (ipowM == ipowY) ? int_pow<T>(x, ipowM) : (isY ? int_pow<T>(x, ipowY) : int_pow<T>(x, ipowM));
-#else
     const T u = (ipowM == ipowY && ipowM != 0) ? int_pow<T>(x, ipowM) : (isY ? M::pow(x, qY, ipowY) : M::pow(x, thetaM, ipowM));
-#endif
     const T w = isB ? xc : u;
     const T q = M::div(c1 * w, M::fma(w, c3, c2));
     T emu;
@@ -1271,7 +734,9 @@ __device__ __forceinline__ void zoo_draw_lut_tile(const int (&kind)[N], const T 
         out[j] = (kind[j] >= 0) ? v : out[j];
         far[j] = f && kind[j] >= 0;
         any_far |= far[j];
-        if constexpr (sizeof(T) == 8 || FISHING_V11_SELECT_SERIAL) __builtin_amdgcn_sched_barrier(0);      // (one env after the other: zoo_draw_select_tile)
+        // float64: one env after the other -- interleaved, the evaluations' temporaries (register pairs) push the fused kernels
+        // into scratch; float32 keeps the interleaving's ILP
+        if constexpr (sizeof(T) == 8) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (sizeof(T) == 8 && FISHING_ZOO_F64_FAR) {
         if (__builtin_expect(any_far, 0)) {         // (zoo_draw_f64: follow the reference's round trip there; ONE copy, real loops)
@@ -1291,72 +756,17 @@ __device__ __forceinline__ void zoo_draw_lut_tile(const int (&kind)[N], const T 
                 // (one compile-time kind per case: the run-time-kind instantiation needs 30 more registers than any of these)
                 double r;
                 switch (kj) {
-                    case FISHING_KIND_ALLEN: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_ALLEN, false>(kj, xj, zj, zoo[FISHING_KIND_ALLEN]); break;
-                    case FISHING_KIND_MYERS: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_MYERS, false>(kj, xj, zj, zoo[FISHING_KIND_MYERS]); break;
-                    case FISHING_KIND_MAY: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_MAY, false>(kj, xj, zj, zoo[FISHING_KIND_MAY]); break;
-                    case FISHING_KIND_RICKER: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_RICKER, false>(kj, xj, zj, zoo[FISHING_KIND_RICKER]); break;
-                    default: r = zoo_draw_round_trip<double, MathLibF64, FISHING_KIND_BEVERTON_HOLT, false>(kj, xj, zj, zoo[FISHING_KIND_BEVERTON_HOLT]); break;
+                    case FISHING_KIND_ALLEN: r = zoo_draw_round_trip<FISHING_KIND_ALLEN, false, T>(kj, xj, zj, zoo[FISHING_KIND_ALLEN]); break;
+                    case FISHING_KIND_MYERS: r = zoo_draw_round_trip<FISHING_KIND_MYERS, false, T>(kj, xj, zj, zoo[FISHING_KIND_MYERS]); break;
+                    case FISHING_KIND_MAY: r = zoo_draw_round_trip<FISHING_KIND_MAY, false, T>(kj, xj, zj, zoo[FISHING_KIND_MAY]); break;
+                    case FISHING_KIND_RICKER: r = zoo_draw_round_trip<FISHING_KIND_RICKER, false, T>(kj, xj, zj, zoo[FISHING_KIND_RICKER]); break;
+                    default: r = zoo_draw_round_trip<FISHING_KIND_BEVERTON_HOLT, false, T>(kj, xj, zj, zoo[FISHING_KIND_BEVERTON_HOLT]); break;
                 }
 #pragma unroll
                 for (int k = 0; k < N; ++k) out[k] = (j == k) ? (T)r : out[k];
             }
         }
     }
-}
-
-// (Round 4 also measured a branch-free "select" form for the float32 layout -- every lane evaluates the (pre, g) of all
-// kinds present in its wave for its own four envs and selects, no LDS: the same 24.2 us per step at N = 2^22 as this
-// regroup, 13 % slower in the VALU-bound random-policy rollout, since it evaluates five functions per env instead of
-// one: profiles/r04_v11_forms.jsonl.  Not kept.)
-template <typename T>
-__device__ __forceinline__ void zoo_draw_regrouped(const int (&kind)[4], const T (&x)[4], const T (&z)[4],
-                                                   const GrowthT<T> (&zoo)[FISHING_N_KINDS], T (&out)[4],
-                                                   ZooSlot<T>* __restrict__ win, int lane, const T* __restrict__ lut = nullptr) {
-    if constexpr (FISHING_V11_FORM == 2 && ((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP))) {
-        // the coefficients from the workgroup's LDS table (every caller of this build hands one over)
-        zoo_draw_lut_tile<T, 4>(kind, x, z, zoo, lut, out);
-        return;
-    }
-    if constexpr (FISHING_V11_FORM == 1 && ((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP))) {
-        // round 5: per lane, one division and one exp per env, selected by kind (zoo_draw_select_tile); `win` stays unused
-        zoo_draw_select_tile<T>(kind, x, z, zoo, out);
-        return;
-    }
-    int slot[4] = {-1, -1, -1, -1};
-    int begin[FISHING_N_KINDS], count[FISHING_N_KINDS];
-    int next = 0;
-    zoo_rank_kind<T, FISHING_KIND_ALLEN>(kind, slot, begin[0], count[0], next);
-    zoo_rank_kind<T, FISHING_KIND_BEVERTON_HOLT>(kind, slot, begin[1], count[1], next);
-    zoo_rank_kind<T, FISHING_KIND_MYERS>(kind, slot, begin[2], count[2], next);
-    zoo_rank_kind<T, FISHING_KIND_MAY>(kind, slot, begin[3], count[3], next);
-    zoo_rank_kind<T, FISHING_KIND_RICKER>(kind, slot, begin[4], count[4], next);
-    static_assert(FISHING_KIND_ALLEN == 0 && FISHING_KIND_BEVERTON_HOLT == 1 && FISHING_KIND_MYERS == 2 &&
-                      FISHING_KIND_MAY == 3 && FISHING_KIND_RICKER == 4 && FISHING_N_KINDS == 5,
-                  "segment order = kind order");
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (slot[j] >= 0) win[slot[j]] = ZooSlot<T>{x[j], z[j]};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // (scheduling fences: each pass fetches ITS parameter set -- wave-uniform kernel arguments -- when it starts; left alone the
-    // scheduler hoists all five sets' scalar loads to the top, 100+ SGPRs live across the whole regroup)
-    zoo_eval_kind<T, FISHING_KIND_ALLEN>(win, begin[0], count[0], zoo[FISHING_KIND_ALLEN], lane);
-    __builtin_amdgcn_sched_barrier(0);
-    zoo_eval_kind<T, FISHING_KIND_BEVERTON_HOLT>(win, begin[1], count[1], zoo[FISHING_KIND_BEVERTON_HOLT], lane);
-    __builtin_amdgcn_sched_barrier(0);
-    zoo_eval_kind<T, FISHING_KIND_MYERS>(win, begin[2], count[2], zoo[FISHING_KIND_MYERS], lane);
-    __builtin_amdgcn_sched_barrier(0);
-    zoo_eval_kind<T, FISHING_KIND_MAY>(win, begin[3], count[3], zoo[FISHING_KIND_MAY], lane);
-    __builtin_amdgcn_sched_barrier(0);
-    zoo_eval_kind<T, FISHING_KIND_RICKER>(win, begin[4], count[4], zoo[FISHING_KIND_RICKER], lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = (slot[j] >= 0) ? win[slot[j]].x : out[j];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();              // the next tile reuses the window
 }
 
 // x / K.  When K is a power of two (the default K = 1 included) the quotient is exact up to the
@@ -1368,11 +778,6 @@ struct DivK {
     float inv_f;
     double inv_d;
 };
-inline DivK make_divk(double K) {
-    int e = 0;
-    const bool p2 = K > 0 && std::isfinite(K) && std::frexp(K, &e) == 0.5 && e > -120 && e < 120;
-    return DivK{p2, p2 ? (float)(1.0 / K) : 0.0f, p2 ? 1.0 / K : 0.0};
-}
 template <typename T>
 __device__ __forceinline__ T div_K(T x, T K, const DivK& d);
 // (a run-time `pow2` is wave-uniform: a real branch -- the empty asm keeps the compiler from evaluating the 10 / 25-instruction
@@ -1416,15 +821,14 @@ __device__ __forceinline__ void env_step_zoo(T obs, int32_t t, T quota, T z, int
 }
 
 // fishing-v11 with a per-env noise scale (the caller's sigma array): one env, its growth function chosen per lane.  The select
-// form with sigma_env in place of the kinds' own sigma (same bits as env_step_zoo<T, -1> on a copy of zoo[kind] with that sigma
-// -- what rounds 2-4 did, and what the other builds still do: a per-lane index into the kernel-argument array, which costs
-// the float64 fused kernel 760 bytes of scratch once the algebraic form reads every field of the set).
+// form with sigma_env in place of the kinds' own sigma: same bits as env_step_zoo<T, -1> on a copy of zoo[kind] with that sigma,
+// without the per-lane index into the kernel-argument array (760 bytes of scratch in the float64 fused kernel).
 template <typename T>
 __device__ __forceinline__ void env_step_zoo_mixed(T obs, int32_t t, T quota, T z, int kind, const GrowthT<T> (&zoo)[FISHING_N_KINDS],
                                                    T sigma_env, T K_obs, int32_t Tmax, T& obs_next, T& reward, bool& done,
                                                    int32_t& t_next, const DivK& dk = DivK{false, 0.0f, 0.0}) {
     const int kk = (kind >= 0 && kind < FISHING_N_KINDS) ? kind : FISHING_KIND_BEVERTON_HOLT;
-    if constexpr ((sizeof(T) == 4 && FISHING_ZOO_F32_MATH == 4) || (sizeof(T) == 8 && !FISHING_ZOO_F64_ROUNDTRIP)) {
+    {
         T x = (obs + (T)1) * K_obs;
         const T h = (quota < x) ? quota : x;
         x = stock_after_harvest<T>(x, h);
@@ -1437,7 +841,7 @@ __device__ __forceinline__ void env_step_zoo_mixed(T obs, int32_t t, T quota, T 
                     if (kk == k) {
                         GrowthT<T> P = zoo[k];
                         P.sigma = sigma_env;
-                        xn = zoo_draw_round_trip<double, MathLibF64, -1, false>(k, x, z, P);
+                        xn = zoo_draw_round_trip<-1, false, T>(k, x, z, P);
                     }
                 }
             }
@@ -1446,10 +850,6 @@ __device__ __forceinline__ void env_step_zoo_mixed(T obs, int32_t t, T quota, T 
         reward = ((T)0 > h) ? (T)0 : h;
         t_next = t + 1;
         done = (t_next > Tmax) || (xn <= (T)0);
-    } else {
-        GrowthT<T> P = zoo[kk];
-        P.sigma = sigma_env;
-        env_step_zoo<T, -1, false>(obs, t, quota, z, kind, P, K_obs, Tmax, obs_next, reward, done, t_next, dk);
     }
 }
 
@@ -1497,17 +897,14 @@ __device__ __forceinline__ double clip_param<double>(double v) {
     return __builtin_fmin(__builtin_fmax(v, 0.0), 1e6);
 }
 // fishing-v11 (growth_models.py:187,200: np.random.choice(models)): a new growth function for the finished envs of one thread's
-// 4-env tile.  Round 5: ONE Philox2x32-10 block per env QUAD on the reset streams -- half the multiplies of the Philox4x32
-// block rounds 1-4 spent here, on a workload where nearly every quad holds a finished env every step (random policy: mean
-// episode length 1.47) -- and four 16-bit draws from its two words: env 4q + j takes half j (w0 low, w0 high, w1 low, w1 high),
+// 4-env tile.  ONE Philox2x32-10 block per env QUAD on the reset streams -- half the multiplies of a Philox4x32 block, on a
+// workload where nearly every quad holds a finished env every step (random policy: mean episode length 1.47) -- and four
+// 16-bit draws from its two words: env 4q + j takes half j (w0 low, w0 high, w1 low, w1 high),
 // index = (half * n_models) >> 16.  Non-uniformity of np.random.choice: the 65536 halves split over n_models buckets whose
 // sizes differ by at most one -> every model's probability is within 2^-16 = 1.5e-5 (absolute) of 1 / n_models (n = 5:
 // 13108 / 13107 x 4).  Block: c0 = quad[31:0], c1 = counter[30:0] | reset-stream bit 31 (^ quad[63:32] * 0xC2B2AE35), key =
 // fishing-v4's param_key ^ a tag ^ counter[62:31] * 0x9E3779B1 -- injective in (quad, counter, stream) while quad < 2^32
 // (2^34 envs) and counter < 2^31, like param_block; mirrored in oracle/fishing_oracle.py: model_words / model_draw.
-#ifndef FISHING_V11_REDRAW_4X32
-#define FISHING_V11_REDRAW_4X32 0
-#endif
 constexpr uint32_t kModelKeyTag = 0x4D4F444Cu;
 __device__ __forceinline__ void model_block(uint64_t seed, uint64_t quad, uint64_t counter, bool reset_stream, uint32_t& w0, uint32_t& w1) {
     // (the key -- and with it the ten round keys -- stays wave-uniform, in SGPRs: the quad's high part, zero below 2^34 envs,
@@ -1530,13 +927,6 @@ __device__ __forceinline__ bool redraw_kinds(uint64_t seed, uint64_t base, uint6
 #pragma unroll
     for (int j = 0; j < N; ++j) any |= fin[j];
     if (!any) return false;
-#if FISHING_V11_REDRAW_4X32      // rounds 1-4, for A/B timing only (the oracle mirrors the 2x32 scheme)
-    static_assert(N == 4, "the A/B build has no pair form");
-    const Words4 w = philox_block(seed, base >> 2, counter, stream);
-    const uint32_t ww[4] = {w.w0, w.w1, w.w2, w.w3};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kind[j] = fin[j] ? kinds[action_int_from_word(ww[j], n_models)] : kind[j];
-#else
     uint32_t w0, w1;
     model_block(seed, base >> 2, counter, stream == kStreamReset, w0, w1);
     if constexpr (N == 4) {
@@ -1548,7 +938,6 @@ __device__ __forceinline__ bool redraw_kinds(uint64_t seed, uint64_t base, uint6
         kind[0] = fin[0] ? kinds[model_index_from_half(w & 0xFFFFu, n_models)] : kind[0];
         kind[1] = fin[1] ? kinds[model_index_from_half(w >> 16, n_models)] : kind[1];
     }
-#endif
     return true;
 }
 
@@ -1735,8 +1124,7 @@ __device__ __forceinline__ void load4(const T* p, int64_t base, int64_t n, bool 
     }
 }
 
-// NT = 1: nontemporal (streaming) store -- an experiment knob (scripts/tune_variants.py);
-// measured no faster than plain stores on gfx950 for this kernel, so the default is 0.
+// NT = 1: nontemporal (streaming) store (the fused kernel's per-step reward rows, which nobody re-reads inside the launch).
 template <typename T, int NT = 0>
 __device__ __forceinline__ void store4(T* p, int64_t base, int64_t n, bool full, const T (&in)[4]) {
     if (full) {

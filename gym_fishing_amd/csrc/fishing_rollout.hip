@@ -14,20 +14,11 @@
 // have all finished leaves the time loop (__all over the per-lane masks).
 // (the float64 zoo's hand-over to the reference's round trip for far stocks / far results is compiled out of the step, fused-step and
 // rollout kernels: fishing_step.hip says why)
-#ifndef FISHING_ZOO_F64_FAR_IN_STEP_KERNELS
-#define FISHING_ZOO_F64_FAR_IN_STEP_KERNELS 0
-#endif
-#ifndef FISHING_ZOO_F64_FAR
-#define FISHING_ZOO_F64_FAR FISHING_ZOO_F64_FAR_IN_STEP_KERNELS
-#endif
+#define FISHING_ZOO_F64_FAR 0
 #include "fishing_common.h"
 #include "fishing_host.h"
 
 namespace fishing {
-
-#ifndef FISHING_ROLLOUT_LOCAL_KEYS
-#define FISHING_ROLLOUT_LOCAL_KEYS 1
-#endif
 
 // PP: one policy parameter PER ENV (fishing_rollout_params_*: `pparams`, real[n]) instead of the scalar -- N fishing-v4 / v11
 // envs each escaping to the S its own BMSY() found (models/policies.py:22-31 per env).  Own instantiations (run-time policy,
@@ -83,10 +74,9 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
         }
     }
 
-    // fishing-v11, -DFISHING_V11_FORM=2: the growth functions' coefficients as a table in LDS (fishing_common.h: zoo_lut_fill), written
-    // once per launch
-    __shared__ alignas(16) T zoo_lut[(zoo_mixed && FISHING_V11_FORM == 2) ? kZooLutSize : 4];
-    if constexpr (zoo_mixed && FISHING_V11_FORM == 2) {
+    // fishing-v11: the growth functions' coefficients as a table in LDS (fishing_common.h: zoo_lut_fill), written once per launch
+    __shared__ alignas(16) T zoo_lut[zoo_mixed ? kZooLutSize : 4];
+    if constexpr (zoo_mixed) {
         if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, p.zoo);
         __syncthreads();
     }
@@ -148,12 +138,8 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             const uint64_t step_counter = step_counter0 + (uint64_t)s;
             T z[4] = {(T)0, (T)0, (T)0, (T)0};
             uint32_t aw[4] = {0u, 0u, 0u, 0u};
-#if FISHING_ROLLOUT_LOCAL_KEYS
             uint64_t seed = seed_arg;       // Philox key schedule next to its rounds, not in long-lived SGPRs (see the
             asm volatile("" : "+s"(seed));  // fused step kernel below)
-#else
-            const uint64_t seed = seed_arg;
-#endif
             if (noise_on) {         // one block for the tile's four normals
                 float zq[4];
                 noise_quad(seed, quad, step_counter, zq);
@@ -224,8 +210,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
             int32_t t2[4];
             bool stepped = false;
             if constexpr (zoo_mixed) {
-                if (!b.sigma) {     // wave-uniform.  fishing-v11: regroup the wave's envs by growth function
-                    __shared__ ZooSlot<T> win[4 * kZooWindowSlots];
+                if (!b.sigma) {     // wave-uniform.  fishing-v11: every env's coefficients from the LDS table
                     T xh[4], hv[4], xn[4];
                     int kk[4];
 #pragma unroll
@@ -237,8 +222,7 @@ rollout_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const u
                         xn[j] = (T)0;
                         kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                     }
-                    zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane,
-                                          FISHING_V11_FORM == 2 ? zoo_lut : nullptr);
+                    zoo_draw_lut_tile<T, 4>(kk, xh, z, p.zoo, zoo_lut, xn);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         o2[j] = xn[j] / KK[j] - (T)1;
@@ -510,9 +494,6 @@ template <typename T, int MODEL>
 using FusedExtra = std::conditional_t<MODEL == kModelZooMixed, FusedMixedArgs<T>, FusedNoExtra>;
 
 constexpr int kPrefetch = 4;
-#ifndef FISHING_FUSED_LOCAL_KEYS
-#define FISHING_FUSED_LOCAL_KEYS 1
-#endif
 
 // RAGGED = false: n is a whole number of 1024-env tiles -- every access an unconditional 16-byte one.  That is not
 // only shorter: with the per-thread `full ? vector : element-wise` choice in the code, the compiler merges the two
@@ -560,9 +541,9 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
         }
     }
 
-    // (fishing-v11, -DFISHING_V11_FORM=2: see rollout_kernel)
-    __shared__ alignas(16) T zoo_lut[(zoo_mixed && FISHING_V11_FORM == 2) ? kZooLutSize : 4];
-    if constexpr (zoo_mixed && FISHING_V11_FORM == 2) {
+    // (fishing-v11: see rollout_kernel)
+    __shared__ alignas(16) T zoo_lut[zoo_mixed ? kZooLutSize : 4];
+    if constexpr (zoo_mixed) {
         if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, ex.zoo);
         __syncthreads();
     }
@@ -645,12 +626,8 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                 if (s + kPrefetch < a.n_steps) load_action(s + kPrefetch, pf_f[u], pf_i[u]);
                 const uint64_t step_counter = step_counter0 + (uint64_t)s;
                 T z[4] = {(T)0, (T)0, (T)0, (T)0};
-#if FISHING_FUSED_LOCAL_KEYS
                 uint64_t seed_s = seed;     // keep the Philox key schedule next to its rounds instead of in 20 SGPRs
                 asm volatile("" : "+s"(seed_s));    // held across the whole step loop (the kernel is short of them)
-#else
-                const uint64_t seed_s = seed;
-#endif
                 if (a.noise == kNoisePhilox) {
                     float zq[4];
                     noise_quad(seed_s, quad, step_counter, zq);
@@ -662,8 +639,7 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                 bool fresh[4];
                 bool stepped = false;
                 if constexpr (zoo_mixed) {
-                    if (!a.sigma_arr) {     // wave-uniform: regroup the wave's envs by growth function, as the per-step kernel
-                        __shared__ ZooSlot<T> win[4 * kZooWindowSlots];
+                    if (!a.sigma_arr) {     // wave-uniform: every env's coefficients from the LDS table, as the per-step kernel
                         T xh[4], hv[4], xn[4];
                         int kk[4];
 #pragma unroll
@@ -677,8 +653,7 @@ step_fused_kernel(const FusedArgs<T> a, const FusedExtra<T, MODEL> ex, const int
                             xn[j] = (T)0;
                             kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                         }
-                        zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane,
-                                              FISHING_V11_FORM == 2 ? zoo_lut : nullptr);
+                        zoo_draw_lut_tile<T, 4>(kk, xh, z, ex.zoo, zoo_lut, xn);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             o2[j] = xn[j] / KK[j] - (T)1;

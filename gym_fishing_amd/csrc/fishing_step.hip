@@ -20,8 +20,7 @@
 //                                  custom launch shapes.  Everything optional is a run-time decision.
 // The float64 zoo's growth functions run on the algebraic form (fishing_common.h: zoo_draw_f64) and follow the reference's own
 // log / exp round trip where ITS rounding exceeds the 2e-14 bar: stocks outside [2^-30, 2^30], results outside [2^-92, 2^92].  In
-// THIS translation unit that hand-over is compiled out (FISHING_ZOO_F64_FAR_IN_STEP_KERNELS=1 builds it back in): a step's outputs
-// cannot carry the difference.  The state leaves a step as obs = x' / K - 1, whose spacing near -1 is 1.1e-16 -- a population below
+// THIS translation unit that hand-over is compiled out (FISHING_ZOO_F64_FAR 0): a step's outputs cannot carry the difference.  The state leaves a step as obs = x' / K - 1, whose spacing near -1 is 1.1e-16 -- a population below
 // 2^-53 K comes out as obs = -1 in the reference and here alike, and for a stock below 2^-30 K the two evaluations differ by
 // < 1e-13 of a result that obs resolves to 1e-7 of itself at best; reward is the harvest (no growth function in it); done tests
 // x' <= 0, and zeros are zeros in both forms.  The other end -- obs beyond 1e9 -- lies nine orders of magnitude outside anything the
@@ -29,12 +28,7 @@
 // which hands x' out itself -- BMSY sweeps, the module-level growth functions, the special-value tests -- keeps the hand-over.  What it
 // costs a kernel that never takes it: 16-32 VGPRs for the inlined logarithms of the cold branch -- fishing-v11 float64 41.9 -> 39.8
 // us at N = 2^22 (0.76 -> 0.80 of the HBM spec), fishing-v8 33.9 -> 33.0, v9 33.0 -> 32.6 (profiles/r05_zoo_f64_far_path.jsonl).
-#ifndef FISHING_ZOO_F64_FAR_IN_STEP_KERNELS
-#define FISHING_ZOO_F64_FAR_IN_STEP_KERNELS 0
-#endif
-#ifndef FISHING_ZOO_F64_FAR
-#define FISHING_ZOO_F64_FAR FISHING_ZOO_F64_FAR_IN_STEP_KERNELS
-#endif
+#define FISHING_ZOO_F64_FAR 0
 #include "fishing_common.h"
 #include "fishing_host.h"
 
@@ -44,40 +38,19 @@
 
 namespace fishing {
 
-#ifndef FISHING_STEP_ATTRS
-#define FISHING_STEP_ATTRS
-#endif
-#ifndef FISHING_NT_STORE
-#define FISHING_NT_STORE 0
+// Byte thresholds of the launch's walk (bytes ONE step streams); the three knobs a deployment on another cache hierarchy may
+// want to move.
+#ifndef FISHING_XZZ_MIN_BYTES
+#define FISHING_XZZ_MIN_BYTES (100ll << 20)         // from here every lean kernel walks its tiles zig-zag
 #endif
 #ifndef FISHING_NTA_MIN_BYTES
-#define FISHING_NTA_MIN_BYTES (200ll << 20)             // ... the zig-zag forms load the caller's actions nontemporal
-#endif
-#ifndef FISHING_LEAN_FENCE
-#define FISHING_LEAN_FENCE 1     // bit 0: scheduling fence after the tile's loads, bit 1: after the Philox block.
-                                 // With one Philox block per tile (quad noise) the compiler otherwise sinks
-                                 // loads behind the generator: 16.6 -> 16.3 us bare, 21.6 -> 21.5 us with
-                                 // returns (bits 1, 2, 3 measure the same; profiles/r01f_lean_fence_ab.txt)
-#endif
-#ifndef FISHING_LEAN_PIN_NOISE
-#define FISHING_LEAN_PIN_NOISE 1
-#endif
-#ifndef FISHING_LEAN_BATCH_ARGS
-#define FISHING_LEAN_BATCH_ARGS 1
-#endif
-#ifndef FISHING_LEAN_LOCAL_KEYS
-#define FISHING_LEAN_LOCAL_KEYS 1
-#endif
-// Bytes one step streams, from which ...
-#ifndef FISHING_XZZ_MIN_BYTES
-#define FISHING_XZZ_MIN_BYTES (100ll << 20)             // ... every lean kernel walks zig-zag (run-time flag zz_rt)
+#define FISHING_NTA_MIN_BYTES (200ll << 20)         // ... and loads the caller's actions nontemporal
 #endif
 #ifndef FISHING_F64_E2_MAX_BYTES
 #define FISHING_F64_E2_MAX_BYTES (512ll << 20)      // float64: two envs per thread below this many bytes per step
 #endif
-#ifndef FISHING_STEP_MAXTHREADS
-#define FISHING_STEP_MAXTHREADS 256      // experiment knob: 512 / 1024-thread workgroups
-#endif
+constexpr int kStepMaxThreads = 256;                // workgroup size cap of the general kernel
+constexpr int kTileEnvsLean = 1024;                 // envs per tile (= per workgroup) of the lean kernels
 
 // An env that was already finished BEFORE this step (stepped on without a reset: years_passed beyond Tmax, or
 // no fish left) must not enter the episodic-return record a second time.
@@ -88,7 +61,7 @@ __device__ __forceinline__ bool was_done(T obs, int32_t t, T K, int32_t Tmax) {
 
 // ---------------------------------------------------------------- general kernel
 template <typename T, int MODEL>
-__global__ void __launch_bounds__(FISHING_STEP_MAXTHREADS) FISHING_STEP_ATTRS
+__global__ void __launch_bounds__(kStepMaxThreads)
 step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
             const uint64_t seed_arg, const uint64_t step_counter_arg, const int noise) {
     // graph-replay safety: with a device-resident counter the launch arguments can stay frozen
@@ -111,9 +84,9 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
     const int zoo_kind = kZoo ? p.kind : FISHING_KIND_BEVERTON_HOLT;
     const GrowthT<T> zoo_base = p.growth;
 
-    // (fishing-v11, -DFISHING_V11_FORM=2: the growth functions' coefficients as a table in LDS, fishing_common.h: zoo_lut_fill)
-    __shared__ alignas(16) T zoo_lut[(zoo_mixed && FISHING_V11_FORM == 2) ? kZooLutSize : 4];
-    if constexpr (zoo_mixed && FISHING_V11_FORM == 2) {
+    // (fishing-v11: the growth functions' coefficients as a table in LDS, fishing_common.h: zoo_lut_fill)
+    __shared__ alignas(16) T zoo_lut[zoo_mixed ? kZooLutSize : 4];
+    if constexpr (zoo_mixed) {
         if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, p.zoo);
         __syncthreads();
     }
@@ -182,8 +155,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         bool dn[4];
         bool stepped = false;
         if constexpr (zoo_mixed) {
-            if (!b.sigma) {     // wave-uniform.  fishing-v11: regroup the wave's envs by growth function
-                __shared__ ZooSlot<T> win[(FISHING_STEP_MAXTHREADS / kWave) * kZooWindowSlots];
+            if (!b.sigma) {     // wave-uniform.  fishing-v11: every env's coefficients from the LDS table
                 T xh[4], hv[4], xn[4];
                 int kk[4];
 #pragma unroll
@@ -196,8 +168,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
                     xn[j] = (T)0;
                     kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
                 }
-                zoo_draw_regrouped<T>(kk, xh, z, p.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots, lane,
-                                      FISHING_V11_FORM == 2 ? zoo_lut : nullptr);
+                zoo_draw_lut_tile<T, 4>(kk, xh, z, p.zoo, zoo_lut, xn);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     obs_next[j] = xn[j] / KK[j] - (T)1;
@@ -242,14 +213,13 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         const bool wave_done = __any(lane_done);
 
         if (active) {
-            if (b.reward) store4<T, FISHING_NT_STORE>(b.reward, base, n, full, rew);
-            if (b.terminal_obs) store4<T, FISHING_NT_STORE>(b.terminal_obs, base, n, full, obs_next);
+            if (b.reward) store4<T>(b.reward, base, n, full, rew);
+            if (b.terminal_obs) store4<T>(b.terminal_obs, base, n, full, obs_next);
             if (b.done) {
                 if (full) {
                     const uint32_t packed = (uint32_t)dn[0] | ((uint32_t)dn[1] << 8) |
                                             ((uint32_t)dn[2] << 16) | ((uint32_t)dn[3] << 24);
-                    if (FISHING_NT_STORE) __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(b.done + base));
-                    else *reinterpret_cast<uint32_t*>(b.done + base) = packed;
+                    *reinterpret_cast<uint32_t*>(b.done + base) = packed;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -316,7 +286,7 @@ step_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint
         }
     }
 
-    if (b.partials) add_block_partials<FISHING_STEP_MAXTHREADS / kWave>(acc, b.partials);
+    if (b.partials) add_block_partials<kStepMaxThreads / kWave>(acc, b.partials);
 }
 
 // ---------------------------------------------------------------- lean fast path
@@ -399,66 +369,21 @@ struct LeanMixedArgs {
     int32_t n_models;
     int32_t kinds[FISHING_N_KINDS];
     GrowthT<T> zoo[FISHING_N_KINDS];
-    T lut[kZooLutSize];      // zoo_lut_rows(zoo): the coefficient table, converted on the host (FISHING_V11_LUT_HOST)
+    T lut[kZooLutSize];      // zoo_lut_rows(zoo): the coefficient table, converted on the host
 };
 struct LeanNoExtra {};
 template <typename T, int MODEL>
 using LeanExtra = std::conditional_t<MODEL == kModelZooMixed, LeanMixedArgs<T>, LeanNoExtra>;
 
-#ifndef FISHING_LEAN_ATTRS
-#define FISHING_LEAN_ATTRS
-#endif
-// (fishing-v11's float32 kernel with returns needs 65 VGPRs, one above what eight waves per SIMD allow: compiled for eight --
-// amdgpu_waves_per_eu(8, 8) -- it spills 24 bytes per lane; left at seven)
 // E = envs per thread: 4 everywhere (16-byte accesses on the 4-byte streams) except the float64 parity layout at
 // cache-resident sizes, which runs E = 2 -- 16 bytes per lane on ITS streams instead of 32 (two 16-byte accesses, half
 // of each 64-byte line per instruction): a copy over the same streams takes 23.5 instead of 27.2 us at N = 2^22
 // (profiles/r02_f64_access_shape.jsonl).  A workgroup is 1024 / E threads on one 1024-env tile; the lane pair that shares
 // an env quad computes the quad's Philox block twice and keeps one Box-Muller pair each.
-// Experiment knobs (product: 1024-env tiles, E = 4 in float32).  -DFISHING_X_TILE_ENVS=512 / 2048 gives every lean kernel
-// 128- / 512-thread workgroups at E = 4; -DFISHING_X_V4_E2 sends fishing-v4's float32 config-5 request to two envs per thread
-// (512-thread workgroups on a 1024-env tile).  Measured on the fishing-v4 kernel itself at its config-5 shard, N = 2^21:
-// profiles/r05_v4_shapes.jsonl (nothing adopted: DESIGN.md section 5).  Batches of a multiple of the tile, no padded tiles.
-#ifndef FISHING_X_TILE_ENVS
-#define FISHING_X_TILE_ENVS 1024
-#endif
-#ifndef FISHING_ZOO_F64_EXACT
-#define FISHING_ZOO_F64_EXACT 1
-#endif
-// TPW (experiment, -DFISHING_X_TPW=2): tiles per workgroup.  2 = a workgroup loads TWO adjacent tiles up front, steps and stores
-// the first while the second's loads land, then the second -- software pipelining inside a wave for the batches that run as
-// one or two rounds of waves (profiles/r05_two_tiles_per_workgroup.jsonl).  Product: 1.
-#ifndef FISHING_X_TPW
-#define FISHING_X_TPW 1
-#endif
-#if FISHING_X_TPW > 1       // (the two-tile experiment splits a tile's body into a load and a step phase: it keeps the forms it was measured with)
-#define FISHING_V11_LUT_HOST 0
-#define FISHING_X_ZEXT_IN_NOISE_BRANCH 0
-#endif
-// Round 5's readings of the ISA, each behind a switch that builds the form before it (1 = the product; the records name the
-// sessions that measured both):
-#ifndef FISHING_V11_LUT_HOST             // fishing-v11's coefficient table made on the host, copied by one vector load
-#define FISHING_V11_LUT_HOST 1           //   (0: filled by the first wave from the per-kind structs)  profiles/r05_walk_word.jsonl
-#endif
-#ifndef FISHING_X_V11_CLAMP_AT_LOAD      // fishing-v11's indices clamped into the zoo where they are loaded (one copy in registers)
-#define FISHING_X_V11_CLAMP_AT_LOAD 1    //   profiles/r05_v11_clamp_at_load.jsonl
-#endif
-#ifndef FISHING_X_V11_KINDS_LATE         // ... and loaded behind the loads that need only preloaded arguments
-#define FISHING_X_V11_KINDS_LATE 1       //   profiles/r05_v11_kinds_late.jsonl
-#endif
-#ifndef FISHING_X_V4_T_FIRST             // fishing-v4 derived: the year counters' load first, the sigma array's last
-#define FISHING_X_V4_T_FIRST 1           //   profiles/r05_v4_t_first.jsonl
-#endif
-#ifndef FISHING_X_T_LATE                 // every other exact kernel: the year counters' load behind the actions'
-#define FISHING_X_T_LATE 1               //   profiles/r05_t_late.jsonl
-#endif
-#ifndef FISHING_X_ZEXT_IN_NOISE_BRANCH   // the catch-alls' external-noise load in the generator's else (no wait for every load of
-#define FISHING_X_ZEXT_IN_NOISE_BRANCH 1 //   the tile in front of the generator)  profiles/r05_catch_all_noise_wait.jsonl
-#endif
-// The launch's walk in the preloaded n_live argument (0: LeanArgs::zz_rt / nta_rt and the step's parity, rounds 4 - 5a).
-#ifndef FISHING_WALK_PRELOADED
-#define FISHING_WALK_PRELOADED 1
-#endif
+// (fishing-v11's float32 kernel with returns needs 65 VGPRs, one above what eight waves per SIMD allow: compiled for eight --
+// amdgpu_waves_per_eu(8, 8) -- it spills 24 bytes per lane; left at seven.)
+// Shapes and orders that were measured and not adopted (128- / 512-thread workgroups, two tiles per workgroup, two envs per thread
+// for fishing-v4, load orders, staggered starts, occupancy caps): profiles/NOTES_r01_r05.md.
 // n_live_p, the fifth leading argument:  bits 0-39 the envs that exist (all ones: no bound), bits 40-57 how many tiles
 // THIS launch walks backwards (0, or ntiles & ~7 on a zig-zag launch's odd steps when the host holds the step counter),
 // bit 58: a zig-zag launch whose step counter lives in device memory (the kernel finds the parity itself), bit 59:
@@ -469,7 +394,7 @@ constexpr int64_t kWalkMask = (1ll << 18) - 1;
 constexpr int64_t kWalkDeviceParityBit = 1ll << 58;
 constexpr int64_t kWalkNtaBit = 1ll << 59;
 template <typename T, int MODEL, int F, int E = 4>
-__global__ void __launch_bounds__(FISHING_X_TILE_ENVS / E) FISHING_LEAN_ATTRS
+__global__ void __launch_bounds__(kTileEnvsLean / E)
 step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p, T* const ep_return_p, const int64_t n_live_p,
                  const LeanArgs<T> a, const LeanExtra<T, MODEL> ex, const int64_t ntiles, const uint64_t env_offset,
                  const uint64_t seed, const uint64_t step_counter_arg) {
@@ -484,7 +409,6 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     // so put FOUR dependent s_load round trips back into every wave (the walk's flag, the step's parity, the batch, the
     // counter); with the walk in the preloaded word there are two, one of them hidden behind the tile's loads: N = 2^19
     // 4.67 -> 4.34 us, 2^20 6.0 -> 5.8, 2^22 18.94 -> 18.76 (profiles/r05_walk_word.jsonl).
-    constexpr int TPW = FISHING_X_TPW;      // (a build-wide experiment knob, not a template parameter: the kernels keep their names)
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     constexpr bool kMixed = (MODEL == kModelZooMixed);    // fishing-v11: growth function per env
     constexpr bool kZoo = is_zoo_tag(MODEL) && !kMixed;   // one growth function of the zoo, compile-time kind
@@ -498,14 +422,11 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     static_assert(!(F & feat::STAMP) || (kOpt && kPerEnv && (F & feat::DERIVED)), "STAMP: fishing-v4's derived catch-all");
     static_assert(!(F & feat::KP2) || (kExact && !kPerEnv && !kZoo && !kMixed), "KP2: exact fishing-v0/v1/v2 instantiations");
     static_assert((F & feat::ONE) != 0, "every lean form is a one-tile form: a workgroup of 1024 / E threads per 1024-env tile");
-#ifndef FISHING_X_V4_E2
-    // (fishing-v11 too since its growth function's coefficients come from an LDS table: the regroup needed a lane's four envs)
-    static_assert(E == 4 || (E == 2 && sizeof(T) == 8 && (!kMixed || FISHING_V11_FORM == 2)), "E = 2: the float64 layout");
-#endif
-    constexpr int kThreads = FISHING_X_TILE_ENVS / E;
-    constexpr int kTileEnvs = FISHING_X_TILE_ENVS;
+    static_assert(E == 4 || (E == 2 && sizeof(T) == 8), "E = 2: the float64 layout");
+    constexpr int kThreads = kTileEnvsLean / E;
+    constexpr int kTileEnvs = kTileEnvsLean;
     // fishing-v4's derived-parameter exact kernels issue the year counters' load first (see the tile's loads)
-    constexpr bool kTFirst = FISHING_X_V4_T_FIRST != 0 && kExact && kPerEnv && (F & feat::DERIVED) != 0;
+    constexpr bool kTFirst = kExact && kPerEnv && (F & feat::DERIVED) != 0;
     // Without OPT these fold to compile-time constants; with OPT they are wave-uniform scalars.
     const bool RET = (F & feat::RET) && (kExact || ep_return_p != nullptr);
     const bool SIGARR = (F & feat::SIGARR) && (kExact || a.sigma_arr != nullptr);
@@ -517,30 +438,17 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
     // (run-time in every form: round 3's exact zig-zag twins of the tile loop went when every batch up to 2^26 envs got a
     // workgroup per tile)
-#if FISHING_WALK_PRELOADED
     // ... and decided by the HOST, in the preloaded n_live argument: as fields of the by-value struct, the walk's flags put one
     // s_load round trip in front of every wave's first global load -- what the kernarg preload had taken away.
     const int64_t n_live = n_live_p & kLiveMask;
-#ifdef FISHING_X_WALK_NO_DEVICE     // (experiment: what the branch below costs -- launches with a device counter walk wrong)
-    constexpr bool ZZ = false;
-#else
     const bool ZZ = (n_live_p & kWalkDeviceParityBit) != 0;     // (the walks that need the step counter BEFORE the tile's loads)
-#endif
     int64_t walk_back = (n_live_p >> kWalkShift) & kWalkMask;
-#else
-    const bool ZZ = a.zz_rt != 0;
-    const int64_t n_live = n_live_p;
-#endif
     // The caller's action stream is read once per step and never again: from ~200 MB per step (N >= 2^23) the zig-zag forms
     // load it nontemporal, so that it does not evict the state lines the reversed walk is about to re-hit.  N = 2^26:
     // 283 -> 262 us bare, 398 -> 380 with returns; 2^25: 128.5 -> 124, 181.5 -> 172.6; 2^23 bare 32.1 -> 31.0.  Not at 2^22:
     // the action ring itself is cache-resident there, the hint costs 6-11 % (profiles/r03_nt_action_loads.jsonl,
     // r03_xcd_zigzag.jsonl).  (Streaming the state STORES of all but the walk's last 128-224 MB as well: < 1 %.)
-#if FISHING_WALK_PRELOADED
     const bool NTA = (n_live_p & kWalkNtaBit) != 0;
-#else
-    const bool NTA = ZZ && a.nta_rt != 0;
-#endif
     const int noise = ((F & feat::kNoiseMask) == feat::kNoiseRT) ? a.noise_rt : (F & feat::kNoiseMask);
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
@@ -548,7 +456,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     // N = 2^22): bare step 16.9 -> 16.5 us; with the return accumulator 21.67 -> 21.45 us, as long as the
     // ep_return / partials pointers stay out of the batch (21.50 with them): profiles/r01f_lean_fence_ab.txt.
     auto batch_args = [&]() {
-    if constexpr (FISHING_LEAN_BATCH_ARGS != 0 && kExact) {     // (the catch-alls are short of SGPRs as it is)
+    if constexpr (kExact) {     // (the catch-alls are short of SGPRs as it is)
         asm volatile("" ::"s"(obs_p), "s"(action_p), "s"(a.reward), "s"(a.done), "s"(t_p), "s"(a.counter), "s"(a.pr),
                      "s"(a.pK), "s"(a.sigma), "s"(a.C), "s"(a.x0), "s"(a.Tmax), "s"(a.n_actions), "s"(a.auto_reset),
                      "s"(ntiles), "s"(env_offset), "s"(seed), "s"(step_counter_arg));
@@ -561,16 +469,12 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         if constexpr (kZoo) {
             asm volatile("" ::"s"(a.growth.r), "s"(a.growth.K), "s"(a.growth.sigma), "s"(a.growth.C), "s"(a.growth.M),
                          "s"(a.growth.theta), "s"(a.growth.q), "s"(a.growth.b), "s"(a.growth.a), "s"(a.growth.bq));
-            if constexpr (zoo_uses_round_trip<T>())
-                asm volatile("" ::"s"(a.growth.logA), "s"(a.growth.B));
-            else
-                asm volatile("" ::"s"(a.growth.A), "s"(a.growth.invK), "s"(a.growth.invM), "s"(a.growth.invB), "s"(a.growth.gc));
+            asm volatile("" ::"s"(a.growth.A), "s"(a.growth.invK), "s"(a.growth.invM), "s"(a.growth.invB), "s"(a.growth.gc));
         }
         if constexpr ((F & feat::DRIFT) != 0) asm volatile("" ::"s"(a.r), "s"(a.alpha));
     }
     };
-    // (behind the tile's loads, which need only the preloaded arguments -- FISHING_LEAN_BATCH_ARGS == 2 puts it up front, for A/B)
-    if constexpr (FISHING_LEAN_BATCH_ARGS == 2) batch_args();
+    // (called behind the tile's loads, which need only the preloaded arguments)
     // graph-replay mode keeps the step counter in device memory (wave-uniform: one scalar load), read AFTER the tile's
     // loads are issued, which do not depend on it
     auto read_counter = [&]() -> uint64_t {
@@ -580,21 +484,14 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         return c + step_counter_arg;
     };
     // (... unless the launch walks zig-zag: the tile index needs the step's parity)
-#if FISHING_WALK_PRELOADED
     uint64_t step_counter = 0;
     if (ZZ) {       // (graph replay at the zig-zag sizes)
         asm volatile("");       // a real branch: flattened, its tests wait for the struct's s_loads in every launch
         step_counter = read_counter();
-        constexpr int64_t G = 8 * TPW;
+        constexpr int64_t G = 8;
         walk_back = (step_counter & 1) ? (ntiles & ~(G - 1)) : 0;
     }
-#else
-    uint64_t step_counter = !ZZ ? step_counter_arg : read_counter();
-#endif
     uint64_t origin_step = a.origin_step, origin_counter = a.origin_counter;
-#if !FISHING_WALK_PRELOADED
-    if (DERIVED) device_origin(a.counter, origin_step, origin_counter);
-#endif
     // an exact RET instantiation is only ever launched with auto-reset on (the dispatch sends RET without it to the
     // catch-all, which carries the LATCH): the flag is a compile-time fact there
     const bool auto_reset = (kExact && (F & feat::RET)) ? true : a.auto_reset != 0;
@@ -603,19 +500,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const T robs_scalar = (MODEL == FISHING_MODEL_V4) ? a.x0 : a.robs;       // (reset_obs<T, MODEL>(a.x0, a.pK))
 
     __shared__ alignas(16) T zoo_lut[kMixed ? kZooLutSize : 4];     // (fishing-v11 only; unused -- and not allocated -- elsewhere)
-#if FISHING_X_TPW > 1
-    struct TileIn {     // what a tile's load phase hands to its step phase (registers; TPW = 2 holds two of them)
-        int64_t it, tile, base;
-        bool live;
-        uint64_t seed_it;
-        T obs[E], rr[E], KK[E], z[E], er[E], sg[E];
-        int32_t t[E], a_i[E], kind[E], st[E];
-        float a_f[E];
-    };
-    auto load_tile = [&](const int64_t it, TileIn& in) {
-#else       // the product: one lambda, one tile (the experiment's split changes the register allocation: kept textually apart)
     auto do_tile = [&](const int64_t it) {
-#endif
         // ZZ: odd steps walk the tiles backwards, so what the previous step touched LAST is what this one reads FIRST -- while
         // it is still cached.  Backwards IN GROUPS OF EIGHT: workgroups are dealt round-robin over the 8 XCDs, each with its
         // own 4 MiB L2 that keeps its lines across launches; tile % 8 == workgroup % 8 in both directions keeps every tile on
@@ -626,28 +511,17 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // better --, and the 256 MiB Infinity Cache at the HBM-resident sizes (N = 2^26 with returns, a workgroup per tile:
         // 406 us forward, 347 zig-zag: profiles/r03_zz_nta_one_tile.jsonl).
         int64_t tile = it;
-#if FISHING_V11_LUT_HOST
         // fishing-v11's coefficient table comes ready-made in the launch's arguments (LeanMixedArgs::lut): its one vector load goes
         // out FIRST, so that the wave's wait for it does not wait for the tile's loads as well (loads return in order)
         T lut_word = (T)0;
-        if constexpr (kMixed && FISHING_V11_FORM == 2) {
+        if constexpr (kMixed) {
             if (threadIdx.x < kZooLutSize) lut_word = ex.lut[threadIdx.x];
         }
-#endif
-#if FISHING_WALK_PRELOADED
         {
-            constexpr int64_t G = 8 * TPW;
-            const int64_t whole = walk_back;
+            constexpr int64_t G = 8;
+            const int64_t whole = walk_back;          // (ntiles & ~7 on a backwards step: a last partial group keeps its place)
             if (it < whole) tile = (whole - G - (it & ~(G - 1))) + (it & (G - 1));
         }
-#else
-        if (ZZ && (step_counter & 1)) {
-            // (TPW tiles per workgroup: groups of 8 * TPW, so that a tile stays on the XCD of the workgroup that owns it)
-            constexpr int64_t G = 8 * TPW;
-            const int64_t whole = ntiles & ~(G - 1);          // (a last partial group keeps its place)
-            if (it < whole) tile = (whole - G - (it & ~(G - 1))) + (it & (G - 1));
-        }
-#endif
         const int64_t base = (tile * kThreads + threadIdx.x) * E;
         // FISHING_FLAG_PADDED_TILES: the state buffers have room for whole tiles, so a batch that is not a multiple of 1024
         // envs still runs in this ONE launch (no second, one-workgroup launch for the tail: 3.7-4.2 us per step).  The
@@ -669,7 +543,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         // fishing-v4 launders (profiles/r02_ab_variants.jsonl).
         uint64_t seed_it = seed;
         // (... and the float32 catch-alls, which sit at the 106-SGPR ceiling: 26 -> 2 SGPR-to-VGPR-lane spills)
-        if constexpr (FISHING_LEAN_LOCAL_KEYS != 0 && (kPerEnv || (kOpt && sizeof(T) == 4))) asm volatile("" : "+s"(seed_it));
+        if constexpr (kPerEnv || (kOpt && sizeof(T) == 4)) asm volatile("" : "+s"(seed_it));
         T obs[E], rr[E], KK[E], z[E], er[E], sg[E];
         int32_t t[E], a_i[E];
         int32_t kind[E], st[E];
@@ -682,7 +556,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         {
             // the year counters: fishing-v4's derivation of (K, r) is the one piece of arithmetic that needs loaded data before it can
             // start (the reset origin of each env), and loads return in the order they were issued -- in the derived-parameter exact
-            // kernels this load goes out FIRST (-DFISHING_X_V4_T_FIRST=0: third, behind the sigma array's and the observations'):
+            // kernels this load goes out FIRST (not third, behind the sigma array's and the observations'):
             // config 5's shard 12.3 -> 11.85 us, N = 2^22 22.4 -> 22.1 (profiles/r05_v4_t_first.jsonl).  (LLVM's wait in front of the
             // derivation covers the observations' load too, vmcnt(3) of five -- they return right behind the counters; an explicit
             // s_waitcnt vmcnt(4) in front of it changes nothing: the compiler's own follows.)
@@ -701,7 +575,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             VecE<int32_t, E> qt;
             if constexpr (kTFirst) {
                 qt = load_t();
-                if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (STAMP) {
                 const VecE<int32_t, E> qs = *reinterpret_cast<const VecE<int32_t, E>*>(a.stamp + base);
@@ -714,22 +588,20 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                 er[j] = (T)0;
             }
             // (fishing-v11's indices: their pointer is a field of the struct -- in the exact kernels the load goes out behind the ones
-            // that need nothing but preloaded arguments, -DFISHING_X_V11_KINDS_LATE=0: in front of them)
+            // that need nothing but preloaded arguments)
             auto load_kinds = [&]() {
                 if constexpr (kMixed) {
                     const VecE<int32_t, E> qk = *reinterpret_cast<const VecE<int32_t, E>*>(ex.model_idx + base);
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < E; ++j) kind[j] = qk.v[j];
-    #if FISHING_X_V11_CLAMP_AT_LOAD
                     // (an index outside the zoo steps as Beverton-Holt in every kernel: clamped HERE, once -- a second, clamped copy next to
                     // the loaded one, kept for the quad's write-back after a redraw, cost the float32 kernel its eighth wave per SIMD)
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < E; ++j)
                         kind[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
-    #endif
                 }
             };
-            constexpr bool kKindsLate = FISHING_X_V11_KINDS_LATE != 0 && kExact && kMixed;
+            constexpr bool kKindsLate = kExact && kMixed;
             if constexpr (!kKindsLate) load_kinds();
             auto load_sigma = [&]() {
                 if (SIGARR) {
@@ -740,13 +612,13 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             };
             if constexpr (!kTFirst) load_sigma();       // (kTFirst: last -- its pointer is a field of the struct, and nothing needs it early)
             const VecE<T, E> q = *reinterpret_cast<const VecE<T, E>*>(obs_p + base);
-            // In every other exact kernel the year counters' load goes out BEHIND the actions' (-DFISHING_X_T_LATE=0: in front): the
+            // In every other exact kernel the year counters' load goes out BEHIND the actions' (not in front): the
             // arithmetic starts on observations and actions -- first wait vmcnt(2) of four loads instead of vmcnt(1) --, the counters
             // are needed at its end.  Builds alternating (profiles/r05_t_late.jsonl): the metric 18.92 -> 18.67 us, fishing-v0 at 2^22
             // 18.93 -> 18.73, fishing-v11 float32 24.7 -> 24.3; N = 2^21 (one exact round of waves, forward walk) 8.33 -> 8.53: the one
             // size that loses; below 2^21 the better of the two within a noisy box.  (The actions' load in FRONT of the observations' --
             // the one stream that is never in the L2s first -- loses: its address takes 20 instructions more, 18.57 -> 18.80 us.)
-            constexpr bool kTLate = FISHING_X_T_LATE != 0 && kExact && !kTFirst;
+            constexpr bool kTLate = kExact && !kTFirst;
             if constexpr (!kTFirst && !kTLate) qt = load_t();
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -806,74 +678,15 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #pragma unroll
                 for (int j = 0; j < E; ++j) er[j] = qe.v[j];
             }
-#if !FISHING_X_ZEXT_IN_NOISE_BRANCH
-            if (noise == kNoiseExt) {
-                const VecE<T, E> qz = *reinterpret_cast<const VecE<T, E>*>(a.z_ext + cbase);
-#pragma unroll
-                for (int j = 0; j < E; ++j) z[j] = qz.v[j];
-            }
-#endif
         }
-#if FISHING_X_TPW > 1
-        in.it = it;
-        in.tile = tile;
-        in.base = base;
-        in.live = live;
-        in.seed_it = seed_it;
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            in.obs[j] = obs[j];
-            in.rr[j] = rr[j];
-            in.KK[j] = KK[j];
-            in.z[j] = z[j];
-            in.er[j] = er[j];
-            in.sg[j] = sg[j];
-            in.t[j] = t[j];
-            in.a_i[j] = a_i[j];
-            in.kind[j] = kind[j];
-            in.st[j] = st[j];
-            in.a_f[j] = a_f[j];
-        }
-    };
-    auto run_tile = [&](TileIn& in) {
-        const int64_t tile = in.tile, base = in.base;
-        const bool live = in.live;
-        const uint64_t seed_it = in.seed_it;
-        T obs[E], rr[E], KK[E], z[E], er[E], sg[E];
-        int32_t t[E], a_i[E], kind[E], st[E];
-        float a_f[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            obs[j] = in.obs[j];
-            rr[j] = in.rr[j];
-            KK[j] = in.KK[j];
-            z[j] = in.z[j];
-            er[j] = in.er[j];
-            sg[j] = in.sg[j];
-            t[j] = in.t[j];
-            a_i[j] = in.a_i[j];
-            kind[j] = in.kind[j];
-            st[j] = in.st[j];
-            a_f[j] = in.a_f[j];
-        }
-#endif
         // the loads above must be in flight BEFORE the ~100-instruction Philox block starts: without
         // this fence the scheduler hoists the (independent) generator above them in some variants
-        if (FISHING_LEAN_FENCE & 1) __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kMixed && FISHING_V11_FORM == 2) {
-            // fishing-v11: the growth functions' coefficient table (fishing_common.h: zoo_lut_fill), written by the first wave while
-            // the tile's loads are in flight and ahead of its own noise block, so that the workgroup barrier in front of the
-            // first lookup finds it done
-#if !FISHING_V11_LUT_HOST
-            if (threadIdx.x < kWave) zoo_lut_fill<T>(zoo_lut, ex.zoo);
-#endif
-        }
-        if constexpr (FISHING_LEAN_BATCH_ARGS == 1) batch_args();
+        __builtin_amdgcn_sched_barrier(0);
+        batch_args();
         // (The zoo's kernels branch per env, and in every such block LLVM re-loads the wave-uniform arguments it needs from the
         // kernarg segment -- ten s_load + s_waitcnt lgkmcnt(0) round trips through fishing-v11's arithmetic.  Pinning them in SGPRs
         // through an empty asm removes the loads and gains nothing: eight waves per SIMD hide them; the single-function float32
         // kernels lose 1 %: profiles/r05_pin_zoo_args.jsonl.)
-#if FISHING_WALK_PRELOADED
         // (graph replay: the origin of the last reset() sits next to the step counter and is read behind the tile's loads like it,
         // in the same batch -- SCALAR loads: as a vector load it sat in the queue the tile's loads return through)
         if (DERIVED && a.counter) {
@@ -884,9 +697,6 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         } else if (!ZZ) {
             step_counter = read_counter();
         }
-#else
-        if (!ZZ) step_counter = read_counter();
-#endif
         if (noise == kNoisePhilox) {
             float zq[E];
             if constexpr (E == 4) {
@@ -904,19 +714,16 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             // Only where it is needed (the kernels without such control flow keep their order by themselves, and pay 0.5 % for the
             // constraint): 13.03 -> 12.43 us for fishing-v4's config-5 shard, 1-2 % for fishing-v6 / v7 / v8 / v10 in both layouts
             // (profiles/r05_noise_pin.jsonl).  fishing-v11: the generator stays in front of the table's barrier.
-            constexpr bool kPinNoise = FISHING_LEAN_PIN_NOISE != 0 &&
-                                       ((kPerEnv && (F & feat::DERIVED) != 0) || (kMixed && FISHING_V11_LUT_HOST != 0) ||
-                                        (kZoo && (kZooKind == FISHING_KIND_BEVERTON_HOLT || kZooKind == FISHING_KIND_MYERS ||
-                                                  kZooKind == FISHING_KIND_MAY)));
+            constexpr bool kPinNoise = (kPerEnv && (F & feat::DERIVED) != 0) || kMixed ||
+                                       (kZoo && (kZooKind == FISHING_KIND_BEVERTON_HOLT || kZooKind == FISHING_KIND_MYERS ||
+                                                 kZooKind == FISHING_KIND_MAY));
             if constexpr (kPinNoise) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) asm volatile("" : "+v"(zq[j]));
             }
 #pragma unroll
             for (int j = 0; j < E; ++j) z[j] = (T)zq[j];
-            if (FISHING_LEAN_FENCE & 2) __builtin_amdgcn_sched_barrier(0);
         }
-#if FISHING_X_ZEXT_IN_NOISE_BRANCH
         // The caller's normals are loaded HERE, in the generator's else: issued with the tile's other loads, their destination
         // registers are the generator's too, and the catch-alls (noise mode at run time) then wait for EVERY load of the tile
         // -- s_waitcnt vmcnt(0) -- before the generator's first write to them, on the path that never issued that load.
@@ -925,7 +732,6 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #pragma unroll
             for (int j = 0; j < E; ++j) z[j] = qz.v[j];
         }
-#endif
         if (DERIVED) {      // needs the year counters: after the noise block, which hid their latency
             // (tile-uniform: the last env of this workgroup's tile and the counters all below 2^32 -> 32-bit integer work)
             if (derive_fits_32(env_offset + (uint64_t)(tile + 1) * (uint64_t)kTileEnvs - 1u, step_counter, origin_step, origin_counter)) {
@@ -950,17 +756,12 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         bool dn[E];
         bool stepped = false;
         if constexpr (kMixed) {
-            if (!SIGARR) {      // wave-uniform: regroup the wave's envs by growth function (fishing_common.h: zoo_draw_regrouped)
-                __shared__ ZooSlot<T> win[(kThreads / kWave) * kZooWindowSlots];     // one window per wave
-                if constexpr (FISHING_V11_FORM == 2) {
-#if FISHING_V11_LUT_HOST
-                    // (one LDS store of the word loaded at the tile's start, behind the noise block that hid its latency -- filled
-                    // from ex.zoo, the first wave strung nine dependent s_load batches and 35 conversions in front of this barrier,
-                    // at which its three sister waves wait)
-                    if (threadIdx.x < kZooLutSize) zoo_lut[threadIdx.x] = lut_word;
-#endif
-                    __syncthreads();      // (the table)
-                }
+            if (!SIGARR) {      // wave-uniform: every env's coefficients from the LDS table (fishing_common.h: zoo_draw_lut_tile)
+                // (one LDS store of the word loaded at the tile's start, behind the noise block that hid its latency -- filled
+                // from ex.zoo, the first wave strung nine dependent s_load batches and 35 conversions in front of this barrier,
+                // at which its three sister waves wait)
+                if (threadIdx.x < kZooLutSize) zoo_lut[threadIdx.x] = lut_word;
+                __syncthreads();      // (the table)
                 T xh[E], hv[E], xn[E];
                 int kk[E];
 #pragma unroll
@@ -972,17 +773,9 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
                     const T d = x - hv[j];
                     xh[j] = d;       // (max(d, 0.0) is the identity here: stock_after_harvest)
                     xn[j] = (T)0;
-#if FISHING_X_V11_CLAMP_AT_LOAD
-                    kk[j] = kind[j];
-#else
-                    kk[j] = (kind[j] >= 0 && kind[j] < FISHING_N_KINDS) ? kind[j] : FISHING_KIND_BEVERTON_HOLT;
-#endif
+                    kk[j] = kind[j];        // (clamped where it was loaded)
                 }
-                if constexpr (FISHING_V11_FORM == 2)
-                    zoo_draw_lut_tile<T, E>(kk, xh, z, ex.zoo, zoo_lut, xn);
-                else if constexpr (E == 4)
-                    zoo_draw_regrouped<T>(kk, xh, z, ex.zoo, xn, win + (threadIdx.x >> 6) * kZooWindowSlots,
-                                          (int)(threadIdx.x & (kWave - 1)));
+                zoo_draw_lut_tile<T, E>(kk, xh, z, ex.zoo, zoo_lut, xn);
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     obs_next[j] = div_K<T>(xn[j], KK[j], a.dk) - (T)1;       // (the env's scalar K: a multiply when it is a power of two)
@@ -1066,11 +859,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
             }
             // the record's atomic first, the tile's stores behind it (round 3's A/B; re-measured in round 5 the other way round:
             // within noise at every size, 18.66 / 18.63 us at N = 2^22)
-#if FISHING_X_TPW > 1
-            if (a.partials) add_block_partials<kThreads / kWave, kThreads / kWave>(acc, a.partials, in.it);     // (a slot per tile)
-#else
             if (a.partials) add_block_partials<kThreads / kWave, kThreads / kWave>(acc, a.partials);
-#endif
             store_outputs();
             VecE<T, E> qe;
 #pragma unroll
@@ -1142,29 +931,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
         }
     };
 
-    // (Round 4 tried starting a CU's eight workgroups of fishing-v4's one-round grid at N = 2^21 in two phases -- s_sleep of
-    // 0.2 .. 14 us in every other workgroup of a CU -- so that one half computes while the other half's loads fly: 13.0-13.5 us
-    // against 13.2 at the short sleeps, worse beyond: profiles/r04_v4_stagger.jsonl.  Not kept.)
-#if FISHING_X_TPW == 1
-    static_assert(TPW == 1, "the product steps one tile per workgroup");
     do_tile(blockIdx.x);
-#else
-    {
-        static_assert(TPW == 2, "one or two tiles per workgroup");
-        const int64_t it0 = (int64_t)blockIdx.x * 2;
-        const bool two = it0 + 1 < ntiles;          // (wave-uniform: an odd tile count leaves the last workgroup one tile)
-        TileIn in0, in1;
-        load_tile(it0, in0);
-        if (two) load_tile(it0 + 1, in1);
-        run_tile(in0);
-        if (two) {
-            __syncthreads();                        // (the record's LDS rows are reused)
-#pragma unroll
-            for (int k = 0; k < kPartialFields; ++k) acc[k] = 0.0;
-            run_tile(in1);
-        }
-    }
-#endif
 }
 
 // ---------------------------------------------------------------- host side
@@ -1181,7 +948,7 @@ int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const Fi
     if (n < 0 || env_offset < 0 || (env_offset & 3)) return FISHING_ERR_SIZE;
     if (p->model == FISHING_MODEL_V0 && p->n_actions <= 0) return FISHING_ERR_SIZE;
     if (p->launch_threads != 0 &&
-        (p->launch_threads < 64 || p->launch_threads > FISHING_STEP_MAXTHREADS || (p->launch_threads & 63)))
+        (p->launch_threads < 64 || p->launch_threads > kStepMaxThreads || (p->launch_threads & 63)))
         return FISHING_ERR_SIZE;
     if (p->launch_blocks < 0) return FISHING_ERR_SIZE;
     if ((p->flags & FISHING_FLAG_T_U8) && (p->Tmax < 0 || p->Tmax > 254)) return FISHING_ERR_SIZE;
@@ -1280,18 +1047,14 @@ struct LeanCall {
 // the fifth leading argument of a launch (see kLiveMask)
 template <typename T>
 int64_t walk_word(const LeanCall<T>& c, const int64_t ntiles) {
-#if FISHING_WALK_PRELOADED
     int64_t w = c.a.n_live & kLiveMask;
     if (c.a.zz_rt) {
-        constexpr int64_t G = 8 * FISHING_X_TPW;
+        constexpr int64_t G = 8;
         if (c.a.counter) w |= kWalkDeviceParityBit;
         else if ((c.step_counter & 1) && ntiles <= kWalkMask) w |= (ntiles & ~(G - 1)) << kWalkShift;
         if (c.a.nta_rt) w |= kWalkNtaBit;
     }
     return w;
-#else
-    return c.a.n_live;
-#endif
 }
 
 template <typename T, int MODEL, int F, int E = 4>
@@ -1308,18 +1071,9 @@ int lean_launch(const LeanCall<T>& c) {
     // a workgroup of 1024 / E threads per 1024-env tile (feat::ONE): 256 x 4 envs, or 512 x 2 for the float64 layout at
     // cache-resident sizes; one return_partials slot per tile either way
     static_assert((F & feat::ONE) != 0, "every lean form is a one-tile form");
-    const int64_t nt = c.ntiles, nb = c.ntiles;
-    // (FISHING_X_DYN_LDS, experiments only: unused dynamic LDS per workgroup caps the workgroups a CU holds at once.  Running
-    // the one-round grids of N = 2^20 .. 2^22 in several rounds never helped -- fishing-v4 at 2^21 13.05 us with 8 workgroups
-    // per CU, 14.6 with 4, 16.5 with 2: profiles/r03_occupancy_cap.jsonl)
-#ifdef FISHING_X_DYN_LDS_KNOB
-    static const size_t x_lds = std::getenv("FISHING_X_DYN_LDS") ? (size_t)std::atol(std::getenv("FISHING_X_DYN_LDS")) : 0;
-#else
-    constexpr size_t x_lds = 0;
-#endif
-    return launch_kernel_lds(step_kernel_lean<T, MODEL, F, E>, (int)((nb + FISHING_X_TPW - 1) / FISHING_X_TPW),
-                             FISHING_X_TILE_ENVS / E, x_lds, c.s, c.a.obs, c.a.action, c.a.t, c.a.ep_return,
-                             walk_word(c, nt), c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
+    const int64_t nt = c.ntiles;
+    return launch_kernel(step_kernel_lean<T, MODEL, F, E>, (int)nt, kTileEnvsLean / E, c.s, c.a.obs, c.a.action, c.a.t,
+                         c.a.ep_return, walk_word(c, nt), c.a, ex, nt, c.env_offset, c.seed, c.step_counter);
 }
 
 // the catch-all mask of a (T, MODEL): every optional stream "may be there", noise mode at run time
@@ -1373,16 +1127,11 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
             FISHING_LEAN_CASE(P | DERIVED);
             FISHING_LEAN_CASE(P | DERIVED | RET);
             FISHING_LEAN_CASE(P | DERIVED | SIGARR);
-#ifdef FISHING_X_V4_E2
-            case (P | DERIVED | SIGARR | RET): return lean_launch<T, MODEL, (P | DERIVED | SIGARR | RET) | ONE, 2>(c);
-#else
             FISHING_LEAN_CASE(P | DERIVED | SIGARR | RET);
-#endif
             default: break;
         }
     }
-#ifndef FISHING_NO_ZOO_HOT
-    // float32 zoo (one growth function each; fishing-v11: growth function per env, regrouped by kind inside the wave):
+    // float32 zoo (one growth function each; fishing-v11: growth function per env, coefficients from the LDS table):
     // bare / with the return record.  Measured against the catch-all at N = 2^22: fishing-v9 16.05 vs 17.7 us.  (The
     // float64 parity layout gains under 1 % from exact instantiations -- 26.65 vs 26.87 us, it is bound by its
     // 32-byte-per-lane access shape -- and runs on its catch-alls: profiles/r02_ab_variants.jsonl.)
@@ -1401,7 +1150,6 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
             default: break;
         }
     }
-#endif
 #undef FISHING_LEAN_CASE
     // float64: two envs per thread up to ~512 MB per step (see the kernel and step_dispatch_range).  Relieved of the
     // 32-byte access shape the layout feels its arithmetic -- two IEEE float64 divisions per env, ~25 instructions each --
@@ -1410,7 +1158,6 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
     // run-time test, plus the straight per-lane switch of the per-env-sigma path: five inlined growth functions for each of
     // a thread's four envs -- spilled (36 B of scratch per lane, 16 SGPRs) at 105 VGPRs; the two hot requests get exact forms
     if constexpr (sizeof(T) == 8 && MODEL == kModelZooMixed) {
-#if FISHING_V11_FORM == 2       // (round 5: no regroup any more, so the float64 layout's two-envs-per-thread shape is open to fishing-v11 too)
         if (c.two_per_thread) {
             switch (req) {
                 case (P): return lean_launch<T, MODEL, (P | ONE), 2>(c);
@@ -1418,7 +1165,6 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
                 default: return lean_launch<T, MODEL, catch_all_mask<MODEL>() | feat::ONE, 2>(c);
             }
         }
-#endif
         switch (req) {
             case (P): return lean_launch<T, MODEL, (P | ONE)>(c);
             case (P | RET): return lean_launch<T, MODEL, (P | RET | ONE)>(c);
@@ -1427,7 +1173,6 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
     }
     if constexpr (sizeof(T) == 8 && MODEL != kModelZooMixed) {
         if (c.two_per_thread) {
-#if FISHING_ZOO_F64_EXACT
             // the float64 zoo's hot requests as exact two-envs-per-thread forms: 370 instead of 484 VALU instructions per thread.
             // Round 4, on the log / exp round trip, they ran within noise of the catch-alls (profiles/r04_zoo_f64_exact.jsonl);
             // on the algebraic form they are worth 1-2 % (fishing-v5 33.5 -> 32.8 us = 0.85 of the spec, v9 33.7 -> 33.1, v8 and
@@ -1446,7 +1191,6 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
                     }
                 }
             }
-#endif
             if constexpr (!is_zoo_tag(MODEL) && MODEL != FISHING_MODEL_V4) {
                 switch (req) {
                     case (P | KP2): return lean_launch<T, MODEL, (P | KP2 | ONE), 2>(c);
@@ -1469,7 +1213,7 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     const int noise = noise_mode(p, b);
     const bool t8 = (p->flags & FISHING_FLAG_T_U8) != 0;
     const bool derived = p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED);
-    const int64_t tile = FISHING_X_TILE_ENVS;       // (256 * kEnvsPerThread)
+    const int64_t tile = kTileEnvsLean;       // (256 * kEnvsPerThread)
     // (under FISHING_FLAG_PADDED_TILES also batches below one tile: 3.1 instead of 5.3 us per step at N = 1000)
     const bool pad_ok = (p->flags & FISHING_FLAG_PADDED_TILES) != 0 && (n % kEnvsPerThread) == 0;
     // The lean kernel runs a workgroup per tile (step_dispatch hands it at most kPartialSlots tiles); an explicit launch

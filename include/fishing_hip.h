@@ -351,15 +351,12 @@ int fishing_step_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint6
 int fishing_reset_normals_f32(int64_t n, int64_t env_offset, uint64_t seed, uint64_t counter, int32_t stream_tag,
                               float* zK, float* zr, fishing_stream_t stream);
 
-/* Test/diagnostic (ABI 6): the elementary functions the zoo's growth functions are built on, applied elementwise --
- * out[i] = fn(in[i]).  The float64 parity layout's log / exp (FISHING_MATH_LOG_F64 / _EXP_F64: the < 1-ulp msun forms
- * of csrc/fishing_common.h, held to <= 1 ulp of libm by tests/test_gpu_zoo.py), the ~1e-11 polynomial forms of the
- * float64-internal builds (_LOG_MID / _EXP_MID) and the hybrid build's float32 expm1 (input and output widened). */
+/* Test/diagnostic: the elementary functions the float64 zoo's growth functions are built on, applied elementwise --
+ * out[i] = fn(in[i]): the < 1-ulp log / exp of csrc/fishing_common.h (msun forms), held to <= 1 ulp of libm by
+ * tests/test_gpu_zoo.py.  Any other fn: FISHING_ERR_SIZE.  (ABI 6-8 also exposed the polynomial forms of builds that no
+ * longer exist, fn 2-4.) */
 #define FISHING_MATH_LOG_F64 0
 #define FISHING_MATH_EXP_F64 1
-#define FISHING_MATH_LOG_MID 2
-#define FISHING_MATH_EXP_MID 3
-#define FISHING_MATH_EXPM1_F32 4
 int fishing_math_f64(int64_t n, int32_t fn, const double* in, double* out, fishing_stream_t stream);
 
 #ifdef __cplusplus
