@@ -10,7 +10,7 @@ import os
 c_i32, c_i64, c_u32, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64
 c_dbl, c_vp = ctypes.c_double, ctypes.c_void_p
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4 = 0, 1, 2, 4
 MODEL_V5, MODEL_V6, MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11 = 5, 6, 7, 8, 9, 10, 11
@@ -22,6 +22,7 @@ FLAG_AUTO_RESET = 1
 FLAG_T_U8 = 4
 FLAG_V4_DERIVED = 8                  # fishing-v4: (K, r) re-derived in-kernel, no r / K arrays
 FLAG_PADDED_TILES = 16               # state buffers hold whole 1024-env tiles: a ragged batch steps in one launch
+FLAG_RESET_COUNTER_ON_DEVICE = 32    # counter is u64[4]; fishing_reset_* reads and bumps the reset counter (word 3) itself
 FLAG_GENERAL_KERNEL = 0x80000000     # FISHING_FLAG_DIAG_GENERAL_KERNEL (tests, A/B timing)
 POLICY_RANDOM, POLICY_CONSTANT, POLICY_ESCAPEMENT, POLICY_MSY = 0, 1, 2, 3
 STREAM_NOISE, STREAM_AUTORESET, STREAM_RESET, STREAM_POLICY = 0, 1, 2, 3

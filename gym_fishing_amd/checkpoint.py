@@ -10,8 +10,11 @@ from ._capi import MODEL_V11
 
 # state_dict() format.  2: carries `format` and `v4_param_stream` (what draws fishing-v4's (K, r): one Philox2x32-10 block
 # per env, fishing_common.h: param_block); _counter holds {step counter, v4 origin step, v4 origin counter}.
-STATE_FORMAT = 2
+# 3: `v11_model_stream` (what draws fishing-v11's per-episode model: one Philox2x32-10 block per env quad, four 16-bit draws,
+# fishing_common.h: model_block -- ABI 8; before, a Philox4x32-10 word per env); _counter gains the reset counter as a fourth word.
+STATE_FORMAT = 3
 V4_PARAM_STREAM = "philox2x32-10/env"
+V11_MODEL_STREAM = "philox2x32-10/quad:u16"
 
 
 class CheckpointAndReplay:
@@ -23,6 +26,13 @@ class CheckpointAndReplay:
         if self._counter is not None:
             self._step_count = int(self._counter[0].item())
         return self._step_count
+
+    def _current_reset_count(self):
+        """How many reset() calls (constructor draw included) this env has made: in graph-replay mode the device word
+        counter[3], which fishing_reset_* bumps itself -- also inside a replayed graph, where the host takes no part."""
+        if self._counter is not None:
+            self._reset_count = int(self._counter[3].item())
+        return self._reset_count
 
     def launch_signature(self):
         """Everything a captured launch has frozen: the parameter struct's source values, fishing-v4's parameter mode and
@@ -48,8 +58,8 @@ class CheckpointAndReplay:
         if self._scalar:
             torch.cuda.current_stream(self.device).synchronize()
         sd = {k: getattr(self, k).clone() for k in self._STATE_TENSORS if getattr(self, k) is not None}
-        sd.update(format=STATE_FORMAT, v4_param_stream=V4_PARAM_STREAM,
-                  seed=self._seed, step_count=self._current_step_count(), reset_count=self._reset_count,
+        sd.update(format=STATE_FORMAT, v4_param_stream=V4_PARAM_STREAM, v11_model_stream=V11_MODEL_STREAM,
+                  seed=self._seed, step_count=self._current_step_count(), reset_count=self._current_reset_count(),
                   params=dict(self.params), Tmax=self.Tmax, init_state=self.init_state,
                   v4_derived=self._derived, v4_origin=tuple(self._host_origin()), auto_reset=self.auto_reset,
                   attrs={k: getattr(self, k) for k in self._STATE_ATTRS if hasattr(self, k)})
@@ -68,6 +78,14 @@ class CheckpointAndReplay:
         that never use that stream (rng="numpy": the scalar protocol's default) load any fishing-v4 state."""
         # everything that can refuse the state is checked BEFORE the first field changes: a failed load leaves the env as it was
         self._check_v4_state(sd, strict, V4_PARAM_STREAM)
+        if self.MODEL == MODEL_V11 and not self._np_rng and sd.get("v11_model_stream") != V11_MODEL_STREAM:
+            # the models IN FORCE travel in _model_idx; what the tag decides is every later redraw (reset / auto-reset)
+            msg = ("fishing-v11 state was written with model stream %r, this library draws %r: the run would continue with "
+                   "other model draws" % (sd.get("v11_model_stream"), V11_MODEL_STREAM))
+            if strict:
+                raise ValueError(msg + " (strict=False loads the models in force)")
+            import warnings
+            warnings.warn(msg)
         v4_arrays = self._per_env and not sd.get("v4_derived", False)
         for k in self._STATE_TENSORS:
             if k in sd and getattr(self, k) is None and k not in ("_counter", "_stamp") and not (k in ("_r_arr", "_K_arr") and v4_arrays):
@@ -86,7 +104,7 @@ class CheckpointAndReplay:
             if k in sd:
                 if getattr(self, k) is None and k == "_counter":
                     self.enable_graph_replay()
-                if k == "_counter":         # (format 1 kept the step counter alone; the origin words follow _origin below)
+                if k == "_counter":         # (format 1 kept the step counter alone, format 2 three words; the others follow below)
                     self._counter[:sd[k].numel()].copy_(sd[k])
                 elif k == "_partials" and sd[k].numel() < self._partials.numel():
                     self._partials.zero_()
@@ -98,6 +116,8 @@ class CheckpointAndReplay:
             # a state taken from a host-counter env, loaded into an env in graph-replay mode: the device word is this env's
             # step count from here on (_current_step_count() reads it back), so it must not keep the value it had
             self._counter[0].fill_(int(sd["step_count"]))
+        if self._counter is not None:       # (the reset counter's device word: absent from a format-2 _counter, or no _counter at all)
+            self._counter[3].fill_(int(sd["reset_count"]))
         self.params.update(sd["params"])
         self.Tmax, self.init_state = sd["Tmax"], sd["init_state"]
         self.auto_reset = sd.get("auto_reset", self.auto_reset)
@@ -126,7 +146,9 @@ class CheckpointAndReplay:
             # origin that the derived fishing-v4 parameters date episodes from -- so in this mode the kernels read the
             # origin from these words (include/fishing_hip.h: FishingBuffers.counter), which reset() rewrites.  fishing-v4
             # stays in the derived mode under graph replay (ABI 4; round 2 fell back to r / K arrays for good).
-            self._counter = torch.tensor([self._step_count, self._origin[0], self._origin[1]], dtype=torch.int64,
-                                         device=self.device)
+            # ... and the reset counter as a fourth word, read and bumped by fishing_reset_* itself
+            # (FISHING_FLAG_RESET_COUNTER_ON_DEVICE, ABI 9): a captured reset() draws fresh parameters at every replay.
+            self._counter = torch.tensor([self._step_count, self._origin[0], self._origin[1], self._reset_count],
+                                         dtype=torch.int64, device=self.device)
             self._cbuf = None
         return self

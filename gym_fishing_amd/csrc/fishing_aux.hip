@@ -12,7 +12,11 @@ namespace fishing {
 template <typename T, int MODEL>
 __global__ void __launch_bounds__(256)
 reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uint64_t env_offset,
-             const uint8_t* __restrict__ mask, const uint64_t seed, const uint64_t reset_counter) {
+             const uint8_t* __restrict__ mask, const uint64_t seed, const uint64_t reset_counter_arg) {
+    // FISHING_FLAG_RESET_COUNTER_ON_DEVICE: the reset counter lives in counter[3] (wave-uniform scalar load), so that a launch
+    // captured in a hipGraph draws with a fresh counter at every replay; reset_counters_kernel bumps it behind this kernel
+    const uint64_t reset_counter =
+        (p.flags & FISHING_FLAG_RESET_COUNTER_ON_DEVICE) ? b.counter[3] + reset_counter_arg : reset_counter_arg;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         if (mask && !mask[i]) continue;
@@ -40,6 +44,17 @@ reset_kernel(const ParamsT<T> p, const BuffersT<T> b, const int64_t n, const uin
         else b.t[i] = 0;
         if (b.ep_return) b.ep_return[i] = (T)0;
     }
+}
+
+// FISHING_FLAG_RESET_COUNTER_ON_DEVICE, behind reset_kernel on the same stream (one thread): a reset of every env moves the
+// episode origin to (step counter, the reset counter it drew with); every reset bumps the reset counter.
+__global__ void reset_counters_kernel(uint64_t* counter, const uint64_t reset_counter_arg, const int full) {
+    const uint64_t drew_with = counter[3] + reset_counter_arg;
+    if (full) {
+        counter[1] = counter[0];
+        counter[2] = drew_with;
+    }
+    counter[3] += 1;
 }
 
 // fishing-v4, derived parameters: the (K, r) in force for each env, from its year counter
@@ -252,6 +267,8 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
     const int rc = check_common(p, n, env_offset, b);
     if (rc != FISHING_OK) return rc;
     if (n == 0) return FISHING_OK;
+    const bool device_counter = (p->flags & FISHING_FLAG_RESET_COUNTER_ON_DEVICE) != 0;
+    if (device_counter && !b->counter) return FISHING_ERR_NULL;
     const ParamsT<T> pt = narrow_params<T>(*p);
     BuffersT<T> bt = typed_buffers<T>(*b);
     if (p->model == FISHING_MODEL_V4 && (p->flags & FISHING_FLAG_V4_DERIVED)) {
@@ -264,7 +281,7 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
     }
     const int blocks = grid_for(n, 2048);
     hipStream_t s = (hipStream_t)stream;
-    return with_model_tag(p->model, [&](auto tag) {
+    const int rc2 = with_model_tag(p->model, [&](auto tag) {
         // reset only distinguishes v4 (parameter redraw, un-normalised obs) and v11 (model draw)
         constexpr int kTag = decltype(tag)::value;
         constexpr int kResetTag = (kTag == FISHING_MODEL_V4) ? FISHING_MODEL_V4
@@ -273,6 +290,8 @@ int reset_impl(const FishingParams* p, int64_t n, int64_t env_offset, const Fish
         return launch_kernel(reset_kernel<T, kResetTag>, blocks, 256, s, pt, bt, n, (uint64_t)env_offset, mask, seed,
                              reset_counter);
     });
+    if (rc2 != FISHING_OK || !device_counter) return rc2;
+    return launch_kernel(reset_counters_kernel, 1, 1, s, const_cast<uint64_t*>(b->counter), reset_counter, mask ? 0 : 1);
 }
 
 template <typename T>

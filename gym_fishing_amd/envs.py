@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import (FLAG_AUTO_RESET, FLAG_PADDED_TILES, FLAG_T_U8, FLAG_V4_DERIVED, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
+from ._capi import (FLAG_AUTO_RESET, FLAG_PADDED_TILES, FLAG_RESET_COUNTER_ON_DEVICE, FLAG_T_U8, FLAG_V4_DERIVED, KIND_OF_NAME, MODEL_V0, MODEL_V1, MODEL_V2, MODEL_V4, MODEL_V5, MODEL_V6,
                     MODEL_V7, MODEL_V8, MODEL_V9, MODEL_V10, MODEL_V11, POLICY_CONSTANT, POLICY_ESCAPEMENT,
                     POLICY_MSY, POLICY_RANDOM, FishingLibraryError)
 from .spaces import space_classes
@@ -361,7 +361,8 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
         cp.n_actions = int(getattr(self, "n_actions", 0) or 0)
         cp.Tmax = int(self.Tmax)
         cp.flags = ((FLAG_AUTO_RESET if self.auto_reset else 0) | (FLAG_T_U8 if self.compact else 0)
-                    | (FLAG_V4_DERIVED if self._derived else 0) | (FLAG_PADDED_TILES if self._padded else 0))
+                    | (FLAG_V4_DERIVED if self._derived else 0) | (FLAG_PADDED_TILES if self._padded else 0)
+                    | (FLAG_RESET_COUNTER_ON_DEVICE if self._counter is not None else 0))
         cp.v4_origin_step, cp.v4_origin_counter = self._origin
         cp.r = float(p["r"])
         cp.K = float(p["K"])
@@ -484,9 +485,11 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
         elif self._derived_capable:
             self._enter_derived_mode_at_full_reset()
         with torch.cuda.device(self.device):
+            # (graph-replay mode: the reset counter is the device word counter[3], which the library reads and bumps itself -- a
+            # captured reset() draws fresh fishing-v4 parameters / fishing-v11 models at every replay)
             rc = self._fn_reset(self._c_params(), self.num_envs, self.env_offset,
                                 self._c_buffers(with_outputs=False), m.data_ptr() if m is not None else None,
-                                self._seed, self._reset_count, self._stream())
+                                self._seed, 0 if self._counter is not None else self._reset_count, self._stream())
         _capi.check(rc, "fishing_reset")
         self._reset_count += 1
         if mask is None and self._stamp is not None:        # (cleared by the kernel: the launches go back to the stamp-free forms)

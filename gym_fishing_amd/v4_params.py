@@ -64,6 +64,7 @@ class V4ParameterModes:
         if self._counter is not None:
             words = self._counter.tolist()
             self._origin = (int(words[1]), int(words[2]))
+            self._step_count, self._reset_count = int(words[0]), int(words[3])
         return self._origin
 
     def _set_origin(self, step_count, reset_count):
@@ -78,14 +79,12 @@ class V4ParameterModes:
     def _enter_derived_mode_at_full_reset(self):
         """reset() of ALL envs: its counters date every episode from here on; arrays and stamps leave the launches."""
         self._derived, self._K_arr, self._r_arr, self._cbuf = True, None, None, None
-        if self._counter is not None:
-            # graph-replay mode: the origin is copied device word to device word on the current stream -- no host read of
-            # the counter, so reset() neither waits for the GPU on the launch-bound path nor breaks a caller's stream
-            # capture.  The host's copy of the origin is read back on demand (_host_origin).
-            self._counter[1:2].copy_(self._counter[0:1])
-            self._counter[2].fill_(self._reset_count)
-        else:
+        if self._counter is None:
             self._set_origin(self._step_count, self._reset_count)
+        # (graph-replay mode: fishing_reset_* itself moves the origin, device word to device word behind the reset kernel --
+        # counter[1] = the step counter, counter[2] = the reset counter it drew with (FISHING_FLAG_RESET_COUNTER_ON_DEVICE) -- so
+        # reset() neither waits for the GPU nor breaks a caller's stream capture, and a REPLAYED reset() dates the episodes from
+        # the replay's own counters.  The host's copy of the origin is read back on demand: _host_origin.)
 
     def _begin_masked_reset(self):
         """Envs reset at different times: in the derived mode each masked env's episode origin goes into its stamp (R 4 + W 4

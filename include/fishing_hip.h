@@ -32,10 +32,12 @@
 extern "C" {
 #endif
 
-/* 8: same entry points and structs as 7; fishing-v11's per-episode model choice is drawn from one Philox2x32-10 block per env
+/* 9: FISHING_FLAG_RESET_COUNTER_ON_DEVICE (the reset counter as a fourth word of FishingBuffers.counter, read and bumped by
+ * fishing_reset_* itself: captured resets draw fresh parameters at every replay); fishing_math_f64 keeps fn 0-1 only.
+ * 8: same entry points and structs as 7; fishing-v11's per-episode model choice is drawn from one Philox2x32-10 block per env
  * quad (four 16-bit draws) instead of a Philox4x32-10 block -- a run of a fishing-v11 batch continues with other model draws
  * than under ABI 7; the float64 zoo evaluates the growth functions' algebraic form (same 2e-14 bar). */
-#define FISHING_ABI_VERSION 8
+#define FISHING_ABI_VERSION 9
 
 typedef void* fishing_stream_t; /* hipStream_t */
 
@@ -81,6 +83,13 @@ typedef void* fishing_stream_t; /* hipStream_t */
                                 launch instead of two (3.7-4.2 us per step less), and a batch below one tile on the lean
                                 kernel.  Same results for the n envs.
                                 Honoured when n is a multiple of 4 (else ignored: two launches as without it).    */
+#define FISHING_FLAG_RESET_COUNTER_ON_DEVICE 32u /* (ABI 9) FishingBuffers.counter is u64[4] = {step counter, v4_origin_step,
+                                v4_origin_counter, reset counter}.  fishing_reset_* then draws with reset counter
+                                counter[3] + reset_counter (its argument) and, behind the reset on the same stream, bumps
+                                counter[3] by one; a reset of every env (mask == NULL) also moves the episode origin:
+                                counter[1] = counter[0], counter[2] = the reset counter it drew with.  All of it on the
+                                device: a hipGraph that captured [reset(), K steps] draws fresh fishing-v4 (K, r) /
+                                fishing-v11 models at every replay, as it draws fresh step noise.  Needs counter.   */
 /* diagnostic (tests, A/B timing): route step() to the general kernel even where a lean instantiation applies */
 #define FISHING_FLAG_DIAG_GENERAL_KERNEL 0x80000000u
 
@@ -164,7 +173,9 @@ typedef struct FishingBuffers {
                                 v4_origin_step, v4_origin_counter}: the kernels take the episode origin
                                 from counter[1..2] and ignore FishingParams.v4_origin_* -- a captured
                                 launch (frozen arguments) keeps deriving the right (K, r) after a
-                                reset() of all envs, which only rewrites those two words (ABI 4).  */
+                                reset() of all envs, which only rewrites those two words (ABI 4).
+                                With FISHING_FLAG_RESET_COUNTER_ON_DEVICE: u64[4], see the flag (fishing_reset_*
+                                writes words 1-3 there: the buffer is in/out for that call).  */
     int32_t* v4_stamp;   /* i32   in/out  FISHING_FLAG_V4_DERIVED only, nullable (ABI 6).  Per-env episode origin for envs
                                 that were reset ONE BY ONE: stamp[i] != 0 says the episode running in env i began with the
                                 masked fishing_reset_* whose reset_counter was stamp[i] - 1, and its (K, r) are that

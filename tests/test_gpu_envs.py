@@ -601,7 +601,7 @@ def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
     graphed.reset()
     assert eager._derived and graphed._derived
     g = GraphedSteps(graphed, acts)                  # 4 steps per replay
-    assert graphed._derived and graphed._K_arr is None and graphed._counter.numel() == 3
+    assert graphed._derived and graphed._K_arr is None and graphed._counter.numel() == 4
     assert graphed.step_kernel_name(acts[0]) == eager.step_kernel_name(acts[0]) == "fishing::step_kernel_lean<float, 4, 8450, 4>"
     for rnd in range(3):
         for _ in range(3):
@@ -614,12 +614,12 @@ def test_graph_replay_of_fishing_v4_survives_a_reset_after_the_capture(gf):
             eager.reset()
             assert eager._derived and graphed._derived
             # (in graph-replay mode reset() moves the origin on the device; the host's copy is read back on demand)
-            assert graphed._counter.tolist() == [graphed._step_count, *graphed._host_origin()]
+            assert graphed._counter.tolist() == [graphed._step_count, *graphed._host_origin(), eager._reset_count]
             assert graphed._host_origin() == eager._host_origin()
             assert torch.equal(graphed.K, eager.K)
     # a checkpoint of the graph-mode env resumes in an env that never saw the capture
     sd = graphed.state_dict()
-    assert sd["format"] == 2 and sd["_counter"].numel() == 3
+    assert sd["format"] == 3 and sd["_counter"].numel() == 4 and sd["reset_count"] == eager._reset_count
     fresh = mk()
     fresh.load_state_dict(sd)
     fresh.step_many(acts, 4)
@@ -741,7 +741,9 @@ def test_reset_in_graph_replay_mode_is_capturable_and_never_reads_the_counter_ba
     """In graph-replay mode a reset() of all envs dates fishing-v4's episodes from the DEVICE's step counter, copied device
     word to device word on the current stream: no host read (reset() does not wait for the GPU on the launch-bound path
     this mode exists for) and therefore legal inside a caller's own stream capture.  A captured [reset(), 3 steps] replayed
-    three times equals an eager env that resets with the same reset counter, bit for bit -- state and the (K, r) in force."""
+    three times equals an eager env that resets and steps three times, bit for bit -- state and the (K, r) in force: the reset
+    counter is a device word too (FISHING_FLAG_RESET_COUNTER_ON_DEVICE), read and bumped by the reset itself, so every replay
+    draws the parameters of ITS reset -- not the captured one's over and over."""
     import torch
     n = 2048
     acts = torch.rand((3, n), device="cuda") * 1.4 - 1.2
@@ -764,12 +766,34 @@ def test_reset_in_graph_replay_mode_is_capturable_and_never_reads_the_counter_ba
     assert graphed._derived
     for rnd in range(3):
         graph.replay()
-        eager._reset_count = rc             # (the captured reset froze its reset counter: every replay redraws under it)
         eager.reset()
         eager.step_many(acts, 3)
         assert torch.equal(graphed.state, eager.state) and torch.equal(graphed._t, eager._t), rnd
         assert torch.equal(graphed.K, eager.K) and torch.equal(graphed.r, eager.r), rnd
-    assert graphed._host_origin() == eager._host_origin() == (3 + 2 * 3, rc)
+        if rnd:         # the episodes of two replays start from different draws
+            assert not torch.equal(graphed.K, K_prev)
+        K_prev = graphed.K.clone()
+    assert graphed._host_origin() == eager._host_origin() == (3 + 2 * 3, rc + 2)
+    assert graphed._current_reset_count() == eager._reset_count == rc + 3
+    # ... and fishing-v11's per-episode model choice follows the same word
+    mk11 = lambda: gf.make("fishing-v11", num_envs=n, seed=21, Tmax=5)  # noqa: E731
+    e11, g11 = mk11(), mk11()
+    g11.enable_graph_replay()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g11.reset()
+    torch.cuda.current_stream().wait_stream(side)
+    e11.reset()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g11.reset()
+    seen = []
+    for rnd in range(3):
+        graph.replay()
+        e11.reset()
+        assert torch.equal(g11.model_idx, e11.model_idx), rnd
+        seen.append(g11.model_idx.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
 
 
 def test_load_state_dict_into_a_graph_replay_env_moves_the_device_counter_and_refuses_stray_stamps(gf):
@@ -842,6 +866,43 @@ def test_v4_state_without_the_stream_tag_loads_where_it_can(gf):
     two = gf.make("fishing-v4")
     two.load_state_dict(sd1)
     assert two.K == one.K and two.r == one.r
+
+
+def test_v11_state_of_another_model_stream_is_refused_or_warned_about(gf):
+    """fishing-v11 redraws its growth function at every reset from a generator that is part of the state's meaning
+    (`v11_model_stream`: one Philox2x32-10 block per env quad since ABI 8; a Philox4x32-10 word per env before).  A format-2
+    state carries no such tag: strict loading refuses it before anything changes, strict=False loads the models in force
+    with a warning; the current format resumes bit for bit; an rng='numpy' env, which never uses that stream, loads either."""
+    import torch
+    import warnings
+    n = 2048
+    acts = torch.rand((3, n), device="cuda") * 1.4 - 1.2
+    mk = lambda **kw: gf.make("fishing-v11", num_envs=n, seed=4, Tmax=3, **kw)  # noqa: E731
+    a = mk()
+    a.reset()
+    a.step_many(acts, 3)
+    sd = a.state_dict()
+    assert sd["format"] == 3 and sd["v11_model_stream"] == "philox2x32-10/quad:u16"
+    b = mk()
+    b.load_state_dict(sd)
+    a.step_many(acts, 9)
+    b.step_many(acts, 9)
+    assert torch.equal(a.state, b.state) and torch.equal(a.model_idx, b.model_idx)
+    old = dict({k: v for k, v in sd.items() if k != "v11_model_stream"}, format=2)
+    c = mk()
+    c.reset()
+    before = (c.state.clone(), c.model_idx.clone())
+    with pytest.raises(ValueError, match="model stream"):
+        c.load_state_dict(old)
+    assert torch.equal(c.state, before[0]) and torch.equal(c.model_idx, before[1])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        c.load_state_dict(old, strict=False)
+    assert len(w) == 1 and "model stream" in str(w[0].message) and torch.equal(c.model_idx, sd["_model_idx"])
+    one = gf.make("fishing-v11")            # scalar protocol, rng="numpy": np.random.choice draws the model
+    one.reset()
+    sd1 = {k: v for k, v in one.state_dict().items() if k != "v11_model_stream"}
+    assert gf.make("fishing-v11").load_state_dict(sd1).model == one.model
 
 
 @pytest.mark.parametrize("env_id", ["fishing-v1", "fishing-v0", "fishing-v4"])

@@ -655,8 +655,8 @@ FULL_N = 1 << 22   # BASELINE.json metric size
 
 def test_full_size_sharding_invariance_and_determinism(hh):
     """N = 2^22, fishing-v1 sigma=0.1 (the bench workload): stepping the whole batch in one
-    call == stepping four shards with env_offset (noise keyed by the global env index), and a
-    repeat run is bitwise identical."""
+    call == stepping four shards with env_offset (noise keyed by the global env index), a
+    repeat run is bitwise identical, and EVERY env of every step equals the oracle fed the device's normals."""
     import torch
     n, seed = FULL_N, 1234
     p = hh.params(fo.MODEL_V1, sigma=0.1, auto_reset=True)
@@ -680,16 +680,21 @@ def test_full_size_sharding_invariance_and_determinism(hh):
     a, b4, a2 = run(1), run(4), run(1)
     assert torch.equal(a.obs, b4.obs) and torch.equal(a.reward, b4.reward) and torch.equal(a.done, b4.done)
     assert torch.equal(a.obs, a2.obs)
-    # oracle spot-check of a 4096-env window in the middle of the batch, step 0
-    lo = n // 2 + 4096
-    z = hh.device_step_noise(4096, seed, 0, lo)
-    eo, er, ed, _, _ = fo.step(fo.MODEL_V1, np.full(4096, -0.25, np.float32), np.zeros(4096, np.int32),
-                              acts[0, lo:lo + 4096].cpu().numpy(), z, 0.3, 1.0, 0.1, dtype=np.float32)
+    # the oracle over the WHOLE batch, all three steps (the zig-zag walk, the tile boundaries and the quad-indexed generator
+    # are index-dependent code: a window in the middle of the batch does not reach them)
     st = hh.State(n, np.float32, fo.MODEL_V1, np.float32(-0.25))
-    o, rew, _, _ = st.step(p, acts[0].cpu().numpy(), seed=seed, step_counter=0)
-    eo = np.where(ed.astype(bool), np.float32(-0.25), eo)        # fused auto-reset
-    assert_same_bits(o[lo:lo + 4096], eo, "window obs")
-    assert_same_bits(rew[lo:lo + 4096], er, "window reward")
+    obs, t = np.full(n, -0.25, np.float32), np.zeros(n, np.int32)
+    K, r = np.ones(n, np.float32), np.full(n, 0.3, np.float32)
+    for s in range(3):
+        a = acts[s].cpu().numpy()
+        o, rew, done, t2 = st.step(p, a, seed=seed, step_counter=s)
+        z = hh.device_step_noise(n, seed, s, 0)
+        eo, er, ed, et, _ = fo.step(fo.MODEL_V1, obs, t, a, z, 0.3, 1.0, 0.1, dtype=np.float32)
+        obs, t, _, _ = fo.auto_reset(fo.MODEL_V1, eo, ed, et, K, r, 0.75, dtype=np.float32)
+        assert_same_bits(o, obs, "obs step %d" % s)
+        assert_same_bits(rew, er, "reward step %d" % s)
+        assert np.array_equal(done, ed) and np.array_equal(t2, t)
+    assert torch.equal(st.obs, a2.obs)
 
 
 def test_full_size_sigma0_lockstep_properties(hh):
@@ -778,18 +783,18 @@ def test_rollout_reproduces_reference_simulate_tables(hh, c):
 
 
 # ------------------------------------------------------------------ the other BASELINE configs at full size
-@pytest.mark.parametrize("cfg", ["metric_v1_2^22", "config3_v0_2^22", "config4_v2_2^22", "config5_v4_2^21_shard",
-                                 "config5_v4_2^21_shard_derived"])
+@pytest.mark.parametrize("cfg", ["metric_v1_2^22", "metric_v1_2^22_f64", "config3_v0_2^22", "config4_v2_2^22",
+                                 "config5_v4_2^21_shard", "config5_v4_2^21_shard_derived"])
 def test_full_size_baseline_configs(hh, cfg):
-    """The metric's config (fishing-v1, N = 2^22: the headline instantiation step_kernel_lean<float, 1, PHILOX | RET>)
-    and BASELINE.json configs 3-5 at their real per-GPU sizes (fishing-v4 with stored arrays and with derived
-    parameters): 3 steps with in-kernel noise and
-    fused auto-reset; (i) a 4096-env window in the middle of the batch against the oracle fed
-    the device's normals -- bit-exact (v2: tolerance), (ii) stepping the batch as 1 shard ==
-    as 8 env_offset shards (the multi-GPU decomposition of configs 4 and 5), (iii) counts."""
+    """The metric's config (fishing-v1, N = 2^22: the headline instantiation step_kernel_lean<float, 1, PHILOX | RET>, and its
+    reference-precision twin step_kernel_lean<double, 1, ..., 2>) and BASELINE.json configs 3-5 at their real per-GPU sizes
+    (fishing-v4 with stored arrays and with derived parameters): 3 steps with in-kernel noise and fused auto-reset;
+    (i) EVERY env of every step against the oracle fed the device's normals -- bit-exact (v2: tolerance) --, (ii) stepping
+    the batch as 1 shard == as 8 env_offset shards (the multi-GPU decomposition of configs 4 and 5), (iii) counts."""
     import torch
     seed = 20240
     derived = cfg.endswith("derived")
+    dtype = np.float64 if cfg.endswith("f64") else np.float32
     if cfg.startswith("metric"):
         model, n, kw = fo.MODEL_V1, 1 << 22, dict(sigma=0.1)
     elif cfg.startswith("config3"):
@@ -799,7 +804,8 @@ def test_full_size_baseline_configs(hh, cfg):
     else:
         model, n, kw = fo.MODEL_V4, 1 << 21, dict(sigma=0.05, K_mean=1.0, r_mean=0.3, sigma_p=0.1)
     per_env = model == fo.MODEL_V4
-    dtype = np.float32
+    esz = np.dtype(dtype).itemsize
+    sfx = "f64" if dtype == np.float64 else "f32"
     p = hh.params(model, auto_reset=True, derived=derived, origin=(0, 0), **kw)
     g = torch.Generator(device="cuda").manual_seed(5)
     if model == fo.MODEL_V0:
@@ -809,19 +815,26 @@ def test_full_size_baseline_configs(hh, cfg):
     else:
         acts = (torch.rand((3, n), device="cuda", generator=g) * 2 - 1).float()
     lib = __import__("gym_fishing_amd")._capi.lib()
+    reset_fn, step_fn = getattr(lib, "fishing_reset_" + sfx), getattr(lib, "fishing_step_" + sfx)
+    if cfg == "metric_v1_2^22_f64":
+        name = hh.kernel_name(p, n, hh.State(4, dtype, model, 0.0, ep_return=True).buffers(acts[0]), dtype, raw=True)
+        assert name.startswith("fishing::step_kernel_lean<double, 1,") and name.endswith(", 2>"), name
+
+    def shift(b, lo, fields):
+        for f in fields:
+            if getattr(b, f):
+                setattr(b, f, getattr(b, f) + (4 if f in ("t", "action") else esz) * lo)
 
     def run(shards):
-        st = hh.State(n, dtype, model, np.float32(0), r=np.float32(0.3) if per_env and not derived else None,
-                      K=np.float32(1) if per_env and not derived else None, sigma=np.float32(0.05) if per_env else None,
+        st = hh.State(n, dtype, model, dtype(0), r=dtype(0.3) if per_env and not derived else None,
+                      K=dtype(1) if per_env and not derived else None, sigma=dtype(0.05) if per_env else None,
                       ep_return=True)
         snaps = []
         for k in range(shards):
             lo, hi = k * n // shards, (k + 1) * n // shards
             b = st.buffers()
-            for f in ("obs", "t", "r", "K", "sigma", "ep_return"):
-                if getattr(b, f):
-                    setattr(b, f, getattr(b, f) + 4 * lo)
-            assert lib.fishing_reset_f32(p, hi - lo, lo, b, None, seed, 0, None) == 0
+            shift(b, lo, ("obs", "t", "r", "K", "sigma", "ep_return"))
+            assert reset_fn(p, hi - lo, lo, b, None, seed, 0, None) == 0
         torch.cuda.synchronize()
         if derived:
             Kd, rd = (torch.as_tensor(x).cuda() for x in st.v4_params(p, seed=seed, step_counter=0))
@@ -832,13 +845,11 @@ def test_full_size_baseline_configs(hh, cfg):
             for k in range(shards):
                 lo, hi = k * n // shards, (k + 1) * n // shards
                 b = st.buffers(acts[s])
-                for f in ("obs", "action", "reward", "t", "r", "K", "sigma", "ep_return"):
-                    if getattr(b, f):
-                        setattr(b, f, getattr(b, f) + 4 * lo)
+                shift(b, lo, ("obs", "action", "reward", "t", "r", "K", "sigma", "ep_return"))
                 b.done = b.done + lo
                 # each shard keeps its own return_partials in a real multi-GPU run; here the 8
                 # shards share one buffer, which only changes the order of the (commutative) sums
-                assert lib.fishing_step_f32(p, hi - lo, lo, b, seed, s, None) == 0
+                assert step_fn(p, hi - lo, lo, b, seed, s, None) == 0
             torch.cuda.synchronize()
             snaps.append((st.obs.clone(), st.reward.clone(), st.done.clone(), st.t.clone()))
         return st, snaps
@@ -850,16 +861,16 @@ def test_full_size_baseline_configs(hh, cfg):
     r1, r8 = one.record(), eight.record()
     assert r1[2] == r8[2] and r1[3] == r8[3] and np.allclose(r1[:2], r8[:2], rtol=1e-12)
     assert r1[2] == sum(int(s[2].sum()) for s in s1[1:])
-    # oracle window
-    lo, w = n // 2 + 8192, 4096
-    env = np.arange(lo, lo + w)
+    # the oracle over the whole batch (rounds 1-5 compared a 4096-env window in its middle: the zig-zag walk, the tile
+    # boundaries and the quad / env-indexed generators are index-dependent code such a window does not reach)
+    lo, w = 0, n
     if per_env:
         _, zK, zr = hh.device_noise(w, seed, 0, fo.STREAM_RESET, lo)
         K, r = fo.draw_model_error_params(zK, zr, 1.0, 0.3, 0.1, dtype)
         assert np.array_equal(s1[0][1][lo:lo + w].cpu().numpy(), K)
-        sig = np.float32(0.05)
+        sig = dtype(0.05)
     else:
-        K, r, sig = np.full(w, 1.0, dtype), np.full(w, 0.3, dtype), np.float32(kw["sigma"])
+        K, r, sig = np.full(w, 1.0, dtype), np.full(w, 0.3, dtype), dtype(kw["sigma"])
     obs = fo.reset_obs(model, 0.75, K, dtype)
     assert np.array_equal(s1[0][0][lo:lo + w].cpu().numpy(), obs)
     t = np.zeros(w, np.int32)
@@ -885,8 +896,8 @@ def test_full_size_baseline_configs(hh, cfg):
             assert np.array_equal(dev_obs[~live], obs[~live])
             obs = dev_obs
         else:
-            assert_same_bits(dev_obs, obs, "%s window obs step %d" % (cfg, s))
-        assert_same_bits(dev_rew, er, "window reward")
+            assert_same_bits(dev_obs, obs, "%s obs step %d" % (cfg, s))
+        assert_same_bits(dev_rew, er, "%s reward step %d" % (cfg, s))
         assert (dev_done == ed).all() and (dev_t == t).all()
 
 

@@ -181,7 +181,21 @@ def test_zoo_philox_auto_reset_vs_oracle(hh, model, dtype):
     """In-kernel noise + fused auto-reset at N = 4099: the oracle is fed the device's normals
     and (fishing-v11) the device's model draws; populations agree within the transcendental
     tolerance, the drift / model bookkeeping exactly."""
-    n, off, seed, T = 4099, 8, 777, 24
+    _zoo_philox_auto_reset_vs_oracle(hh, model, dtype, n=4099, off=8, T=24)
+
+
+@pytest.mark.parametrize("model", [fo.MODEL_V9, fo.MODEL_V11])
+def test_zoo_full_size_batch_vs_oracle(hh, model):
+    """The same comparison over EVERY env of a BASELINE-sized batch, N = 2^22 in the float32 layout (fishing-v9: one growth
+    function; fishing-v11: growth function per env from the LDS table, model redraws on the auto-reset stream): three steps,
+    each output of each env against the oracle fed the device's normals -- the zig-zag walk, the tile boundaries and the
+    quad-indexed generators are index-dependent code that a window in the middle of the batch does not reach.  Tolerances
+    unchanged (1e-6 on obs and reward); the oracle's exp is NumPy's here (1 ulp from libm's, 1e-16: see simd_exp)."""
+    _zoo_philox_auto_reset_vs_oracle(hh, model, np.float32, n=1 << 22, off=1 << 20, T=3, simd_exp=True)
+
+
+def _zoo_philox_auto_reset_vs_oracle(hh, model, dtype, n, off, T, simd_exp=False):
+    seed = 777
     env_id = {v: k for k, v in fo.MODEL_OF_ID.items()}[model]
     P = dict(ZOO_DEFAULTS[env_id])
     P.update(sigma=0.1)
@@ -218,7 +232,7 @@ def test_zoo_philox_auto_reset_vs_oracle(hh, model, dtype):
             got_r = st.r.cpu().numpy()
             assert np.array_equal(got_r, r_arr)
         eo, er, ed, et, ex = fo.step_zoo(model, obs.astype(np.float64), t, a, z, table if model == fo.MODEL_V11 else Pstep,
-                                         K, Tmax=Tmax, kind=kind)
+                                         K, Tmax=Tmax, kind=kind, simd_exp=simd_exp)
         term = st.terminal.cpu().numpy()
         pop_close(term, eo, K, rtol)
         assert np.abs(rew.astype(np.float64) - er).max() <= (0 if dtype == np.float64 else F32_ATOL)
@@ -440,6 +454,49 @@ def test_zoo_f64_step_outputs_do_not_depend_on_how_a_far_stock_is_evaluated(hh):
     eo, er, ed, et, ex = fo.step_zoo(fo.MODEL_V11, obs, t, a, z, table, 1.0, Tmax=100, kind=kinds)
     assert np.array_equal(o.view(np.uint64), np.asarray(eo, np.float64).view(np.uint64))
     assert np.array_equal(rew, er) and np.array_equal(done, ed)
+
+
+def test_zoo_f64_fused_and_rollout_kernels_on_tiny_stocks(hh):
+    """The same argument for the other two translation-unit-local copies of the float64 growth functions (fishing_rollout.hip
+    is built with FISHING_ZOO_F64_FAR 0 like fishing_step.hip): the fused K-step kernel and the in-kernel-policy rollout kernel,
+    one step each from stocks of 2^-31 ... 2^-53 K -- everything obs can hold below the hand-over line; a stock of 1e-30 K has no
+    obs of its own, obs = -1 is the extinct stock -- with in-kernel noise, against the float64 oracle (the reference's round
+    trip) fed the device's normals: the same obs bits, reward and done for every growth function and for fishing-v11."""
+    from gym_fishing_amd import _capi
+    n, seed = 4096, 31
+    rng = np.random.default_rng(12)
+    expo = rng.integers(31, 54, n)
+    obs = (np.ldexp(1.0, -expo) - 1.0).astype(np.float64)
+    assert ((obs + 1.0) == np.ldexp(1.0, -expo)).all()
+    t = rng.integers(0, 50, n).astype(np.int32)
+    a = np.full(n, -1.0, np.float32)                                # quota 0
+    z = hh.device_step_noise(n, seed, 5, 0).astype(np.float64)
+    table = [dict(d, sigma=0.1, K=1.0) for d in fo.V11_TABLE]
+    kinds = rng.integers(0, 5, n).astype(np.int32)
+    cases = [(fo.MODEL_V5, fo.KIND_ALLEN), (fo.MODEL_V6, fo.KIND_BH), (fo.MODEL_V8, fo.KIND_MYERS), (fo.MODEL_V7, fo.KIND_MAY),
+             (fo.MODEL_V9, fo.KIND_RICKER), (fo.MODEL_V11, None)]
+    for model, kind in cases:
+        if model == fo.MODEL_V11:
+            pk = hh.params(model, sigma=0.0, K=1.0, x0=0.75, Tmax=100, models=[0, 1, 2, 3, 4], zoo_table=table)
+            eo, er, ed, et, ex = fo.step_zoo(model, obs, t, a, z, table, 1.0, Tmax=100, kind=kinds)
+        else:
+            P = table[kind]
+            pk = hh.params(model, r=float(P["r"]), K=1.0, sigma=0.1, C=float(P.get("C", 0.5)), M=float(P.get("M", 0.0)),
+                           theta=float(P.get("theta", 0.0)), q=float(P.get("q", 0.0)), b=float(P.get("b", 0.0)),
+                           a=float(P.get("a", 0.0)), x0=0.75, Tmax=100)
+            eo, er, ed, et, ex = fo.step_zoo(model, obs, t, a, z, dict(P, init_state=0.75), 1.0, Tmax=100)
+        assert (ex > 0).all() and (ex < 2.0 ** -25).all()
+        mk = lambda: hh.State(n, np.float64, model, obs, t=t, model_idx=kinds if model == fo.MODEL_V11 else None)      # noqa: E731
+        st = mk()
+        rs, ds = st.step_fused(pk, a[None, :], 1, seed=seed, step_counter=5)
+        o, _, _, t2 = st.host()
+        assert np.array_equal(o.view(np.uint64), np.asarray(eo, np.float64).view(np.uint64)), ("fused", model)
+        assert np.array_equal(rs[0], er) and np.array_equal(ds[0], ed) and np.array_equal(t2, et), ("fused", model)
+        st = mk()
+        st.rollout(pk, _capi.POLICY_CONSTANT, -1.0, 1, seed=seed, step_counter=5)
+        o, rew, done, t2 = st.host()
+        assert np.array_equal(o.view(np.uint64), np.asarray(eo, np.float64).view(np.uint64)), ("rollout", model)
+        assert np.array_equal(rew, er) and np.array_equal(done, ed) and np.array_equal(t2, et), ("rollout", model)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
