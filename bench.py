@@ -59,6 +59,10 @@ BYTES_RK_ARRAYS = 16        # fishing-v4 --v4-stored: per-env r, K read every st
 BYTES_F64 = 12              # --f64, the parity layout: obs R+W and reward W are 8 bytes wide (25 -> 37 B); the return accumulator +16
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 HBM_COPY_GBS = 6290.0       # measured float4 copy on the same table
+L2_GBS = 34500.0            # aggregate L2 rate, 8 XCDs x 4 MiB (same guide, "L2 (per XCD)")
+L2_BYTES = 32 << 20
+INFINITY_CACHE_GBS = 8600.0  # same guide, "Indexed rows": 38 MB table served from the Infinity Cache, 8.6 TB/s chip-wide -- a LOWER bound there
+MAX_CPU_WORKERS = 64        # cap of the all-cores CPU baseline (a box without a cgroup quota reports 256 CPUs)
 
 CONFIGS = {
     "v1": dict(env_id="fishing-v1", kwargs=dict(sigma=0.1), actions=("uniform", -1.0, 1.0), log2_n=22, log2_n_multi=22,
@@ -168,12 +172,10 @@ def cpu_baseline(seconds, cfg_name):
     n = int(max(50_000, min(rate * seconds, 5_000_000)))
     rate, _ = time_random_rollout(scalar_id, n, seed=1, **skw)
     out = {"value": rate, "unit": "env-steps/s", "cores": 1, "kind": "port", "host_cores": host_cores()[1],
-           "sample": "oracle/scalar_env.py (per-env NumPy step(): the reference's arithmetic with its five helper calls and "
-                     "the isinstance test inlined -- leaner than the reference it stands for): "
-                     "%d env-steps of %s sigma=%g, random policy, reset on done, 1 core" % (n, scalar_id, skw["sigma"]),
+           "sample": "oracle/scalar_env.py (the reference's per-env NumPy step(), helper calls inlined): %d env-steps of %s "
+                     "sigma=%g, random policy, reset on done, 1 core" % (n, scalar_id, skw["sigma"]),
            "reference_build_container": {"value": 1.1e5, "unit": "env-steps/s", "cores": 1,
-                                         "source": "SURVEY.md section 6: the unmodified reference's step() timed in the build "
-                                                   "container (it cannot travel to the GPU box); the port above runs ~2.7x that"}}
+                                         "source": "SURVEY.md 6: the unmodified reference timed in the build container"}}
     try:    # the same Python port on every host core (os.cpu_count() workers, the count reported);
         # independent `python -c` workers: nothing here depends on how this file was started.  Every worker imports first
         # and then waits for one common start time, so the workers really run side by side (a box whose cgroup grants fewer
@@ -181,6 +183,7 @@ def cpu_baseline(seconds, cfg_name):
         # host_cores(), and says so): `value` is the aggregate, all env-steps / (last finish - common start); the sum of the
         # workers' own rates is kept beside it.  Bounded: ~2 n env-steps in total, whatever the core count.
         procs, cores_info = host_cores()
+        procs = min(procs, MAX_CPU_WORKERS)
         per = max(4_000, (2 * n) // procs)
         t_go = time.time() + 1.5 + 0.05 * procs
         code = ("import sys, time; sys.path.insert(0, %r); from oracle.scalar_env import time_random_rollout\n"
@@ -189,16 +192,24 @@ def cpu_baseline(seconds, cfg_name):
                 "print(r, t0, t1)" % (ROOT, t_go, scalar_id, per, skw["sigma"]))
         kids = [subprocess.Popen([sys.executable, "-c", code, str(100 + i)], stdout=subprocess.PIPE,
                                  stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
-        rows = [[float(v) for v in k.communicate(timeout=240)[0].strip().splitlines()[-1].split()] for k in kids]
-        if all(k.returncode == 0 for k in kids):
+        deadline = t_go + max(30.0, 6.0 * seconds)          # ONE deadline for the whole section; stragglers are killed
+        rows = []
+        try:
+            for k in kids:
+                rows.append([float(v) for v in k.communicate(timeout=max(0.1, deadline - time.time()))[0].strip().splitlines()[-1].split()])
+        finally:
+            for k in kids:
+                if k.poll() is None:
+                    k.kill()
+                    k.communicate()
+        if len(rows) == procs and all(k.returncode == 0 for k in kids):
             late = sum(1 for r in rows if r[1] > t_go + 0.05)
             wall = max(r[2] for r in rows) - min(r[1] for r in rows)
-            out["python_port_all_cores"] = dict({"value": procs * per / wall, "unit": "env-steps/s", "cores": procs}, **cores_info,
+            # (a worker that finished importing after the common start skews the aggregate: then only the sum of rates stands)
+            out["python_port_all_cores"] = dict({"value": procs * per / wall if late == 0 else None, "unit": "env-steps/s", "cores": procs},
                                                 sum_of_worker_rates=sum(r[0] for r in rows), workers_started_late=late,
-                                                sample="%d concurrent processes -- one per core this container can run on: "
-                                                       "min(os.cpu_count(), sched affinity, cgroup CPU quota) -- x %d env-steps "
-                                                       "each from one common start time; all env-steps / (last finish - first "
-                                                       "start)" % (procs, per))
+                                                sample="%d processes (one per usable core, capped at %d) x %d env-steps from one "
+                                                       "common start; all env-steps / (last finish - first start)" % (procs, MAX_CPU_WORKERS, per))
     except Exception as e:  # noqa: BLE001
         out["python_port_all_cores_error"] = repr(e)[:200]
     try:    # the NumPy-vectorised (N,) restatement, one process
@@ -212,8 +223,7 @@ def cpu_baseline(seconds, cfg_name):
         time_vectorised_rollout(env_id, nv, 3, seed=0, **vkw)
         vrate, _ = time_vectorised_rollout(env_id, nv, tv, seed=1, **vkw)
         out["numpy_vectorised"] = {"value": vrate, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                                   "sample": "oracle/vector_env.py: the oracle's float64 step() over (N,) arrays, N = %d envs x "
-                                             "%d steps of %s, np.random.normal(0, 1, N) per step, 1 process" % (nv, tv, env_id)}
+                                   "sample": "oracle/vector_env.py: float64 step() over (N,) arrays, %d envs x %d steps" % (nv, tv)}
     except Exception as e:  # noqa: BLE001
         out["numpy_vectorised_error"] = repr(e)[:200]
     try:    # stronger CPU figure for context: the plain-C oracle over all host cores
@@ -472,32 +482,77 @@ def steady_launch_us(torch, env, actions, launches=256, lead=16, spin_ms=60.0):
     return e0.elapsed_time(e1) * 1e3 / launches
 
 
-# BASELINE.json's configs 2-5 at their per-GPU-shard and whole sizes, and SURVEY.md section 8(d)'s spill sizes of configs 3 / 4:
-# (key, config, log2 N, what it is)
+# BASELINE.json's configs 2-5 at their per-GPU-shard and whole sizes, SURVEY.md section 8(d)'s spill sizes of configs 3 / 4, and the
+# metric's workload in the REFERENCE's precision (float64: bit-exact against its NumPy arithmetic; 53 B with the return accumulator,
+# 37 B bare): (key, config, log2 N, float64?, per-env returns?)
 CONFIG_RECORDS = (
-    ("config2_v1_2p20", "v1", 20, "BASELINE config 2: fishing-v1 sigma=0.1, N = 2^20, one GPU"),
-    ("config3_v0_2p22", "v0", 22, "BASELINE config 3: fishing-v0 n_actions=100, N = 2^22, one GPU"),
-    ("config4_v2_2p19_shard", "v2", 19, "BASELINE config 4: fishing-v2, N = 2^22 over 8 GPUs -> the 2^19 envs of one GPU"),
-    ("config4_v2_2p22", "v2", 22, "BASELINE config 4 whole on one GPU (N = 2^22)"),
-    ("config5_v4_2p21_shard", "v4", 21, "BASELINE config 5: fishing-v4, N = 2^24 over 8 GPUs -> the 2^21 envs of one GPU"),
-    ("config5_v4_2p24", "v4", 24, "BASELINE config 5 whole on one GPU (N = 2^24: 620 MB of streams, HBM-resident)"),
-    ("config3_v0_2p26", "v0", 26, "config 3's workload at SURVEY 8(d)'s spill size N = 2^26 (HBM-resident)"),
-    ("config4_v2_2p26", "v2", 26, "config 4's workload at SURVEY 8(d)'s spill size N = 2^26 (HBM-resident)"),
+    ("config2_v1_2p20", "v1", 20, False, True),
+    ("config3_v0_2p22", "v0", 22, False, True),
+    ("config4_v2_2p19_shard", "v2", 19, False, True),
+    ("config4_v2_2p22", "v2", 22, False, True),
+    ("config5_v4_2p21_shard", "v4", 21, False, True),
+    ("config5_v4_2p24", "v4", 24, False, True),
+    ("config3_v0_2p26", "v0", 26, False, True),
+    ("config4_v2_2p26", "v2", 26, False, True),
+    ("metric_v1_2p22_f64", "v1", 22, True, True),
+    ("metric_v1_2p22_f64_bare", "v1", 22, True, False),
 )
+
+
+def floor_launch_us(torch, env, acts, n, mode, launches=256, lead=16, spin_ms=10.0):
+    """steady_launch_us for the library's floor kernels (fishing_step_floor_f32: the step launch's grid, argument list and
+    kernarg preload; mode 0 an empty body, mode 1 a copy over the step's streams -- it clobbers reward / done / ep_return, so
+    the env is scratch afterwards)."""
+    from gym_fishing_amd import _capi
+    lib, bufs, stream = env._lib, env._c_buffers(acts[0]), env._stream()
+    run = lambda k: _capi.check(lib.fishing_step_floor_f32(mode, n, bufs, k, stream), "fishing_step_floor_f32")  # noqa: E731
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < spin_ms:
+        run(64)
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    run(lead)
+    e0.record()
+    run(launches)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / launches
+
+
+def latency_floor(torch, env, acts, n, step_bytes, resident, us):
+    """The roof of a launch-bound size.  latency_floor_us = the empty kernel of the step's grid and argument shape, measured here,
+    + the step's algorithmic bytes / the rate of the cache level its resident streams fit (the guide's figures: aggregate L2
+    34.5 TB/s up to 32 MiB, Infinity Cache 8.6 TB/s -- which the guide gives as a lower bound -- up to 256 MiB);
+    copy_floor_us = a copy over the fishing-v1 stream set (33 B per env) in the step's access shape, measured here."""
+    empty = statistics.median(floor_launch_us(torch, env, acts, n, 0) for _ in range(3))
+    copy = statistics.median(floor_launch_us(torch, env, acts, n, 1) for _ in range(3))
+    level, rate = ("L2", L2_GBS) if resident <= L2_BYTES else ("infinity-cache", INFINITY_CACHE_GBS)
+    floor = empty + n * step_bytes / rate / 1e3
+    out = {"empty_launch_us": round(empty, 3), "copy_floor_us": round(copy, 3), "copy_bytes_per_env_step": 33,
+           "latency_floor_us": round(floor, 3), "floor_level": level, "floor_rate_GBps": rate}
+    # (a fraction of a floor is at most 1; where the step beats the estimate -- the guide's Infinity-Cache rate is a lower
+    # bound -- the ratio is written as such and the fraction is null: no `frac*` field of this file ever exceeds 1)
+    for name, f in (("floor", floor / us), ("copy", copy / us)):
+        out["frac_of_" + name] = round(f, 4) if f <= 1.0 else None
+        if f > 1.0:
+            out[name + "_over_launch_ratio"] = round(f, 4)
+    return out
 
 
 def config_records(torch, gf, launches=256):
     """Every BASELINE config under THIS run's clock (the driver times the default command only): per record the kernel the
     dispatch picked, its algorithmic bytes per env-step, the average launch duration (steady_launch_us: HIP events over
-    >= 256 launches behind a lead-in) and the roofline figure with its regime.  Per-env episodic returns on, as in the
-    headline; config 2 additionally carries its in-kernel random-policy rollout (env-steps/s; not an HBM-bound kernel)."""
+    >= 256 launches behind a lead-in) and the roofline figure with its regime; at the launch-bound shard sizes (N <= 2^21) also
+    the floor such a launch stands on (latency_floor).  Config 2 additionally carries its in-kernel random-policy rollout
+    (env-steps/s; not an HBM-bound kernel)."""
     out = {}
-    for key, name, ln, what in CONFIG_RECORDS:
+    for key, name, ln, f64, with_returns in CONFIG_RECORDS:
         try:
             n = 1 << ln
             rows = RING if ln <= 22 else 4
             cfg = CONFIGS[name]
-            env = make_env(gf, torch, name, n, 0, True)
+            env = make_env(gf, torch, name, n, 0, with_returns, f64=f64)
             env.reset()
             acts = make_actions(torch, cfg, n, rows)
             env.step_many(acts, 24)
@@ -505,13 +560,17 @@ def config_records(torch, gf, launches=256):
             # N = 2^19 on one box within one minute --: five brackets, the median reported, every one listed)
             runs = [steady_launch_us(torch, env, acts, launches, spin_ms=60.0 if i == 0 else 10.0) for i in range(5 if ln <= 21 else 1)]
             us = statistics.median(runs)
-            b = bytes_per_env_step(name, True)
-            fits = resident_bytes(name, n, True, rows) < 256 * 2 ** 20
-            rec = {"what": what, "n_envs": n, "kernel": env.step_kernel_name(acts[0]), "bytes_per_env_step": b,
-                   "avg_launch_us": us, "launches": launches, "env_steps_per_s": n / us * 1e6}
+            b = bytes_per_env_step(name, with_returns, f64=f64)
+            resident = resident_bytes(name, n, with_returns, rows, f64=f64)
+            rec = {"n_envs": n, "kernel": env.step_kernel_name(acts[0]).replace("fishing::step_kernel_", ""), "bytes_per_env_step": b,
+                   "avg_launch_us": round(us, 3), "env_steps_per_s": n / us * 1e6}
+            if f64:
+                rec["dtype"] = "f64"
             if len(runs) > 1:
-                rec["avg_launch_us_brackets"] = [round(r, 3) for r in runs]
-            rec.update(roof(n * b / us / 1e3, fits))
+                rec["brackets_us"] = [round(r, 2) for r in runs]
+            r = roof(n * b / us / 1e3, resident < 256 * 2 ** 20)
+            r.pop("roof_note", None)
+            rec.update({k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()})
             if key == "config2_v1_2p20":        # "random-policy rollout": the policy drawn in-kernel, no action traffic at all
                 env.rollout(101, policy="random")
                 torch.cuda.synchronize()
@@ -522,16 +581,47 @@ def config_records(torch, gf, launches=256):
                 r1.record()
                 torch.cuda.synchronize()
                 us_r = r0.elapsed_time(r1) * 1e3 / (8 * 101)
-                rec["random_policy_rollout"] = {"us_per_step": us_r, "env_steps_per_s": n / us_r * 1e6, "steps_per_launch": 101,
-                                                "kernel": "fishing::rollout_kernel (in-kernel policy; VALU-bound, 0 B of action traffic)"}
+                rec["random_policy_rollout"] = {"us_per_step": round(us_r, 4), "env_steps_per_s": n / us_r * 1e6}
+            if ln <= 21 and not f64 and with_returns:
+                rec.update(latency_floor(torch, env, acts, n, b, resident, us))
             out[key] = rec
             del env, acts
         except Exception as e:  # noqa: BLE001 - a sub-record must not take the headline down
-            out[key] = {"what": what, "error": repr(e)[:300]}
+            out[key] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
-    out["note"] = ("same clock, same process as the headline: HIP events around %d back-to-back fishing_step_f32 launches behind a "
-                   "16-launch lead-in, per-env episodic returns on; frac = achieved / 8 TB/s HBM spec (null + hbm_spec_ratio when "
-                   "cache-resident streams beat it); rocprofv3 records of the same commands: profiles/r05_step_*_summary.json" % launches)
+    out["note"] = ("HIP events around %d back-to-back step launches behind a 16-launch lead-in, same process as the headline; frac = of "
+                   "the 8 TB/s HBM spec (null + hbm_spec_ratio when cache-resident streams beat it); latency_floor_us = empty kernel of "
+                   "the same grid (measured) + bytes / the guide's L2 or Infinity-Cache rate; rocprofv3 twins: profiles/r06_step_*" % launches)
+    return out
+
+
+def python_step_loop(torch, gf, calls=2000):
+    """What a drop-in caller of the reference's env.step() runs: a Python loop, one env.step(actions[k]) per step (SURVEY 8d:
+    "kernel-only and end-to-end (Python loop / hipGraph)").  enqueue_us = host time per call, nothing waited for; wall_us = the
+    loop including the final synchronize, per step; step_many_us = the same launches enqueued by one C call."""
+    out = {}
+    for ln in (20, 22):
+        try:
+            n = 1 << ln
+            env = make_env(gf, torch, "v1", n, 0, True)
+            env.reset()
+            acts = make_actions(torch, CONFIGS["v1"], n, RING)
+            for k in range(200):
+                env.step(acts[k % RING])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(calls):
+                env.step(acts[k % RING])
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            many = steady_launch_us(torch, env, acts, 256, spin_ms=10.0)
+            out["2^%d" % ln] = {"calls": calls, "enqueue_us": round((t1 - t0) / calls * 1e6, 3), "wall_us": round((t2 - t0) / calls * 1e6, 3),
+                                "env_steps_per_s": n * calls / (t2 - t0), "step_many_us": round(many, 3)}
+            del env, acts
+        except Exception as e:  # noqa: BLE001
+            out["2^%d" % ln] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     return out
 
 
@@ -754,7 +844,9 @@ def main():
                                    ("; r / K arrays in HBM" if args.v4_stored else "; (K, r) re-derived in-kernel, no r / K arrays"
                                     + (", per-env origin stamps after a masked reset of one env in eight" if stamped else ""))
                                    if args.config == "v4" else "", "f64" if args.f64 else "f32"),
-                   "name": args.config, "baseline_config": cfg["baseline_config"],
+                   "name": args.config,
+                   "baseline_config": cfg["baseline_config"] if not (args.config == "v1" and n != 1 << 20)
+                   else "metric (config 2's workload at N = %d)" % n,
                    "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-shard x%d" % world,
                    "collective": "1 all-reduce of 4 doubles per rollout (%s)" % ("RCCL" if backend == "nccl" else backend)
                                  if world > 1 else "none",
@@ -908,8 +1000,11 @@ def main():
                                                   "reported as env-steps/s, never the headline")
         env = None
         mark("fused_step_many")
+        configs = None
         if args.config == "v1" and with_returns and not args.no_configs:
-            out["configs"] = config_records(torch, gf)
+            out["python_step_loop"] = python_step_loop(torch, gf)
+            mark("python_step_loop")
+            configs = config_records(torch, gf)
             mark("configs")
 
     if args.extra and rank == 0:
@@ -950,6 +1045,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     out["bench_wall_s"] = dict(wall_s, total=round(sum(wall_s.values()), 3))
+    if subrecords and configs is not None:
+        out["configs"] = configs            # LAST on the line: the driver keeps the tail of stdout
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -90,6 +90,7 @@ SIGNATURES = {
     "fishing_step_normals_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_vp, c_vp]),
     "fishing_reset_normals_f32": (c_i32, [c_i64, c_i64, c_u64, c_u64, c_i32, c_vp, c_vp, c_vp]),
     "fishing_math_f64": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "fishing_step_floor_f32": (c_i32, [c_i32, c_i64, _BP, c_i32, c_vp]),
 }
 
 _lib = None

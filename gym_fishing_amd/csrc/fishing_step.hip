@@ -934,6 +934,35 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     do_tile(blockIdx.x);
 }
 
+// ---------------------------------------------------------------- the floor a lean launch stands on (diagnostic)
+// The grid, workgroup size, argument list (hence kernarg size and preload) of step_kernel_lean<float, MODEL, F, 4>, and
+//   MODE 0: an empty body -- what launching that grid costs, whatever it moves;
+//   MODE 1: a copy over the step's streams with the step's access shape -- 16-byte loads of obs, action, t, ep_return, the
+//           stores of obs, reward, done (one dword), t, ep_return, and nothing in between but an add.
+// bench.py times both beside the step kernel at the launch-bound shard sizes (N = 2^19 .. 2^21), where "fraction of the HBM
+// spec" says nothing about how close the kernel is to ITS floor.
+template <int MODE>
+__global__ void __launch_bounds__(kTileEnvsLean / 4)
+step_floor_kernel(float* const obs_p, const void* const action_p, int32_t* const t_p, float* const ep_return_p,
+                  const int64_t n_live_p, const LeanArgs<float> a, const LeanNoExtra ex, const int64_t ntiles,
+                  const uint64_t env_offset, const uint64_t seed, const uint64_t step_counter_arg) {
+    if constexpr (MODE == 1) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef int32_t i4 __attribute__((ext_vector_type(4)));
+        const int64_t base = ((int64_t)blockIdx.x * (kTileEnvsLean / 4) + threadIdx.x) * 4;
+        const f4 o = *reinterpret_cast<const f4*>(obs_p + base);
+        const f4 ac = *reinterpret_cast<const f4*>((const float*)action_p + base);
+        const i4 t = *reinterpret_cast<const i4*>(t_p + base);
+        const f4 er = *reinterpret_cast<const f4*>(ep_return_p + base);
+        const f4 rew = o + ac;
+        __builtin_nontemporal_store(rew, reinterpret_cast<f4*>(a.reward + base));
+        __builtin_nontemporal_store((uint32_t)(t[0] & 0x01010101), reinterpret_cast<uint32_t*>(a.done + base));
+        *reinterpret_cast<f4*>(ep_return_p + base) = er + rew;
+        *reinterpret_cast<f4*>(obs_p + base) = o;
+        *reinterpret_cast<i4*>(t_p + base) = t;
+    }
+}
+
 // ---------------------------------------------------------------- host side
 int check_common(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b) {
     if (!p || !b) return FISHING_ERR_NULL;
@@ -1358,9 +1387,41 @@ int kernel_name_impl(const FishingParams* p, int64_t n, const FishingBuffers* b,
     return FISHING_OK;
 }
 
+int step_floor_impl(int32_t mode, int64_t n, const FishingBuffers* b, int32_t n_launches, fishing_stream_t stream) {
+    if (!b) return FISHING_ERR_NULL;
+    if (mode < 0 || mode > 1 || n <= 0 || (n % kTileEnvsLean) || n / kTileEnvsLean > kPartialSlots || n_launches < 0)
+        return FISHING_ERR_SIZE;
+    if (mode == 1 && (!b->obs || !b->action || !b->reward || !b->done || !b->t || !b->ep_return)) return FISHING_ERR_NULL;
+    const void* ptrs[] = {b->obs, b->action, b->reward, b->done, b->t, b->ep_return};
+    for (const void* q : ptrs)
+        if (misaligned(q)) return FISHING_ERR_ALIGN;
+    LeanArgs<float> a{};
+    a.obs = (float*)b->obs;
+    a.action = b->action;
+    a.reward = (float*)b->reward;
+    a.done = b->done;
+    a.t = b->t;
+    a.ep_return = (float*)b->ep_return;
+    const int64_t ntiles = n / kTileEnvsLean;
+    for (int32_t k = 0; k < n_launches; ++k) {
+        const int rc = mode == 0 ? launch_kernel(step_floor_kernel<0>, (int)ntiles, kTileEnvsLean / 4, (hipStream_t)stream, a.obs,
+                                                 a.action, a.t, a.ep_return, (int64_t)kLiveMask, a, LeanNoExtra{}, ntiles,
+                                                 (uint64_t)0, (uint64_t)0, (uint64_t)k)
+                                 : launch_kernel(step_floor_kernel<1>, (int)ntiles, kTileEnvsLean / 4, (hipStream_t)stream, a.obs,
+                                                 a.action, a.t, a.ep_return, (int64_t)kLiveMask, a, LeanNoExtra{}, ntiles,
+                                                 (uint64_t)0, (uint64_t)0, (uint64_t)k);
+        if (rc != FISHING_OK) return rc;
+    }
+    return FISHING_OK;
+}
+
 }  // namespace fishing
 
 extern "C" {
+
+int fishing_step_floor_f32(int32_t mode, int64_t n, const FishingBuffers* b, int32_t n_launches, fishing_stream_t stream) {
+    return fishing::step_floor_impl(mode, n, b, n_launches, stream);
+}
 
 int fishing_step_f32(const FishingParams* p, int64_t n, int64_t env_offset, const FishingBuffers* b,
                      uint64_t seed, uint64_t step_counter, fishing_stream_t stream) {

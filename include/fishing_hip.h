@@ -292,6 +292,15 @@ int fishing_v4_params_f64(const FishingParams* p, int64_t n, int64_t env_offset,
 int fishing_step_kernel_name_f32(const FishingParams* p, int64_t n, const FishingBuffers* b, char* out, int64_t len);
 int fishing_step_kernel_name_f64(const FishingParams* p, int64_t n, const FishingBuffers* b, char* out, int64_t len);
 
+/* Diagnostic (ABI 9): the floor a fishing_step_f32 launch over n envs stands on -- n_launches back-to-back launches of a kernel
+ * with that launch's grid (n / 1024 workgroups of 256 threads), argument list and kernarg preload, and
+ *   mode 0: an empty body (what launching the grid costs, whatever it moves);
+ *   mode 1: a copy over the step's streams in the step's access shape (R obs, action, t, ep_return; W obs, reward, done, t,
+ *           ep_return: 33 B per env, no arithmetic but an add) -- CLOBBERS reward, done and ep_return: scratch buffers only.
+ * n a positive multiple of 1024 (at most 2^26); mode 1 needs obs, action, reward, done, t, ep_return.  bench.py times both
+ * beside the step kernel at the launch-bound shard sizes (configs.*.latency_floor_us / copy_floor_us). */
+int fishing_step_floor_f32(int32_t mode, int64_t n, const FishingBuffers* b, int32_t n_launches, fishing_stream_t stream);
+
 /* *counter += delta on `stream` (one thread).  Pair with FishingBuffers.counter to make a
  * captured step() / rollout() replayable: capture {step, counter_add(1)} once, replay K times. */
 int fishing_counter_add(uint64_t* counter, uint64_t delta, fishing_stream_t stream);

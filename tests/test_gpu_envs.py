@@ -815,7 +815,7 @@ def test_load_state_dict_into_a_graph_replay_env_moves_the_device_counter_and_re
     b.enable_graph_replay()
     b.step_many(acts, 2)
     b.load_state_dict(sd)
-    assert b._counter.tolist() == [5, *sd["v4_origin"]]
+    assert b._counter.tolist() == [5, *sd["v4_origin"], sd["reset_count"]]
     a.step_many(acts, 4)
     b.step_many(acts, 4)
     assert torch.equal(a.state, b.state) and torch.equal(a.K, b.K) and b._current_step_count() == 9

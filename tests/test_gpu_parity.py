@@ -744,6 +744,37 @@ def test_abi_rejects_bad_arguments(hh):
     assert b"aligned" in lib.fishing_error_string(-3)
 
 
+def test_step_floor_diagnostic_moves_the_steps_streams_and_nothing_else(hh):
+    """fishing_step_floor_f32 (what bench.py times beside the step kernel at the launch-bound sizes): mode 0 launches the step's
+    grid with an empty body and touches nothing; mode 1 is a copy over the step's streams -- obs and t come back as they
+    were, reward = obs + action, done = t & 1, ep_return += reward, once per launch; bad arguments are refused."""
+    import torch
+    from gym_fishing_amd import _capi
+    lib = _capi.lib()
+    n = 3 * 1024
+    rng = np.random.default_rng(2)
+    obs, t = rng.uniform(-1, 1, n).astype(np.float32), rng.integers(0, 100, n).astype(np.int32)
+    a = rng.uniform(-1, 1, n).astype(np.float32)
+    st = hh.State(n, np.float32, fo.MODEL_V1, obs, t=t, ep_return=True)
+    at = st.action_tensor(a)
+    b = st.buffers(at)
+    assert lib.fishing_step_floor_f32(0, n, b, 5, None) == 0
+    torch.cuda.synchronize()
+    o, rew, done, t2 = st.host()
+    assert np.array_equal(o, obs) and np.array_equal(t2, t) and not rew.any() and not done.any() and not st.ep_return.any()
+    assert lib.fishing_step_floor_f32(1, n, b, 3, None) == 0
+    torch.cuda.synchronize()
+    o, rew, done, t2 = st.host()
+    assert np.array_equal(o, obs) and np.array_equal(t2, t)
+    assert np.array_equal(rew, obs + a) and np.array_equal(done, (t & 1).astype(np.uint8))
+    er = np.zeros(n, np.float32)
+    for _ in range(3):
+        er = er + (obs + a)
+    assert np.array_equal(st.ep_return.cpu().numpy(), er)
+    assert lib.fishing_step_floor_f32(2, n, b, 1, None) == -4 and lib.fishing_step_floor_f32(1, n - 4, b, 1, None) == -4
+    assert lib.fishing_step_floor_f32(1, n, st.buffers(None), 1, None) == -1 and lib.fishing_step_floor_f32(0, n, None, 1, None) == -1
+
+
 # ------------------------------------------------------------------ reference simulate() tables
 from conftest import load_policy_sims  # noqa: E402
 
