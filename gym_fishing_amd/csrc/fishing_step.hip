@@ -956,7 +956,8 @@ step_floor_kernel(float* const obs_p, const void* const action_p, int32_t* const
         const f4 er = *reinterpret_cast<const f4*>(ep_return_p + base);
         const f4 rew = o + ac;
         __builtin_nontemporal_store(rew, reinterpret_cast<f4*>(a.reward + base));
-        __builtin_nontemporal_store((uint32_t)(t[0] & 0x01010101), reinterpret_cast<uint32_t*>(a.done + base));
+        const uint32_t flags = (uint32_t)(t[0] & 1) | ((uint32_t)(t[1] & 1) << 8) | ((uint32_t)(t[2] & 1) << 16) | ((uint32_t)(t[3] & 1) << 24);
+        __builtin_nontemporal_store(flags, reinterpret_cast<uint32_t*>(a.done + base));
         *reinterpret_cast<f4*>(ep_return_p + base) = er + rew;
         *reinterpret_cast<f4*>(obs_p + base) = o;
         *reinterpret_cast<i4*>(t_p + base) = t;

@@ -119,9 +119,11 @@ def test_driver_command_carries_every_baseline_config_and_no_fraction_above_one(
         assert r["achieved_GBps"] == pytest.approx(n * nbytes / r["avg_launch_us"] / 1e3, rel=1e-3)
         assert (r["frac"] is None and r["hbm_spec_ratio"] > 1.0) or r["frac"] == pytest.approx(r["achieved_GBps"] / 8000.0, rel=1e-3)
         if n <= 1 << 21:        # launch-bound: its own roof
-            assert 1.0 < r["empty_launch_us"] < r["copy_floor_us"] < 1.3 * r["avg_launch_us"]
-            assert r["latency_floor_us"] == pytest.approx(r["empty_launch_us"] + n * nbytes / r["floor_rate_GBps"] / 1e3, abs=2e-3)
-            assert r["floor_level"] == ("L2" if n == 1 << 19 else "infinity-cache")
+            assert 1.0 < r["empty_launch_us"] < 1.15 * r["copy_floor_us"] and r["copy_floor_us"] < 1.3 * r["avg_launch_us"]
+            l2 = r["bytes_from_L2"]
+            assert l2 == {19: nbytes, 20: nbytes - 4, 21: 0}[n.bit_length() - 1]
+            assert r["latency_floor_us"] == pytest.approx(r["empty_launch_us"] + n * l2 / 34.5e6 + n * (nbytes - l2) / 8.6e6, abs=2e-3)
+            assert r["floor_level"].startswith("L2") == (n < 1 << 21)
             assert (r["frac_of_floor"] is None) != ("floor_over_launch_ratio" not in r)
         else:
             assert "latency_floor_us" not in r
