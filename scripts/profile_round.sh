@@ -13,6 +13,10 @@ TAG="${1:-r06}"
 PART="${2:-A}"
 O="$REPO/gpurun_out/${TAG}_prof"; mkdir -p "$O/summ"
 cd "$REPO"
+# which box, and its clocks / temperatures / memory state before and after (the float64 N = 2^24 step has read 129 us on some boxes and
+# 138 us on others with the same library: whatever differs between boxes should show here)
+smi() { { hostname; date +%s; rocm-smi --showclocks --showtemp --showpower --showmemuse --showperflevel --json 2>/dev/null; } > "$O/smi_${PART}_$1.txt" 2>&1 || true; }
+smi before
 if [ "$PART" = A ]; then
   timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_driver.json" 2> "$O/bench_driver.err" || exit 1
   echo "driver line done"
@@ -30,5 +34,7 @@ for spec in "${SPECS[@]}"; do
   python3 scripts/summarize_profile.py "$O/prof_$tag" "$O/summ/${TAG}_step_$tag" --latest > /dev/null || { echo "summary $tag failed"; exit 3; }
   rm -rf "$O/prof_$tag"
   echo "profiled $tag"
+  case "$tag" in v1_f64_2p24|v1_2p26|v4_24) smi "after_$tag";; esac
 done
+smi after
 echo done
