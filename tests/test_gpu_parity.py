@@ -814,26 +814,30 @@ def test_rollout_reproduces_reference_simulate_tables(hh, c):
 
 
 # ------------------------------------------------------------------ the other BASELINE configs at full size
-@pytest.mark.parametrize("cfg", ["metric_v1_2^22", "metric_v1_2^22_f64", "config3_v0_2^22", "config4_v2_2^22",
-                                 "config5_v4_2^21_shard", "config5_v4_2^21_shard_derived"])
+@pytest.mark.parametrize("cfg", ["metric_v1_2^22", "metric_v1_2^22_f64", "config2_v1_2^20", "config3_v0_2^22", "config4_v2_2^22",
+                                 "config4_v2_2^19_shard", "config5_v4_2^21_shard", "config5_v4_2^21_shard_derived",
+                                 "config5_v4_2^24_whole_derived"])
 def test_full_size_baseline_configs(hh, cfg):
     """The metric's config (fishing-v1, N = 2^22: the headline instantiation step_kernel_lean<float, 1, PHILOX | RET>, and its
-    reference-precision twin step_kernel_lean<double, 1, ..., 2>) and BASELINE.json configs 3-5 at their real per-GPU sizes
-    (fishing-v4 with stored arrays and with derived parameters): 3 steps with in-kernel noise and fused auto-reset;
+    reference-precision twin step_kernel_lean<double, 1, ..., 2>) and BASELINE.json configs 2-5 at their real whole and per-GPU
+    sizes (config 2: 2^20; config 4: 2^22 and its 2^19 shard; config 5: the 2^21 shard with stored arrays and with derived
+    parameters, and the whole 2^24 batch): 3 steps with in-kernel noise and fused auto-reset;
     (i) EVERY env of every step against the oracle fed the device's normals -- bit-exact (v2: tolerance) --, (ii) stepping
     the batch as 1 shard == as 8 env_offset shards (the multi-GPU decomposition of configs 4 and 5), (iii) counts."""
     import torch
     seed = 20240
     derived = cfg.endswith("derived")
     dtype = np.float64 if cfg.endswith("f64") else np.float32
-    if cfg.startswith("metric"):
-        model, n, kw = fo.MODEL_V1, 1 << 22, dict(sigma=0.1)
+    log2n = int(cfg.split("2^")[1].split("_")[0])
+    n = 1 << log2n
+    if cfg.startswith(("metric", "config2")):
+        model, kw = fo.MODEL_V1, dict(sigma=0.1)
     elif cfg.startswith("config3"):
-        model, n, kw = fo.MODEL_V0, 1 << 22, dict(sigma=0.1, n_actions=100)
+        model, kw = fo.MODEL_V0, dict(sigma=0.1, n_actions=100)
     elif cfg.startswith("config4"):
-        model, n, kw = fo.MODEL_V2, 1 << 22, dict(sigma=0.1, C=0.5)
-    else:
-        model, n, kw = fo.MODEL_V4, 1 << 21, dict(sigma=0.05, K_mean=1.0, r_mean=0.3, sigma_p=0.1)
+        model, kw = fo.MODEL_V2, dict(sigma=0.1, C=0.5)
+    else:           # (config 5 whole: N = 2^24, whose 8 shards below are exactly the per-GPU blocks of the 8-GPU run)
+        model, kw = fo.MODEL_V4, dict(sigma=0.05, K_mean=1.0, r_mean=0.3, sigma_p=0.1)
     per_env = model == fo.MODEL_V4
     esz = np.dtype(dtype).itemsize
     sfx = "f64" if dtype == np.float64 else "f32"

@@ -190,3 +190,24 @@ def test_only_tests_smoke_and_bench_touch_the_oracle():
             if re.search(r"^\s*(from|import)\s+oracle\b", code, flags=re.M) and path not in allowed:
                 offenders.append(os.path.relpath(path, ROOT))
     assert not offenders, offenders
+
+
+def test_build_keeps_every_translation_unit_its_own_device_link_and_csrc_free_of_build_variants():
+    """(1) fishing_common.h's inline device templates have different bodies per translation unit (FISHING_ZOO_F64_FAR: 1 in
+    fishing_aux.hip, 0 in fishing_step.hip / fishing_rollout.hip) -- sound only while no device symbol crosses units, i.e. while the
+    library is built without relocatable device code; and -ffp-contract=off is part of the numerical contract.  (2) The product
+    kernels carry no experiment scaffolding: a handful of preprocessor conditionals (the partial-slot count, three byte thresholds
+    of the launch's walk, that per-unit setting), nothing else."""
+    import glob
+    import re
+    from gym_fishing_amd import build
+    assert "-fno-gpu-rdc" in build.HIPCC_FLAGS and "-ffp-contract=off" in build.HIPCC_FLAGS
+    src = {f: open(f).read() for f in glob.glob(os.path.join(build.CSRC, "*"))}
+    units = {os.path.basename(f): re.findall(r"^#define FISHING_ZOO_F64_FAR (\d)", s, re.M) for f, s in src.items() if f.endswith(".hip")}
+    assert units == {"fishing_step.hip": ["0"], "fishing_rollout.hip": ["0"], "fishing_aux.hip": []}, units
+    conditionals = [ln.strip() for s in src.values() for ln in s.splitlines() if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", ln)]
+    assert len(conditionals) <= 15, conditionals
+    knobs = sorted(set(re.findall(r"#\s*ifn?def\s+(FISHING_\w+)", "\n".join(src.values()))))
+    assert knobs == ["FISHING_F64_E2_MAX_BYTES", "FISHING_NTA_MIN_BYTES", "FISHING_PARTIAL_SLOTS", "FISHING_XZZ_MIN_BYTES",
+                     "FISHING_ZOO_F64_FAR"], knobs
+    assert len(src[os.path.join(build.CSRC, "fishing_common.h")].splitlines()) < 1400
