@@ -66,7 +66,7 @@ def hipcc_path():
 def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every csrc/*.hip into one shared library.  Returns its path.
     `out` + `extra_flags` build an experimental variant next to the default library
-    (used by scripts/tune_variants.py; the product always loads LIB_PATH)."""
+    (scripts/build_variants.py: today the host-side UBSan build; the product always loads LIB_PATH)."""
     if out is not None:
         return _compile(out, verbose, extra_flags)
     if not force and not is_stale():
@@ -85,10 +85,7 @@ def _compile(out_path, verbose, extra_flags):
     objs = ["%s.%d.o" % (tmp, i) for i in range(len(srcs))]
     # one hipcc per translation unit, side by side (the two kernel files take about as long as each other),
     # then one link step
-    tu_flags = dict(TU_FLAGS)
-    for unit in ("step", "rollout", "aux"):     # experiments: FISHING_<UNIT>_TU_FLAGS replaces that unit's own flags
-        if os.environ.get("FISHING_%s_TU_FLAGS" % unit.upper()) is not None:
-            tu_flags["fishing_%s.hip" % unit] = os.environ["FISHING_%s_TU_FLAGS" % unit.upper()].split()
+    tu_flags = TU_FLAGS
     cmds = [[hipcc] + flags + tu_flags.get(os.path.basename(src), []) + ["-c", src, "-o", obj] for src, obj in zip(srcs, objs)]
     procs = []
     for cmd in cmds:

@@ -6,7 +6,7 @@
 // f32 / i32 stream is read or written with one 16-byte access per lane (1 KiB per wave
 // instruction) and the done bytes with one dword per lane.  No env ever reads another env's
 // state: there is no LDS staging of the streams (nothing is reused) -- LDS only carries the
-// per-workgroup reduction of the episodic-return record and fishing-v11's regroup-by-kind windows.
+// per-workgroup reduction of the episodic-return record and fishing-v11's coefficient table.
 //
 // Roofline: HBM.  Algorithmic bytes per env-step: f32 layout 25 B
 // (R obs 4 + action 4 + t 4; W obs 4 + reward 4 + done 1 + t 4); fishing-v4 +4 B (sigma array) with
@@ -452,7 +452,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const int noise = ((F & feat::kNoiseMask) == feat::kNoiseRT) ? a.noise_rt : (F & feat::kNoiseMask);
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
-    // trips in front of the first global load of every wave.  Measured (scripts/exp/ab_lean_variants.py,
+    // trips in front of the first global load of every wave.  Measured (round 1,
     // N = 2^22): bare step 16.9 -> 16.5 us; with the return accumulator 21.67 -> 21.45 us, as long as the
     // ep_return / partials pointers stay out of the batch (21.50 with them): profiles/r01f_lean_fence_ab.txt.
     auto batch_args = [&]() {
