@@ -133,10 +133,12 @@ class CheckpointAndReplay:
         return self
 
     def enable_graph_replay(self):
-        """Keep the step counter in device memory from now on.  step() / step_many() / rollout()
+        """Keep the step counter -- and the reset counter -- in device memory from now on.  step() / step_many() / rollout()
         then launch with frozen arguments plus a one-thread counter bump, so a hipGraph that
         captured them (gym_fishing_amd.graphs.GraphedSteps, or a caller's own torch.cuda.CUDAGraph) draws
-        fresh noise on every replay.  Same noise stream as the host-counter mode.
+        fresh noise on every replay; reset() draws fishing-v4's (K, r) / fishing-v11's models with the device's reset counter
+        and bumps it itself, so a captured [reset(), K steps] collection loop starts every replayed episode from a fresh draw.
+        Same streams as the host-counter mode: an eager env making the same calls lands on the same bits.
         What a capture freezes besides the counter: every scalar of the parameter struct, fishing-v4's parameter mode
         (derived / stored arrays) and every stream's address -- launch_signature().  GraphedSteps re-captures when that
         changes; a caller replaying a torch.cuda.CUDAGraph of its own must compare launch_signature() itself.  The env
