@@ -80,7 +80,7 @@ reduce_returns_kernel(const double* __restrict__ partials, const int passes, dou
     // One workgroup of 16 waves, one pass per kReduceSlots = 4096 slots.  In a pass thread i owns slots i, i + 1024,
     // i + 2048, i + 3072: four 32-byte reads (a slot's four fields are contiguous), all issued before the first add;
     // then a fixed tree -- slot order inside the thread, a shuffle tree inside the wave, wave order across the
-    // workgroup: same bits on every run.  (Round 2's form -- 256 threads, 64 strided 8-byte reads each -- took 8 us
+    // workgroup: same bits on every run.  (256 threads with 64 strided 8-byte reads each took 8 us
     // of the bench's 20-step region; this one ~3 for one pass = every batch up to N = 2^22.)
     static_assert(kPartialSlots % kReduceSlots == 0, "whole passes");
     typedef double d2 __attribute__((ext_vector_type(2)));

@@ -576,8 +576,8 @@ __device__ __forceinline__ T zoo_population_draw(int kind_rt, T x, T z, const Gr
 // minus that quotient (May).  So a lane evaluates ONE division and ONE exp per env at full lane occupancy -- no ballots, no
 // divergent passes -- once it has its env's coefficients: from a 5 x 8 table in LDS (zoo_draw_lut_tile, the step / rollout
 // kernels) or, on the per-env-sigma path, by selects over the wave-uniform parameter sets (zoo_draw_select_one).  Both run the
-// operations of zoo_pre_g_f32 / zoo_pre_g_f64 of the env's kind on the same operands: the same bits.  (The regroup-by-kind form of
-// rounds 2-4 and the measurements of all three: profiles/NOTES_r01_r05.md, profiles/r05_v11_forms.jsonl.)
+// operations of zoo_pre_g_f32 / zoo_pre_g_f64 of the env's kind on the same operands: the same bits.  (An earlier
+// regroup-by-kind form and the measurements of all three: profiles/NOTES_r01_r05.md, profiles/r05_v11_forms.jsonl.)
 template <typename W>
 struct ZooSelectMath;
 template <>

@@ -309,13 +309,13 @@ constexpr int SIGARR = 1 << 3;     // per-env noise scale
 constexpr int T8 = 1 << 4;         // compact layout: one-byte year counters
 constexpr int TERM = 1 << 5;       // terminal_obs: the observation before the fused auto-reset (SB3)
 constexpr int BITS = 1 << 6;       // done_bits: wave-ballot termination mask
-// (1 << 7 was round 2's compile-time zig-zag walk: LeanArgs::zz_rt now)
+// (1 << 7: unused -- the zig-zag walk is a run-time property of the launch, LeanArgs::zz_rt)
 constexpr int DERIVED = 1 << 8;    // fishing-v4: (K, r) re-derived from the Philox streams, no r / K arrays
 constexpr int DRIFT = 1 << 9;      // fishing-v10: per-env r, drifting by alpha every draw
 constexpr int OPT = 1 << 10;
 constexpr int LATCH = 1 << 11;     // RET without auto-reset: a finished env that is stepped on must not enter the record
                                    // again.  Catch-all only -- the exact RET instantiations are the auto-reset ones.
-constexpr int ONE = 1 << 13;       // one tile per workgroup (grid == ntiles; every lean launch since round 3): no tile loop, and with RET the
+constexpr int ONE = 1 << 13;       // one tile per workgroup (grid == ntiles; every lean launch): no tile loop, and with RET the
                                    // return record -- workgroup reduction + its atomic -- is issued BEFORE the tile's stores, so the
                                    // atomic's round trip runs under theirs.  Exact instantiations and catch-alls alike.  Per step at N = 2^19 / 2^20 /
                                    // 2^21, back to back: 4.75 -> 4.09, 6.15 -> 5.71, 9.78 -> 8.15 us (profiles/r03_small_n/).
@@ -405,10 +405,10 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     // not preloaded), and fetches the rest of its arguments in one batch.  Per step, back to back, against the same kernel
     // without preload: N = 2^20 6.04 -> 5.75 us, 2^22 21.41 -> 20.87, 2^19 unchanged
     // (profiles/r03_small_n/s15_kernarg_preload_product.jsonl; harness sweep of 4 .. 14 dwords: s14_*).  Firmware without
-    // the feature runs the kernel's own s_load prologue.  Round 4 made the zig-zag walk a run-time field of the struct and
-    // so put FOUR dependent s_load round trips back into every wave (the walk's flag, the step's parity, the batch, the
-    // counter); with the walk in the preloaded word there are two, one of them hidden behind the tile's loads: N = 2^19
-    // 4.67 -> 4.34 us, 2^20 6.0 -> 5.8, 2^22 18.94 -> 18.76 (profiles/r05_walk_word.jsonl).
+    // the feature runs the kernel's own s_load prologue.  The launch's walk rides in the same preloaded word (n_live_p): as
+    // run-time fields of the struct its flags string FOUR dependent s_load round trips through every wave (the walk's flag,
+    // the step's parity, the batch, the counter); in the word there are two, one of them hidden behind the tile's loads:
+    // N = 2^19 4.67 -> 4.34 us, 2^20 6.0 -> 5.8, 2^22 18.94 -> 18.76 (profiles/r05_walk_word.jsonl).
     constexpr bool kPerEnv = (MODEL == FISHING_MODEL_V4);
     constexpr bool kMixed = (MODEL == kModelZooMixed);    // fishing-v11: growth function per env
     constexpr bool kZoo = is_zoo_tag(MODEL) && !kMixed;   // one growth function of the zoo, compile-time kind
@@ -436,9 +436,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const bool DERIVED = (F & feat::DERIVED) && (kExact || a.derived_rt != 0);
     const bool STAMP = (F & feat::STAMP) && DERIVED && a.stamp != nullptr;
     const bool DRIFT = (F & feat::DRIFT) && (kExact || a.drift_rt != 0);
-    // (run-time in every form: round 3's exact zig-zag twins of the tile loop went when every batch up to 2^26 envs got a
-    // workgroup per tile)
-    // ... and decided by the HOST, in the preloaded n_live argument: as fields of the by-value struct, the walk's flags put one
+    // The walk is a run-time property of the launch, decided by the HOST, in the preloaded n_live argument: as fields of the by-value struct, the walk's flags put one
     // s_load round trip in front of every wave's first global load -- what the kernarg preload had taken away.
     const int64_t n_live = n_live_p & kLiveMask;
     const bool ZZ = (n_live_p & kWalkDeviceParityBit) != 0;     // (the walks that need the step counter BEFORE the tile's loads)
@@ -452,8 +450,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
     const int noise = ((F & feat::kNoiseMask) == feat::kNoiseRT) ? a.noise_rt : (F & feat::kNoiseMask);
     // Pull the kernel arguments into SGPRs in ONE batch of scalar loads.  Left alone, the compiler
     // loads arguments next to their first use, which strings five dependent s_load / s_waitcnt round
-    // trips in front of the first global load of every wave.  Measured (round 1,
-    // N = 2^22): bare step 16.9 -> 16.5 us; with the return accumulator 21.67 -> 21.45 us, as long as the
+    // trips in front of the first global load of every wave.  Measured at N = 2^22: bare step 16.9 -> 16.5 us; with the return accumulator 21.67 -> 21.45 us, as long as the
     // ep_return / partials pointers stay out of the batch (21.50 with them): profiles/r01f_lean_fence_ab.txt.
     auto batch_args = [&]() {
     if constexpr (kExact) {     // (the catch-alls are short of SGPRs as it is)
@@ -857,8 +854,7 @@ step_kernel_lean(T* const obs_p, const void* const action_p, int32_t* const t_p,
 #pragma unroll
                 for (int j = 0; j < E; ++j) er[j] = (dn[j] && auto_reset) ? (T)0 : er[j];
             }
-            // the record's atomic first, the tile's stores behind it (round 3's A/B; re-measured in round 5 the other way round:
-            // within noise at every size, 18.66 / 18.63 us at N = 2^22)
+            // the record's atomic first, the tile's stores behind it (the other order measures the same: 18.66 / 18.63 us at 2^22)
             if (a.partials) add_block_partials<kThreads / kWave, kThreads / kWave>(acc, a.partials);
             store_outputs();
             VecE<T, E> qe;
@@ -1203,10 +1199,9 @@ int lean_dispatch(int req, const LeanCall<T>& c) {
     }
     if constexpr (sizeof(T) == 8 && MODEL != kModelZooMixed) {
         if (c.two_per_thread) {
-            // the float64 zoo's hot requests as exact two-envs-per-thread forms: 370 instead of 484 VALU instructions per thread.
-            // Round 4, on the log / exp round trip, they ran within noise of the catch-alls (profiles/r04_zoo_f64_exact.jsonl);
-            // on the algebraic form they are worth 1-2 % (fishing-v5 33.5 -> 32.8 us = 0.85 of the spec, v9 33.7 -> 33.1, v8 and
-            // v7 unchanged: profiles/r05_zoo_f64_exact.jsonl) -- the layout sits 6 % behind fishing-v1's 31.1 us whatever it executes
+            // the float64 zoo's hot requests as exact two-envs-per-thread forms: 370 instead of 484 VALU instructions per thread,
+            // worth 1-2 % (fishing-v5 33.5 -> 32.8 us = 0.85 of the spec, v9 33.7 -> 33.1, v8 and v7 unchanged:
+            // profiles/r05_zoo_f64_exact.jsonl) -- the layout sits 6 % behind fishing-v1's 31.1 us whatever it executes
             if constexpr (is_zoo_tag(MODEL)) {
                 switch (req) {
                     case (P): return lean_launch<T, MODEL, (P | ONE), 2>(c);
@@ -1252,8 +1247,6 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
     const bool covers = tiles_up <= kPartialSlots && (!p->launch_blocks || p->launch_blocks >= tiles_up);
     const bool lean = !(p->flags & FISHING_FLAG_DIAG_GENERAL_KERNEL) && b->reward && b->done &&
                       (p->launch_threads == 0 || p->launch_threads == 256) && (n >= tile || pad_ok) && covers;
-    // (fishing-v11 in float64 too: as a one-tile form its catch-all needs 105 VGPRs and spills 16 SGPRs -- 58 us per step
-    // at N = 2^22 against 81 on the general kernel, where rounds 1-2 kept it)
     if (!lean) {
         int blocks, threads;
         launch_shape(p, n, blocks, threads);
@@ -1271,12 +1264,10 @@ int step_dispatch_range(const FishingParams* p, const ParamsT<T>& pt, int64_t n,
                   pt.r_mean, pt.K_mean, pt.sigma_p, pt.Tmax, pt.n_actions, (uint32_t)(p->flags & FISHING_FLAG_AUTO_RESET),
                   noise, (uint32_t)t8, (uint32_t)derived, (uint32_t)drift, 0u, 0u, padded ? n : INT64_MAX, pt.origin_step,
                   pt.origin_counter, pt.growth, pt.alpha, make_divk((double)pt.K), (T)(pt.x0 / pt.K - (T)1)};
-    // Launch geometry.  Rounds 1-2 capped the grid (4096 workgroups, 768 from N = 2^25: of two LOOPING grids the smaller
-    // streamed better from HBM: profiles/r02_caps_large_n.jsonl).  Round 3: a workgroup per tile at every size -- with
-    // returns 2^24 83 -> 80 us, 2^26 376 -> 345; the float32 catch-all 101 -> 91 / 423 -> 389; float64 bare 2^24
-    // 108.6 -> 96.7, 2^25 233 -> 194 (profiles/r03_one_tile_large_n.jsonl, r03_full_grid_loops.jsonl).  Batches beyond
-    // the 65536 slots are stepped in ranges of 2^26 envs (step_dispatch below: the tile loop took 587 / 819 us at
-    // N = 2^27 on 768 workgroups, 564 / 772 on 65536; two ranges take 528 / 742).
+    // Launch geometry: a workgroup per tile at every size -- a grid of one-tile workgroups keeps the memory system full
+    // through the dispatcher where a capped, looping grid has one tile's loads in flight per workgroup (with returns 2^24
+    // 83 -> 80 us, 2^26 376 -> 345; float64 bare 2^24 108.6 -> 96.7: profiles/r03_one_tile_large_n.jsonl).  Batches beyond
+    // the 65536 slots are stepped in ranges of 2^26 envs (step_dispatch below).
     int req = noise;
     if (b->ep_return) req |= feat::RET;
     if (b->ep_return && !(p->flags & FISHING_FLAG_AUTO_RESET)) req |= feat::LATCH;
