@@ -1055,7 +1055,9 @@ def main():
         out["cpu_baseline"] = None
     out["bench_wall_s"] = dict(wall_s, total=round(sum(wall_s.values()), 3))
     if subrecords and configs is not None:
-        out["configs"] = configs            # LAST on the line: the driver keeps the tail of stdout
+        # LAST on the line (the driver keeps the last 8 KB of stdout): the Python loop and every config's own record
+        out["python_step_loop"] = out.pop("python_step_loop")
+        out["configs"] = configs
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

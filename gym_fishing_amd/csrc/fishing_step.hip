@@ -12,22 +12,23 @@
 // (R obs 4 + action 4 + t 4; W obs 4 + reward 4 + done 1 + t 4); fishing-v4 +4 B (sigma array) with
 // derived parameters, +12 B with stored r / K arrays; f64 parity layout 37 B; +4/8 B per optional stream.
 //
-// Two kernels:
-//   step_kernel_lean<T, MODEL, F>  whole 1024-env tiles, one body, the optional streams selected by the
-//                                  feature mask F (namespace feat).  Only the masks a request can reach
-//                                  are instantiated (lean_table below).
-//   step_kernel<T, MODEL>          the general kernel: ragged tails, batches below one tile, fishing-v11,
-//                                  custom launch shapes.  Everything optional is a run-time decision.
-// The float64 zoo's growth functions run on the algebraic form (fishing_common.h: zoo_draw_f64) and follow the reference's own
-// log / exp round trip where ITS rounding exceeds the 2e-14 bar: stocks outside [2^-30, 2^30], results outside [2^-92, 2^92].  In
-// THIS translation unit that hand-over is compiled out (FISHING_ZOO_F64_FAR 0): a step's outputs cannot carry the difference.  The state leaves a step as obs = x' / K - 1, whose spacing near -1 is 1.1e-16 -- a population below
-// 2^-53 K comes out as obs = -1 in the reference and here alike, and for a stock below 2^-30 K the two evaluations differ by
-// < 1e-13 of a result that obs resolves to 1e-7 of itself at best; reward is the harvest (no growth function in it); done tests
-// x' <= 0, and zeros are zeros in both forms.  The other end -- obs beyond 1e9 -- lies nine orders of magnitude outside anything the
-// dynamics reach (a stock cannot grow past ~10 K in a step) and outside the observation space.  population_draw (fishing_aux.hip),
-// which hands x' out itself -- BMSY sweeps, the module-level growth functions, the special-value tests -- keeps the hand-over.  What it
-// costs a kernel that never takes it: 16-32 VGPRs for the inlined logarithms of the cold branch -- fishing-v11 float64 41.9 -> 39.8
-// us at N = 2^22 (0.76 -> 0.80 of the HBM spec), fishing-v8 33.9 -> 33.0, v9 33.0 -> 32.6 (profiles/r05_zoo_f64_far_path.jsonl).
+// Three kernels:
+//   step_kernel_lean<T, MODEL, F, E>  whole 1024-env tiles, one tile per workgroup, one body; the optional streams are
+//                                     selected by the feature mask F (namespace feat).  Only the masks a request can
+//                                     reach are instantiated (lean_dispatch below).
+//   step_kernel<T, MODEL>             the general kernel: ragged tails, batches below one tile, explicit launch
+//                                     shapes.  Everything optional is a run-time decision.
+//   step_floor_kernel<MODE>           diagnostic: the empty / copy floor of a lean launch (bench.py).
+//
+// FISHING_ZOO_F64_FAR 0: the float64 zoo's growth functions run on the algebraic form (fishing_common.h: zoo_draw_f64);
+// the hand-over to the reference's own log / exp round trip for far stocks / far results is compiled out of THIS
+// translation unit, because a step's outputs cannot carry the difference: the state leaves a step as obs = x' / K - 1,
+// whose spacing near -1 is 1.1e-16 -- a population below 2^-53 K is obs = -1 in the reference and here alike, and below
+// 2^-30 K the two evaluations differ by < 1e-13 of a result that obs resolves to 1e-7 of itself; reward is the harvest,
+// done tests x' <= 0, zeros are zeros in both forms; obs beyond 1e9 lies nine orders of magnitude outside anything the
+// dynamics reach.  population_draw (fishing_aux.hip), which hands x' out itself, keeps the hand-over.  The cold branch
+// cost every kernel 16-32 VGPRs (fishing-v11 float64 41.9 -> 39.8 us at N = 2^22: profiles/r05_zoo_f64_far_path.jsonl);
+// tests/test_gpu_zoo.py::test_zoo_f64_step_outputs_do_not_depend_on_how_a_far_stock_is_evaluated holds the argument.
 #define FISHING_ZOO_F64_FAR 0
 #include "fishing_common.h"
 #include "fishing_host.h"
