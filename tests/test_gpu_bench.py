@@ -110,7 +110,7 @@ def test_driver_command_carries_every_baseline_config_and_no_fraction_above_one(
             "config3_v0_2p26": ("<float, 0, 12294, 4>", 33, 1 << 26, False), "config4_v2_2p26": ("<float, 2, 12294, 4>", 33, 1 << 26, False),
             # the reference's precision: float64, two envs per thread (the bit-exact parity layout)
             "metric_v1_2p22_f64": ("<double, 1, 12294, 2>", 53, 1 << 22, True), "metric_v1_2p22_f64_bare": ("<double, 1, 12290, 2>", 37, 1 << 22, True)}
-    assert list(out)[-1] == "configs" and len(json.dumps(cfg)) < 7000        # (the driver keeps the last 8 KB of stdout)
+    assert list(out)[-2:] == ["python_step_loop", "configs"] and len(json.dumps(cfg)) < 7000        # (the driver keeps the last 8 KB of stdout)
     for key, (kernel, nbytes, n, resident) in want.items():
         r = cfg[key]
         assert "error" not in r, r
