@@ -418,12 +418,14 @@ ROLLOUT_KW = dict(sigma=0.1, C=0.5, x0=0.75, Tmax=7, sigma_p=0.15)
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("model", [fo.MODEL_V0, fo.MODEL_V1, fo.MODEL_V2, fo.MODEL_V4])
 @pytest.mark.parametrize("policy", ["random", "constant", "escapement", "msy"])
-def test_fused_rollout_equals_stepwise(hh, model, dtype, policy, seed_offset=0):
+def test_fused_rollout_equals_stepwise(hh, model, dtype, policy, seed_offset=0, size=None):
     """T steps inside one kernel == T step() calls fed the policy's actions (bit-exact: both
     run the same device arithmetic and the same Philox blocks).
     (`seed_offset` != 0, tests/fuzz_differential.py: the same body with K, r, the noise scale, the policy's parameter, the seed, the env
     offset and the batch size drawn from that number -- power-of-two and other K, whole tiles and ragged batches.)"""
     n, off, seed, T = 2052, 4, 99, 25
+    if size is not None:            # (test_in_kernel_policy_rollouts_at_the_configs_real_sizes)
+        n, off, T = size
     per_env = model == fo.MODEL_V4
     r0, K0, kw = 0.3, 1.0, dict(ROLLOUT_KW)
     pol, param = _policy_setup(hh, policy, model)
@@ -458,9 +460,21 @@ def test_fused_rollout_equals_stepwise(hh, model, dtype, policy, seed_offset=0):
     assert (A.t.cpu().numpy() == B.t.cpu().numpy()).all()
     assert_same_bits(A.ep_return.cpu().numpy(), B.ep_return.cpu().numpy(), "ep_return")
     ra, rb = A.record(), B.record()
-    assert ra[2] == rb[2] and (ra[2] >= n or seed_offset) and np.allclose(ra, rb, rtol=1e-12, equal_nan=True)
+    assert ra[2] == rb[2] and (ra[2] >= n or seed_offset or size) and np.allclose(ra, rb, rtol=1e-12, equal_nan=True)
     if per_env:
         assert_same_bits(A.K.cpu().numpy(), B.K.cpu().numpy(), "K")
+
+
+@pytest.mark.parametrize("model,policy,log2n", [(fo.MODEL_V1, "random", 20), (fo.MODEL_V0, "random", 22), (fo.MODEL_V2, "escapement", 19),
+                                                (fo.MODEL_V4, "random", 21)],
+                         ids=["config2_v1_random_2^20", "config3_v0_random_2^22", "config4_v2_escapement_2^19_shard",
+                              "config5_v4_random_2^21_shard"])
+def test_in_kernel_policy_rollouts_at_the_configs_real_sizes(hh, model, policy, log2n):
+    """BASELINE config 2 is a "random-policy rollout" at N = 2^20: the fused kernel with the policy drawn in-kernel, every env of
+    every step of its [T, 4, N] record against step() fed the oracle's policy actions -- bit for bit -- at that size, and the same
+    for the other configs' workloads at their per-GPU sizes (the shard's env_offset is that of the last rank of eight)."""
+    n = 1 << log2n
+    test_fused_rollout_equals_stepwise(hh, model, np.float32, policy, size=(n, 7 * n, 4))
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
