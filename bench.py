@@ -526,8 +526,8 @@ def latency_floor(torch, env, acts, n, step_bytes, resident, us):
     the aggregate L2 (32 MiB, 34.5 TB/s) serves everything when the whole resident set -- state streams + action ring -- fits it,
     the state streams alone (a tile stays on its XCD from step to step) when only they fit, nothing otherwise; the rest comes from
     the Infinity Cache (8.6 TB/s -- a figure the guide gives as a lower bound).  copy_floor_us = a copy over the fishing-v1
-    stream set (33 B per env) in the step's access shape, measured here: where it beats the computed floor, the guide's
-    Infinity-Cache rate is the pessimistic term."""
+    stream set (33 B per env) in the step's access shape, measured here (frac_of_copy scales its memory part to the config's
+    bytes): where it beats the computed floor, the guide's Infinity-Cache rate is the pessimistic term."""
     empty = statistics.median(floor_launch_us(torch, env, acts, n, 0) for _ in range(3))
     copy = statistics.median(floor_launch_us(torch, env, acts, n, 1) for _ in range(3))
     ring = acts.shape[0] * (n + 3072) * 4
@@ -542,7 +542,11 @@ def latency_floor(torch, env, acts, n, step_bytes, resident, us):
            "latency_floor_us": round(floor, 3), "floor_level": level, "bytes_from_L2": l2_bytes}
     # (a fraction of a floor is at most 1; where the step beats the estimate -- the guide's Infinity-Cache rate is a lower
     # bound -- the ratio is written as such and the fraction is null: no `frac*` field of this file ever exceeds 1)
-    for name, f in (("floor", floor / us), ("copy", copy / us)):
+    # the measured copy moves fishing-v1's 33 B per env; a config that streams more (fishing-v4: 37 B) scales its memory part
+    copy_scaled = empty + max(copy - empty, 0.0) * step_bytes / 33.0
+    if step_bytes != 33:
+        out["copy_floor_scaled_us"] = round(copy_scaled, 3)
+    for name, f in (("floor", floor / us), ("copy", copy_scaled / us)):
         out["frac_of_" + name] = round(f, 4) if f <= 1.0 else None
         if f > 1.0:
             out[name + "_over_launch_ratio"] = round(f, 4)
