@@ -102,6 +102,10 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
 
     metadata = {"render.modes": ["human"]}
     MODEL = MODEL_V1
+    # what FishingParams is built from beyond the base fields, per class: attributes / entries of `params` the model's kernels
+    # read (_param_key compares them on every step(): only what can matter is looked at)
+    _KEY_ATTRS = ()
+    _KEY_PARAMS = ()
     _STREAM_STAGGER = 12288      # bytes between the arena's stream starts beyond their sizes (see __init__)
 
     def __init__(self, params=None, Tmax=100, file=None, *, num_envs=None, device=None, seed=0,
@@ -342,12 +346,10 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
         p = self.params
         if self.compact and self.Tmax > 254:
             raise ValueError("compact layout needs Tmax <= 254")
+        ka, kp = self._KEY_ATTRS, self._KEY_PARAMS
         return (self.Tmax, self.init_state, self.auto_reset, self._derived, None if self._counter is not None else self._origin,
-                self._sigma_scalar, p["r"],
-                p["K"], self._launch,
-                getattr(self, "n_actions", 0), getattr(self, "C", None), getattr(self, "r_mean", None),
-                getattr(self, "K_mean", None), getattr(self, "sigma_p", None),
-                tuple(p.get(k) for k in ("C", "M", "theta", "q", "b", "a", "alpha")))
+                self._sigma_scalar, p["r"], p["K"], self._launch,
+                tuple([getattr(self, k) for k in ka]) if ka else ka, tuple([p.get(k) for k in kp]) if kp else kp)
 
     def _c_params(self):
         """FishingParams for the next call; rebuilt only when a source attribute changed
@@ -768,6 +770,7 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
 class FishingEnv(BaseFishingEnv):
     """fishing-v0 (fishing_env.py:6-24): Discrete(n_actions), quota = a / n_actions * K."""
     MODEL = MODEL_V0
+    _KEY_ATTRS = ("n_actions",)
 
     def __init__(self, r=0.3, K=1, sigma=0.0, n_actions=100, init_state=0.75, Tmax=100, file=None, **vec):
         self.n_actions = int(n_actions)
@@ -787,6 +790,7 @@ class FishingCtsEnv(BaseFishingEnv):
 class FishingTippingEnv(BaseFishingEnv):
     """fishing-v2 (fishing_tipping_env.py:6-35): tipping-point growth with parameter C."""
     MODEL = MODEL_V2
+    _KEY_ATTRS = ("C",)
 
     def __init__(self, r=0.3, K=1, C=0.5, sigma=0.0, init_state=0.75, Tmax=100, file=None, **vec):
         self.C = C
@@ -798,6 +802,7 @@ class FishingModelError(BaseFishingEnv):
     """fishing-v4 (fishing_model_error.py:6-48): K, r ~ N(mean, sigma_p) clipped to [0, 1e6],
     redrawn per env at construction and at every reset; reset obs is x0 un-normalised."""
     MODEL = MODEL_V4
+    _KEY_ATTRS = ("K_mean", "r_mean", "sigma_p")
 
     def __init__(self, K_mean=1.0, r_mean=0.3, price=1.0, sigma=0.0, sigma_p=0.1, init_state=0.75, Tmax=100,
                  file=None, **vec):
@@ -830,6 +835,7 @@ class FishingModelError(BaseFishingEnv):
 class Allen(BaseFishingEnv):
     """fishing-v5 (growth_models.py:6-25; allen() :208-217)."""
     MODEL = MODEL_V5
+    _KEY_PARAMS = ("C",)
 
     def __init__(self, r=0.3, K=1, C=0.5, sigma=0.0, init_state=0.75, Tmax=100, file=None, **vec):
         super().__init__(params={"r": r, "K": K, "sigma": sigma, "C": C, "x0": init_state}, Tmax=Tmax, file=file, **vec)
@@ -846,6 +852,7 @@ class BevertonHolt(BaseFishingEnv):
 class Myers(BaseFishingEnv):
     """fishing-v8 (growth_models.py:43-70; myers() :247-255)."""
     MODEL = MODEL_V8
+    _KEY_PARAMS = ("theta", "M")
 
     def __init__(self, r=1.0, K=1.0, M=1.0, theta=3.0, sigma=0.0, init_state=1.5, Tmax=100, file=None, **vec):
         super().__init__(params={"r": r, "K": K, "sigma": sigma, "theta": theta, "M": M, "x0": init_state},
@@ -855,6 +862,7 @@ class Myers(BaseFishingEnv):
 class May(BaseFishingEnv):
     """fishing-v7 (growth_models.py:75-108; may() :229-242)."""
     MODEL = MODEL_V7
+    _KEY_PARAMS = ("q", "b", "a", "M")
 
     def __init__(self, r=0.7, K=1.5, M=1.5, q=3, b=0.15, sigma=0.0, a=0.2, init_state=0.75, Tmax=100, file=None,
                  **vec):
@@ -874,6 +882,7 @@ class NonStationary(BaseFishingEnv):
     """fishing-v10 (growth_models.py:126-154): Beverton-Holt whose r drifts by alpha at every
     population draw and is never restored by reset() -- r is per-env state here."""
     MODEL = MODEL_V10
+    _KEY_PARAMS = ("alpha",)
 
     def __init__(self, r=0.8, K=1, sigma=0.0, alpha=-0.007, init_state=0.75, Tmax=100, file=None, **vec):
         super().__init__(params={"r": r, "K": K, "sigma": sigma, "alpha": alpha, "x0": init_state}, Tmax=Tmax,
