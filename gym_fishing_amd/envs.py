@@ -24,6 +24,7 @@ methods -- get_quota ... population_draw, simulate, plot -- (reference_helpers.p
 constructor raises FishingLibraryError.
 """
 import csv
+import ctypes
 
 import numpy as np
 import torch
@@ -166,6 +167,7 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
 
         self._lib = _capi.lib()                      # raises if the HIP library is missing
         self.device = _require_device(device)
+        self._dev_index = self.device.index
         self._suffix = "f32" if dtype == torch.float32 else "f64"
         self._fn_step = getattr(self._lib, "fishing_step_" + self._suffix)
         self._fn_reset = getattr(self._lib, "fishing_reset_" + self._suffix)
@@ -240,7 +242,7 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
         self._action_buf = None
         self._scalar_views = None
         self._last_action = None
-        self._cparams = self._pkey = self._cbuf = None
+        self._cparams = self._pkey = self._cbuf = self._cparams_ref = self._cbuf_ref = None
         self._counter = None          # device-resident step counter (graph-replay mode), else host int
         self._want = torch.int32 if self.MODEL == MODEL_V0 else torch.float32
         if self._scalar:
@@ -386,6 +388,7 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
                 for k in ("r", "K", "sigma", "C", "M", "theta", "q", "b", "a"):
                     setattr(g, k, float(d.get(k, 0.0) or 0.0))
         self._cparams, self._pkey = cp, key
+        self._cparams_ref = ctypes.byref(cp)        # (step() passes this: no temporary pointer object per call)
         return cp
 
     def _c_buffers(self, action=None, z_ext=None, with_outputs=True):
@@ -404,10 +407,11 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
         b = self._cbuf
         if b is None:
             b = self._cbuf = self._c_buffers()
+            self._cbuf_ref = ctypes.byref(b)
         b.action = action_ptr
         b.z_ext = z_ptr
         b.sigma = self._sigma_arr.data_ptr() if self._sigma_arr is not None else None
-        return b
+        return self._cbuf_ref
 
     def _stream(self):
         return _current_stream_ptr(self.device.index)
@@ -563,15 +567,17 @@ class BaseFishingEnv(V4ParameterModes, CheckpointAndReplay, ReferenceHelpers, _g
         bufs = self._step_buffers(a.data_ptr(), z.data_ptr() if z is not None else None)
         on_device = self._counter is not None
         host_count = 0 if on_device else self._step_count
-        if torch.cuda.current_device() == self.device.index:
-            stream = _current_stream_ptr(self.device.index)
-            rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed, host_count, stream)
+        self._c_params()                      # (rebuilt only when a source attribute changed; the call passes its cached reference)
+        dev = self._dev_index
+        if torch.cuda.current_device() == dev:
+            stream = _current_stream_ptr(dev)
+            rc = self._fn_step(self._cparams_ref, self.num_envs, self.env_offset, bufs, self._seed, host_count, stream)
             if on_device and not rc:
                 rc = self._lib.fishing_counter_add(self._counter.data_ptr(), 1, stream)
         else:
             with torch.cuda.device(self.device):
                 stream = self._stream()
-                rc = self._fn_step(self._c_params(), self.num_envs, self.env_offset, bufs, self._seed, host_count,
+                rc = self._fn_step(self._cparams_ref, self.num_envs, self.env_offset, bufs, self._seed, host_count,
                                    stream)
                 if on_device and not rc:
                     rc = self._lib.fishing_counter_add(self._counter.data_ptr(), 1, stream)
