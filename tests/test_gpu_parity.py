@@ -830,12 +830,13 @@ def test_rollout_reproduces_reference_simulate_tables(hh, c):
 # ------------------------------------------------------------------ the other BASELINE configs at full size
 @pytest.mark.parametrize("cfg", ["metric_v1_2^22", "metric_v1_2^22_f64", "config2_v1_2^20", "config3_v0_2^22", "config4_v2_2^22",
                                  "config4_v2_2^19_shard", "config5_v4_2^21_shard", "config5_v4_2^21_shard_derived",
-                                 "config5_v4_2^24_whole_derived"])
+                                 "config5_v4_2^24_whole_derived", "metric_v1_2^24_spill", "config3_v0_2^26_spill"])
 def test_full_size_baseline_configs(hh, cfg):
     """The metric's config (fishing-v1, N = 2^22: the headline instantiation step_kernel_lean<float, 1, PHILOX | RET>, and its
     reference-precision twin step_kernel_lean<double, 1, ..., 2>) and BASELINE.json configs 2-5 at their real whole and per-GPU
     sizes (config 2: 2^20; config 4: 2^22 and its 2^19 shard; config 5: the 2^21 shard with stored arrays and with derived
-    parameters, and the whole 2^24 batch): 3 steps with in-kernel noise and fused auto-reset;
+    parameters, and the whole 2^24 batch) and SURVEY 8(d)'s spill sizes (2^24 and 2^26: HBM-resident streams, a workgroup per
+    tile beyond 4096 tiles, the zig-zag walk with nontemporal action loads): 3 steps with in-kernel noise and fused auto-reset;
     (i) EVERY env of every step against the oracle fed the device's normals -- bit-exact (v2: tolerance) --, (ii) stepping
     the batch as 1 shard == as 8 env_offset shards (the multi-GPU decomposition of configs 4 and 5), (iii) counts."""
     import torch
