@@ -1305,6 +1305,22 @@ def test_batches_beyond_65536_tiles_run_as_ranges(hh):
         assert torch.equal(x.view(it), y.view(it)), nm
     ra, rb = A.record(), B.record()
     assert ra[2] == rb[2] > n // 2 and ra[3] == rb[3] and np.allclose(ra[:2], rb[:2], rtol=1e-12)
+    # ... and against the oracle, every env of both ranges (fed the device's normals): state, last step's outputs, running returns
+    a_h = a.cpu().numpy()
+    obs, tt, er = np.full(n, -0.25, np.float32), np.zeros(n, np.int32), np.zeros(n, np.float32)
+    K, r = np.ones(n, np.float32), np.full(n, 0.3, np.float32)
+    episodes = 0
+    for s in range(3):
+        z = hh.device_step_noise(n, 11, 6 + s, 0)
+        eo, rew, ed, et, _ = fo.step(fo.MODEL_V1, obs, tt, a_h, z, 0.3, 1.0, 0.1, Tmax=2, dtype=np.float32)
+        er = (er + rew).astype(np.float32)
+        obs, tt, _, _ = fo.auto_reset(fo.MODEL_V1, eo, ed, et, K, r, 0.75, dtype=np.float32)
+        er = np.where(ed.astype(bool), np.float32(0), er)
+        episodes += int(ed.sum())
+    assert_same_bits(A.obs.cpu().numpy(), obs, "obs after 3 steps, two ranges")
+    assert_same_bits(A.reward.cpu().numpy(), rew, "reward of the last step")
+    assert_same_bits(A.ep_return.cpu().numpy(), er, "running returns")
+    assert np.array_equal(A.done.cpu().numpy(), ed) and np.array_equal(A.t.cpu().numpy(), tt) and ra[2] == episodes
     del A, B, outs
     torch.cuda.empty_cache()
 
