@@ -121,12 +121,20 @@ def test_fused_step_many_at_the_launch_bound_sizes(hh):
     import torch
     from gym_fishing_amd import _capi
     lib = _capi.lib()
-    for model, n, t8 in ((fo.MODEL_V1, 1 << 20, False), (fo.MODEL_V2, 1 << 19, False), (fo.MODEL_V1, 1 << 18, True)):
-        p = hh.params(model, sigma=0.1, C=0.5, auto_reset=True, t_u8=t8)
+    # (... and the other configs' real sizes: the metric's 2^22, config 3's fishing-v0 at 2^22, config 5's fishing-v4 shard at 2^21
+    # on derived parameters with its sigma array)
+    for model, n, t8 in ((fo.MODEL_V1, 1 << 20, False), (fo.MODEL_V2, 1 << 19, False), (fo.MODEL_V1, 1 << 18, True),
+                         (fo.MODEL_V1, 1 << 22, False), (fo.MODEL_V0, 1 << 22, False), (fo.MODEL_V4, 1 << 21, False)):
+        v4 = model == fo.MODEL_V4
+        p = hh.params(model, sigma=0.05 if v4 else 0.1, C=0.5, auto_reset=True, t_u8=t8, derived=v4)
         g = torch.Generator(device="cuda").manual_seed(n)
-        ring = (torch.rand((8, n), device="cuda", generator=g) * 2 - 1).float()
-        A = hh.State(n, np.float32, model, np.full(n, -0.25), ep_return=True, t_u8=t8)
-        B = hh.State(n, np.float32, model, np.full(n, -0.25), ep_return=True, t_u8=t8)
+        if model == fo.MODEL_V0:
+            ring = torch.randint(0, 100, (8, n), device="cuda", generator=g, dtype=torch.int32)
+        else:
+            ring = (torch.rand((8, n), device="cuda", generator=g) * 2 - 1).float()
+        mk = lambda: hh.State(n, np.float32, model, np.full(n, 0.75 if v4 else -0.25, np.float32), ep_return=True, t_u8=t8,   # noqa: E731
+                              sigma=np.float32(0.05) if v4 else None)
+        A, B = mk(), mk()
         assert lib.fishing_step_many_f32(p, n, 0, A.buffers(ring), n, 8, 101, 7, 0, None) == 0
         assert lib.fishing_step_fused_f32(p, n, 0, B.buffers(ring), n, 8, 101, None, None, 0, 7, 0, None) == 0
         torch.cuda.synchronize()
