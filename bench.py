@@ -782,6 +782,10 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # (... and the collection itself is tens of milliseconds during which the device idles and its clocks drop; the rehearsal's
+    # 0.4 ms of launches do not bring them back -- a region timed behind it read 410-416 us where the same region in a loop that
+    # keeps the device busy reads 397, profiles/r06_region_fixed_cost.json -- so the spin-up's launches run once more, briefly)
+    respin_ms, respin_launches = spin_up(torch, env, actions, min(args.spinup_ms, 30.0), rt) if args.spinup_ms > 0 else (0.0, 0)
     sync_all()
     region(with_events=True)
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)     # HIP events around the rehearsal's K launches
@@ -869,9 +873,11 @@ def main():
                    "ranks": ranks,
                    "record_is_sum_of_rank_records": True if ranks is not None else None,
                    "rehearsal": rt.name},
-        "spinup": {"ms": spin_ms, "launches": spin_launches, "rehearsal_launches": args.steps,
-                   "note": "same launches as the timed region, ahead of --warmup; then one untimed dress rehearsal of the timed "
-                           "sequence itself (K launches + record + barrier); none of it timed"},
+        "spinup": {"ms": spin_ms, "launches": spin_launches, "respin_ms": respin_ms, "respin_launches": respin_launches,
+                   "rehearsal_launches": args.steps,
+                   "note": "same launches as the timed region, ahead of --warmup; behind the warm-up a second, short spin (the "
+                           "host work in between lets the clocks drop) and one untimed dress rehearsal of the timed sequence "
+                           "itself (K launches + record + barrier); none of it timed"},
         "roofline": {"bound": "infinity-cache/hbm" if fits else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": head["frac"], "hbm_spec_ratio": head.get("hbm_spec_ratio"), "traffic": traffic, "traffic_source": traffic_src,
                      # traffic: a LOOKUP of the committed rocprofv3 --pmc record of this command (bench.py cannot read counters
