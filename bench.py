@@ -22,7 +22,8 @@ and exits with the children's status; started by torch.distributed.run it is one
 its own envs (weak scaling; global env index = rank * n + i keys the noise), no data-path collective; one
 all-reduce of the 4-double episodic-return record per rollout, inside the timed region.
 
-Timed region: a device spin-up (the same launches, >= --spinup-ms, reported) and W warm-up steps come first;
+Timed region: a device spin-up (the same launches, >= --spinup-ms, reported), W warm-up steps, a short second spin and one
+untimed dress rehearsal of the timed sequence come first;
 then EXACTLY K steps between barrier + synchronize on both sides: K launches + the record's reduce kernel
 (+ the all-reduce) enqueued, one synchronize.  The record is read back to the host after the clock stops.
 
